@@ -1,0 +1,412 @@
+"""Host-side mirror of the reference facade (cv::cuda::EfficientFeatures, cv::cuda::BAD, cv::cuda::HashSIFT)
+over the C ABI of libefx_hip.so (include/efx.h).
+
+Reference interface: modules/cuda_efficient_features/include/cuda_efficient_features.h:28-98 and
+cuda_efficient_descriptors.h:27-126.  Method names, argument meaning and error behaviour follow it
+(bad arguments raise, like CV_Assert / CV_Error); device buffers are torch CUDA tensors, which play the
+role of cv::cuda::GpuMat, and host images / keypoints are numpy arrays (cv::Mat / std::vector<KeyPoint>).
+
+There is NO CPU fallback: importing works without a GPU (so the ABI can be inspected), but creating a
+detector or describer raises EfxError when libefx_hip.so or a HIP device is missing.
+
+The directory name contains '-', so import it through cef_loader.load() (repo root), which registers it
+as module `cef_amd`.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libefx_hip.so")
+
+EFX_OK = 0
+STATUS_NAMES = {0: "EFX_OK", -1: "EFX_ERR_BAD_ARG", -2: "EFX_ERR_UNSUPPORTED", -3: "EFX_ERR_HIP",
+                -4: "EFX_ERR_NO_DEVICE", -5: "EFX_ERR_NOMEM"}
+
+# every symbol include/efx.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "efx_default_params", "efx_create", "efx_destroy", "efx_last_error", "efx_version",
+    "efx_set_max_features", "efx_get_max_features", "efx_set_scale_factor", "efx_get_scale_factor",
+    "efx_set_nlevels", "efx_get_nlevels", "efx_set_first_level", "efx_get_first_level",
+    "efx_set_fast_threshold", "efx_get_fast_threshold", "efx_set_nonmax_radius", "efx_get_nonmax_radius",
+    "efx_set_descriptor_type", "efx_get_descriptor_type",
+    "efx_descriptor_size", "efx_descriptor_dtype", "efx_default_norm",
+    "efx_detect_async", "efx_detect_and_compute_async", "efx_compute_async", "efx_compute_kp4_async",
+    "efx_last_count", "efx_last_level_stats",
+    "efx_detect", "efx_compute", "efx_detect_and_compute", "efx_convert",
+    "efx_bad_create", "efx_hashsift_create", "efx_describer_destroy", "efx_describer_descriptor_size",
+    "efx_describer_last_error", "efx_describer_compute_kp4_async", "efx_describer_compute_async",
+    "efx_describer_compute", "efx_describer_hashsift_debug_async",
+    "efx_level_geometry", "efx_copy_level_async",
+]
+
+
+class EfxError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"{STATUS_NAMES.get(status, status)}: {message}")
+        self.status = status
+
+
+class Params(C.Structure):
+    _fields_ = [("nfeatures", C.c_int), ("scale_factor", C.c_float), ("nlevels", C.c_int), ("first_level", C.c_int),
+                ("fast_threshold", C.c_int), ("nonmax_radius", C.c_int), ("descriptor_type", C.c_int)]
+
+
+class LevelStats(C.Structure):
+    _fields_ = [("n_candidates", C.c_int), ("n_after_nms", C.c_int), ("n_kept", C.c_int)]
+
+
+# efx_keypoint / cv::KeyPoint as a numpy record
+KEYPOINT_DTYPE = np.dtype([("x", np.float32), ("y", np.float32), ("size", np.float32), ("angle", np.float32),
+                           ("response", np.float32), ("octave", np.int32), ("class_id", np.int32)])
+
+_lib = None
+
+
+def lib():
+    """Loads libefx_hip.so; fails loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EfxError(-4, f"{LIB_PATH} is missing: build it with __graft_entry__.build() "
+                               "(make -C cuda-efficient-features_amd/csrc); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.efx_last_error.restype = C.c_char_p
+        L.efx_last_error.argtypes = [C.c_void_p]
+        L.efx_describer_last_error.restype = C.c_char_p
+        L.efx_describer_last_error.argtypes = [C.c_void_p]
+        L.efx_get_scale_factor.restype = C.c_float
+        L.efx_get_scale_factor.argtypes = [C.c_void_p]
+        L.efx_set_scale_factor.argtypes = [C.c_void_p, C.c_float]
+        for name in ("efx_set_max_features", "efx_set_nlevels", "efx_set_first_level", "efx_set_fast_threshold",
+                     "efx_set_nonmax_radius", "efx_set_descriptor_type"):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_int]
+        for name in ("efx_get_max_features", "efx_get_nlevels", "efx_get_first_level", "efx_get_fast_threshold",
+                     "efx_get_nonmax_radius", "efx_get_descriptor_type", "efx_descriptor_size", "efx_descriptor_dtype",
+                     "efx_default_norm", "efx_destroy"):
+            getattr(L, name).argtypes = [C.c_void_p]
+        L.efx_create.argtypes = [C.POINTER(Params), C.POINTER(C.c_void_p)]
+        L.efx_detect_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t,
+                                       C.c_int, C.c_void_p, C.c_void_p]
+        L.efx_detect_and_compute_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p,
+                                                   C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+        L.efx_compute_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t,
+                                        C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.efx_compute_kp4_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_int,
+                                            C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.efx_last_count.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        L.efx_last_level_stats.argtypes = [C.c_void_p, C.POINTER(LevelStats), C.c_int, C.POINTER(C.c_int)]
+        L.efx_detect.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        L.efx_compute.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+        L.efx_detect_and_compute.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p,
+                                             C.c_size_t, C.c_int, C.POINTER(C.c_int)]
+        L.efx_convert.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+        L.efx_bad_create.argtypes = [C.c_float, C.c_int, C.POINTER(C.c_void_p)]
+        L.efx_hashsift_create.argtypes = [C.c_float, C.c_int, C.POINTER(C.c_void_p)]
+        L.efx_describer_destroy.argtypes = [C.c_void_p]
+        L.efx_describer_descriptor_size.argtypes = [C.c_void_p]
+        L.efx_describer_compute_kp4_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p,
+                                                      C.c_int, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.efx_describer_compute_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p,
+                                                  C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.efx_describer_compute.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_int,
+                                            C.c_void_p, C.c_size_t]
+        L.efx_describer_hashsift_debug_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p,
+                                                         C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.efx_level_geometry.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                         C.POINTER(C.c_float)]
+        L.efx_copy_level_async.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _stream_ptr(stream):
+    import torch
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return C.c_void_p(s.cuda_stream)
+
+
+def _host_image(image):
+    img = np.ascontiguousarray(image)
+    if img.dtype != np.uint8 or img.ndim != 2:
+        raise EfxError(-1, "Image should be 8UC1")        # CV_Assert(_image.type() == CV_8U), .cpp:228
+    return img
+
+
+def _dev_image(image):
+    import torch
+    if not (isinstance(image, torch.Tensor) and image.is_cuda and image.dtype == torch.uint8 and image.dim() == 2
+            and image.stride(1) == 1):
+        raise EfxError(-1, "device image must be a 2-D uint8 CUDA tensor with unit column stride")
+    return image
+
+
+def keypoints_array(n):
+    return np.zeros(n, dtype=KEYPOINT_DTYPE)
+
+
+class EfficientFeatures:
+    """cv::cuda::EfficientFeatures (cuda_efficient_features.h:28-98)."""
+    LOCATION_ROW, RESPONSE_ROW, ANGLE_ROW, OCTAVE_ROW, SIZE_ROW, ROWS_COUNT = 0, 1, 2, 3, 4, 5
+    BAD_256, BAD_512, HASH_SIFT_256, HASH_SIFT_512 = 0, 1, 2, 3
+
+    def __init__(self, nfeatures=5000, scaleFactor=1.2, nlevels=8, firstLevel=0, fastThreshold=20, nonmaxRadius=15,
+                 dtype=2):
+        self._h = C.c_void_p()
+        p = Params(nfeatures, scaleFactor, nlevels, firstLevel, fastThreshold, nonmaxRadius, dtype)
+        rc = lib().efx_create(C.byref(p), C.byref(self._h))
+        if rc != EFX_OK:
+            self._h = C.c_void_p()
+            raise EfxError(rc, lib().efx_last_error(None).decode())
+
+    @staticmethod
+    def create(nfeatures=5000, scaleFactor=1.2, nlevels=8, firstLevel=0, fastThreshold=20, nonmaxRadius=15, dtype=2):
+        return EfficientFeatures(nfeatures, scaleFactor, nlevels, firstLevel, fastThreshold, nonmaxRadius, dtype)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                lib().efx_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != EFX_OK:
+            raise EfxError(rc, lib().efx_last_error(self._h).decode())
+
+    # ---- getters / setters (cuda_efficient_features.h:78-97) ----
+    def setMaxFeatures(self, v): self._check(lib().efx_set_max_features(self._h, int(v)))
+    def getMaxFeatures(self): return lib().efx_get_max_features(self._h)
+    def setScaleFactor(self, v): self._check(lib().efx_set_scale_factor(self._h, float(v)))
+    def getScaleFactor(self): return lib().efx_get_scale_factor(self._h)
+    def setNLevels(self, v): self._check(lib().efx_set_nlevels(self._h, int(v)))
+    def getNLevels(self): return lib().efx_get_nlevels(self._h)
+    def setFirstLevel(self, v): self._check(lib().efx_set_first_level(self._h, int(v)))
+    def getFirstLevel(self): return lib().efx_get_first_level(self._h)
+    def setFastThreshold(self, v): self._check(lib().efx_set_fast_threshold(self._h, int(v)))
+    def getFastThreshold(self): return lib().efx_get_fast_threshold(self._h)
+    def setNonmaxRadius(self, v): self._check(lib().efx_set_nonmax_radius(self._h, int(v)))
+    def getNonmaxRadius(self): return lib().efx_get_nonmax_radius(self._h)
+    def setDescriptorType(self, v): self._check(lib().efx_set_descriptor_type(self._h, int(v)))
+    def getDescriptorType(self): return lib().efx_get_descriptor_type(self._h)
+    def descriptorSize(self): return lib().efx_descriptor_size(self._h)
+    def descriptorType(self): return lib().efx_descriptor_dtype(self._h)
+    def defaultNorm(self): return lib().efx_default_norm(self._h)
+
+    # ---- asynchronous device API ----
+    def detectAsync(self, image, keypoints=None, count=None, capacity=None, stream=None):
+        """image: 2-D uint8 CUDA tensor.  Returns (keypoints 5 x capacity float32 tensor, count int32 tensor)."""
+        import torch
+        image = _dev_image(image)
+        capacity = self.getMaxFeatures() if capacity is None else int(capacity)
+        if keypoints is None:
+            keypoints = torch.zeros((5, max(capacity, 1)), dtype=torch.float32, device=image.device)
+        if count is None:
+            count = torch.zeros(1, dtype=torch.int32, device=image.device)
+        self._check(lib().efx_detect_async(self._h, image.data_ptr(), image.shape[0], image.shape[1], image.stride(0),
+                                           keypoints.data_ptr(), keypoints.stride(0) * 4, capacity, count.data_ptr(),
+                                           _stream_ptr(stream)))
+        return keypoints, count
+
+    def detectAndComputeAsync(self, image, keypoints=None, descriptors=None, count=None, capacity=None, stream=None):
+        import torch
+        image = _dev_image(image)
+        capacity = self.getMaxFeatures() if capacity is None else int(capacity)
+        if keypoints is None:
+            keypoints = torch.zeros((5, max(capacity, 1)), dtype=torch.float32, device=image.device)
+        if descriptors is None:
+            descriptors = torch.zeros((max(capacity, 1), self.descriptorSize()), dtype=torch.uint8, device=image.device)
+        if count is None:
+            count = torch.zeros(1, dtype=torch.int32, device=image.device)
+        self._check(lib().efx_detect_and_compute_async(
+            self._h, image.data_ptr(), image.shape[0], image.shape[1], image.stride(0), keypoints.data_ptr(),
+            keypoints.stride(0) * 4, descriptors.data_ptr(), descriptors.stride(0), capacity, count.data_ptr(),
+            _stream_ptr(stream)))
+        return keypoints, descriptors, count
+
+    def computeAsync(self, image, keypoints, n=None, descriptors=None, stream=None):
+        """keypoints: 5 x N float32 CUDA tensor (the detector's layout; size forced to 31)."""
+        import torch
+        image = _dev_image(image)
+        if keypoints.dim() != 2 or keypoints.shape[0] != 5 or keypoints.dtype != torch.float32:
+            raise EfxError(-1, "keypoints must be a 5 x N float32 matrix")    # CV_Assert(tmp.rows == 5 ...), .cpp:111
+        n = keypoints.shape[1] if n is None else int(n)
+        if descriptors is None:
+            descriptors = torch.zeros((max(n, 1), self.descriptorSize()), dtype=torch.uint8, device=image.device)
+        self._check(lib().efx_compute_async(self._h, image.data_ptr(), image.shape[0], image.shape[1], image.stride(0),
+                                            keypoints.data_ptr(), keypoints.stride(0) * 4, n, descriptors.data_ptr(),
+                                            descriptors.stride(0), _stream_ptr(stream)))
+        return descriptors[:n]
+
+    def lastCount(self):
+        n = C.c_int(0)
+        self._check(lib().efx_last_count(self._h, C.byref(n)))
+        return n.value
+
+    def lastLevelStats(self):
+        st = (LevelStats * 32)()
+        nl = C.c_int(0)
+        self._check(lib().efx_last_level_stats(self._h, st, 32, C.byref(nl)))
+        return [dict(n_candidates=st[i].n_candidates, n_after_nms=st[i].n_after_nms, n_kept=st[i].n_kept)
+                for i in range(nl.value)]
+
+    def levelGeometry(self, rows, cols, level):
+        r, c, s = C.c_int(), C.c_int(), C.c_float()
+        self._check(lib().efx_level_geometry(self._h, rows, cols, level, C.byref(r), C.byref(c), C.byref(s)))
+        return r.value, c.value, s.value
+
+    def copyLevel(self, level, rows, cols, stream=None):
+        import torch
+        r, c, _ = self.levelGeometry(rows, cols, level)
+        out = torch.zeros((r, c), dtype=torch.uint8, device="cuda")
+        self._check(lib().efx_copy_level_async(self._h, level, out.data_ptr(), out.stride(0), _stream_ptr(stream)))
+        return out
+
+    # ---- synchronous host API ----
+    def detect(self, image, capacity=None):
+        img = _host_image(image)
+        capacity = self.getMaxFeatures() if capacity is None else int(capacity)
+        kps = keypoints_array(max(capacity, 1))
+        n = C.c_int(0)
+        self._check(lib().efx_detect(self._h, img.ctypes.data, img.shape[0], img.shape[1], img.strides[0],
+                                     kps.ctypes.data, capacity, C.byref(n)))
+        return kps[:n.value].copy()
+
+    def compute(self, image, keypoints):
+        img = _host_image(image)
+        kps = np.ascontiguousarray(keypoints, dtype=KEYPOINT_DTYPE)
+        desc = np.zeros((max(len(kps), 1), self.descriptorSize()), dtype=np.uint8)
+        self._check(lib().efx_compute(self._h, img.ctypes.data, img.shape[0], img.shape[1], img.strides[0],
+                                      kps.ctypes.data, len(kps), desc.ctypes.data, desc.strides[0]))
+        return desc[:len(kps)]
+
+    def detectAndCompute(self, image, capacity=None, useProvidedKeypoints=False):
+        if useProvidedKeypoints:
+            raise EfxError(-1, "useProvidedKeypoints is not supported")     # CV_Assert(!useProvidedKeypoints), .cpp:229
+        img = _host_image(image)
+        capacity = self.getMaxFeatures() if capacity is None else int(capacity)
+        kps = keypoints_array(max(capacity, 1))
+        desc = np.zeros((max(capacity, 1), self.descriptorSize()), dtype=np.uint8)
+        n = C.c_int(0)
+        self._check(lib().efx_detect_and_compute(self._h, img.ctypes.data, img.shape[0], img.shape[1], img.strides[0],
+                                                 kps.ctypes.data, desc.ctypes.data, desc.strides[0], capacity, C.byref(n)))
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    @staticmethod
+    def convert(gpu_keypoints, n=None):
+        """5 x N matrix (CUDA tensor or ndarray) -> keypoint records (cuda_efficient_features.cpp:323-349)."""
+        arr = gpu_keypoints.detach().cpu().numpy() if hasattr(gpu_keypoints, "detach") else np.asarray(gpu_keypoints)
+        arr = np.ascontiguousarray(arr, dtype=np.float32)
+        n = arr.shape[1] if n is None else int(n)
+        out = keypoints_array(max(n, 1))
+        rc = lib().efx_convert(arr.ctypes.data, arr.strides[0], n, out.ctypes.data)
+        if rc != EFX_OK:
+            raise EfxError(rc, "efx_convert")
+        return out[:n].copy()
+
+
+class _Describer:
+    SIZE_512_BITS, SIZE_256_BITS = 100, 101
+
+    def __init__(self, kind, scale, nbits):
+        self._h = C.c_void_p()
+        fn = lib().efx_bad_create if kind == "bad" else lib().efx_hashsift_create
+        rc = fn(C.c_float(scale), int(nbits), C.byref(self._h))
+        if rc != EFX_OK:
+            self._h = C.c_void_p()
+            raise EfxError(rc, lib().efx_describer_last_error(None).decode())
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                lib().efx_describer_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != EFX_OK:
+            raise EfxError(rc, lib().efx_describer_last_error(self._h).decode())
+
+    def descriptorSize(self): return lib().efx_describer_descriptor_size(self._h)
+    def descriptorType(self): return 0
+    def defaultNorm(self): return 6
+
+    def compute(self, image, keypoints):
+        """image: host uint8; keypoints: KEYPOINT_DTYPE records or (n,4) float32 {x,y,size,angle}."""
+        img = _host_image(image)
+        kps = np.asarray(keypoints)
+        if kps.dtype != KEYPOINT_DTYPE:
+            k4 = np.ascontiguousarray(kps, dtype=np.float32).reshape(-1, 4)
+            kps = keypoints_array(len(k4))
+            kps["x"], kps["y"], kps["size"], kps["angle"] = k4[:, 0], k4[:, 1], k4[:, 2], k4[:, 3]
+        kps = np.ascontiguousarray(kps)
+        desc = np.zeros((max(len(kps), 1), self.descriptorSize()), dtype=np.uint8)
+        self._check(lib().efx_describer_compute(self._h, img.ctypes.data, img.shape[0], img.shape[1], img.strides[0],
+                                                kps.ctypes.data, len(kps), desc.ctypes.data, desc.strides[0]))
+        return desc[:len(kps)]
+
+    def computeAsync(self, image, keypoints, n=None, descriptors=None, max_size=0.0, stream=None):
+        """keypoints: 5 x N float32 CUDA tensor (detector layout) or N x 4 float32 CUDA tensor {x,y,size,angle}."""
+        import torch
+        image = _dev_image(image)
+        five = keypoints.dim() == 2 and keypoints.shape[0] == 5 and keypoints.shape[1] != 4
+        n = (keypoints.shape[1] if five else keypoints.shape[0]) if n is None else int(n)
+        if descriptors is None:
+            descriptors = torch.zeros((max(n, 1), self.descriptorSize()), dtype=torch.uint8, device=image.device)
+        if five:
+            self._check(lib().efx_describer_compute_async(
+                self._h, image.data_ptr(), image.shape[0], image.shape[1], image.stride(0), keypoints.data_ptr(),
+                keypoints.stride(0) * 4, n, descriptors.data_ptr(), descriptors.stride(0), _stream_ptr(stream)))
+        else:
+            k = keypoints.contiguous()
+            self._check(lib().efx_describer_compute_kp4_async(
+                self._h, image.data_ptr(), image.shape[0], image.shape[1], image.stride(0), k.data_ptr(), n,
+                C.c_float(max_size), descriptors.data_ptr(), descriptors.stride(0), _stream_ptr(stream)))
+        return descriptors[:n]
+
+
+class BAD(_Describer):
+    """cv::cuda::BAD (cuda_efficient_descriptors.h:66-90)."""
+    def __init__(self, scaleFactor, nbits=_Describer.SIZE_256_BITS):
+        super().__init__("bad", scaleFactor, nbits)
+
+    @staticmethod
+    def create(scaleFactor, nbits=_Describer.SIZE_256_BITS):
+        return BAD(scaleFactor, nbits)
+
+
+class HashSIFT(_Describer):
+    """cv::cuda::HashSIFT (cuda_efficient_descriptors.h:101-121)."""
+    def __init__(self, croppingScale, nbits=_Describer.SIZE_256_BITS):
+        super().__init__("hashsift", croppingScale, nbits)
+
+    @staticmethod
+    def create(croppingScale, nbits=_Describer.SIZE_256_BITS):
+        return HashSIFT(croppingScale, nbits)
+
+    def debug(self, image, kp4, max_size=0.0, stream=None):
+        """Returns (129-vectors n x 129, pre-threshold projections n x nbits) as CUDA tensors."""
+        import torch
+        image = _dev_image(image)
+        k = kp4.contiguous()
+        n = k.shape[0]
+        nbits = self.descriptorSize() * 8
+        resp = torch.zeros((max(n, 1), 129), dtype=torch.float32, device=image.device)
+        T = torch.zeros((max(n, 1), nbits), dtype=torch.float32, device=image.device)
+        self._check(lib().efx_describer_hashsift_debug_async(
+            self._h, image.data_ptr(), image.shape[0], image.shape[1], image.stride(0), k.data_ptr(), n,
+            C.c_float(max_size), resp.data_ptr(), T.data_ptr(), _stream_ptr(stream)))
+        return resp[:n], T[:n]
+
+
+def unpack_keypoints(kps):
+    """(5,N) float32 ndarray -> dict of x, y (int16), response, angle, octave (int32), size."""
+    kps = np.ascontiguousarray(kps, dtype=np.float32)
+    loc = kps[0].view(np.uint32)
+    x = (loc & 0xFFFF).astype(np.uint16).view(np.int16)
+    y = (loc >> 16).astype(np.uint16).view(np.int16)
+    return dict(x=x, y=y, response=kps[1].copy(), angle=kps[2].copy(), octave=kps[3].view(np.int32).copy(),
+                size=kps[4].copy())

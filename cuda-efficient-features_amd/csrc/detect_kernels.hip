@@ -1,0 +1,665 @@
+// detect_kernels.hip -- pyramid + FAST-9 + Harris + radius-NMS + top-N + IC-angle for gfx950 (wave64).
+//
+// What the kernels compute follows the reference's CUDA detector
+//   modules/cuda_efficient_features/src/cuda_fast.cu:33-222            (FAST-9 segment test)
+//   modules/cuda_efficient_features/src/cuda_efficient_features.cu:62-248 (NMS predicate, Harris, IC angle, scaling)
+//   modules/cuda_efficient_features/src/cuda_efficient_features.cpp:136-321 (pyramid, quotas, border, flow)
+// with the spec decisions of DESIGN.md (canonical order, deterministic cap / ties, integer Harris sums,
+// shared atan2).  How it is computed is MI355X-first: one fused pass per level reads the level once into
+// LDS, runs FAST + Harris on it and writes the next pyramid level; all counts stay on the device (no host
+// synchronisation anywhere, the reference does 16 per frame); compaction is ballot/bitmap based and
+// deterministic.
+//
+// Compile with -ffp-contract=off: the float expressions below must not be fused.
+
+#include "efx_device.h"
+
+namespace {
+
+__device__ __forceinline__ int lane_id()
+{
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+// inclusive scan across the 64 lanes of a wave
+__device__ __forceinline__ int wave_incl_scan(int v)
+{
+    const int lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// exclusive scan over a block of NW waves; `scratch` holds NW+1 ints of LDS. Returns the exclusive prefix,
+// *total receives the block sum. Contains two barriers.
+template <int NW>
+__device__ __forceinline__ int block_excl_scan(int v, int* scratch, int* total)
+{
+    const int lane = lane_id();
+    const int wid = threadIdx.x >> 6;
+    const int incl = wave_incl_scan(v);
+    if (lane == 63) scratch[wid] = incl;
+    __syncthreads();
+    if (wid == 0) {
+        int w = lane < NW ? scratch[lane] : 0;
+        const int wi = wave_incl_scan(w);
+        if (lane < NW) scratch[lane] = wi - w;     // exclusive prefix of the wave totals
+        if (lane == NW - 1) scratch[NW] = wi;
+    }
+    __syncthreads();
+    const int r = scratch[wid] + incl - v;
+    *total = scratch[NW];
+    __syncthreads();                               // scratch may be reused by the caller
+    return r;
+}
+
+// XCD-aware block -> tile mapping: workgroup b runs on XCD b % 8 (observed dispatch order), so give every
+// XCD one contiguous run of tiles; neighbouring tiles then share halo lines in the same L2.
+__device__ __forceinline__ int xcd_chunked(int bid, int n)
+{
+    const int q = n / EFX_NXCD, r = n % EFX_NXCD;
+    const int xcd = bid % EFX_NXCD, idx = bid / EFX_NXCD;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// ------------------------------------------------------------------------------------------------
+// FAST-9 segment test on an LDS tile (cuda_fast.cu:33-222).  c points at the centre pixel, P = LDS pitch.
+// Circle order as cuda_fast.cu:179-207: k=0 at (0,+3) walking towards +x.
+// ------------------------------------------------------------------------------------------------
+template <int P>
+__device__ __forceinline__ bool fast9_lds(const uint8_t* c, int t)
+{
+    const int p = c[0];
+    const int hi = p + t, lo = p - t;
+    const int c0 = c[3 * P], c4 = c[3], c8 = c[-3 * P], c12 = c[-3];
+    // a 9-arc always contains two neighbouring compass points (pure early-out, cf. cuda_fast.cu:193-197)
+    const bool b0 = c0 > hi, b4 = c4 > hi, b8 = c8 > hi, b12 = c12 > hi;
+    const bool d0 = c0 < lo, d4 = c4 < lo, d8 = c8 < lo, d12 = c12 < lo;
+    const bool quick = (b0 && b4) || (b4 && b8) || (b8 && b12) || (b12 && b0) ||
+                       (d0 && d4) || (d4 && d8) || (d8 && d12) || (d12 && d0);
+    if (!quick) return false;
+    const int v[16] = { c0,          c[3 * P + 1],  c[2 * P + 2],  c[P + 3],
+                        c4,          c[-P + 3],     c[-2 * P + 2], c[-3 * P + 1],
+                        c8,          c[-3 * P - 1], c[-2 * P - 2], c[-P - 3],
+                        c12,         c[P - 3],      c[2 * P - 2],  c[3 * P - 1] };
+    unsigned br = 0, dk = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        br |= (unsigned)(v[k] > hi) << k;
+        dk |= (unsigned)(v[k] < lo) << k;
+    }
+    br |= br << 16; dk |= dk << 16;
+    br &= br >> 1; br &= br >> 2; br &= br >> 4; br &= br >> 1;   // runs of >= 9
+    dk &= dk >> 1; dk &= dk >> 2; dk &= dk >> 4; dk &= dk >> 1;
+    return ((br | dk) & 0xffffu) != 0;
+}
+
+// Harris response, spec S4 (cuda_efficient_features.cu:99-139): exact int32 sums of the 49 Sobel products,
+// then one fixed, uncontracted float formula.
+template <int P>
+__device__ __forceinline__ float harris_lds(const uint8_t* c)
+{
+    int sxx = 0, sxy = 0, syy = 0;
+    int r0[9], r1[9], r2[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) { r0[i] = c[-4 * P + i - 4]; r1[i] = c[-3 * P + i - 4]; }
+#pragma unroll
+    for (int iy = -3; iy <= 3; iy++) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) r2[i] = c[(iy + 1) * P + i - 4];
+#pragma unroll
+        for (int ix = 0; ix < 7; ix++) {
+            const int dx = (r0[ix + 2] + 2 * r1[ix + 2] + r2[ix + 2]) - (r0[ix] + 2 * r1[ix] + r2[ix]);
+            const int dy = (r2[ix] + 2 * r2[ix + 1] + r2[ix + 2]) - (r0[ix] + 2 * r0[ix + 1] + r0[ix + 2]);
+            sxx += dx * dx; sxy += dx * dy; syy += dy * dy;
+        }
+#pragma unroll
+        for (int i = 0; i < 9; i++) { r0[i] = r1[i]; r1[i] = r2[i]; }
+    }
+    const float SCALE = 1.f / (float)(4 * 7 * 255);
+    const float K = SCALE * SCALE;
+    const float a = (float)sxx * K, b = (float)syy * K, cc = (float)sxy * K;
+    const float det = a * b - cc * cc;
+    const float tr = a + b;
+    return det - 0.04f * tr * tr;
+}
+
+__device__ __forceinline__ uint8_t sat_u8_rne(float v)
+{
+    const float r = rintf(v);                       // v_rndne_f32: round half to even (cvRound)
+    return (uint8_t)(r < 0.f ? 0.f : (r > 255.f ? 255.f : r));
+}
+
+// smallest ox >= 0 with floor(ox * f) >= v  (float product, monotone in ox)
+__device__ __forceinline__ int first_ge(int v, float f, int limit)
+{
+    if (v <= 0) return 0;
+    int e = (int)((float)v / f);
+    if (e > limit) e = limit;
+    while (e > 0 && (int)floorf((float)(e - 1) * f) >= v) e--;
+    while (e < limit && (int)floorf((float)e * f) < v) e++;
+    return e;
+}
+
+// ================================================================================================
+// Kernel A: one 64x64 tile of level s per workgroup.
+//   load tile+halo -> LDS | FAST-9 -> corner bitmap (ballot) | canonical enumeration (cell-major)
+//   | Harris on the corners | append {xy, response} to the level's corner array + tile header
+//   | bilinear resize of the tile's share of level s+1 (spec S5)
+// Algorithmic HBM bytes: every level read once and every derived level written once.
+// ================================================================================================
+template <bool ALIGNED>
+__global__ __launch_bounds__(256) void pyr_fast_kernel(
+    const uint8_t* __restrict__ src, int spitch, int rows, int cols, int tiles_x, int tiles_y,
+    uint8_t* __restrict__ dst, int dpitch, int drows, int dcols, float fx, float fy,
+    int threshold, int do_fast,
+    Corner* __restrict__ cand, TileHdr* __restrict__ hdr, int* __restrict__ cand_total)
+{
+    __shared__ uint32_t s_tile[EFX_LT * (EFX_LT / 4)];
+    __shared__ unsigned long long s_bitmap[EFX_TILE];
+    __shared__ uint16_t s_list[EFX_TILE * EFX_TILE];
+    __shared__ int s_scan[8];
+    __shared__ int s_celloff[EFX_CELLS_PER_TILE + 1];
+    __shared__ int s_start;
+
+    const int tid = threadIdx.x;
+    const int ntiles = tiles_x * tiles_y;
+    const int tile = xcd_chunked(blockIdx.x, ntiles);
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int x0 = tx * EFX_TILE, y0 = ty * EFX_TILE;
+    const uint8_t* tb = reinterpret_cast<const uint8_t*>(s_tile);
+
+    // ---- phase 0: tile + halo -> LDS (coalesced dword loads when the image allows it) ----
+    for (int i = tid; i < EFX_LT * (EFX_LT / 4); i += 256) {
+        const int r = i / (EFX_LT / 4), c4 = i % (EFX_LT / 4);
+        const int gy = y0 - EFX_HALO + r;
+        const int gx = x0 - EFX_HALO + c4 * 4;
+        uint32_t v = 0;
+        if (gy >= 0 && gy < rows) {
+            const uint8_t* p = src + (size_t)gy * spitch;
+            if (ALIGNED && gx >= 0 && gx + 4 <= cols) {
+                v = *reinterpret_cast<const uint32_t*>(p + gx);
+            } else {
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const int x = gx + b;
+                    if (x >= 0 && x < cols) v |= (uint32_t)p[x] << (8 * b);
+                }
+            }
+        }
+        s_tile[i] = v;
+    }
+    __syncthreads();
+
+    int total = 0;
+    if (do_fast) {
+        // ---- phase 1: FAST-9, lane = column, wave = 16 rows; one ballot per row = one bitmap row ----
+        const int lane = tid & 63, wid = tid >> 6;
+        const int x = x0 + lane;
+        const bool xin = x >= EFX_HALF_PATCH && x < cols - EFX_HALF_PATCH;     // mask, .cpp:176-182
+        for (int r = 0; r < 16; r++) {
+            const int ly = wid * 16 + r;
+            const int y = y0 + ly;
+            bool corner = false;
+            if (xin && y >= EFX_HALF_PATCH && y < rows - EFX_HALF_PATCH)
+                corner = fast9_lds<EFX_LT>(tb + (ly + EFX_HALO) * EFX_LT + lane + EFX_HALO, threshold);
+            const unsigned long long m = __ballot(corner);
+            if (lane == 0) s_bitmap[ly] = m;
+        }
+        __syncthreads();
+
+        // ---- phase 2: canonical enumeration (spec S1): cell-major, raster inside the 16x16 cell ----
+        const int cell = tid >> 4, rr = tid & 15;
+        const int cy = cell >> 2, cx = cell & 3;
+        const int brow = cy * 16 + rr;
+        unsigned bits = (unsigned)(s_bitmap[brow] >> (cx * 16)) & 0xffffu;
+        const int cnt = __popc(bits);
+        const int pre = block_excl_scan<4>(cnt, s_scan, &total);
+        if (rr == 0) s_celloff[cell] = pre;
+        if (tid == 0) s_celloff[EFX_CELLS_PER_TILE] = total;
+        int pos = pre;
+        while (bits) {
+            const int b = __ffs(bits) - 1;
+            bits &= bits - 1;
+            s_list[pos++] = (uint16_t)((cx * 16 + b) | (brow << 8));
+        }
+        if (tid == 0) s_start = total > 0 ? atomicAdd(cand_total, total) : 0;
+        __syncthreads();
+
+        // ---- phase 3: Harris on the corners, append to the level's corner array ----
+        const int start = s_start;
+        for (int k = tid; k < total; k += 256) {
+            const int lx = s_list[k] & 0xff, ly = s_list[k] >> 8;
+            const float resp = harris_lds<EFX_LT>(tb + (ly + EFX_HALO) * EFX_LT + lx + EFX_HALO);
+            Corner c;
+            c.xy = (uint32_t)(x0 + lx) | ((uint32_t)(y0 + ly) << 16);
+            c.resp = resp;
+            cand[(size_t)start + k] = c;
+        }
+        TileHdr* h = hdr + tile;
+        if (tid <= EFX_CELLS_PER_TILE) h->cell_off[tid] = (uint16_t)s_celloff[tid];
+        if (tid == 32) { h->cand_start = (uint32_t)start; h->cand_rank = 0; h->surv_start = 0; h->surv_count = 0; h->out_off = 0; }
+    }
+
+    // ---- phase 4: this tile's share of level s+1 (spec S5; cv::cuda::resize, .cpp:154) ----
+    if (dst != nullptr) {
+        const int ox_b = first_ge(x0, fx, dcols);
+        const int ox_e = (tx == tiles_x - 1) ? dcols : first_ge(x0 + EFX_TILE, fx, dcols);
+        const int oy_b = first_ge(y0, fy, drows);
+        const int oy_e = (ty == tiles_y - 1) ? drows : first_ge(y0 + EFX_TILE, fy, drows);
+        const int nx = ox_e - ox_b, ny = oy_e - oy_b;
+        if (nx > 0 && ny > 0) {
+            for (int i = tid; i < nx * ny; i += 256) {
+                const int oy = oy_b + i / nx, ox = ox_b + i % nx;
+                const float sx = (float)ox * fx, sy = (float)oy * fy;
+                int x1 = (int)floorf(sx), y1 = (int)floorf(sy);
+                if (x1 > cols - 1) x1 = cols - 1;
+                if (y1 > rows - 1) y1 = rows - 1;
+                const int x2 = x1 + 1, y2 = y1 + 1;
+                const int x2r = x2 < cols - 1 ? x2 : cols - 1;
+                const int y2r = y2 < rows - 1 ? y2 : rows - 1;
+                const uint8_t* pa = tb + (y1 - y0 + EFX_HALO) * EFX_LT + (x1 - x0 + EFX_HALO);
+                const uint8_t* pb = tb + (y2r - y0 + EFX_HALO) * EFX_LT + (x1 - x0 + EFX_HALO);
+                const int dxr = x2r - x1;
+                float out = 0.f;
+                out = out + (float)pa[0] * (((float)x2 - sx) * ((float)y2 - sy));
+                out = out + (float)pa[dxr] * ((sx - (float)x1) * ((float)y2 - sy));
+                out = out + (float)pb[0] * (((float)x2 - sx) * (sy - (float)y1));
+                out = out + (float)pb[dxr] * ((sx - (float)x1) * (sy - (float)y1));
+                dst[(size_t)oy * dpitch + ox] = sat_u8_rne(out);
+            }
+        }
+    }
+}
+
+// ================================================================================================
+// Kernel B: canonical rank of every tile's first corner = exclusive scan of the tile counts in tile
+// order (needed to apply the 10% cap deterministically, spec S2).  One workgroup per level.
+// ================================================================================================
+__global__ __launch_bounds__(1024) void tile_rank_scan_kernel(const LevelTable* __restrict__ T, TileHdr* __restrict__ hdr)
+{
+    __shared__ int s_scan[20];
+    const LevelDev& L = T->lv[blockIdx.x];
+    if (!L.active) return;
+    const int n = L.tiles_x * L.tiles_y;
+    TileHdr* h = hdr + L.tile_base;
+    int running = 0;
+    for (int t0 = 0; t0 < n; t0 += 1024) {
+        const int t = t0 + threadIdx.x;
+        const int v = t < n ? (int)h[t].cell_off[EFX_CELLS_PER_TILE] : 0;
+        int tot;
+        const int pre = block_excl_scan<16>(v, s_scan, &tot);
+        if (t < n) h[t].cand_rank = (uint32_t)(running + pre);
+        running += tot;
+    }
+}
+
+// level of a global tile index
+__device__ __forceinline__ int level_of_tile(const LevelTable* T, int gt)
+{
+    int l = 0;
+    for (int i = 1; i < T->nlevels; i++)
+        if (gt >= T->lv[i].tile_base) l = i;
+    return l;
+}
+
+// ================================================================================================
+// Kernel C: radius non-max suppression (radiusSuppressionKernel + IsMaxPoint, .cu:62-97, 202-216).
+// One workgroup per tile; every corner of the tile scans the corners of the cells within blockRadius.
+// Survivors are compacted in canonical order and appended to the level's survivor array.
+// ================================================================================================
+__global__ __launch_bounds__(256) void nms_kernel(const LevelTable* __restrict__ T, TileHdr* __restrict__ hdr,
+                                                  const Corner* __restrict__ cand_all, Corner* __restrict__ surv_all,
+                                                  Counters* __restrict__ cnt, int radius)
+{
+    __shared__ Corner s_surv[EFX_TILE * EFX_TILE];
+    __shared__ int s_scan[8];
+    __shared__ int s_start;
+
+    const int gt = blockIdx.x;
+    const int l = level_of_tile(T, gt);
+    const LevelDev& L = T->lv[l];
+    if (!L.active) return;
+    const int tile = gt - L.tile_base;
+    const int tx = tile % L.tiles_x, ty = tile / L.tiles_x;
+    TileHdr* hl = hdr + L.tile_base;
+    const TileHdr& h = hl[tile];
+    const Corner* cand = cand_all + L.cand_base;
+
+    const int n_own = h.cell_off[EFX_CELLS_PER_TILE];
+    int n_valid = L.cap - (int)h.cand_rank;            // cap in canonical order (spec S2; cuda_fast.cu:245)
+    n_valid = n_valid < 0 ? 0 : (n_valid > n_own ? n_own : n_valid);
+
+    const int image_radius = radius * radius;           // cvCeil(radius * radius), .cu:291
+    const int block_radius = (radius + EFX_CELL - 1) / EFX_CELL;   // cvCeil(radius / CELL_SIZE), .cu:292
+    const int gw = (L.cols + EFX_CELL - 1) / EFX_CELL, gh = (L.rows + EFX_CELL - 1) / EFX_CELL;
+
+    int nsurv = 0;
+    for (int k0 = 0; k0 < n_valid; k0 += 256) {
+        const int k = k0 + threadIdx.x;
+        bool keep = false;
+        Corner me; me.xy = 0; me.resp = 0.f;
+        if (k < n_valid) {
+            me = cand[(size_t)h.cand_start + k];
+            const int mx = me.xy & 0xffff, my = me.xy >> 16;
+            const int bx1 = mx / EFX_CELL, by1 = my / EFX_CELL;
+            const int minx = max(bx1 - block_radius, 0), maxx = min(bx1 + block_radius, gw - 1);
+            const int miny = max(by1 - block_radius, 0), maxy = min(by1 + block_radius, gh - 1);
+            keep = true;
+            for (int by = miny; by <= maxy && keep; by++) {
+                for (int bx = minx; bx <= maxx && keep; bx++) {
+                    const int ntile = (by >> 2) * L.tiles_x + (bx >> 2);
+                    const TileHdr& nh = hl[ntile];
+                    const int c = (by & 3) * 4 + (bx & 3);
+                    int nn = L.cap - (int)nh.cand_rank;                 // valid corners of that tile
+                    const int b = nh.cell_off[c];
+                    int e = nh.cell_off[c + 1];
+                    if (e > nn) e = nn;
+                    const Corner* q = cand + nh.cand_start;
+                    for (int j = b; j < e; j++) {
+                        const Corner o = q[j];
+                        if (o.xy == me.xy) continue;                     // idx1 == idx2
+                        const int dx = mx - (int)(o.xy & 0xffff), dy = my - (int)(o.xy >> 16);
+                        if (me.resp <= o.resp && dx * dx + dy * dy < image_radius) { keep = false; break; }
+                    }
+                }
+            }
+        }
+        int tot;
+        const int pre = block_excl_scan<4>(keep ? 1 : 0, s_scan, &tot);
+        if (keep) s_surv[nsurv + pre] = me;
+        nsurv += tot;
+    }
+    if (threadIdx.x == 0) s_start = nsurv > 0 ? atomicAdd(&cnt->surv_total[l], nsurv) : 0;
+    __syncthreads();
+    const int start = s_start;
+    Corner* surv = surv_all + L.surv_base;
+    for (int i = threadIdx.x; i < nsurv; i += 256) surv[(size_t)start + i] = s_surv[i];
+    if (threadIdx.x == 0) { hl[tile].surv_start = (uint32_t)start; hl[tile].surv_count = (uint32_t)nsurv; }
+}
+
+// ================================================================================================
+// Kernel D: per-level quota (limitPoints, .cu:344-358, spec S3) + output offsets.  One workgroup per
+// level: if the survivors exceed the quota, an MSB-first radix select over the 64-bit keys
+// (response desc, raster asc) finds the quota-th largest key; then the selected survivors of every tile
+// are counted and scanned in canonical tile order to give each tile its output offset.
+// ================================================================================================
+#define SEL_BITS 12
+#define SEL_BINS (1 << SEL_BITS)
+
+__global__ __launch_bounds__(1024) void select_kernel(const LevelTable* __restrict__ T, TileHdr* __restrict__ hdr,
+                                                      const Corner* __restrict__ surv_all, Counters* __restrict__ cnt,
+                                                      int capacity, int* __restrict__ d_count)
+{
+    __shared__ int s_hist[SEL_BINS];
+    __shared__ int s_scan[20];
+    __shared__ int s_bin, s_rem;
+
+    const int l = blockIdx.x;
+    const LevelDev& L = T->lv[l];
+    const int tid = threadIdx.x;
+
+    // output base of this level: sum over lower levels of min(survivors, quota)  (.cpp:292-314)
+    int base = 0, all = 0;
+    for (int i = 0; i < T->nlevels; i++) {
+        const int k = T->lv[i].active ? min(cnt->surv_total[i], T->lv[i].quota) : 0;
+        if (i < l) base += k;
+        all += k;
+    }
+    if (tid == 0) {
+        cnt->level_out_base[l] = base;
+        if (l == T->nlevels - 1) cnt->level_out_base[T->nlevels] = all;
+        if (l == 0) { const int n = all < capacity ? all : capacity; cnt->n_out = n; if (d_count) *d_count = n; }
+    }
+    if (!L.active) { if (tid == 0) { cnt->kept[l] = 0; cnt->thresh[l] = 0; } return; }
+
+    const int n = cnt->surv_total[l];
+    const Corner* surv = surv_all + L.surv_base;
+    unsigned long long thresh = 0;
+    if (n > L.quota) {
+        unsigned long long prefix = 0;       // decided high bits, right-aligned
+        int remaining = L.quota;
+        int decided = 0;
+        while (decided < 64) {
+            const int width = (64 - decided) < SEL_BITS ? (64 - decided) : SEL_BITS;
+            const int shift = 64 - decided - width;
+            for (int i = tid; i < SEL_BINS; i += 1024) s_hist[i] = 0;
+            __syncthreads();
+            for (int i = tid; i < n; i += 1024) {
+                const Corner c = surv[i];
+                const unsigned long long k = efx_select_key(c.xy, c.resp);
+                const bool match = decided == 0 ? true : ((k >> (64 - decided)) == prefix);
+                if (match) atomicAdd(&s_hist[(int)((k >> shift) & ((1u << width) - 1))], 1);
+            }
+            __syncthreads();
+            // walk the bins from the top: thread t owns bins [hi-4t-3, hi-4t]
+            const int nb = 1 << width;
+            int loc[4]; int sum = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int b = nb - 1 - (tid * 4 + j);
+                loc[j] = b >= 0 ? s_hist[b] : 0;
+                sum += loc[j];
+            }
+            int tot;
+            int before = block_excl_scan<16>(sum, s_scan, &tot);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int b = nb - 1 - (tid * 4 + j);
+                if (b >= 0 && before < remaining && remaining <= before + loc[j]) { s_bin = b; s_rem = remaining - before; }
+                before += loc[j];
+            }
+            __syncthreads();
+            prefix = (prefix << width) | (unsigned long long)s_bin;
+            remaining = s_rem;
+            decided += width;
+            __syncthreads();
+        }
+        thresh = prefix;                     // exactly `quota` keys are >= thresh (keys are unique)
+    }
+    if (tid == 0) cnt->thresh[l] = thresh;
+
+    // selected survivors per tile, exclusive scan in canonical tile order
+    const int ntiles = L.tiles_x * L.tiles_y;
+    TileHdr* hl = hdr + L.tile_base;
+    int running = 0;
+    for (int t0 = 0; t0 < ntiles; t0 += 1024) {
+        const int t = t0 + tid;
+        int c = 0;
+        if (t < ntiles) {
+            const int sc = (int)hl[t].surv_count;
+            const Corner* q = surv + hl[t].surv_start;
+            for (int j = 0; j < sc; j++) c += efx_select_key(q[j].xy, q[j].resp) >= thresh ? 1 : 0;
+        }
+        int tot;
+        const int pre = block_excl_scan<16>(c, s_scan, &tot);
+        if (t < ntiles) hl[t].out_off = (uint32_t)(base + running + pre);
+        running += tot;
+    }
+    if (tid == 0) cnt->kept[l] = running;
+}
+
+// Spec S7: deterministic double-precision atan2 (octant reduction + odd Taylor series), the same
+// arithmetic as the CPU checker.  IEEE +,-,*,/ only; no contraction.
+__device__ __forceinline__ float atan2_deg(int m01, int m10)
+{
+    const double PI = 3.14159265358979323846;
+    const double y = (double)m01, x = (double)m10;
+    const double ax = x < 0 ? -x : x, ay = y < 0 ? -y : y;
+    if (ax == 0 && ay == 0) return 0.f;
+    const double mn = ax < ay ? ax : ay, mx = ax < ay ? ay : ax;
+    const double t = mn / mx;
+    double base = 0.0, u = t;
+    if (t > 0.41421356237309503) { base = PI / 4; u = (t - 1.0) / (t + 1.0); }
+    const double u2 = u * u;
+    double s = 0.0;
+#pragma unroll
+    for (int k = 23; k >= 0; k--) {
+        const double ck = 1.0 / (double)(2 * k + 1);
+        s = (k & 1 ? -ck : ck) + u2 * s;
+    }
+    double a = base + u * s;
+    if (ay > ax) a = PI / 2 - a;
+    if (x < 0) a = PI - a;
+    if (y < 0) a = -a;
+    if (a < 0) a = a + 2 * PI;
+    return (float)(a * (180.0 / PI));
+}
+
+// IC_Angle (cuda_efficient_features.cu:141-172): integer moments over the radius-15 disc
+__device__ __forceinline__ float ic_angle(const uint8_t* img, int pitch, int x, int y)
+{
+    const int U_MAX[16] = { 15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3 };
+    int m01 = 0, m10 = 0;
+    const uint8_t* c = img + (size_t)y * pitch + x;
+    for (int dx = -EFX_HALF_PATCH; dx <= EFX_HALF_PATCH; dx++) m10 += dx * (int)c[dx];
+    for (int dy = 1; dy <= EFX_HALF_PATCH; dy++) {
+        int ysum = 0;
+        const int d = U_MAX[dy];
+        const uint8_t* pt = c - (size_t)dy * pitch;
+        const uint8_t* pb = c + (size_t)dy * pitch;
+        for (int dx = -d; dx <= d; dx++) {
+            const int vT = pt[dx], vB = pb[dx];
+            ysum += (vB - vT);
+            m10 += dx * (vB + vT);
+        }
+        m01 += dy * ysum;
+    }
+    return atan2_deg(m01, m10);
+}
+
+// ================================================================================================
+// Kernel E: emit the selected survivors in canonical order: IC angle (calcAngles, .cu:376-390),
+// scalePoints (.cu:236-248), 5xN output rows, and the level-local float4 list for the describers
+// (convertKeypointsKernel, .cu:250-263).
+// ================================================================================================
+__global__ __launch_bounds__(64) void emit_kernel(const LevelTable* __restrict__ T, const TileHdr* __restrict__ hdr,
+                                                  const Corner* __restrict__ surv_all, const Counters* __restrict__ cnt,
+                                                  const uint8_t* __restrict__ img0, int pitch0, const uint8_t* __restrict__ pyramid,
+                                                  uint8_t* __restrict__ kps, size_t kps_pitch, int capacity,
+                                                  float4* __restrict__ kp4, int* __restrict__ kp_level)
+{
+    const int gt = blockIdx.x;
+    const int l = level_of_tile(T, gt);
+    const LevelDev& L = T->lv[l];
+    if (!L.active) return;
+    const TileHdr& h = hdr[gt];
+    const int sc = (int)h.surv_count;
+    if (sc == 0) return;
+    const unsigned long long thresh = cnt->thresh[l];
+    const Corner* q = surv_all + L.surv_base + h.surv_start;
+    const uint8_t* img = l == 0 ? img0 : pyramid + L.img_off;
+    const int pitch = l == 0 ? pitch0 : L.pitch;
+    const int lane = threadIdx.x;
+
+    int running = 0;
+    for (int i0 = 0; i0 < sc; i0 += 64) {
+        const int i = i0 + lane;
+        Corner c; c.xy = 0; c.resp = 0.f;
+        bool sel = false;
+        if (i < sc) { c = q[i]; sel = efx_select_key(c.xy, c.resp) >= thresh; }
+        const unsigned long long m = __ballot(sel);
+        const int rank = __popcll(m & ((1ull << lane) - 1ull));
+        const int out = (int)h.out_off + running + rank;
+        running += __popcll(m);
+        if (sel && out < capacity) {
+            const int x = c.xy & 0xffff, y = c.xy >> 16;
+            const float angle = ic_angle(img, pitch, x, y);
+            const short sx = (short)(L.scale * (float)x + 0.5f);
+            const short sy = (short)(L.scale * (float)y + 0.5f);
+            if (kps) {
+                *reinterpret_cast<uint32_t*>(kps + 0 * kps_pitch + 4 * (size_t)out) = (uint32_t)(uint16_t)sx | ((uint32_t)(uint16_t)sy << 16);
+                *reinterpret_cast<float*>(kps + 1 * kps_pitch + 4 * (size_t)out) = c.resp;
+                *reinterpret_cast<float*>(kps + 2 * kps_pitch + 4 * (size_t)out) = angle;
+                *reinterpret_cast<int*>(kps + 3 * kps_pitch + 4 * (size_t)out) = l;
+                *reinterpret_cast<float*>(kps + 4 * kps_pitch + 4 * (size_t)out) = L.scale * (float)EFX_PATCH_SIZE;
+            }
+            kp4[out] = make_float4((float)x, (float)y, (float)EFX_PATCH_SIZE, angle);
+            kp_level[out] = l;
+        }
+    }
+}
+
+__global__ void convert_keypoints_kernel(const uint8_t* __restrict__ kps, size_t kps_pitch, int n, float4* __restrict__ kp4)
+{
+    // convertKeypointsKernel, cuda_efficient_features.cu:250-263: size hard-wired to PATCH_SIZE
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t loc = *reinterpret_cast<const uint32_t*>(kps + 4 * (size_t)i);
+    const float ang = *reinterpret_cast<const float*>(kps + 2 * kps_pitch + 4 * (size_t)i);
+    const short x = (short)(loc & 0xffff), y = (short)(loc >> 16);
+    kp4[i] = make_float4((float)x, (float)y, (float)EFX_PATCH_SIZE, ang);
+}
+
+__global__ void copy2d_kernel(const uint8_t* __restrict__ src, size_t spitch, uint8_t* __restrict__ dst, size_t dpitch, int rows, int cols)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x < cols && y < rows) dst[(size_t)y * dpitch + x] = src[(size_t)y * spitch + x];
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------------
+// host launchers
+// ------------------------------------------------------------------------------------------------
+hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
+{
+    const LevelTable& H = *a.h_table;
+    hipError_t e = hipMemsetAsync(a.counters, 0, sizeof(Counters), stream);
+    if (e != hipSuccess) return e;
+
+    for (int s = 0; s < H.nlevels; s++) {
+        const LevelDev& L = H.lv[s];
+        if (L.rows <= 0 || L.cols <= 0) continue;
+        const uint8_t* src = s == 0 ? a.img0 : a.pyramid + L.img_off;
+        const int spitch = s == 0 ? a.pitch0 : L.pitch;
+        uint8_t* dst = nullptr; int dpitch = 0, drows = 0, dcols = 0; float fx = 1.f, fy = 1.f;
+        if (s + 1 < H.nlevels && H.lv[s + 1].rows > 0 && H.lv[s + 1].cols > 0) {
+            const LevelDev& N = H.lv[s + 1];
+            dst = a.pyramid + N.img_off; dpitch = N.pitch; drows = N.rows; dcols = N.cols; fx = N.fx; fy = N.fy;
+        }
+        const int do_fast = L.active;
+        if (!do_fast && dst == nullptr) continue;
+        const int ntiles = L.tiles_x * L.tiles_y;
+        const bool aligned = (((uintptr_t)src | (uintptr_t)spitch) & 3u) == 0;
+        Corner* cand = a.cand + L.cand_base;
+        TileHdr* hdr = a.hdr + L.tile_base;
+        int* ctot = &a.counters->cand_total[s];
+        if (aligned)
+            hipLaunchKernelGGL(pyr_fast_kernel<true>, dim3(ntiles), dim3(256), 0, stream, src, spitch, L.rows, L.cols,
+                               L.tiles_x, L.tiles_y, dst, dpitch, drows, dcols, fx, fy, a.threshold, do_fast, cand, hdr, ctot);
+        else
+            hipLaunchKernelGGL(pyr_fast_kernel<false>, dim3(ntiles), dim3(256), 0, stream, src, spitch, L.rows, L.cols,
+                               L.tiles_x, L.tiles_y, dst, dpitch, drows, dcols, fx, fy, a.threshold, do_fast, cand, hdr, ctot);
+    }
+    hipLaunchKernelGGL(tile_rank_scan_kernel, dim3(H.nlevels), dim3(1024), 0, stream, a.d_table, a.hdr);
+    hipLaunchKernelGGL(nms_kernel, dim3(H.total_tiles), dim3(256), 0, stream, a.d_table, a.hdr, a.cand, a.surv,
+                       a.counters, a.nonmax_radius);
+    hipLaunchKernelGGL(select_kernel, dim3(H.nlevels), dim3(1024), 0, stream, a.d_table, a.hdr, a.surv, a.counters,
+                       a.capacity, a.d_count);
+    hipLaunchKernelGGL(emit_kernel, dim3(H.total_tiles), dim3(64), 0, stream, a.d_table, a.hdr, a.surv, a.counters,
+                       a.img0, a.pitch0, a.pyramid, (uint8_t*)a.d_keypoints, a.kps_pitch, a.capacity, a.kp4, a.kp_level);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (a.h_mirror) e = hipMemcpyAsync(a.h_mirror, a.counters, sizeof(Counters), hipMemcpyDeviceToHost, stream);
+    return e;
+}
+
+hipError_t efx_launch_convert_keypoints(const void* d_keypoints, size_t kps_pitch, int n, float4* kp4, hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(convert_keypoints_kernel, dim3((n + 255) / 256), dim3(256), 0, stream,
+                       (const uint8_t*)d_keypoints, kps_pitch, n, kp4);
+    return hipGetLastError();
+}
+
+hipError_t efx_launch_copy2d(const uint8_t* src, size_t spitch, uint8_t* dst, size_t dpitch, int rows, int cols, hipStream_t stream)
+{
+    if (rows <= 0 || cols <= 0) return hipSuccess;
+    hipLaunchKernelGGL(copy2d_kernel, dim3((cols + 255) / 256, rows), dim3(256), 0, stream, src, spitch, dst, dpitch, rows, cols);
+    return hipGetLastError();
+}

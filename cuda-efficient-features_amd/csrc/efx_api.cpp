@@ -1,0 +1,659 @@
+// efx_api.cpp -- C ABI (include/efx.h) over the HIP kernels.  Host-side orchestration of
+// EfficientFeaturesImpl::detectAndComputeAsync (cuda_efficient_features.cpp:225-321) re-thought for MI355X:
+// all per-level counts stay on the device, every stage is one launch over all levels where possible, and the
+// context owns grow-only HBM buffers sized for the frame (the reference's DeviceBuffer arena,
+// device_buffer.cpp:29-69, without its mid-pipeline host syncs).
+
+#include "../../include/efx.h"
+#include "efx_device.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+#include <string>
+#include <vector>
+
+// learned parameter blobs, embedded by params_embed.S
+extern "C" {
+extern const unsigned char efx_blob_bad256[], efx_blob_bad512[], efx_blob_hashsift256[], efx_blob_hashsift512[];
+}
+
+#define HS_KPAD 132
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {                     // grow-only device allocation
+    void* p = nullptr;
+    size_t bytes = 0;
+    hipError_t reserve(size_t n)
+    {
+        if (n <= bytes) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; bytes = 0; if (e != hipSuccess) return e; }
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) bytes = n;
+        return e;
+    }
+    void release() { if (p) hipFree(p); p = nullptr; bytes = 0; }
+};
+
+struct Describer {                  // cuda::BAD / cuda::HashSIFT state
+    int kind = 0;                   // 0 BAD, 1 HashSIFT
+    int nbits = 256;
+    float scale = 1.f;              // BAD scaleFactor / HashSIFT croppingScale
+    float reach = 0.f;              // BAD: max (centre distance + radius) in patch units
+    DevBuf params;                  // BadParamsDev, or W (nbits x 132) + 30x30 weight table
+    DevBuf responses;               // HashSIFT scratch, n x 132
+    DevBuf kp4;                     // float4 keypoints for the stand-alone / compute paths
+    DevBuf img, desc;               // staging for the host entry points
+    std::string err;
+    ~Describer() { params.release(); responses.release(); kp4.release(); img.release(); desc.release(); }
+};
+
+int set_err(std::string& dst, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    dst = buf;
+    return code;
+}
+
+#define HIP_TRY(errstr, call)                                                                         \
+    do {                                                                                              \
+        hipError_t e__ = (call);                                                                      \
+        if (e__ != hipSuccess)                                                                        \
+            return set_err(errstr, EFX_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+    } while (0)
+
+int nbits_from_enum(int e) { return e == EFX_SIZE_512_BITS ? 512 : (e == EFX_SIZE_256_BITS ? 256 : 0); }
+
+int describer_init(Describer& d, int kind, int nbits, float scale)
+{
+    d.kind = kind; d.nbits = nbits; d.scale = scale;
+    if (kind == 0) {
+        // BAD_Impl ctor, bad.cpp:300-317 / loadBoxPairParams, cuda_bad.cu:318-334 (per-instance here)
+        const unsigned char* blob = nbits == 256 ? efx_blob_bad256 : efx_blob_bad512;
+        const int32_t* boxes = reinterpret_cast<const int32_t*>(blob);
+        const float* thr = reinterpret_cast<const float*>(blob + (size_t)nbits * 5 * 4);
+        BadParamsDev* h = new (std::nothrow) BadParamsDev;
+        if (!h) return set_err(d.err, EFX_ERR_NOMEM, "out of host memory");
+        memset(h, 0, sizeof(*h));
+        h->nbits = nbits;
+        float reach = 0.f;
+        for (int i = 0; i < nbits; i++) {
+            const int x1 = boxes[5 * i + 0], x2 = boxes[5 * i + 1], y1 = boxes[5 * i + 2], y2 = boxes[5 * i + 3], r = boxes[5 * i + 4];
+            h->box[i] = make_int4(x1 | (x2 << 8), y1 | (y2 << 8), r, 0);
+            h->thr[i] = thr[i];
+            const float d1 = sqrtf((float)((x1 - 16) * (x1 - 16) + (y1 - 16) * (y1 - 16))) + (float)r;
+            const float d2 = sqrtf((float)((x2 - 16) * (x2 - 16) + (y2 - 16) * (y2 - 16))) + (float)r;
+            reach = fmaxf(reach, fmaxf(d1, d2));
+        }
+        h->reach = reach;
+        d.reach = reach;
+        hipError_t e = d.params.reserve(sizeof(BadParamsDev));
+        if (e == hipSuccess) e = hipMemcpy(d.params.p, h, sizeof(BadParamsDev), hipMemcpyHostToDevice);
+        delete h;
+        if (e != hipSuccess) return set_err(d.err, EFX_ERR_HIP, "BAD parameter upload failed: %s", hipGetErrorString(e));
+    } else {
+        // HashSIFTImpl ctor, hash_sift.cpp:384-397: Mat(nbits,129,CV_64F).convertTo(CV_32F)
+        const double* w64 = reinterpret_cast<const double*>(nbits == 256 ? efx_blob_hashsift256 : efx_blob_hashsift512);
+        std::vector<float> w((size_t)nbits * HS_KPAD + 900, 0.f);
+        for (int j = 0; j < nbits; j++)
+            for (int k = 0; k < 129; k++) w[(size_t)j * HS_KPAD + k] = (float)w64[(size_t)j * 129 + k];
+        // Gaussian pixel weights of computePatchSIFT (hash_sift.cpp:220-224,247): host expf, same call as the CPU code
+        const float kp_scale = 1.f / 6;
+        const float kp_radius = kp_scale * (float)32 * 0.5f;
+        const float kernel_sigma = 0.5f * (float)4 * 3.f * kp_radius;
+        const float dist_scale = -1.f / ((float)2 * kernel_sigma * kernel_sigma);
+        const float cx = 0.5f * (float)30, cy = 0.5f * (float)30;
+        for (int y = 0; y < 30; y++)
+            for (int x = 0; x < 30; x++) {
+                const float ddx = (float)x - cx, ddy = (float)y - cy;
+                w[(size_t)nbits * HS_KPAD + y * 30 + x] = expf(dist_scale * (ddx * ddx + ddy * ddy));
+            }
+        hipError_t e = d.params.reserve(w.size() * sizeof(float));
+        if (e == hipSuccess) e = hipMemcpy(d.params.p, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e != hipSuccess) return set_err(d.err, EFX_ERR_HIP, "HashSIFT weight upload failed: %s", hipGetErrorString(e));
+    }
+    return EFX_OK;
+}
+
+// one describe call: keypoints as float4 on the device
+int describer_run(Describer& d, std::string& err, DescribeLaunch a, float* dbg_resp, float* dbg_T, hipStream_t stream)
+{
+    a.scale_factor = d.scale;
+    if (a.n <= 0) return EFX_OK;
+    if (d.kind == 0) {
+        hipError_t e = efx_launch_bad(a, static_cast<const BadParamsDev*>(d.params.p), d.reach, stream);
+        if (e == hipErrorInvalidValue) return set_err(err, EFX_ERR_UNSUPPORTED, "keypoint size %.1f needs a window larger than the 160 KB LDS", a.max_size);
+        if (e != hipSuccess) return set_err(err, EFX_ERR_HIP, "BAD launch failed: %s", hipGetErrorString(e));
+    } else {
+        if (a.desc && ((((uintptr_t)a.desc) | a.desc_pitch) & 3u))
+            return set_err(err, EFX_ERR_BAD_ARG, "HashSIFT descriptors need a 4-byte aligned base and pitch");
+        HIP_TRY(err, d.responses.reserve((size_t)a.n * HS_KPAD * sizeof(float)));
+        HashSiftDev h;
+        h.nbits = d.nbits;
+        h.W = static_cast<const float*>(d.params.p);
+        h.responses = static_cast<float*>(d.responses.p);
+        h.dbg_responses = dbg_resp;
+        h.dbg_T = dbg_T;
+        hipError_t e = efx_launch_hashsift(a, h, stream);
+        if (e == hipErrorInvalidValue) return set_err(err, EFX_ERR_UNSUPPORTED, "keypoint size %.1f needs a window larger than the LDS", a.max_size);
+        if (e != hipSuccess) return set_err(err, EFX_ERR_HIP, "HashSIFT launch failed: %s", hipGetErrorString(e));
+    }
+    return EFX_OK;
+}
+
+int cv_round_f(float v) { return (int)lrintf(v); }
+int cv_round_d(double v) { return (int)lrint(v); }
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+} // namespace
+
+struct efx_describer { Describer d; };
+
+struct efx_context {
+    efx_params p;
+    Describer desc;                 // describer_ (cuda_efficient_features.cpp:402), rebuilt by setDescriptorType
+    std::string err;
+
+    // geometry cache
+    int g_rows = -1, g_cols = -1;
+    efx_params g_p;
+    LevelTable h_table;
+    DevBuf d_table, pyramid, hdr, cand, surv, counters, kp4, kp_level, img, kps, descout, count;
+    Counters* h_mirror = nullptr;   // pinned
+    bool has_frame = false;
+    const uint8_t* last_img0 = nullptr; int last_pitch0 = 0;
+
+    ~efx_context()
+    {
+        d_table.release(); pyramid.release(); hdr.release(); cand.release(); surv.release(); counters.release();
+        kp4.release(); kp_level.release(); img.release(); kps.release(); descout.release(); count.release();
+        if (h_mirror) hipHostFree(h_mirror);
+    }
+};
+
+namespace {
+
+int validate_params(const efx_params& p, std::string& err)
+{
+    if (p.nfeatures < 0) return set_err(err, EFX_ERR_BAD_ARG, "nfeatures must be >= 0");
+    if (!(p.scale_factor > 1.0f)) return set_err(err, EFX_ERR_BAD_ARG, "scale_factor must be > 1");
+    if (p.nlevels < 1 || p.nlevels > EFX_MAX_LEVELS) return set_err(err, EFX_ERR_BAD_ARG, "nlevels must be in [1, %d]", EFX_MAX_LEVELS);
+    if (p.first_level < 0) return set_err(err, EFX_ERR_BAD_ARG, "first_level must be >= 0");
+    if (p.fast_threshold < 0 || p.fast_threshold > 255) return set_err(err, EFX_ERR_BAD_ARG, "fast_threshold must be in [0, 255]");
+    if (p.nonmax_radius < 0 || p.nonmax_radius > 1024) return set_err(err, EFX_ERR_BAD_ARG, "nonmax_radius must be in [0, 1024]");
+    if (p.descriptor_type < EFX_BAD_256 || p.descriptor_type > EFX_HASH_SIFT_512) return set_err(err, EFX_ERR_BAD_ARG, "unknown descriptor type %d", p.descriptor_type);
+    return EFX_OK;
+}
+
+// pyramid geometry, quotas, caps (calcImagePyramid .cpp:136-157, calcNumFeaturesPerLevel :159-174, :252)
+int build_geometry(efx_context* c, int rows, int cols)
+{
+    const efx_params& p = c->p;
+    if (c->g_rows == rows && c->g_cols == cols && memcmp(&c->g_p, &p, sizeof(p)) == 0) return EFX_OK;
+    LevelTable& T = c->h_table;
+    memset(&T, 0, sizeof(T));
+    T.nlevels = p.nlevels;
+
+    int quota[EFX_MAX_LEVELS];
+    {
+        const double factor = (double)(1 / p.scale_factor);       // float division widened to double (.cpp:164)
+        double nf = p.nfeatures * (1 - factor) / (1 - pow(factor, p.nlevels));
+        int sum = 0;
+        for (int s = 0; s < p.nlevels - 1; s++) { quota[s] = cv_round_d(nf); sum += quota[s]; nf *= factor; }
+        quota[p.nlevels - 1] = p.nfeatures - sum > 0 ? p.nfeatures - sum : 0;
+    }
+    float scale = 1.f;
+    size_t pyr = 0, ncand = 0, nsurv = 0;
+    int tiles = 0;
+    for (int s = 0; s < p.nlevels; s++) {
+        LevelDev& L = T.lv[s];
+        if (s > 0) scale *= p.scale_factor;
+        const float inv = 1.f / scale;
+        L.rows = s == 0 ? rows : cv_round_f(inv * (float)rows);
+        L.cols = s == 0 ? cols : cv_round_f(inv * (float)cols);
+        if (L.rows < 0) L.rows = 0;
+        if (L.cols < 0) L.cols = 0;
+        L.scale = scale;
+        L.active = s >= p.first_level && L.rows > 0 && L.cols > 0;
+        L.quota = quota[s];
+        L.cap = cv_round_d(0.1 * (double)((long long)L.rows * L.cols));
+        L.tiles_x = (L.cols + EFX_TILE - 1) / EFX_TILE;
+        L.tiles_y = (L.rows + EFX_TILE - 1) / EFX_TILE;
+        L.tile_base = tiles;
+        tiles += L.tiles_x * L.tiles_y;
+        if (s > 0) {
+            const LevelDev& P = T.lv[s - 1];
+            L.pitch = (int)align_up((size_t)L.cols, 256);
+            L.img_off = pyr;
+            pyr += (size_t)L.pitch * L.rows;
+            if (L.cols > 0 && L.rows > 0 && P.cols > 0 && P.rows > 0) {
+                L.fx = (float)(1.0 / ((double)L.cols / (double)P.cols));       // spec S5
+                L.fy = (float)(1.0 / ((double)L.rows / (double)P.rows));
+            }
+        }
+        L.cand_base = ncand;
+        L.surv_base = nsurv;
+        if (L.active) { ncand += (size_t)L.rows * L.cols; nsurv += (size_t)L.cap; }
+    }
+    T.total_tiles = tiles;
+    if (rows > 32767 || cols > 32767) return set_err(c->err, EFX_ERR_UNSUPPORTED, "image larger than 32767 (short2 coordinates)");
+
+    HIP_TRY(c->err, c->d_table.reserve(sizeof(LevelTable)));
+    HIP_TRY(c->err, c->pyramid.reserve(pyr + 256));
+    HIP_TRY(c->err, c->hdr.reserve((size_t)(tiles + 1) * sizeof(TileHdr)));
+    HIP_TRY(c->err, c->cand.reserve((ncand + 1) * sizeof(Corner)));
+    HIP_TRY(c->err, c->surv.reserve((nsurv + 1) * sizeof(Corner)));
+    HIP_TRY(c->err, c->counters.reserve(sizeof(Counters)));
+    HIP_TRY(c->err, c->count.reserve(sizeof(int)));
+    if (!c->h_mirror) HIP_TRY(c->err, hipHostMalloc(reinterpret_cast<void**>(&c->h_mirror), sizeof(Counters), hipHostMallocDefault));
+    // synchronous upload: geometry changes are rare (first frame / size or parameter change)
+    HIP_TRY(c->err, hipMemcpy(c->d_table.p, &T, sizeof(LevelTable), hipMemcpyHostToDevice));
+    c->g_rows = rows; c->g_cols = cols; c->g_p = p;
+    return EFX_OK;
+}
+
+int detect_common(efx_context* c, const uint8_t* d_image, int rows, int cols, size_t pitch,
+                  void* d_keypoints, size_t kps_pitch, uint8_t* d_desc, size_t desc_pitch,
+                  int capacity, int* d_count, hipStream_t stream)
+{
+    // CV_Assert(_image.type() == CV_8U) etc. (.cpp:228-229)
+    if (!d_image || rows <= 0 || cols <= 0 || pitch < (size_t)cols) return set_err(c->err, EFX_ERR_BAD_ARG, "bad image arguments");
+    if (capacity < 0) return set_err(c->err, EFX_ERR_BAD_ARG, "capacity must be >= 0");
+    if (d_keypoints && (kps_pitch < (size_t)capacity * 4 || (kps_pitch & 3))) return set_err(c->err, EFX_ERR_BAD_ARG, "kps_pitch too small or unaligned");
+    if (d_desc && desc_pitch < (size_t)efx_descriptor_size(c)) return set_err(c->err, EFX_ERR_BAD_ARG, "desc_pitch smaller than the descriptor");
+    int rc = validate_params(c->p, c->err);
+    if (rc) return rc;
+    rc = build_geometry(c, rows, cols);
+    if (rc) return rc;
+    const int cap_alloc = capacity > 0 ? capacity : 1;
+    HIP_TRY(c->err, c->kp4.reserve((size_t)cap_alloc * sizeof(float4)));
+    HIP_TRY(c->err, c->kp_level.reserve((size_t)cap_alloc * sizeof(int)));
+
+    DetectLaunch a;
+    memset(&a, 0, sizeof(a));
+    a.img0 = d_image; a.pitch0 = (int)pitch;
+    a.pyramid = static_cast<uint8_t*>(c->pyramid.p);
+    a.d_table = static_cast<const LevelTable*>(c->d_table.p);
+    a.h_table = &c->h_table;
+    a.hdr = static_cast<TileHdr*>(c->hdr.p);
+    a.cand = static_cast<Corner*>(c->cand.p);
+    a.surv = static_cast<Corner*>(c->surv.p);
+    a.counters = static_cast<Counters*>(c->counters.p);
+    a.threshold = c->p.fast_threshold;
+    a.nonmax_radius = c->p.nonmax_radius;
+    a.first_level = c->p.first_level;
+    a.d_keypoints = d_keypoints; a.kps_pitch = kps_pitch; a.capacity = capacity;
+    a.d_count = d_count ? d_count : static_cast<int*>(c->count.p);
+    a.kp4 = static_cast<float4*>(c->kp4.p);
+    a.kp_level = static_cast<int*>(c->kp_level.p);
+    a.h_mirror = reinterpret_cast<int*>(c->h_mirror);
+    hipError_t e = efx_launch_detect(a, stream);
+    if (e != hipSuccess) return set_err(c->err, EFX_ERR_HIP, "detect launch failed: %s", hipGetErrorString(e));
+    c->has_frame = true; c->last_img0 = d_image; c->last_pitch0 = (int)pitch;
+
+    if (d_desc && capacity > 0) {
+        // blur + describe per level (.cpp:302-307), here one launch over the keypoints of all levels
+        DescribeLaunch dl;
+        memset(&dl, 0, sizeof(dl));
+        dl.img0 = d_image; dl.pitch0 = (int)pitch; dl.rows0 = rows; dl.cols0 = cols;
+        dl.pyramid = a.pyramid; dl.d_table = a.d_table;
+        dl.kp4 = a.kp4; dl.kp_level = a.kp_level; dl.d_count = a.d_count;
+        dl.n = capacity < c->p.nfeatures ? capacity : c->p.nfeatures;
+        dl.blur = 1;
+        dl.max_size = (float)EFX_PATCH_SIZE;
+        dl.desc = d_desc; dl.desc_pitch = desc_pitch;
+        rc = describer_run(c->desc, c->err, dl, nullptr, nullptr, stream);
+        if (rc) return rc;
+    }
+    return EFX_OK;
+}
+
+int describe_single(Describer& d, std::string& err, const uint8_t* d_image, int rows, int cols, size_t pitch,
+                    const float4* kp4, int n, float max_size, uint8_t* d_desc, size_t desc_pitch,
+                    float* dbg_resp, float* dbg_T, hipStream_t stream)
+{
+    if (!d_image || rows <= 0 || cols <= 0 || pitch < (size_t)cols) return set_err(err, EFX_ERR_BAD_ARG, "bad image arguments");
+    if (n < 0) return set_err(err, EFX_ERR_BAD_ARG, "n must be >= 0");
+    if (n == 0) return EFX_OK;           // empty keypoints: nothing to do (cuda_bad.cpp:51-56)
+    if (!kp4) return set_err(err, EFX_ERR_BAD_ARG, "null keypoints");
+    if (d_desc && desc_pitch < (size_t)(d.nbits / 8)) return set_err(err, EFX_ERR_BAD_ARG, "desc_pitch smaller than the descriptor");
+    DescribeLaunch dl;
+    memset(&dl, 0, sizeof(dl));
+    dl.img0 = d_image; dl.pitch0 = (int)pitch; dl.rows0 = rows; dl.cols0 = cols;
+    dl.kp4 = kp4; dl.n = n; dl.blur = 0; dl.max_size = max_size;
+    dl.desc = d_desc; dl.desc_pitch = desc_pitch;
+    return describer_run(d, err, dl, dbg_resp, dbg_T, stream);
+}
+
+int describe_5xn(Describer& d, std::string& err, const uint8_t* d_image, int rows, int cols, size_t pitch,
+                 const void* d_keypoints, size_t kps_pitch, int n, uint8_t* d_desc, size_t desc_pitch, hipStream_t stream)
+{
+    if (n < 0) return set_err(err, EFX_ERR_BAD_ARG, "n must be >= 0");
+    if (n == 0) return EFX_OK;
+    if (!d_keypoints || kps_pitch < (size_t)n * 4) return set_err(err, EFX_ERR_BAD_ARG, "bad keypoint matrix");   // CV_Assert(rows == 5), .cpp:111
+    HIP_TRY(err, d.kp4.reserve((size_t)n * sizeof(float4)));
+    hipError_t e = efx_launch_convert_keypoints(d_keypoints, kps_pitch, n, static_cast<float4*>(d.kp4.p), stream);
+    if (e != hipSuccess) return set_err(err, EFX_ERR_HIP, "convertKeypoints failed: %s", hipGetErrorString(e));
+    return describe_single(d, err, d_image, rows, cols, pitch, static_cast<const float4*>(d.kp4.p), n, (float)EFX_PATCH_SIZE,
+                           d_desc, desc_pitch, nullptr, nullptr, stream);
+}
+
+int describe_host(Describer& d, std::string& err, const uint8_t* h_image, int rows, int cols, size_t pitch,
+                  const efx_keypoint* kps, int n, uint8_t* h_desc, size_t desc_pitch)
+{
+    if (!h_image || rows <= 0 || cols <= 0 || pitch < (size_t)cols) return set_err(err, EFX_ERR_BAD_ARG, "bad image arguments");
+    if (n < 0) return set_err(err, EFX_ERR_BAD_ARG, "n must be >= 0");
+    if (n == 0) return EFX_OK;
+    if (!kps || !h_desc) return set_err(err, EFX_ERR_BAD_ARG, "null keypoints / descriptors");
+    const int nbytes = d.nbits / 8;
+    if (desc_pitch < (size_t)nbytes) return set_err(err, EFX_ERR_BAD_ARG, "desc_pitch smaller than the descriptor");
+    const size_t ipitch = align_up((size_t)cols, 256);
+    HIP_TRY(err, d.img.reserve(ipitch * rows));
+    HIP_TRY(err, d.kp4.reserve((size_t)n * sizeof(float4)));
+    HIP_TRY(err, d.desc.reserve((size_t)n * nbytes));
+    // getKeypointsMat host branch, cuda_efficient_features.cpp:116-128: {pt.x, pt.y, size, angle}
+    std::vector<float4> h((size_t)n);
+    float max_size = 0.f;
+    for (int i = 0; i < n; i++) {
+        h[i] = make_float4(kps[i].x, kps[i].y, kps[i].size, kps[i].angle);
+        max_size = fmaxf(max_size, fabsf(kps[i].size));
+    }
+    HIP_TRY(err, hipMemcpy2D(d.img.p, ipitch, h_image, pitch, cols, rows, hipMemcpyHostToDevice));
+    HIP_TRY(err, hipMemcpy(d.kp4.p, h.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice));
+    int rc = describe_single(d, err, static_cast<const uint8_t*>(d.img.p), rows, cols, ipitch, static_cast<const float4*>(d.kp4.p), n,
+                             max_size, static_cast<uint8_t*>(d.desc.p), nbytes, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    HIP_TRY(err, hipMemcpy2D(h_desc, desc_pitch, d.desc.p, nbytes, nbytes, n, hipMemcpyDeviceToHost));
+    return EFX_OK;
+}
+
+int ctx_rebuild_describer(efx_context* c)
+{
+    // createDescriber, cuda_efficient_features.cpp:48-69: scale 1 for every type
+    const int t = c->p.descriptor_type;
+    const int kind = (t == EFX_BAD_256 || t == EFX_BAD_512) ? 0 : 1;
+    const int nbits = (t == EFX_BAD_256 || t == EFX_HASH_SIFT_256) ? 256 : 512;
+    int rc = describer_init(c->desc, kind, nbits, 1.f);
+    if (rc) c->err = c->desc.err;
+    return rc;
+}
+
+} // namespace
+
+extern "C" {
+
+int efx_version(void) { return EFX_VERSION; }
+
+void efx_default_params(efx_params* p)
+{
+    if (!p) return;
+    p->nfeatures = 5000; p->scale_factor = 1.2f; p->nlevels = 8; p->first_level = 0;
+    p->fast_threshold = 20; p->nonmax_radius = 15; p->descriptor_type = EFX_HASH_SIFT_256;
+}
+
+int efx_create(const efx_params* p, efx_context** out)
+{
+    if (!out) return set_err(g_create_error, EFX_ERR_BAD_ARG, "null output handle");
+    *out = nullptr;
+    efx_params q;
+    if (p) q = *p; else efx_default_params(&q);
+    int rc = validate_params(q, g_create_error);
+    if (rc) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return set_err(g_create_error, EFX_ERR_NO_DEVICE, "no HIP device: the efficient-features path has no CPU fallback");
+    efx_context* c = new (std::nothrow) efx_context;
+    if (!c) return set_err(g_create_error, EFX_ERR_NOMEM, "out of host memory");
+    c->p = q;
+    memset(&c->g_p, 0, sizeof(c->g_p));
+    rc = ctx_rebuild_describer(c);
+    if (rc) { g_create_error = c->err; delete c; return rc; }
+    *out = c;
+    return EFX_OK;
+}
+
+int efx_destroy(efx_context* ctx) { delete ctx; return EFX_OK; }
+
+const char* efx_last_error(const efx_context* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+#define EFX_SETTER(name, field, type)                                                        \
+    int efx_set_##name(efx_context* ctx, type v)                                             \
+    {                                                                                        \
+        if (!ctx) return EFX_ERR_BAD_ARG;                                                    \
+        efx_params q = ctx->p; q.field = v;                                                  \
+        int rc = validate_params(q, ctx->err);                                               \
+        if (rc) return rc;                                                                   \
+        ctx->p = q; return EFX_OK;                                                           \
+    }                                                                                        \
+    type efx_get_##name(const efx_context* ctx) { return ctx ? ctx->p.field : (type)0; }
+
+EFX_SETTER(max_features, nfeatures, int)
+EFX_SETTER(scale_factor, scale_factor, float)
+EFX_SETTER(nlevels, nlevels, int)
+EFX_SETTER(first_level, first_level, int)
+EFX_SETTER(fast_threshold, fast_threshold, int)
+EFX_SETTER(nonmax_radius, nonmax_radius, int)
+
+int efx_set_descriptor_type(efx_context* ctx, int v)
+{
+    // setDescriptorType rebuilds the describer (cuda_efficient_features.cpp:373-377)
+    if (!ctx) return EFX_ERR_BAD_ARG;
+    efx_params q = ctx->p; q.descriptor_type = v;
+    int rc = validate_params(q, ctx->err);
+    if (rc) return rc;
+    if (v == ctx->p.descriptor_type) return EFX_OK;
+    ctx->p = q;
+    return ctx_rebuild_describer(ctx);
+}
+int efx_get_descriptor_type(const efx_context* ctx) { return ctx ? ctx->p.descriptor_type : -1; }
+
+int efx_descriptor_size(const efx_context* ctx) { return ctx ? ctx->desc.nbits / 8 : 0; }
+int efx_descriptor_dtype(const efx_context*) { return 0; /* CV_8U */ }
+int efx_default_norm(const efx_context*) { return 6; /* cv::NORM_HAMMING */ }
+
+int efx_detect_async(efx_context* ctx, const uint8_t* d_image, int rows, int cols, size_t pitch,
+                     void* d_keypoints, size_t kps_pitch, int capacity, int* d_count, void* stream)
+{
+    if (!ctx) return EFX_ERR_BAD_ARG;
+    return detect_common(ctx, d_image, rows, cols, pitch, d_keypoints, kps_pitch, nullptr, 0, capacity, d_count, (hipStream_t)stream);
+}
+
+int efx_detect_and_compute_async(efx_context* ctx, const uint8_t* d_image, int rows, int cols, size_t pitch,
+                                 void* d_keypoints, size_t kps_pitch, uint8_t* d_descriptors, size_t desc_pitch,
+                                 int capacity, int* d_count, void* stream)
+{
+    if (!ctx) return EFX_ERR_BAD_ARG;
+    return detect_common(ctx, d_image, rows, cols, pitch, d_keypoints, kps_pitch, d_descriptors, desc_pitch, capacity, d_count, (hipStream_t)stream);
+}
+
+int efx_compute_async(efx_context* ctx, const uint8_t* d_image, int rows, int cols, size_t pitch,
+                      const void* d_keypoints, size_t kps_pitch, int n, uint8_t* d_descriptors, size_t desc_pitch, void* stream)
+{
+    if (!ctx) return EFX_ERR_BAD_ARG;
+    return describe_5xn(ctx->desc, ctx->err, d_image, rows, cols, pitch, d_keypoints, kps_pitch, n, d_descriptors, desc_pitch, (hipStream_t)stream);
+}
+
+int efx_compute_kp4_async(efx_context* ctx, const uint8_t* d_image, int rows, int cols, size_t pitch,
+                          const float* d_kp4, int n, float max_size, uint8_t* d_descriptors, size_t desc_pitch, void* stream)
+{
+    if (!ctx) return EFX_ERR_BAD_ARG;
+    return describe_single(ctx->desc, ctx->err, d_image, rows, cols, pitch, reinterpret_cast<const float4*>(d_kp4), n, max_size,
+                           d_descriptors, desc_pitch, nullptr, nullptr, (hipStream_t)stream);
+}
+
+int efx_last_count(const efx_context* ctx, int* n)
+{
+    if (!ctx || !n || !ctx->h_mirror || !ctx->has_frame) return EFX_ERR_BAD_ARG;
+    *n = ctx->h_mirror->n_out;
+    return EFX_OK;
+}
+
+int efx_last_level_stats(const efx_context* ctx, efx_level_stats* stats, int max_levels, int* nlevels)
+{
+    if (!ctx || !stats || !ctx->h_mirror || !ctx->has_frame) return EFX_ERR_BAD_ARG;
+    const int nl = ctx->h_table.nlevels < max_levels ? ctx->h_table.nlevels : max_levels;
+    for (int i = 0; i < nl; i++) {
+        stats[i].n_candidates = ctx->h_mirror->cand_total[i];
+        stats[i].n_after_nms = ctx->h_mirror->surv_total[i];
+        stats[i].n_kept = ctx->h_mirror->kept[i];
+    }
+    if (nlevels) *nlevels = nl;
+    return EFX_OK;
+}
+
+int efx_convert(const void* h_keypoints, size_t kps_pitch, int n, efx_keypoint* out)
+{
+    // EfficientFeaturesImpl::convert, cuda_efficient_features.cpp:323-349
+    if (n < 0 || (n > 0 && (!h_keypoints || !out))) return EFX_ERR_BAD_ARG;
+    const unsigned char* b = static_cast<const unsigned char*>(h_keypoints);
+    for (int i = 0; i < n; i++) {
+        uint32_t loc; float resp, ang, size; int32_t oct;
+        memcpy(&loc, b + 0 * kps_pitch + 4 * (size_t)i, 4);
+        memcpy(&resp, b + 1 * kps_pitch + 4 * (size_t)i, 4);
+        memcpy(&ang, b + 2 * kps_pitch + 4 * (size_t)i, 4);
+        memcpy(&oct, b + 3 * kps_pitch + 4 * (size_t)i, 4);
+        memcpy(&size, b + 4 * kps_pitch + 4 * (size_t)i, 4);
+        out[i].x = (float)(int16_t)(loc & 0xffff);
+        out[i].y = (float)(int16_t)(loc >> 16);
+        out[i].response = resp; out[i].angle = ang; out[i].octave = oct; out[i].size = size; out[i].class_id = -1;
+    }
+    return EFX_OK;
+}
+
+static int host_detect_impl(efx_context* ctx, const uint8_t* h_image, int rows, int cols, size_t pitch,
+                            efx_keypoint* keypoints, uint8_t* h_desc, size_t desc_pitch, int capacity, int* n, bool want_desc)
+{
+    if (!ctx) return EFX_ERR_BAD_ARG;
+    if (!h_image || rows <= 0 || cols <= 0 || pitch < (size_t)cols) return set_err(ctx->err, EFX_ERR_BAD_ARG, "bad image arguments");
+    if (capacity < 0 || !n || (capacity > 0 && !keypoints)) return set_err(ctx->err, EFX_ERR_BAD_ARG, "bad output arguments");
+    const int nbytes = efx_descriptor_size(ctx);
+    if (want_desc && (!h_desc || desc_pitch < (size_t)nbytes)) return set_err(ctx->err, EFX_ERR_BAD_ARG, "bad descriptor buffer");
+    const size_t ipitch = align_up((size_t)cols, 256);
+    const size_t kpitch = align_up((size_t)(capacity > 0 ? capacity : 1) * 4, 256);
+    HIP_TRY(ctx->err, ctx->img.reserve(ipitch * rows));
+    HIP_TRY(ctx->err, ctx->kps.reserve(kpitch * EFX_ROWS_COUNT));
+    if (want_desc) HIP_TRY(ctx->err, ctx->descout.reserve((size_t)(capacity > 0 ? capacity : 1) * nbytes));
+    HIP_TRY(ctx->err, hipMemcpy2D(ctx->img.p, ipitch, h_image, pitch, cols, rows, hipMemcpyHostToDevice));   // getInputMat upload, .cpp:75-77
+    int rc = detect_common(ctx, static_cast<const uint8_t*>(ctx->img.p), rows, cols, ipitch, ctx->kps.p, kpitch,
+                           want_desc ? static_cast<uint8_t*>(ctx->descout.p) : nullptr, nbytes, capacity, nullptr, nullptr);
+    if (rc) return rc;
+    HIP_TRY(ctx->err, hipStreamSynchronize(nullptr));
+    const int cnt = ctx->h_mirror->n_out;
+    *n = cnt;
+    if (cnt > 0) {
+        std::vector<unsigned char> tmp(kpitch * EFX_ROWS_COUNT);
+        HIP_TRY(ctx->err, hipMemcpy(tmp.data(), ctx->kps.p, kpitch * EFX_ROWS_COUNT, hipMemcpyDeviceToHost));
+        efx_convert(tmp.data(), kpitch, cnt, keypoints);
+        if (want_desc) HIP_TRY(ctx->err, hipMemcpy2D(h_desc, desc_pitch, ctx->descout.p, nbytes, nbytes, cnt, hipMemcpyDeviceToHost));
+    }
+    return EFX_OK;
+}
+
+int efx_detect(efx_context* ctx, const uint8_t* h_image, int rows, int cols, size_t pitch,
+               efx_keypoint* keypoints, int capacity, int* n)
+{
+    return host_detect_impl(ctx, h_image, rows, cols, pitch, keypoints, nullptr, 0, capacity, n, false);
+}
+
+int efx_detect_and_compute(efx_context* ctx, const uint8_t* h_image, int rows, int cols, size_t pitch,
+                           efx_keypoint* keypoints, uint8_t* h_descriptors, size_t desc_pitch, int capacity, int* n)
+{
+    return host_detect_impl(ctx, h_image, rows, cols, pitch, keypoints, h_descriptors, desc_pitch, capacity, n, true);
+}
+
+int efx_compute(efx_context* ctx, const uint8_t* h_image, int rows, int cols, size_t pitch,
+                const efx_keypoint* keypoints, int n, uint8_t* h_descriptors, size_t desc_pitch)
+{
+    if (!ctx) return EFX_ERR_BAD_ARG;
+    return describe_host(ctx->desc, ctx->err, h_image, rows, cols, pitch, keypoints, n, h_descriptors, desc_pitch);
+}
+
+// ---- stand-alone describers ----
+static int describer_create(int kind, float scale, int nbits_enum, efx_describer** out)
+{
+    if (!out) return set_err(g_create_error, EFX_ERR_BAD_ARG, "null output handle");
+    *out = nullptr;
+    const int nbits = nbits_from_enum(nbits_enum);
+    if (!nbits) return set_err(g_create_error, EFX_ERR_BAD_ARG, "n_bits should be either SIZE_512_BITS or SIZE_256_BITS");   // bad.cpp:316
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return set_err(g_create_error, EFX_ERR_NO_DEVICE, "no HIP device: the efficient-features path has no CPU fallback");
+    efx_describer* d = new (std::nothrow) efx_describer;
+    if (!d) return set_err(g_create_error, EFX_ERR_NOMEM, "out of host memory");
+    int rc = describer_init(d->d, kind, nbits, scale);
+    if (rc) { g_create_error = d->d.err; delete d; return rc; }
+    *out = d;
+    return EFX_OK;
+}
+
+int efx_bad_create(float scale_factor, int nbits, efx_describer** out) { return describer_create(0, scale_factor, nbits, out); }
+int efx_hashsift_create(float cropping_scale, int nbits, efx_describer** out) { return describer_create(1, cropping_scale, nbits, out); }
+int efx_describer_destroy(efx_describer* d) { delete d; return EFX_OK; }
+int efx_describer_descriptor_size(const efx_describer* d) { return d ? d->d.nbits / 8 : 0; }
+const char* efx_describer_last_error(const efx_describer* d) { return d ? d->d.err.c_str() : g_create_error.c_str(); }
+
+int efx_describer_compute_kp4_async(efx_describer* d, const uint8_t* d_image, int rows, int cols, size_t pitch,
+                                    const float* d_kp4, int n, float max_size, uint8_t* d_descriptors, size_t desc_pitch, void* stream)
+{
+    if (!d) return EFX_ERR_BAD_ARG;
+    return describe_single(d->d, d->d.err, d_image, rows, cols, pitch, reinterpret_cast<const float4*>(d_kp4), n, max_size,
+                           d_descriptors, desc_pitch, nullptr, nullptr, (hipStream_t)stream);
+}
+
+int efx_describer_compute_async(efx_describer* d, const uint8_t* d_image, int rows, int cols, size_t pitch,
+                                const void* d_keypoints, size_t kps_pitch, int n, uint8_t* d_descriptors, size_t desc_pitch, void* stream)
+{
+    if (!d) return EFX_ERR_BAD_ARG;
+    return describe_5xn(d->d, d->d.err, d_image, rows, cols, pitch, d_keypoints, kps_pitch, n, d_descriptors, desc_pitch, (hipStream_t)stream);
+}
+
+int efx_describer_compute(efx_describer* d, const uint8_t* h_image, int rows, int cols, size_t pitch,
+                          const efx_keypoint* keypoints, int n, uint8_t* h_descriptors, size_t desc_pitch)
+{
+    if (!d) return EFX_ERR_BAD_ARG;
+    return describe_host(d->d, d->d.err, h_image, rows, cols, pitch, keypoints, n, h_descriptors, desc_pitch);
+}
+
+int efx_describer_hashsift_debug_async(efx_describer* d, const uint8_t* d_image, int rows, int cols, size_t pitch,
+                                       const float* d_kp4, int n, float max_size, float* d_responses, float* d_T, void* stream)
+{
+    if (!d) return EFX_ERR_BAD_ARG;
+    if (d->d.kind != 1) return set_err(d->d.err, EFX_ERR_BAD_ARG, "not a HashSIFT describer");
+    return describe_single(d->d, d->d.err, d_image, rows, cols, pitch, reinterpret_cast<const float4*>(d_kp4), n, max_size,
+                           nullptr, 0, d_responses, d_T, (hipStream_t)stream);
+}
+
+int efx_level_geometry(const efx_context* ctx, int rows, int cols, int level, int* lrows, int* lcols, float* scale)
+{
+    if (!ctx || level < 0 || level >= ctx->p.nlevels) return EFX_ERR_BAD_ARG;
+    float s = 1.f;
+    for (int i = 1; i <= level; i++) s *= ctx->p.scale_factor;
+    const float inv = 1.f / s;
+    if (lrows) *lrows = level == 0 ? rows : cv_round_f(inv * (float)rows);
+    if (lcols) *lcols = level == 0 ? cols : cv_round_f(inv * (float)cols);
+    if (scale) *scale = s;
+    return EFX_OK;
+}
+
+int efx_copy_level_async(efx_context* ctx, int level, uint8_t* d_dst, size_t dst_pitch, void* stream)
+{
+    if (!ctx || !ctx->has_frame || level < 0 || level >= ctx->h_table.nlevels || !d_dst) return EFX_ERR_BAD_ARG;
+    const LevelDev& L = ctx->h_table.lv[level];
+    const uint8_t* src = level == 0 ? ctx->last_img0 : static_cast<const uint8_t*>(ctx->pyramid.p) + L.img_off;
+    const size_t sp = level == 0 ? (size_t)ctx->last_pitch0 : (size_t)L.pitch;
+    hipError_t e = efx_launch_copy2d(src, sp, d_dst, dst_pitch, L.rows, L.cols, (hipStream_t)stream);
+    if (e != hipSuccess) return set_err(ctx->err, EFX_ERR_HIP, "copy failed: %s", hipGetErrorString(e));
+    return EFX_OK;
+}
+
+} // extern "C"

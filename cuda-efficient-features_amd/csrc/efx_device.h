@@ -1,0 +1,141 @@
+// efx_device.h -- device-side data layout shared by the HIP kernels and the C-ABI host code.
+//
+// HBM layout of one context (all owned by the context, grow-only, reused across frames):
+//   pyramid   : levels 1..n-1, u8, row pitch rounded up to 256 B (level 0 is the caller's image, aliased)
+//   cand      : per level, compact array of FAST corners {xy, harris} (8 B), filled tile by tile; the
+//               physical order of tiles is arbitrary (atomic chunk allocation), the logical order is given
+//               by the tile headers (canonical order)
+//   surv      : per level, compact array of radius-NMS survivors (8 B), same scheme
+//   tile_hdr  : one 64-B header per 64x64 tile of every level
+//   kp4/lvl   : float4 {x, y, 31, angle} level-local keypoints + their level, input of the describers
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define EFX_TILE 64            // canonical-order tile edge (pixels)
+#define EFX_CELL 16            // NMS cell edge (CELL_SIZE, cuda_efficient_features.cu:35)
+#define EFX_CELLS_PER_TILE 16
+#define EFX_HALO 4             // FAST needs 3, Harris 7x7 of 3x3 Sobel needs 4, resize needs 1
+#define EFX_LT (EFX_TILE + 2 * EFX_HALO)   // LDS tile edge (72)
+#define EFX_MAX_LEVELS 32
+#define EFX_HALF_PATCH 15      // cuda_efficient_features.cpp:34
+#define EFX_PATCH_SIZE 31      // cuda_efficient_features.cpp:33
+#define EFX_NXCD 8
+
+struct LevelDev {
+    int rows, cols;
+    int pitch;                  // bytes; level 0: patched per call
+    int tiles_x, tiles_y;
+    int tile_base;              // index of the level's first tile in the global tile arrays
+    int cap;                    // cvRound(0.1 * area), cuda_efficient_features.cpp:252
+    int quota;                  // calcNumFeaturesPerLevel, cuda_efficient_features.cpp:159-174
+    float scale;                // level scale (1.2^s in float)
+    float fx, fy;               // resize factors with THIS level as destination: src = dst * f
+    int active;                 // s >= firstLevel
+    unsigned long long img_off; // byte offset of the level in the pyramid buffer (levels >= 1)
+    unsigned long long cand_base;   // entry offset of the level in the cand array
+    unsigned long long surv_base;   // entry offset of the level in the surv array
+};
+
+struct LevelTable {
+    int nlevels;
+    int total_tiles;
+    LevelDev lv[EFX_MAX_LEVELS];
+};
+
+struct __attribute__((aligned(64))) TileHdr {
+    uint32_t cand_start;        // physical start of the tile's corners in the level's cand array
+    uint32_t cand_rank;         // canonical rank of the tile's first corner (exclusive scan over tiles)
+    uint32_t surv_start;        // physical start of the tile's survivors in the level's surv array
+    uint32_t surv_count;
+    uint32_t out_off;           // output index of the tile's first selected survivor
+    uint16_t cell_off[EFX_CELLS_PER_TILE + 1];   // start of each cell's corners inside the tile list
+    uint16_t pad[5];
+};
+static_assert(sizeof(TileHdr) == 64, "TileHdr must be 64 bytes");
+
+struct Counters {               // zeroed at the start of every frame
+    int cand_total[EFX_MAX_LEVELS];
+    int surv_total[EFX_MAX_LEVELS];
+    int kept[EFX_MAX_LEVELS];           // after quota
+    int level_out_base[EFX_MAX_LEVELS + 1];
+    unsigned long long thresh[EFX_MAX_LEVELS];   // selection threshold key per level
+    int n_out;                          // N written to the caller
+};
+
+// one FAST corner / survivor
+struct __attribute__((aligned(8))) Corner {
+    uint32_t xy;       // x | y << 16, level coordinates
+    float resp;        // Harris response (spec S4)
+};
+
+// 64-bit selection key: response descending, then raster (y, x) ascending (spec S3).
+__host__ __device__ inline unsigned long long efx_select_key(uint32_t xy, float resp)
+{
+    union { float f; uint32_t u; } c;
+    c.f = resp;
+    uint32_t u = c.u;
+    if (u == 0x80000000u) u = 0;                        // -0 == +0
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);     // order-preserving float -> uint
+    const uint32_t x = xy & 0xffffu, y = xy >> 16;
+    return ((unsigned long long)u << 32) | (unsigned long long)(0xffffffffu - ((y << 16) | x));
+}
+
+struct BadParamsDev {           // per-context copy of the learned tables (no process-global constants)
+    int nbits;
+    float reach;                // max over boxes of (centre distance from (16,16) + radius), patch units
+    int4 box[512];              // {x1 | x2<<8, y1 | y2<<8, radius, 0}
+    float thr[512];
+};
+
+// ---- launchers (host side, defined in the .hip files) ----
+struct DetectLaunch {
+    const uint8_t* img0;        // level 0 (caller's image)
+    int pitch0;
+    uint8_t* pyramid;           // levels >= 1
+    const LevelTable* d_table;  // device copy
+    const LevelTable* h_table;  // host copy (same contents)
+    TileHdr* hdr;
+    Corner* cand;
+    Corner* surv;
+    Counters* counters;
+    int threshold;
+    int nonmax_radius;
+    int first_level;
+    // outputs
+    void* d_keypoints; size_t kps_pitch; int capacity; int* d_count;
+    float4* kp4; int* kp_level;
+    int* h_mirror;              // pinned host mirror of Counters (may be null)
+};
+
+hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream);
+
+struct DescribeLaunch {
+    const uint8_t* img0; int pitch0; int rows0, cols0;     // image for level index 0 / single-image mode
+    const uint8_t* pyramid; const LevelTable* d_table;     // null in single-image mode
+    const float4* kp4; const int* kp_level;                // kp_level null -> all keypoints on img0
+    const int* d_count;                                    // device N (null -> use n)
+    int n;                                                 // grid size (upper bound of N)
+    int blur;                                              // 1: 7x7 sigma-2 Gaussian first (detectAndCompute)
+    float scale_factor;                                    // BAD scaleFactor / HashSIFT croppingScale
+    float max_size;                                        // upper bound of keypoint size (LDS window)
+    uint8_t* desc; size_t desc_pitch;
+};
+
+hipError_t efx_launch_bad(const DescribeLaunch& a, const BadParamsDev* d_params, float reach, hipStream_t stream);
+
+struct HashSiftDev {
+    int nbits;
+    const float* W;             // nbits x 132 (129 padded to 132), fp32, device
+    float* responses;           // scratch n x 132
+    float* dbg_responses;       // optional n x 129
+    float* dbg_T;               // optional n x nbits
+};
+hipError_t efx_launch_hashsift(const DescribeLaunch& a, const HashSiftDev& h, hipStream_t stream);
+
+// 5xN keypoint matrix -> float4 {x, y, 31, angle} (convertKeypointsKernel, cuda_efficient_features.cu:250-263)
+hipError_t efx_launch_convert_keypoints(const void* d_keypoints, size_t kps_pitch, int n, float4* kp4, hipStream_t stream);
+hipError_t efx_launch_copy2d(const uint8_t* src, size_t spitch, uint8_t* dst, size_t dpitch, int rows, int cols, hipStream_t stream);
+
+void efx_gaussian_taps_host(float taps[7]);

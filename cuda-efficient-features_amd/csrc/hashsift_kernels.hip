@@ -1,0 +1,355 @@
+// hashsift_kernels.hip -- HashSIFT descriptor for gfx950: PatchSIFT 129-vectors + fp32 MFMA projection.
+//
+// Arithmetic: the reference CPU descriptor, modules/efficient_features/src/hash_sift.cpp
+//   rectifyPatch / warpAffineLinear :68-138, HistBin :162-184, distribute :193-198,
+//   computePatchSIFT :200-331, normalize :150-160, matmulAndSign :353-378.
+//
+// MI355X design
+//   * one workgroup per keypoint; the (optionally Gaussian-blurred, spec S6) window the rotated 32x32
+//     patch can touch is staged in LDS, so detectAndCompute needs no global blur pass;
+//   * the 6x6x10 gradient histogram is accumulated WITHOUT float atomics: one lane owns one spatial bin
+//     and visits its pixels in raster order, i.e. every bin sees its additions in exactly the order of the
+//     serial CPU loop (hash_sift.cpp:233-290) -- the reference's CUDA kernel uses shared-memory atomics
+//     (cuda_hash_sift.cu:282-289) and is order-nondeterministic;
+//   * the Gaussian pixel weights expf(...) are a 30x30 table computed on the host with the same libm call
+//     the CPU code makes; sqrtf is IEEE; atan2f/cosf/sinf are the device versions (tolerance: DESIGN.md);
+//   * projection T = R[N x 129] . W^T is the one real GEMM of the path: v_mfma_f32_32x32x2_f32 (exact fp32
+//     FMA chain), fused with the sign test and MSB-first bit packing (no T matrix in HBM, no separate
+//     binarize pass as in cuda_hash_sift.cu:414-435).
+
+#include "efx_device.h"
+
+#define HS_KPAD 132   // 129 padded to a multiple of 4 floats
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ int reflect101(int p, int len)
+{
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) {
+        if (p < 0) p = -p;
+        else p = 2 * (len - 1) - p;
+    }
+    return p;
+}
+
+struct AffineF { float m00, m01, m02, m10, m11, m12, pad0, pad1; };
+
+// LDS plan (dynamic, BLUR only): [ hblur (S+6)*S float | raw (S+6)^2 u8 | win S*S u8 ]
+template <bool BLUR>
+__global__ __launch_bounds__(256) void patch_sift_kernel(
+    const uint8_t* __restrict__ img0, int pitch0, int rows0, int cols0,
+    const uint8_t* __restrict__ pyramid, const LevelTable* __restrict__ T,
+    const float4* __restrict__ kp4, const int* __restrict__ kp_level, const int* __restrict__ d_count, int n,
+    float crop_scale, int smax, const float* __restrict__ mag_scale /*30*30*/,
+    float taps0, float taps1, float taps2, float taps3,
+    float* __restrict__ responses /* n x HS_KPAD */, float* __restrict__ dbg_responses /* n x 129 or null */)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ AffineF s_aff;
+    __shared__ uint8_t s_patch[32 * 32];
+    __shared__ float s_mag[900];
+    __shared__ float s_of[900];
+    __shared__ uint8_t s_oi[900];
+    __shared__ float s_hist[6 * 6 * 10];
+    __shared__ float s_desc[128];
+    __shared__ float s_rf[32], s_cf[32];
+    __shared__ int s_ri[32], s_ci[32];
+    __shared__ float s_scale;
+
+    const int kid = blockIdx.x;
+    const int count = d_count ? min(*d_count, n) : n;
+    if (kid >= count) return;
+    const int tid = threadIdx.x;
+
+    const float4 kp = kp4[kid];
+    const uint8_t* img = img0; int pitch = pitch0, rows = rows0, cols = cols0;
+    if (kp_level) {
+        const int l = kp_level[kid];
+        if (l > 0) { const LevelDev& L = T->lv[l]; img = pyramid + L.img_off; pitch = L.pitch; rows = L.rows; cols = L.cols; }
+        else { rows = T->lv[0].rows; cols = T->lv[0].cols; }
+    }
+    const float px = kp.x, py = kp.y, size = kp.z, angle = kp.w;
+
+    // rectifyPatch, hash_sift.cpp:111-132
+    if (tid == 0) {
+        const float PI_1 = (float)3.1415926535897932384626433832795;
+        const float s = crop_scale * size / (0.5f * (float)(32 + 32));
+        const float theta = PI_1 * angle / 180;
+        const float cost = s * (angle >= 0 ? cosf(theta) : 1.f);
+        const float sint = s * (angle >= 0 ? sinf(theta) : 0.f);
+        AffineF A;
+        A.m00 = +cost; A.m01 = -sint; A.m02 = (-cost + sint) * (float)32 / 2.f + px;
+        A.m10 = +sint; A.m11 = +cost; A.m12 = (-sint - cost) * (float)32 / 2.f + py;
+        A.pad0 = 0; A.pad1 = 0;
+        s_aff = A;
+    }
+    // HistBin rows/cols (hash_sift.cpp:162-184), kpScale = 1/6
+    if (tid >= 64 && tid < 64 + 32) {
+        const int i = tid - 64;
+        const float kp_scale = 1.f / 6;
+        const float cellh = 3.f * (kp_scale * (float)32 * 0.5f);
+        const float scaleR = 1.f / cellh;
+        const float bin = scaleR * ((float)i - 0.5f * (float)32) + ((float)(4 / 2) - 0.5f);
+        const int bi = (int)floorf(bin);
+        s_ri[i] = bi; s_rf[i] = bin - (float)bi;
+        s_ci[i] = bi; s_cf[i] = bin - (float)bi;       // cellw == cellh, same formula for columns
+    }
+    for (int i = tid; i < 360; i += 256) s_hist[i] = 0.f;
+
+    // window the patch can touch
+    const float sg = fabsf(crop_scale * size / 32.f);
+    int R = (int)floorf(sg * 22.63f + 3.f);
+    int S = 2 * R + 2;
+    const bool fits = !BLUR || (S <= smax && S > 0);
+    if (!fits) S = smax;
+    const int ix = (int)floorf(px), iy = (int)floorf(py);
+    const int wx0 = min(max(ix - R, 0), max(cols - S, 0));
+    const int wy0 = min(max(iy - R, 0), max(rows - S, 0));
+    float* hb = reinterpret_cast<float*>(smem);
+    uint8_t* raw = reinterpret_cast<uint8_t*>(hb + (S + 6) * S);
+    const int RP = S + 6;
+    uint8_t* win = raw + RP * RP;
+
+    if (BLUR && fits) {
+        for (int i = tid; i < RP * RP; i += 256) {
+            const int r = i / RP, c = i % RP;
+            const int gy = reflect101(wy0 - 3 + r, rows), gx = reflect101(wx0 - 3 + c, cols);
+            raw[i] = img[(size_t)gy * pitch + gx];
+        }
+        __syncthreads();
+        const float tp[7] = { taps0, taps1, taps2, taps3, taps2, taps1, taps0 };
+        for (int i = tid; i < RP * S; i += 256) {
+            const int r = i / S, c = i % S;
+            const uint8_t* p = raw + r * RP + c;
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < 7; j++) acc = acc + tp[j] * (float)p[j];
+            hb[i] = acc;
+        }
+        __syncthreads();
+        for (int i = tid; i < S * S; i += 256) {
+            const int r = i / S, c = i % S;
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < 7; j++) acc = acc + tp[j] * hb[(r + j) * S + c];
+            float v = rintf(acc);
+            v = v < 0.f ? 0.f : (v > 255.f ? 255.f : v);
+            win[i] = (uint8_t)v;
+        }
+    }
+    __syncthreads();
+
+    // warpAffineLinear, hash_sift.cpp:68-109
+    {
+        const AffineF A = s_aff;
+        for (int i = tid; i < 1024; i += 256) {
+            const int y = i >> 5, x = i & 31;
+            const float u = A.m00 * (float)x + A.m01 * (float)y + A.m02;
+            const float v = A.m10 * (float)x + A.m11 * (float)y + A.m12;
+            uint8_t val = 0;
+            const int ui = (int)floorf(u), vi = (int)floorf(v);
+            if (fits && ui >= 0 && ui + 1 < cols && vi >= 0 && vi + 1 < rows) {
+                float p00, p01, p10, p11;
+                if (BLUR) {
+                    const int lx = min(max(ui - wx0, 0), S - 2), ly = min(max(vi - wy0, 0), S - 2);
+                    const uint8_t* p = win + ly * S + lx;
+                    p00 = (float)p[0]; p01 = (float)p[1]; p10 = (float)p[S]; p11 = (float)p[S + 1];
+                } else {
+                    const uint8_t* p = img + (size_t)vi * pitch + ui;
+                    p00 = (float)p[0]; p01 = (float)p[1]; p10 = (float)p[pitch]; p11 = (float)p[pitch + 1];
+                }
+                const float du = u - (float)ui, dv = v - (float)vi;
+                const float t0 = (1 - du) * p00 + du * p01;
+                const float t1 = (1 - du) * p10 + du * p11;
+                const float t2 = (1 - dv) * t0 + dv * t1;
+                int iv = (int)(t2 + 0.5f);
+                if (iv > 255) iv = 255;
+                val = (uint8_t)iv;
+            }
+            s_patch[i] = val;
+        }
+    }
+    __syncthreads();
+
+    // gradients, magnitude, orientation of the 30x30 interior (hash_sift.cpp:244-260)
+    {
+        const float PI_2 = (float)6.283185307179586476925286766559;
+        const float scaleO = (float)8 / PI_2;
+        for (int i = tid; i < 900; i += 256) {
+            const int y = i / 30, x = i % 30;           // patch pixel (x+1, y+1)
+            const uint8_t* pc = s_patch + (y + 1) * 32 + (x + 1);
+            const float dx = (float)((int)pc[1] - (int)pc[-1]);
+            const float dy = (float)((int)pc[-32] - (int)pc[32]);
+            const float mag = mag_scale[i] * sqrtf(dx * dx + dy * dy);
+            const float ori = atan2f(dy, dx);
+            const float obin = scaleO * ori;
+            int oi = (int)floorf(obin);
+            const float of = obin - (float)oi;
+            if (oi < 0) oi += 8;
+            if (oi >= 8) oi -= 8;
+            s_mag[i] = mag; s_of[i] = of; s_oi[i] = (uint8_t)oi;
+        }
+    }
+    __syncthreads();
+
+    // trilinear histogram, one lane per spatial bin, pixels in raster order (hash_sift.cpp:233-290)
+    if (tid < 36) {
+        const int RB = tid / 6, CB = tid % 6;
+        float* h = s_hist + tid * 10;
+        for (int y = 1; y <= 30; y++) {
+            const int ri = s_ri[y];
+            const int rsel = (ri + 1 == RB) ? 0 : ((ri + 2 == RB) ? 1 : -1);
+            if (rsel < 0) continue;
+            const float rf = s_rf[y];
+            for (int x = 1; x <= 30; x++) {
+                const int ci = s_ci[x];
+                const int csel = (ci + 1 == CB) ? 0 : ((ci + 2 == CB) ? 1 : -1);
+                if (csel < 0) continue;
+                const int i = (y - 1) * 30 + (x - 1);
+                const float mag = s_mag[i];
+                const float v1 = rf * mag, v0 = mag - v1;             // distribute along r
+                const float a = rsel ? v1 : v0;
+                const float cf = s_cf[x];
+                const float a1 = cf * a, a0 = a - a1;                 // distribute along c
+                const float b = csel ? a1 : a0;
+                const float of = s_of[i];
+                const float b1 = of * b, b0 = b - b1;                 // distribute along o
+                const int oi = s_oi[i];
+                h[oi] += b0;
+                h[oi + 1] += b1;
+            }
+        }
+    }
+    __syncthreads();
+    // circular fold + copy (hash_sift.cpp:293-308)
+    if (tid < 16) {
+        const int r = tid >> 2, c = tid & 3;
+        float* ph = s_hist + ((r + 1) * 6 + (c + 1)) * 10;
+        ph[0] += ph[8];
+        ph[1] += ph[9];
+        for (int k = 0; k < 8; k++) s_desc[(r * 4 + c) * 8 + k] = ph[k];
+    }
+    __syncthreads();
+    // L2 normalise, clip at 0.2, renormalise, x512 -> uchar (hash_sift.cpp:311-330); the 128-term sums are
+    // serial in the CPU code, so one lane adds them in the same order
+    for (int pass = 0; pass < 2; pass++) {
+        if (tid == 0) {
+            float sum = 0;
+            for (int i = 0; i < 128; i++) sum += s_desc[i] * s_desc[i];
+            float norm = sqrtf(sum);
+            if (norm < 1.1920929e-07f) norm = 1.1920929e-07f;          // FLT_EPSILON
+            s_scale = 1.f / norm;
+        }
+        __syncthreads();
+        if (tid < 128) {
+            float v = s_desc[tid] * s_scale;
+            if (pass == 0) v = v < 0.2f ? v : 0.2f;
+            s_desc[tid] = v;
+        }
+        __syncthreads();
+    }
+    float* out = responses + (size_t)kid * HS_KPAD;
+    if (tid < 128) {
+        float v = rintf(512.f * s_desc[tid]);                           // saturate_cast<uchar>: cvRound + clamp
+        v = v < 0.f ? 0.f : (v > 255.f ? 255.f : v);
+        out[1 + tid] = v;
+        if (dbg_responses) dbg_responses[(size_t)kid * 129 + 1 + tid] = v;
+    }
+    if (tid == 128) { out[0] = 1.f; out[129] = 0.f; out[130] = 0.f; out[131] = 0.f; if (dbg_responses) dbg_responses[(size_t)kid * 129] = 1.f; }
+}
+
+// ================================================================================================
+// Projection + sign + pack.  T[i][j] = sum_k R[i][k] * W[j][k]  (matmulAndSign, hash_sift.cpp:353-378).
+// One wave computes a 32 (keypoints) x 64 (bits) tile with two v_mfma_f32_32x32x2_f32 accumulators;
+// a workgroup of 4 waves covers 128 keypoints x 64 bits.  A/B are read straight from L2 (R is 528 B per
+// keypoint, W is 270 KB total and stays cache resident).
+// ================================================================================================
+__global__ __launch_bounds__(256) void project_sign_kernel(const float* __restrict__ Rm, const float* __restrict__ W,
+                                                           const int* __restrict__ d_count, int n, int nbits,
+                                                           uint8_t* __restrict__ desc, size_t desc_pitch, float* __restrict__ dbg_T)
+{
+    const int count = d_count ? min(*d_count, n) : n;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int m0 = blockIdx.x * 128 + wid * 32;
+    const int n0 = blockIdx.y * 64;
+    if (m0 >= count) return;
+    const int li = lane & 31, lk = lane >> 5;
+    const int arow = min(m0 + li, count - 1);
+    const float* pa = Rm + (size_t)arow * HS_KPAD + lk;
+    const float* pb0 = W + (size_t)(n0 + li) * HS_KPAD + lk;
+    const float* pb1 = W + (size_t)(n0 + 32 + li) * HS_KPAD + lk;
+    f32x16 acc0 = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    f32x16 acc1 = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+#pragma unroll 6
+    for (int k = 0; k < HS_KPAD; k += 2) {
+        const float a = pa[k], b0 = pb0[k], b1 = pb1[k];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+    }
+    // C layout 32x32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int row = (r & 3) + 8 * (r >> 2);
+        const unsigned long long ba = __ballot(acc0[r] > 0.f);
+        const unsigned long long bb = __ballot(acc1[r] > 0.f);
+        if (dbg_T) {
+            const int i = m0 + row + 4 * lk;
+            if (i < count) { dbg_T[(size_t)i * nbits + n0 + li] = acc0[r]; dbg_T[(size_t)i * nbits + n0 + 32 + li] = acc1[r]; }
+        }
+        if (lane < 4) {
+            // lane 0/1: rows `row` (bits n0.., n0+32..), lane 2/3: rows `row+4`
+            const int hi = lane >> 1, second = lane & 1;
+            const unsigned long long m = second ? bb : ba;
+            const unsigned w = hi ? (unsigned)(m >> 32) : (unsigned)m;
+            const int i = m0 + row + 4 * hi;
+            if (i < count) {
+                // bit j of w -> byte j/8, bit 7 - j%8 (MSB first, hash_sift.cpp:367-374)
+                const unsigned v = __builtin_bswap32(__brev(w));
+                *reinterpret_cast<unsigned*>(desc + (size_t)i * desc_pitch + (n0 + 32 * second) / 8) = v;
+            }
+        }
+    }
+}
+
+} // namespace
+
+static int hs_smax_for(float max_size, float crop_scale)
+{
+    const float sg = fabsf(crop_scale * max_size / 32.f);
+    const int R = (int)floorf(sg * 22.63f + 3.f);
+    return 2 * R + 2;
+}
+
+hipError_t efx_launch_hashsift(const DescribeLaunch& a, const HashSiftDev& h, hipStream_t stream)
+{
+    if (a.n <= 0) return hipSuccess;
+    const float max_size = a.max_size > 0.f ? a.max_size : (float)EFX_PATCH_SIZE;
+    const int S = hs_smax_for(max_size, a.scale_factor);
+    size_t lds = 0;
+    if (a.blur) {
+        lds = (size_t)(S + 6) * S * 4 + (size_t)(S + 6) * (S + 6) + (size_t)S * S;
+        lds = (lds + 15) & ~(size_t)15;
+        if (lds > 140 * 1024) return hipErrorInvalidValue;
+    }
+    float t[7];
+    efx_gaussian_taps_host(t);
+    const float* mag = h.W + (size_t)h.nbits * HS_KPAD;    // the 30x30 weight table is stored behind W
+    if (a.blur) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_sift_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(patch_sift_kernel<true>, dim3(a.n), dim3(256), lds, stream, a.img0, a.pitch0, a.rows0, a.cols0,
+                           a.pyramid, a.d_table, a.kp4, a.kp_level, a.d_count, a.n, a.scale_factor, S, mag,
+                           t[0], t[1], t[2], t[3], h.responses, h.dbg_responses);
+    } else {
+        hipLaunchKernelGGL(patch_sift_kernel<false>, dim3(a.n), dim3(256), 0, stream, a.img0, a.pitch0, a.rows0, a.cols0,
+                           a.pyramid, a.d_table, a.kp4, a.kp_level, a.d_count, a.n, a.scale_factor, S, mag,
+                           t[0], t[1], t[2], t[3], h.responses, h.dbg_responses);
+    }
+    if (a.desc || h.dbg_T) {
+        hipLaunchKernelGGL(project_sign_kernel, dim3((a.n + 127) / 128, h.nbits / 64), dim3(256), 0, stream,
+                           h.responses, h.W, a.d_count, a.n, h.nbits, a.desc, a.desc_pitch, h.dbg_T);
+    }
+    return hipGetLastError();
+}

@@ -1,0 +1,207 @@
+/*
+ * efx.h -- C ABI of the MI355X-native efficient-features library (libefx_hip.so).
+ *
+ * This is the drop-in boundary for the detect / describe hot path of fixstars/cuda-efficient-features:
+ * the entry points are what a binding of the reference's Feature2D facade would call.  Each declaration
+ * cites the reference interface it replaces (paths relative to the reference repository).
+ *
+ *   - plain pointers and sizes only; device pointers are ordinary HIP device addresses;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *   - every function returns an efx_status; efx_last_error() gives the message of the last failure;
+ *   - a context is NOT re-entrant: one context per (thread, stream, device), exactly like an
+ *     EfficientFeaturesImpl instance (cuda_efficient_features.cpp:391-403).  Parameter tables are
+ *     per-context (the reference's process-global __constant__ tables, cuda_bad.cu:49-50, are not copied).
+ *
+ * Keypoint matrix layout ("5xN"), identical to the reference (cuda_efficient_features.h:32-37):
+ *   row 0 LOCATION  short2 (x, y) bit-packed in 4 bytes      row 3 OCTAVE   int32
+ *   row 1 RESPONSE  float                                    row 4 SIZE     float
+ *   row 2 ANGLE     float, degrees
+ * Rows are `kps_pitch` BYTES apart.  Descriptors are N x (nbits/8) bytes, rows `desc_pitch` bytes apart,
+ * type u8, norm HAMMING (cuda_bad.cpp:82-84, cuda_hash_sift.cpp:149-151).
+ */
+#ifndef EFX_H
+#define EFX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EFX_VERSION 100
+
+typedef enum efx_status {
+    EFX_OK = 0,
+    EFX_ERR_BAD_ARG = -1,       /* CV_Assert / CV_Error(StsBadArg) in the reference */
+    EFX_ERR_UNSUPPORTED = -2,
+    EFX_ERR_HIP = -3,           /* a HIP runtime call failed (the reference only printf's: cuda_macro.h:23-28) */
+    EFX_ERR_NO_DEVICE = -4,
+    EFX_ERR_NOMEM = -5
+} efx_status;
+
+/* cuda_efficient_features.h:39-45 */
+typedef enum efx_descriptor_type {
+    EFX_BAD_256 = 0,
+    EFX_BAD_512 = 1,
+    EFX_HASH_SIFT_256 = 2,
+    EFX_HASH_SIFT_512 = 3
+} efx_descriptor_type;
+
+/* cuda_efficient_descriptors.h:75-78, 109-112 (BADSize / HashSIFTSize) */
+enum { EFX_SIZE_512_BITS = 100, EFX_SIZE_256_BITS = 101 };
+
+/* cuda_efficient_features.h:32-37 */
+enum { EFX_LOCATION_ROW = 0, EFX_RESPONSE_ROW = 1, EFX_ANGLE_ROW = 2, EFX_OCTAVE_ROW = 3, EFX_SIZE_ROW = 4,
+       EFX_ROWS_COUNT = 5 };
+
+/* Arguments of EfficientFeatures::create (cuda_efficient_features.h:47-48). */
+typedef struct efx_params {
+    int nfeatures;          /* 5000 */
+    float scale_factor;     /* 1.2f */
+    int nlevels;            /* 8    */
+    int first_level;        /* 0    */
+    int fast_threshold;     /* 20   */
+    int nonmax_radius;      /* 15   */
+    int descriptor_type;    /* EFX_HASH_SIFT_256 */
+} efx_params;
+
+/* cv::KeyPoint as the facade hands it out (EfficientFeaturesImpl::convert, cuda_efficient_features.cpp:323-349). */
+typedef struct efx_keypoint {
+    float x, y;       /* pt */
+    float size;
+    float angle;      /* degrees, -1 = not applicable */
+    float response;
+    int octave;
+    int class_id;     /* always -1 */
+} efx_keypoint;
+
+typedef struct efx_context efx_context;       /* EfficientFeaturesImpl */
+typedef struct efx_describer efx_describer;   /* cuda::BAD / cuda::HashSIFT stand-alone describers */
+
+/* Per-stage device counters of the last detect call (diagnostics; no reference equivalent). */
+typedef struct efx_level_stats {
+    int n_candidates;   /* FAST corners found              */
+    int n_after_nms;    /* survivors of radius suppression */
+    int n_kept;         /* after the per-level quota       */
+} efx_level_stats;
+
+/* ------------------------------------------------------------------------------------------------ */
+/* life cycle                                                                                        */
+
+void efx_default_params(efx_params* p);                         /* the defaults of create(), .h:47-48 */
+int efx_create(const efx_params* p, efx_context** out);         /* EfficientFeatures::create, .cpp:406-411 */
+int efx_destroy(efx_context* ctx);                              /* ~EfficientFeatures, .cpp:413-415 */
+const char* efx_last_error(const efx_context* ctx);             /* ctx may be NULL: last create() error */
+int efx_version(void);
+
+/* getters / setters, cuda_efficient_features.h:78-97, impl .cpp:355-379 */
+int efx_set_max_features(efx_context* ctx, int v);       int efx_get_max_features(const efx_context* ctx);
+int efx_set_scale_factor(efx_context* ctx, float v);     float efx_get_scale_factor(const efx_context* ctx);
+int efx_set_nlevels(efx_context* ctx, int v);            int efx_get_nlevels(const efx_context* ctx);
+int efx_set_first_level(efx_context* ctx, int v);        int efx_get_first_level(const efx_context* ctx);
+int efx_set_fast_threshold(efx_context* ctx, int v);     int efx_get_fast_threshold(const efx_context* ctx);
+int efx_set_nonmax_radius(efx_context* ctx, int v);      int efx_get_nonmax_radius(const efx_context* ctx);
+int efx_set_descriptor_type(efx_context* ctx, int v);    int efx_get_descriptor_type(const efx_context* ctx);
+
+int efx_descriptor_size(const efx_context* ctx);   /* bytes per descriptor, .cpp:351 */
+int efx_descriptor_dtype(const efx_context* ctx);  /* 0 == CV_8U, .cpp:352 */
+int efx_default_norm(const efx_context* ctx);      /* 6 == cv::NORM_HAMMING, .cpp:353 */
+
+/* ------------------------------------------------------------------------------------------------ */
+/* asynchronous device entry points (inputs and outputs resident in HBM)                             */
+
+/* detectAsync (cuda_efficient_features.cpp:215-218).  d_image: rows x cols u8, `pitch` bytes per row.
+ * d_keypoints: 5 x capacity matrix (layout above).  d_count: device int receiving N (<= capacity).
+ * The mask argument of the reference is accepted and ignored there (.cpp:225-250); it has no parameter here.
+ * No host synchronisation happens inside; N is also mirrored to pinned host memory, readable with
+ * efx_last_count() once the stream has been synchronised. */
+int efx_detect_async(efx_context* ctx, const uint8_t* d_image, int rows, int cols, size_t pitch,
+                     void* d_keypoints, size_t kps_pitch, int capacity, int* d_count, void* stream);
+
+/* detectAndComputeAsync (cuda_efficient_features.cpp:225-321) with useProvidedKeypoints == false. */
+int efx_detect_and_compute_async(efx_context* ctx, const uint8_t* d_image, int rows, int cols, size_t pitch,
+                                 void* d_keypoints, size_t kps_pitch,
+                                 uint8_t* d_descriptors, size_t desc_pitch,
+                                 int capacity, int* d_count, void* stream);
+
+/* computeAsync with the 5xN GPU keypoint matrix (cuda_efficient_features.cpp:220-223 ->
+ * getKeypointsMat :102-115 -> convertKeypointsKernel .cu:250-263): size is forced to 31, the OCTAVE and
+ * SIZE rows are ignored, no blur is applied. */
+int efx_compute_async(efx_context* ctx, const uint8_t* d_image, int rows, int cols, size_t pitch,
+                      const void* d_keypoints, size_t kps_pitch, int n,
+                      uint8_t* d_descriptors, size_t desc_pitch, void* stream);
+
+/* computeAsync for keypoints already packed as float4 {x, y, size, angle} on the device
+ * (the std::vector<KeyPoint> branch of getKeypointsMat, cuda_efficient_features.cpp:116-128).
+ * max_size: an upper bound of the `size` fields (sizes the LDS window; 0 = 31). */
+int efx_compute_kp4_async(efx_context* ctx, const uint8_t* d_image, int rows, int cols, size_t pitch,
+                          const float* d_kp4, int n, float max_size,
+                          uint8_t* d_descriptors, size_t desc_pitch, void* stream);
+
+/* N of the last detect / detectAndCompute on this context (valid after the stream was synchronised). */
+int efx_last_count(const efx_context* ctx, int* n);
+/* Per-level counters of the last detect call (valid after the stream was synchronised). */
+int efx_last_level_stats(const efx_context* ctx, efx_level_stats* stats, int max_levels, int* nlevels);
+
+/* ------------------------------------------------------------------------------------------------ */
+/* synchronous host entry points (upload, run, download), the cv::Mat branches of the facade         */
+
+/* detect (cuda_efficient_features.cpp:197-201): h_image is host memory; keypoints returned as structs. */
+int efx_detect(efx_context* ctx, const uint8_t* h_image, int rows, int cols, size_t pitch,
+               efx_keypoint* keypoints, int capacity, int* n);
+
+/* compute (cuda_efficient_features.cpp:203-206): keypoints given as structs (size and angle honoured). */
+int efx_compute(efx_context* ctx, const uint8_t* h_image, int rows, int cols, size_t pitch,
+                const efx_keypoint* keypoints, int n, uint8_t* h_descriptors, size_t desc_pitch);
+
+/* detectAndCompute (cuda_efficient_features.cpp:208-213). */
+int efx_detect_and_compute(efx_context* ctx, const uint8_t* h_image, int rows, int cols, size_t pitch,
+                           efx_keypoint* keypoints, uint8_t* h_descriptors, size_t desc_pitch,
+                           int capacity, int* n);
+
+/* convert (cuda_efficient_features.cpp:323-349): HOST 5xN matrix -> keypoint structs. */
+int efx_convert(const void* h_keypoints, size_t kps_pitch, int n, efx_keypoint* out);
+
+/* ------------------------------------------------------------------------------------------------ */
+/* stand-alone describers: cuda::BAD::create / cuda::HashSIFT::create                                 */
+/* (cuda_efficient_descriptors.h:89,120; cuda_bad.cpp:36-98; cuda_hash_sift.cpp:95-167)             */
+
+int efx_bad_create(float scale_factor, int nbits /* EFX_SIZE_*_BITS */, efx_describer** out);
+int efx_hashsift_create(float cropping_scale, int nbits /* EFX_SIZE_*_BITS */, efx_describer** out);
+int efx_describer_destroy(efx_describer* d);
+int efx_describer_descriptor_size(const efx_describer* d);
+const char* efx_describer_last_error(const efx_describer* d);
+
+/* EfficientDescriptorsAsync::computeAsync, float4 keypoints on the device. */
+int efx_describer_compute_kp4_async(efx_describer* d, const uint8_t* d_image, int rows, int cols, size_t pitch,
+                                    const float* d_kp4, int n, float max_size,
+                                    uint8_t* d_descriptors, size_t desc_pitch, void* stream);
+/* EfficientDescriptorsAsync::computeAsync, 5xN keypoint matrix on the device (size forced to 31). */
+int efx_describer_compute_async(efx_describer* d, const uint8_t* d_image, int rows, int cols, size_t pitch,
+                                const void* d_keypoints, size_t kps_pitch, int n,
+                                uint8_t* d_descriptors, size_t desc_pitch, void* stream);
+/* EfficientDescriptorsAsync::compute, host image + keypoint structs. */
+int efx_describer_compute(efx_describer* d, const uint8_t* h_image, int rows, int cols, size_t pitch,
+                          const efx_keypoint* keypoints, int n, uint8_t* h_descriptors, size_t desc_pitch);
+
+/* HashSIFT intermediate results for tolerance-based parity tests: the 129-vectors
+ * (computePatchSIFTs, hash_sift.cpp:333-351) and the pre-threshold projections T (matmulAndSign :353-378).
+ * d_responses: n x 129 floats (may be NULL); d_T: n x nbits floats (may be NULL). */
+int efx_describer_hashsift_debug_async(efx_describer* d, const uint8_t* d_image, int rows, int cols, size_t pitch,
+                                       const float* d_kp4, int n, float max_size,
+                                       float* d_responses, float* d_T, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ */
+/* introspection used by the parity tests (no reference equivalent)                                  */
+
+/* Geometry of pyramid level `level` for a rows x cols frame with the context's parameters
+ * (calcImagePyramid, cuda_efficient_features.cpp:136-157). */
+int efx_level_geometry(const efx_context* ctx, int rows, int cols, int level, int* lrows, int* lcols, float* scale);
+/* Copies pyramid level `level` of the LAST processed frame into d_dst (tight rows x cols, dst_pitch bytes). */
+int efx_copy_level_async(efx_context* ctx, int level, uint8_t* d_dst, size_t dst_pitch, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EFX_H */

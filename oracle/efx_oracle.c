@@ -32,14 +32,17 @@ static uint8_t sat_u8_f(float v)
 
 void efxo_integral(const uint8_t* img, int rows, int cols, int stride, int32_t* out)
 {
-    /* cv::integral(CV_8U -> CV_32S): out[(y+1)][(x+1)] = sum_{v<=y,u<=x} img[v][u]  (bad.cpp:286) */
+    /* cv::integral(CV_8U -> CV_32S): out[(y+1)][(x+1)] = sum_{v<=y,u<=x} img[v][u]  (bad.cpp:286).
+     * CV_32S wraps for frames above ~8.4 Mpx of bright pixels (8K); sums are taken mod 2^32 (unsigned
+     * arithmetic, defined behaviour) so that box differences stay exact, as they do in OpenCV. */
     const int ow = cols + 1;
+    uint32_t* o32 = (uint32_t*)out;
     memset(out, 0, sizeof(int32_t) * (size_t)ow);
     for (int y = 0; y < rows; y++) {
-        int32_t* o = out + (size_t)(y + 1) * ow;
-        const int32_t* up = out + (size_t)y * ow;
+        uint32_t* o = o32 + (size_t)(y + 1) * ow;
+        const uint32_t* up = o32 + (size_t)y * ow;
         const uint8_t* p = img + (size_t)y * stride;
-        int32_t run = 0;
+        uint32_t run = 0;
         o[0] = 0;
         for (int x = 0; x < cols; x++) {
             run += p[x];
@@ -119,16 +122,17 @@ static float bad_response_clamped(const box_t* bp, const int32_t* I, int fw, int
 {
     int x1, y1, x2, y2;
     clamp_box(bp->x1, bp->y1, bp->r, fw, fh, &x1, &y1, &x2, &y2);
-    int A = I[(size_t)y1 * fw + x1], B = I[(size_t)y1 * fw + x2];
-    int C = I[(size_t)y2 * fw + x1], D = I[(size_t)y2 * fw + x2];
-    const float sum1 = (float)(A + D - B - C);
+    const uint32_t* U = (const uint32_t*)I;     /* box sums mod 2^32: exact whenever the true sum fits */
+    uint32_t A = U[(size_t)y1 * fw + x1], B = U[(size_t)y1 * fw + x2];
+    uint32_t C = U[(size_t)y2 * fw + x1], D = U[(size_t)y2 * fw + x2];
+    const float sum1 = (float)(int32_t)(A + D - B - C);
     const int area1 = (y2 - y1) * (x2 - x1);
     const float avg1 = sum1 / (float)area1;
 
     clamp_box(bp->x2, bp->y2, bp->r, fw, fh, &x1, &y1, &x2, &y2);
-    A = I[(size_t)y1 * fw + x1]; B = I[(size_t)y1 * fw + x2];
-    C = I[(size_t)y2 * fw + x1]; D = I[(size_t)y2 * fw + x2];
-    const float sum2 = (float)(A + D - B - C);
+    A = U[(size_t)y1 * fw + x1]; B = U[(size_t)y1 * fw + x2];
+    C = U[(size_t)y2 * fw + x1]; D = U[(size_t)y2 * fw + x2];
+    const float sum2 = (float)(int32_t)(A + D - B - C);
     const int area2 = (y2 - y1) * (x2 - x1);
     const float avg2 = sum2 / (float)area2;
     return avg1 - avg2;
@@ -173,10 +177,11 @@ void efxo_bad_compute(const uint8_t* img, int rows, int cols, int stride,
                 const int bx1 = clampi(bp[b].x2 - r, 0, fw - 1), by1 = clampi(bp[b].y2 - r, 0, fh - 1);
                 const int bx2 = clampi(bp[b].x2 + r + 1, 0, fw - 1), by2 = clampi(bp[b].y2 + r + 1, 0, fh - 1);
                 const int side = 1 + (r << 1);
-                const int area_resp = (I[(size_t)ay1 * fw + ax1] + I[(size_t)ay2 * fw + ax2]
-                                     - I[(size_t)ay1 * fw + ax2] - I[(size_t)ay2 * fw + ax1]
-                                     - I[(size_t)by1 * fw + bx1] - I[(size_t)by2 * fw + bx2]
-                                     + I[(size_t)by1 * fw + bx2] + I[(size_t)by2 * fw + bx1]);
+                const uint32_t* U = (const uint32_t*)I;
+                const int area_resp = (int32_t)(U[(size_t)ay1 * fw + ax1] + U[(size_t)ay2 * fw + ax2]
+                                     - U[(size_t)ay1 * fw + ax2] - U[(size_t)ay2 * fw + ax1]
+                                     - U[(size_t)by1 * fw + bx1] - U[(size_t)by2 * fw + bx2]
+                                     + U[(size_t)by1 * fw + bx2] + U[(size_t)by2 * fw + bx1]);
                 byte |= (uint8_t)(((float)area_resp <= (thresholds[b] * (float)(side * side))) << bit);
                 if (bit == 0) { *d++ = byte; byte = 0; }
             }

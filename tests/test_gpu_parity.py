@@ -1,0 +1,299 @@
+"""GPU parity tests (run with -m gpu on the MI355X box): the HIP path, called through the C ABI, against the
+CPU oracle on the same seeded inputs.  Integer / byte / index results must be bit-exact; HashSIFT has a stated
+float tolerance before thresholding (reference tests: tests/descriptor_test.cpp:19-75, which allow 2e-5 / 1e-4
+differing bytes GPU-vs-CPU; here BAD must be exact)."""
+import numpy as np
+import pytest
+
+from tools import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cef():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import cef_loader
+    return cef_loader.load()
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    return torch
+
+
+def _dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _detect_both(cef, torch, oracle, img, desc_type=-1, **kw):
+    nfeatures = kw.get("nfeatures", 5000)
+    det = cef.EfficientFeatures.create(nfeatures, kw.get("scale_factor", 1.2), kw.get("nlevels", 8),
+                                       kw.get("first_level", 0), kw.get("fast_threshold", 20),
+                                       kw.get("nonmax_radius", 15), max(desc_type, 0))
+    d_img = _dev(torch, img)
+    if desc_type >= 0:
+        kps, desc, cnt = det.detectAndComputeAsync(d_img)
+    else:
+        kps, cnt = det.detectAsync(d_img)
+        desc = None
+    torch.cuda.synchronize()
+    n = int(cnt.item())
+    assert det.lastCount() == n
+    ref = oracle.detect_and_compute(img, desc_type=desc_type, **kw)
+    got = dict(n=n, kps=kps[:, :n].cpu().numpy(), desc=None if desc is None else desc[:n].cpu().numpy(),
+               stats=det.lastLevelStats(), det=det)
+    return got, ref
+
+
+def _assert_same_keypoints(got, ref):
+    st = got["stats"]
+    for l, s in enumerate(st):
+        assert s["n_candidates"] == ref["stats"]["n_candidates"][l], f"level {l}: FAST corner count"
+        assert s["n_after_nms"] == ref["stats"]["n_after_nms"][l], f"level {l}: NMS survivor count"
+        assert s["n_kept"] == ref["stats"]["n_kept"][l], f"level {l}: kept count"
+    assert got["n"] == ref["n"]
+    g, r = got["kps"].view(np.uint32), ref["kps"].view(np.uint32)
+    for row, name in enumerate(["location", "response", "angle", "octave", "size"]):
+        bad = np.nonzero(g[row] != r[row])[0]
+        assert bad.size == 0, f"{name} row differs at {bad[:8]} (of {bad.size}); got {got['kps'][row][bad[:4]]} want {ref['kps'][row][bad[:4]]}"
+
+
+@pytest.mark.parametrize("shape", [(480, 640), (501, 703), (1080, 1920)])
+def test_pyramid_levels_bit_exact(cef, torch_mod, oracle, shape):
+    """Spec S5 resize chain (cuda_efficient_features.cpp:136-157)."""
+    img = synth.synth_frame(shape[0], shape[1], seed=11)
+    det = cef.EfficientFeatures.create(1000)
+    det.detectAsync(_dev(torch_mod, img))
+    torch_mod.cuda.synchronize()
+    for level in range(8):
+        got = det.copyLevel(level, shape[0], shape[1]).cpu().numpy()
+        want = oracle.pyramid_level(img, level)
+        assert got.shape == want.shape
+        assert np.array_equal(got, want), f"level {level}: {np.count_nonzero(got != want)} pixels differ"
+
+
+@pytest.mark.parametrize("shape,nfeatures", [((480, 640), 1000), ((501, 703), 5000), ((1080, 1920), 40000), ((1080, 1920), 2000)])
+def test_detect_bit_exact(cef, torch_mod, oracle, shape, nfeatures):
+    """detectAsync == oracle: same keypoints, same canonical order, all five rows bit for bit."""
+    img = synth.synth_frame(shape[0], shape[1], seed=1000)
+    got, ref = _detect_both(cef, torch_mod, oracle, img, nfeatures=nfeatures)
+    _assert_same_keypoints(got, ref)
+
+
+def test_detect_unaligned_pitch(cef, torch_mod, oracle):
+    """A view with an odd row pitch takes the byte-load path of the tile loader."""
+    img = synth.synth_frame(400, 601, seed=5)
+    big = np.zeros((400, 777), np.uint8)
+    big[:, 3:604] = img
+    d = _dev(torch_mod, big)[:, 3:604]
+    det = cef.EfficientFeatures.create(3000)
+    kps, cnt = det.detectAsync(d)
+    torch_mod.cuda.synchronize()
+    n = int(cnt.item())
+    ref = oracle.detect_and_compute(img, nfeatures=3000)
+    assert n == ref["n"]
+    assert np.array_equal(kps[:, :n].cpu().numpy().view(np.uint32), ref["kps"].view(np.uint32))
+
+
+@pytest.mark.parametrize("kw", [dict(first_level=2), dict(nlevels=4), dict(nonmax_radius=0), dict(nonmax_radius=5),
+                                dict(nonmax_radius=16), dict(nonmax_radius=33), dict(fast_threshold=5),
+                                dict(fast_threshold=60), dict(scale_factor=1.5, nlevels=5), dict(nlevels=1)])
+def test_detect_parameters(cef, torch_mod, oracle, kw):
+    img = synth.synth_frame(600, 800, seed=21)
+    got, ref = _detect_both(cef, torch_mod, oracle, img, nfeatures=3000, **kw)
+    _assert_same_keypoints(got, ref)
+
+
+def test_candidate_cap_on_noise(cef, torch_mod, oracle):
+    """> 10 % FAST corners: the cap is applied in canonical order (spec S2, cuda_fast.cu:245)."""
+    img = synth.noise_frame(300, 400, seed=7)
+    got, ref = _detect_both(cef, torch_mod, oracle, img, nfeatures=5000)
+    assert any(c > k for c, k in zip(ref["stats"]["n_candidates"], ref["stats"]["n_after_cap"])), "cap not exercised"
+    _assert_same_keypoints(got, ref)
+
+
+def test_tiny_and_empty(cef, torch_mod, oracle):
+    flat = np.full((200, 300), 77, np.uint8)
+    got, ref = _detect_both(cef, torch_mod, oracle, flat, nfeatures=500)
+    assert got["n"] == 0 and ref["n"] == 0
+    small = synth.synth_frame(40, 50, seed=3)          # upper levels have no pixel inside the 15-px border
+    got, ref = _detect_both(cef, torch_mod, oracle, small, nfeatures=500)
+    _assert_same_keypoints(got, ref)
+
+
+def test_capacity_smaller_than_n(cef, torch_mod, oracle):
+    img = synth.synth_frame(480, 640, seed=1000)
+    det = cef.EfficientFeatures.create(5000)
+    kps, cnt = det.detectAsync(_dev(torch_mod, img), capacity=100)
+    torch_mod.cuda.synchronize()
+    assert int(cnt.item()) == 100
+    ref = oracle.detect_and_compute(img, nfeatures=5000, capacity=100)
+    assert np.array_equal(kps[:, :100].cpu().numpy().view(np.uint32), ref["kps"].view(np.uint32))
+
+
+@pytest.mark.parametrize("desc_type", [0, 1])
+@pytest.mark.parametrize("shape", [(480, 640), (1080, 1920)])
+def test_detect_and_compute_bad_bit_exact(cef, torch_mod, oracle, desc_type, shape):
+    """detectAndCompute: blurred level (spec S6) + BAD at level coordinates (cuda_efficient_features.cpp:302-307)."""
+    img = synth.synth_frame(shape[0], shape[1], seed=1001)
+    got, ref = _detect_both(cef, torch_mod, oracle, img, desc_type=desc_type, nfeatures=8000)
+    _assert_same_keypoints(got, ref)
+    bad = np.nonzero((got["desc"] != ref["desc"]).any(axis=1))[0]
+    assert bad.size == 0, f"{bad.size} of {got['n']} descriptors differ, first rows {bad[:8]}"
+
+
+@pytest.mark.parametrize("nbits", [256, 512])
+def test_compute_bad_random_keypoints(cef, torch_mod, oracle, nbits):
+    """compute(): bit-exact BAD bytes for identical (image, x, y, size, angle), including border keypoints,
+    angle == -1 and angle < 0 (bad.cpp:127,138; tests/descriptor_test.cpp:19-46)."""
+    img = synth.synth_frame(480, 640, seed=4)
+    kps = synth.random_keypoints(480, 640, 3000, seed=9)
+    enum = cef.BAD.SIZE_256_BITS if nbits == 256 else cef.BAD.SIZE_512_BITS
+    bad = cef.BAD.create(1.0, enum)
+    got = bad.compute(img, kps)
+    want = oracle.bad_compute(img, kps, nbits)
+    diff = np.nonzero((got != want).any(axis=1))[0]
+    assert diff.size == 0, f"{diff.size} descriptors differ, first {diff[:8]}, kps {kps[diff[:4]]}"
+
+
+def test_compute_bad_matches_reference_hash(cef):
+    """The SURVEY Appendix B known-answer vector of the reference CPU code, through the HIP path."""
+    from tests.lcg_probe import REFERENCE_HASHES, fnv1a32, probe_input
+    img, kps = probe_input()
+    for nbits, enum in ((256, cef.BAD.SIZE_256_BITS), (512, cef.BAD.SIZE_512_BITS)):
+        got = cef.BAD.create(1.0, enum).compute(img, kps)
+        assert fnv1a32(got) == REFERENCE_HASHES[("bad", nbits)]
+
+
+@pytest.mark.parametrize("size,scale", [(31.0, 1.0), (12.0, 1.0), (64.0, 1.0), (31.0, 2.5), (5.0, 5.0)])
+def test_compute_bad_sizes(cef, oracle, size, scale):
+    img = synth.synth_frame(480, 640, seed=6)
+    kps = synth.random_keypoints(480, 640, 800, seed=13, size=size)
+    got = cef.BAD.create(scale, cef.BAD.SIZE_256_BITS).compute(img, kps)
+    want = oracle.bad_compute(img, kps, 256, scale_factor=scale)
+    assert np.array_equal(got, want)
+
+
+def test_compute_async_5xn_forces_size_31(cef, torch_mod, oracle):
+    """computeAsync on the detector's 5xN matrix: size forced to 31, raw image, no blur
+    (cuda_efficient_features.cpp:102-115, .cu:250-263; sample_benchmark.cpp:132-141)."""
+    img = synth.synth_frame(480, 640, seed=1000)
+    det = cef.EfficientFeatures.create(3000, dtype=cef.EfficientFeatures.BAD_512)
+    d_img = _dev(torch_mod, img)
+    kps, cnt = det.detectAsync(d_img)
+    torch_mod.cuda.synchronize()
+    n = int(cnt.item())
+    desc = det.computeAsync(d_img, kps, n=n)
+    torch_mod.cuda.synchronize()
+    k = cef.unpack_keypoints(kps[:, :n].cpu().numpy())
+    kp4 = np.stack([k["x"].astype(np.float32), k["y"].astype(np.float32), np.full(n, 31, np.float32), k["angle"]], axis=1)
+    want = oracle.bad_compute(img, kp4, 512)
+    assert np.array_equal(desc.cpu().numpy(), want)
+
+
+# ---- HashSIFT: float tolerance before thresholding ----
+HS_T_ABS_TOL = 2e-2      # |T_hip - T_oracle|; T is a sum of 129 products of magnitude <= 255 * |w|
+HS_VEC_FRAC = 2e-3       # fraction of 129-vector elements allowed to differ by exactly 1 (atan2f / libm last-ulp)
+
+
+@pytest.mark.parametrize("nbits", [256, 512])
+def test_hashsift_compute_tolerance(cef, torch_mod, oracle, nbits):
+    img = synth.synth_frame(480, 640, seed=4)
+    kps = synth.random_keypoints(480, 640, 2000, seed=17)
+    enum = cef.HashSIFT.SIZE_256_BITS if nbits == 256 else cef.HashSIFT.SIZE_512_BITS
+    hs = cef.HashSIFT.create(1.0, enum)
+    d_img = _dev(torch_mod, img)
+    d_k = _dev(torch_mod, kps)
+    resp, T = hs.debug(d_img, d_k, max_size=31.0)
+    desc = hs.computeAsync(d_img, d_k, max_size=31.0)
+    torch_mod.cuda.synchronize()
+    resp, T, desc = resp.cpu().numpy(), T.cpu().numpy(), desc.cpu().numpy()
+    want_resp = oracle.hashsift_responses(img, kps)
+    want_T, want_desc = oracle.hashsift_project(want_resp, nbits)
+    d = np.abs(resp - want_resp)
+    assert d.max() <= 1.0, f"129-vector element off by {d.max()}"
+    assert (d > 0).mean() <= HS_VEC_FRAC, f"{(d > 0).mean():.2e} of the 129-vector elements differ"
+    # projection of identical vectors: fp32 FMA chain (MFMA) vs double accumulation
+    same = (d == 0).all(axis=1)
+    assert np.abs(T[same] - want_T[same]).max() <= HS_T_ABS_TOL
+    # bits must agree wherever |T| exceeds the tolerance
+    bits = np.unpackbits(desc, axis=1).astype(bool)
+    wbits = np.unpackbits(want_desc, axis=1).astype(bool)
+    decided = np.abs(want_T) > HS_T_ABS_TOL
+    assert np.array_equal(bits[same][decided[same]], wbits[same][decided[same]])
+    # and overall the reference's own tolerance (1e-4 of the bytes, descriptor_test.cpp:72) must hold
+    assert np.count_nonzero(desc != want_desc) <= max(1, int(1e-4 * desc.size))
+    # packed bits must be exactly sign(T) of the HIP path
+    assert np.array_equal(bits, T > 0)
+
+
+@pytest.mark.parametrize("desc_type", [2, 3])
+def test_detect_and_compute_hashsift(cef, torch_mod, oracle, desc_type):
+    img = synth.synth_frame(480, 640, seed=1002)
+    got, ref = _detect_both(cef, torch_mod, oracle, img, desc_type=desc_type, nfeatures=4000)
+    _assert_same_keypoints(got, ref)
+    assert np.count_nonzero(got["desc"] != ref["desc"]) <= max(1, int(1e-4 * got["desc"].size))
+
+
+def test_host_api_round_trip(cef, oracle):
+    """detect / compute / detectAndCompute with host images (cv::Mat branch, cuda_efficient_features.cpp:197-213)."""
+    img = synth.synth_frame(480, 640, seed=1000)
+    det = cef.EfficientFeatures.create(3000, dtype=cef.EfficientFeatures.BAD_256)
+    kps = det.detect(img)
+    ref = oracle.detect_and_compute(img, nfeatures=3000)
+    k = oracle.unpack_keypoints(ref["kps"])
+    assert len(kps) == ref["n"]
+    assert np.array_equal(kps["x"], k["x"].astype(np.float32)) and np.array_equal(kps["y"], k["y"].astype(np.float32))
+    assert np.array_equal(kps["angle"], k["angle"]) and np.array_equal(kps["octave"], k["octave"])
+    assert np.array_equal(kps["size"], k["size"]) and np.array_equal(kps["response"], k["response"])
+    assert (kps["class_id"] == -1).all()
+    # compute() honours kp.size (cuda_efficient_features.cpp:125): level-0 coordinates, scaled sizes, raw image
+    desc = det.compute(img, kps)
+    kp4 = np.stack([kps["x"], kps["y"], kps["size"], kps["angle"]], axis=1)
+    assert np.array_equal(desc, oracle.bad_compute(img, kp4, 256))
+    kps2, desc2 = det.detectAndCompute(img)
+    ref2 = oracle.detect_and_compute(img, nfeatures=3000, desc_type=oracle.BAD_256)
+    assert len(kps2) == ref2["n"] and np.array_equal(desc2, ref2["desc"])
+
+
+def test_errors(cef, torch_mod):
+    det = cef.EfficientFeatures.create(100)
+    with pytest.raises(cef.EfxError):
+        det.detect(np.zeros((10, 10, 3), np.uint8))           # not 8UC1
+    with pytest.raises(cef.EfxError):
+        det.detectAndCompute(np.zeros((64, 64), np.uint8), useProvidedKeypoints=True)
+    with pytest.raises(cef.EfxError):
+        det.setNLevels(0)
+    with pytest.raises(cef.EfxError):
+        cef.BAD.create(1.0, 123)                              # n_bits should be SIZE_512_BITS or SIZE_256_BITS
+    with pytest.raises(cef.EfxError):
+        det.computeAsync(torch_mod.zeros((64, 64), dtype=torch_mod.uint8, device="cuda"),
+                         torch_mod.zeros((4, 10), dtype=torch_mod.float32, device="cuda"))
+    # setters / getters round trip (cuda_efficient_features.cpp:355-379)
+    det.setMaxFeatures(123); det.setScaleFactor(1.3); det.setNLevels(5); det.setFirstLevel(1)
+    det.setFastThreshold(11); det.setNonmaxRadius(7); det.setDescriptorType(cef.EfficientFeatures.BAD_512)
+    assert (det.getMaxFeatures(), det.getNLevels(), det.getFirstLevel(), det.getFastThreshold(), det.getNonmaxRadius(),
+            det.getDescriptorType()) == (123, 5, 1, 11, 7, 1)
+    assert abs(det.getScaleFactor() - 1.3) < 1e-6
+    assert det.descriptorSize() == 64 and det.descriptorType() == 0 and det.defaultNorm() == 6
+
+
+def test_determinism(cef, torch_mod):
+    """Same frame twice on the same context and on a fresh one: identical bytes (the reference's atomic
+    append order is nondeterministic; ours is canonical)."""
+    img = synth.synth_frame(720, 1280, seed=1003)
+    d_img = _dev(torch_mod, img)
+    outs = []
+    det = cef.EfficientFeatures.create(6000, dtype=cef.EfficientFeatures.BAD_256)
+    for i in range(3):
+        if i == 2:
+            det = cef.EfficientFeatures.create(6000, dtype=cef.EfficientFeatures.BAD_256)
+        kps, desc, cnt = det.detectAndComputeAsync(d_img)
+        torch_mod.cuda.synchronize()
+        n = int(cnt.item())
+        outs.append((n, kps[:, :n].cpu().numpy().tobytes(), desc[:n].cpu().numpy().tobytes()))
+    assert outs[0] == outs[1] == outs[2]
