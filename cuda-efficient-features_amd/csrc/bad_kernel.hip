@@ -246,12 +246,12 @@ hipError_t efx_launch_bad(const DescribeLaunch& a, const BadParamsDev* d_params,
     float t[7];
     efx_gaussian_taps_host(t);
     if (a.blur) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&bad_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bad_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(bad_kernel<true>, dim3(a.n), dim3(256), lds, stream, a.img0, a.pitch0, a.rows0, a.cols0, a.pyramid,
                            a.d_table, a.kp4, a.kp_level, a.d_count, a.n, a.scale_factor, S, d_params, t[0], t[1], t[2], t[3],
                            a.desc, a.desc_pitch);
     } else {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&bad_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bad_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(bad_kernel<false>, dim3(a.n), dim3(256), lds, stream, a.img0, a.pitch0, a.rows0, a.cols0, a.pyramid,
                            a.d_table, a.kp4, a.kp_level, a.d_count, a.n, a.scale_factor, S, d_params, t[0], t[1], t[2], t[3],
                            a.desc, a.desc_pitch);

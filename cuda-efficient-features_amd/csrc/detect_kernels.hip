@@ -324,7 +324,6 @@ __global__ __launch_bounds__(256) void nms_kernel(const LevelTable* __restrict__
     const LevelDev& L = T->lv[l];
     if (!L.active) return;
     const int tile = gt - L.tile_base;
-    const int tx = tile % L.tiles_x, ty = tile / L.tiles_x;
     TileHdr* hl = hdr + L.tile_base;
     const TileHdr& h = hl[tile];
     const Corner* cand = cand_all + L.cand_base;

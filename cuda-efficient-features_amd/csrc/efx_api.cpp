@@ -38,7 +38,7 @@ struct DevBuf {                     // grow-only device allocation
         if (e == hipSuccess) bytes = n;
         return e;
     }
-    void release() { if (p) hipFree(p); p = nullptr; bytes = 0; }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
 };
 
 struct Describer {                  // cuda::BAD / cuda::HashSIFT state
@@ -104,7 +104,7 @@ int describer_init(Describer& d, int kind, int nbits, float scale)
     } else {
         // HashSIFTImpl ctor, hash_sift.cpp:384-397: Mat(nbits,129,CV_64F).convertTo(CV_32F)
         const double* w64 = reinterpret_cast<const double*>(nbits == 256 ? efx_blob_hashsift256 : efx_blob_hashsift512);
-        std::vector<float> w((size_t)nbits * HS_KPAD + 900, 0.f);
+        std::vector<float> w((size_t)nbits * HS_KPAD + 900 + 511 * 511, 0.f);
         for (int j = 0; j < nbits; j++)
             for (int k = 0; k < 129; k++) w[(size_t)j * HS_KPAD + k] = (float)w64[(size_t)j * 129 + k];
         // Gaussian pixel weights of computePatchSIFT (hash_sift.cpp:220-224,247): host expf, same call as the CPU code
@@ -118,6 +118,15 @@ int describer_init(Describer& d, int kind, int nbits, float scale)
                 const float ddx = (float)x - cx, ddy = (float)y - cy;
                 w[(size_t)nbits * HS_KPAD + y * 30 + x] = expf(dist_scale * (ddx * ddx + ddy * ddy));
             }
+        // orientation bins scaleO * atan2f(dy, dx) for every integer gradient (hash_sift.cpp:171,254,258)
+        {
+            const float PI_2 = (float)6.283185307179586476925286766559;
+            const float scaleO = (float)8 / PI_2;
+            float* lut = w.data() + (size_t)nbits * HS_KPAD + 900;
+            for (int dy = -255; dy <= 255; dy++)
+                for (int dx = -255; dx <= 255; dx++)
+                    lut[(dy + 255) * 511 + (dx + 255)] = scaleO * atan2f((float)dy, (float)dx);
+        }
         hipError_t e = d.params.reserve(w.size() * sizeof(float));
         if (e == hipSuccess) e = hipMemcpy(d.params.p, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice);
         if (e != hipSuccess) return set_err(d.err, EFX_ERR_HIP, "HashSIFT weight upload failed: %s", hipGetErrorString(e));
@@ -177,7 +186,7 @@ struct efx_context {
     {
         d_table.release(); pyramid.release(); hdr.release(); cand.release(); surv.release(); counters.release();
         kp4.release(); kp_level.release(); img.release(); kps.release(); descout.release(); count.release();
-        if (h_mirror) hipHostFree(h_mirror);
+        if (h_mirror) (void)hipHostFree(h_mirror);
     }
 };
 

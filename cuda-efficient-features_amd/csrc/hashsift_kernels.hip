@@ -11,8 +11,9 @@
 //     and visits its pixels in raster order, i.e. every bin sees its additions in exactly the order of the
 //     serial CPU loop (hash_sift.cpp:233-290) -- the reference's CUDA kernel uses shared-memory atomics
 //     (cuda_hash_sift.cu:282-289) and is order-nondeterministic;
-//   * the Gaussian pixel weights expf(...) are a 30x30 table computed on the host with the same libm call
-//     the CPU code makes; sqrtf is IEEE; atan2f/cosf/sinf are the device versions (tolerance: DESIGN.md);
+//   * the Gaussian pixel weights expf(...) (30x30) and the orientation bins scaleO*atan2f(dy,dx) (511x511
+//     integer gradients) are tables computed on the host with the same libm calls the CPU code makes;
+//     sqrtf is IEEE; cosf/sinf of the keypoint angle are taken as the rounded double result;
 //   * projection T = R[N x 129] . W^T is the one real GEMM of the path: v_mfma_f32_32x32x2_f32 (exact fp32
 //     FMA chain), fused with the sign test and MSB-first bit packing (no T matrix in HBM, no separate
 //     binarize pass as in cuda_hash_sift.cu:414-435).
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(256) void patch_sift_kernel(
     const uint8_t* __restrict__ img0, int pitch0, int rows0, int cols0,
     const uint8_t* __restrict__ pyramid, const LevelTable* __restrict__ T,
     const float4* __restrict__ kp4, const int* __restrict__ kp_level, const int* __restrict__ d_count, int n,
-    float crop_scale, int smax, const float* __restrict__ mag_scale /*30*30*/,
+    float crop_scale, int smax, const float* __restrict__ mag_scale /*30*30*/, const float* __restrict__ obin_lut /*511*511*/,
     float taps0, float taps1, float taps2, float taps3,
     float* __restrict__ responses /* n x HS_KPAD */, float* __restrict__ dbg_responses /* n x 129 or null */)
 {
@@ -78,8 +79,10 @@ __global__ __launch_bounds__(256) void patch_sift_kernel(
         const float PI_1 = (float)3.1415926535897932384626433832795;
         const float s = crop_scale * size / (0.5f * (float)(32 + 32));
         const float theta = PI_1 * angle / 180;
-        const float cost = s * (angle >= 0 ? cosf(theta) : 1.f);
-        const float sint = s * (angle >= 0 ? sinf(theta) : 0.f);
+        // cosf/sinf of the CPU code: evaluated in double and rounded, i.e. the correctly rounded float
+        // result (the device's float versions are a few ulp off, which occasionally flips a patch pixel)
+        const float cost = s * (angle >= 0 ? (float)cos((double)theta) : 1.f);
+        const float sint = s * (angle >= 0 ? (float)sin((double)theta) : 0.f);
         AffineF A;
         A.m00 = +cost; A.m01 = -sint; A.m02 = (-cost + sint) * (float)32 / 2.f + px;
         A.m10 = +sint; A.m11 = +cost; A.m12 = (-sint - cost) * (float)32 / 2.f + py;
@@ -176,16 +179,15 @@ __global__ __launch_bounds__(256) void patch_sift_kernel(
 
     // gradients, magnitude, orientation of the 30x30 interior (hash_sift.cpp:244-260)
     {
-        const float PI_2 = (float)6.283185307179586476925286766559;
-        const float scaleO = (float)8 / PI_2;
         for (int i = tid; i < 900; i += 256) {
             const int y = i / 30, x = i % 30;           // patch pixel (x+1, y+1)
             const uint8_t* pc = s_patch + (y + 1) * 32 + (x + 1);
-            const float dx = (float)((int)pc[1] - (int)pc[-1]);
-            const float dy = (float)((int)pc[-32] - (int)pc[32]);
+            const int idx = (int)pc[1] - (int)pc[-1], idy = (int)pc[-32] - (int)pc[32];
+            const float dx = (float)idx, dy = (float)idy;
             const float mag = mag_scale[i] * sqrtf(dx * dx + dy * dy);
-            const float ori = atan2f(dy, dx);
-            const float obin = scaleO * ori;
+            // scaleO * atan2f(dy, dx): dx, dy are integers in [-255, 255], so the host tabulates the CPU
+            // code's own libm result for all 511 x 511 gradients (hash_sift.cpp:254,258)
+            const float obin = obin_lut[(idy + 255) * 511 + (idx + 255)];
             int oi = (int)floorf(obin);
             const float of = obin - (float)oi;
             if (oi < 0) oi += 8;
@@ -299,7 +301,7 @@ __global__ __launch_bounds__(256) void project_sign_kernel(const float* __restri
             const int i = m0 + row + 4 * lk;
             if (i < count) { dbg_T[(size_t)i * nbits + n0 + li] = acc0[r]; dbg_T[(size_t)i * nbits + n0 + 32 + li] = acc1[r]; }
         }
-        if (lane < 4) {
+        if (desc != nullptr && lane < 4) {
             // lane 0/1: rows `row` (bits n0.., n0+32..), lane 2/3: rows `row+4`
             const int hi = lane >> 1, second = lane & 1;
             const unsigned long long m = second ? bb : ba;
@@ -337,14 +339,15 @@ hipError_t efx_launch_hashsift(const DescribeLaunch& a, const HashSiftDev& h, hi
     float t[7];
     efx_gaussian_taps_host(t);
     const float* mag = h.W + (size_t)h.nbits * HS_KPAD;    // the 30x30 weight table is stored behind W
+    const float* lut = mag + 900;                          // followed by the 511x511 orientation-bin table
     if (a.blur) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_sift_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_sift_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(patch_sift_kernel<true>, dim3(a.n), dim3(256), lds, stream, a.img0, a.pitch0, a.rows0, a.cols0,
-                           a.pyramid, a.d_table, a.kp4, a.kp_level, a.d_count, a.n, a.scale_factor, S, mag,
+                           a.pyramid, a.d_table, a.kp4, a.kp_level, a.d_count, a.n, a.scale_factor, S, mag, lut,
                            t[0], t[1], t[2], t[3], h.responses, h.dbg_responses);
     } else {
         hipLaunchKernelGGL(patch_sift_kernel<false>, dim3(a.n), dim3(256), 0, stream, a.img0, a.pitch0, a.rows0, a.cols0,
-                           a.pyramid, a.d_table, a.kp4, a.kp_level, a.d_count, a.n, a.scale_factor, S, mag,
+                           a.pyramid, a.d_table, a.kp4, a.kp_level, a.d_count, a.n, a.scale_factor, S, mag, lut,
                            t[0], t[1], t[2], t[3], h.responses, h.dbg_responses);
     }
     if (a.desc || h.dbg_T) {

@@ -67,7 +67,8 @@ def test_pyramid_levels_bit_exact(cef, torch_mod, oracle, shape):
     """Spec S5 resize chain (cuda_efficient_features.cpp:136-157)."""
     img = synth.synth_frame(shape[0], shape[1], seed=11)
     det = cef.EfficientFeatures.create(1000)
-    det.detectAsync(_dev(torch_mod, img))
+    d_img = _dev(torch_mod, img)            # level 0 aliases the caller's image: keep it alive
+    det.detectAsync(d_img)
     torch_mod.cuda.synchronize()
     for level in range(8):
         got = det.copyLevel(level, shape[0], shape[1]).cpu().numpy()
@@ -196,8 +197,11 @@ def test_compute_async_5xn_forces_size_31(cef, torch_mod, oracle):
 
 
 # ---- HashSIFT: float tolerance before thresholding ----
-HS_T_ABS_TOL = 2e-2      # |T_hip - T_oracle|; T is a sum of 129 products of magnitude <= 255 * |w|
-HS_VEC_FRAC = 2e-3       # fraction of 129-vector elements allowed to differ by exactly 1 (atan2f / libm last-ulp)
+HS_T_ABS_TOL = 2e-3      # |T_hip - T_oracle| for identical 129-vectors: fp32 FMA chain (MFMA) vs double accumulation
+                         # of 129 products; |T| is typically ~15, at most ~400; measured max 2.2e-4
+HS_VEC_FRAC = 1e-4       # fraction of 129-vector elements allowed to differ (cosf/sinf of the keypoint angle are
+                         # taken as rounded double results; expf and atan2f are host tables, sqrtf is IEEE)
+HS_VEC_MAX = 4.0         # a one-grey-level flip of a patch pixel moves an element by a few units
 
 
 @pytest.mark.parametrize("nbits", [256, 512])
@@ -215,7 +219,7 @@ def test_hashsift_compute_tolerance(cef, torch_mod, oracle, nbits):
     want_resp = oracle.hashsift_responses(img, kps)
     want_T, want_desc = oracle.hashsift_project(want_resp, nbits)
     d = np.abs(resp - want_resp)
-    assert d.max() <= 1.0, f"129-vector element off by {d.max()}"
+    assert d.max() <= HS_VEC_MAX, f"129-vector element off by {d.max()}"
     assert (d > 0).mean() <= HS_VEC_FRAC, f"{(d > 0).mean():.2e} of the 129-vector elements differ"
     # projection of identical vectors: fp32 FMA chain (MFMA) vs double accumulation
     same = (d == 0).all(axis=1)
