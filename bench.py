@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""bench.py -- the reference's headline benchmark on MI355X.
+
+Metric (BASELINE.json): Mkeypoints/s of detectAndCompute on 8K frames, 40 000 keypoints requested, BAD512,
+reference defaults otherwise (8 levels, scale 1.2, FAST threshold 20, NMS radius 15) -- the protocol of
+samples/sample_benchmark.cpp:104-142 (input already resident on the device, async call + stream sync).
+
+A "step" is one pass of the hot path over one batch of FRAMES_PER_STEP independent synthetic 8K frames
+(seeds 1000+k, BASELINE.json configs[4]: 64 frames over 8 GPUs = 8 per GPU).  Frames shard across ranks with
+no data-path collective (weak scaling); RCCL is used only to reduce the timing / keypoint counters.
+
+Output: ONE JSON line on rank 0 (driver contract) with `roofline` (dominant kernel = pyramid+FAST+Harris,
+HBM bound, timed live with HIP events on the launch stream) and `cpu_baseline` (the oracle timed on the
+host cores, rank 0, N=1 only, one 8K frame).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ROWS, COLS = 4320, 7680            # 8K
+NFEATURES = 40000
+HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def detect_algorithmic_bytes(det, rows, cols, nlevels=8):
+    """every level read once + every derived level written once, per frame."""
+    px = [det.levelGeometry(rows, cols, l)[0] * det.levelGeometry(rows, cols, l)[1] for l in range(nlevels)]
+    per_level = [px[l] + (px[l + 1] if l + 1 < nlevels else 0) for l in range(nlevels)]
+    return per_level, float(sum(per_level))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames-per-step", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import cef_loader
+    cef = cef_loader.load()
+    from tools import synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)   # nccl == RCCL on ROCm
+
+    F = args.frames_per_step
+    # per-rank frames: global frame k = rank * F + i uses seed 1000 + k
+    frames = [torch.from_numpy(synth.synth_frame(ROWS, COLS, seed=1000 + rank * F + i)).cuda() for i in range(F)]
+
+    det = cef.EfficientFeatures.create(NFEATURES, 1.2, 8, 0, 20, 15, cef.EfficientFeatures.BAD_512)
+    kps = [torch.zeros((5, NFEATURES), dtype=torch.float32, device="cuda") for _ in range(F)]
+    desc = [torch.zeros((NFEATURES, 64), dtype=torch.uint8, device="cuda") for _ in range(F)]
+    cnt = [torch.zeros(1, dtype=torch.int32, device="cuda") for _ in range(F)]
+
+    def step():
+        for i in range(F):
+            det.detectAndComputeAsync(frames[i], kps[i], desc[i], cnt[i], capacity=NFEATURES)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    det.profileEnable(args.steps * F * 8)          # one HIP event pair per pyramid+FAST launch of the timed region
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    ms, lvl = det.profileRead()
+
+    nkp = int(sum(int(c.item()) for c in cnt))      # keypoints per step on this rank
+    t_max = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    kp_sum = torch.tensor([nkp], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        dist.all_reduce(kp_sum, op=dist.ReduceOp.SUM)
+    t_max = float(t_max.item())
+    kp_total = float(kp_sum.item()) * args.steps     # keypoints all ranks processed in the timed region
+
+    if rank == 0:
+        per_level, bytes_frame = detect_algorithmic_bytes(det, ROWS, COLS)
+        # dominant kernel: pyr_fast_kernel, 8 launches (one per level) per frame.  Algorithmic bytes per launch =
+        # bytes_frame / 8 on average; duration per launch = mean of the HIP-event pairs of the timed region.
+        nl = len(ms)
+        avg_ms = float(ms.mean()) if nl else float("nan")
+        achieved = (bytes_frame / 8.0) / (avg_ms * 1e-3) / 1e9 if nl else float("nan")
+        l0 = ms[lvl == 0]
+        roof = {"bound": "hbm", "kernel": "pyr_fast_kernel (pyramid level s -> FAST-9 + Harris + level s+1)",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "algorithmic_bytes_per_launch": bytes_frame / 8.0, "avg_launch_ms": round(avg_ms, 5),
+                "launches_timed": int(nl),
+                "level0": {"algorithmic_bytes": per_level[0], "avg_launch_ms": round(float(l0.mean()), 5) if len(l0) else None,
+                           "achieved": round(per_level[0] / (float(l0.mean()) * 1e-3) / 1e9, 1) if len(l0) else None}}
+        tr_path = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tr_path):
+            try:
+                roof["traffic"] = json.load(open(tr_path)).get("pyr_fast_kernel_bytes_per_launch")
+            except Exception:
+                pass
+
+        out = {"metric": "Mkeypoints/s detectAndCompute (8K, 40k kp, BAD512)",
+               "value": round(kp_total / t_max / 1e6, 3), "unit": "Mkeypoints/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(t_max / args.steps * 1e3, 4),
+               "ms_per_frame": round(t_max / args.steps / F * 1e3, 4),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+               "data": "synthetic",
+               "config": {"workload": "detectAndCompute BAD512 on 8K (7680x4320) synthetic frames, nfeatures=40000, "
+                                      "8 levels, scale 1.2, FAST threshold 20, NMS radius 15 (BASELINE.json configs[4])",
+                          "frames_per_step_per_gpu": F, "frames_per_step": F * world,
+                          "keypoints_per_frame": round(nkp / F, 1), "parallelism": f"frames sharded over {world} GPU(s)"},
+               "roofline": roof}
+
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import pyoracle
+            img = frames[0].cpu().numpy()
+            t1 = time.perf_counter()
+            ref = pyoracle.detect_and_compute(img, nfeatures=NFEATURES, desc_type=pyoracle.BAD_512)
+            t_cpu = time.perf_counter() - t1
+            out["cpu_baseline"] = {"value": round(ref["n"] / t_cpu / 1e6, 5), "unit": "Mkeypoints/s", "cores": 1,
+                                   "kind": "port", "ms_per_frame": round(t_cpu * 1e3, 1),
+                                   "sample": "one 8K frame (seed 1000) of the same workload, oracle/efx_oracle.c, "
+                                             f"single thread as the reference CPU module; {ref['n']} keypoints",
+                                   "host_cores_available": os.cpu_count()}
+            # the bench frame doubles as a full-size parity check (bit-exact keypoints + BAD512 bytes)
+            n0 = int(cnt[0].item())
+            same = (n0 == ref["n"] and np.array_equal(kps[0][:, :n0].cpu().numpy().view(np.uint32), ref["kps"].view(np.uint32))
+                    and np.array_equal(desc[0][:n0].cpu().numpy(), ref["desc"]))
+            out["parity_8k_frame0"] = bool(same)
+        print(json.dumps(out), flush=True)
+
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

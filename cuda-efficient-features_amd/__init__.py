@@ -38,6 +38,7 @@ ABI_SYMBOLS = [
     "efx_bad_create", "efx_hashsift_create", "efx_describer_destroy", "efx_describer_descriptor_size",
     "efx_describer_last_error", "efx_describer_compute_kp4_async", "efx_describer_compute_async",
     "efx_describer_compute", "efx_describer_hashsift_debug_async",
+    "efx_profile_enable", "efx_profile_read",
     "efx_level_geometry", "efx_copy_level_async",
 ]
 
@@ -114,6 +115,8 @@ def lib():
                                             C.c_void_p, C.c_size_t]
         L.efx_describer_hashsift_debug_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p,
                                                          C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.efx_profile_enable.argtypes = [C.c_void_p, C.c_int]
+        L.efx_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]
         L.efx_level_geometry.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                          C.POINTER(C.c_float)]
         L.efx_copy_level_async.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
@@ -251,6 +254,17 @@ class EfficientFeatures:
         self._check(lib().efx_last_level_stats(self._h, st, 32, C.byref(nl)))
         return [dict(n_candidates=st[i].n_candidates, n_after_nms=st[i].n_after_nms, n_kept=st[i].n_kept)
                 for i in range(nl.value)]
+
+    def profileEnable(self, max_launches):
+        self._check(lib().efx_profile_enable(self._h, int(max_launches)))
+
+    def profileRead(self, capacity=65536):
+        """(ms, level) arrays of the recorded pyramid+FAST launches; call after synchronising the stream."""
+        ms = (C.c_float * capacity)()
+        lv = (C.c_int * capacity)()
+        n = C.c_int(0)
+        self._check(lib().efx_profile_read(self._h, ms, lv, capacity, C.byref(n)))
+        return np.array(ms[:n.value], dtype=np.float64), np.array(lv[:n.value], dtype=np.int64)
 
     def levelGeometry(self, rows, cols, level):
         r, c, s = C.c_int(), C.c_int(), C.c_float()

@@ -628,12 +628,15 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
         Corner* cand = a.cand + L.cand_base;
         TileHdr* hdr = a.hdr + L.tile_base;
         int* ctot = &a.counters->cand_total[s];
+        const bool prof = a.prof_count && *a.prof_count < a.prof_capacity;
+        if (prof) (void)hipEventRecord(a.prof_start[*a.prof_count], stream);
         if (aligned)
             hipLaunchKernelGGL(pyr_fast_kernel<true>, dim3(ntiles), dim3(256), 0, stream, src, spitch, L.rows, L.cols,
                                L.tiles_x, L.tiles_y, dst, dpitch, drows, dcols, fx, fy, a.threshold, do_fast, cand, hdr, ctot);
         else
             hipLaunchKernelGGL(pyr_fast_kernel<false>, dim3(ntiles), dim3(256), 0, stream, src, spitch, L.rows, L.cols,
                                L.tiles_x, L.tiles_y, dst, dpitch, drows, dcols, fx, fy, a.threshold, do_fast, cand, hdr, ctot);
+        if (prof) { (void)hipEventRecord(a.prof_stop[*a.prof_count], stream); a.prof_level[*a.prof_count] = s; ++*a.prof_count; }
     }
     hipLaunchKernelGGL(tile_rank_scan_kernel, dim3(H.nlevels), dim3(1024), 0, stream, a.d_table, a.hdr);
     hipLaunchKernelGGL(nms_kernel, dim3(H.total_tiles), dim3(256), 0, stream, a.d_table, a.hdr, a.cand, a.surv,

@@ -181,12 +181,18 @@ struct efx_context {
     Counters* h_mirror = nullptr;   // pinned
     bool has_frame = false;
     const uint8_t* last_img0 = nullptr; int last_pitch0 = 0;
+    // per-launch timing of the pyramid+FAST kernel (efx_profile_*)
+    std::vector<hipEvent_t> prof_start, prof_stop;
+    std::vector<int> prof_level;
+    int prof_count = 0;
 
     ~efx_context()
     {
         d_table.release(); pyramid.release(); hdr.release(); cand.release(); surv.release(); counters.release();
         kp4.release(); kp_level.release(); img.release(); kps.release(); descout.release(); count.release();
         if (h_mirror) (void)hipHostFree(h_mirror);
+        for (hipEvent_t e : prof_start) (void)hipEventDestroy(e);
+        for (hipEvent_t e : prof_stop) (void)hipEventDestroy(e);
     }
 };
 
@@ -306,6 +312,10 @@ int detect_common(efx_context* c, const uint8_t* d_image, int rows, int cols, si
     a.kp4 = static_cast<float4*>(c->kp4.p);
     a.kp_level = static_cast<int*>(c->kp_level.p);
     a.h_mirror = reinterpret_cast<int*>(c->h_mirror);
+    if (!c->prof_start.empty()) {
+        a.prof_start = c->prof_start.data(); a.prof_stop = c->prof_stop.data(); a.prof_level = c->prof_level.data();
+        a.prof_count = &c->prof_count; a.prof_capacity = (int)c->prof_start.size();
+    }
     hipError_t e = efx_launch_detect(a, stream);
     if (e != hipSuccess) return set_err(c->err, EFX_ERR_HIP, "detect launch failed: %s", hipGetErrorString(e));
     c->has_frame = true; c->last_img0 = d_image; c->last_pitch0 = (int)pitch;
@@ -640,6 +650,37 @@ int efx_describer_hashsift_debug_async(efx_describer* d, const uint8_t* d_image,
     if (d->d.kind != 1) return set_err(d->d.err, EFX_ERR_BAD_ARG, "not a HashSIFT describer");
     return describe_single(d->d, d->d.err, d_image, rows, cols, pitch, reinterpret_cast<const float4*>(d_kp4), n, max_size,
                            nullptr, 0, d_responses, d_T, (hipStream_t)stream);
+}
+
+int efx_profile_enable(efx_context* ctx, int max_launches)
+{
+    if (!ctx || max_launches < 0 || max_launches > 65536) return EFX_ERR_BAD_ARG;
+    for (hipEvent_t e : ctx->prof_start) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->prof_stop) (void)hipEventDestroy(e);
+    ctx->prof_start.clear(); ctx->prof_stop.clear(); ctx->prof_level.clear(); ctx->prof_count = 0;
+    for (int i = 0; i < max_launches; i++) {
+        hipEvent_t a, b;
+        HIP_TRY(ctx->err, hipEventCreate(&a));
+        HIP_TRY(ctx->err, hipEventCreate(&b));
+        ctx->prof_start.push_back(a); ctx->prof_stop.push_back(b);
+    }
+    ctx->prof_level.assign((size_t)max_launches, 0);
+    return EFX_OK;
+}
+
+int efx_profile_read(efx_context* ctx, float* ms, int* level, int capacity, int* n)
+{
+    if (!ctx || !n) return EFX_ERR_BAD_ARG;
+    const int cnt = ctx->prof_count < capacity ? ctx->prof_count : capacity;
+    for (int i = 0; i < cnt; i++) {
+        float t = 0.f;
+        HIP_TRY(ctx->err, hipEventElapsedTime(&t, ctx->prof_start[i], ctx->prof_stop[i]));
+        if (ms) ms[i] = t;
+        if (level) level[i] = ctx->prof_level[i];
+    }
+    *n = cnt;
+    ctx->prof_count = 0;
+    return EFX_OK;
 }
 
 int efx_level_geometry(const efx_context* ctx, int rows, int cols, int level, int* lrows, int* lcols, float* scale)

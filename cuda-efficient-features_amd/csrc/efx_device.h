@@ -107,6 +107,8 @@ struct DetectLaunch {
     void* d_keypoints; size_t kps_pitch; int capacity; int* d_count;
     float4* kp4; int* kp_level;
     int* h_mirror;              // pinned host mirror of Counters (may be null)
+    // optional per-launch timing of the pyramid+FAST kernel (bench roofline): event pairs + their level
+    hipEvent_t* prof_start; hipEvent_t* prof_stop; int* prof_level; int* prof_count; int prof_capacity;
 };
 
 hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream);

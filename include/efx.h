@@ -195,6 +195,14 @@ int efx_describer_hashsift_debug_async(efx_describer* d, const uint8_t* d_image,
 /* ------------------------------------------------------------------------------------------------ */
 /* introspection used by the parity tests (no reference equivalent)                                  */
 
+/* Per-launch timing of the dominant kernel (pyramid + FAST + Harris, one launch per level) with HIP events on
+ * the caller's stream: efx_profile_enable allocates `max_launches` event pairs (0 disables); every following
+ * detect call records one pair per level launch until the pairs are used up.  efx_profile_read (after the
+ * stream was synchronised) returns the elapsed milliseconds and the pyramid level of each recorded launch and
+ * rewinds the recorder. */
+int efx_profile_enable(efx_context* ctx, int max_launches);
+int efx_profile_read(efx_context* ctx, float* ms, int* level, int capacity, int* n);
+
 /* Geometry of pyramid level `level` for a rows x cols frame with the context's parameters
  * (calcImagePyramid, cuda_efficient_features.cpp:136-157). */
 int efx_level_geometry(const efx_context* ctx, int rows, int cols, int level, int* lrows, int* lcols, float* scale);
