@@ -29,7 +29,8 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 
 struct Affine { float m00, m01, m02, m10, m11, m12, s; };
 
-// LDS plan (dynamic): [ integral (S+1)^2 int32 | hblur (S+6)*S float | raw (S+6)^2 u8 (pitch S+6) ]
+// LDS plan (dynamic): [ I: (S+1)^2 int32, aliased by raw: (S+6) x RPB u8 | hb: (8G+6) x HP float ]
+//   G = ceil(S/8) groups of 8 outputs, HP = 8G, RPB = 4*ceil((S+12)/4) (room for the dword-alignment slack)
 template <bool BLUR>
 __global__ __launch_bounds__(256) void bad_kernel(
     const uint8_t* __restrict__ img0, int pitch0, int rows0, int cols0,
@@ -45,6 +46,7 @@ __global__ __launch_bounds__(256) void bad_kernel(
     const int count = d_count ? min(*d_count, n) : n;
     if (kid >= count) return;
     const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
 
     const float4 kp = kp4[kid];
     const uint8_t* img = img0; int pitch = pitch0, rows = rows0, cols = cols0;
@@ -56,8 +58,9 @@ __global__ __launch_bounds__(256) void bad_kernel(
     const int nbits = P->nbits;
     const float x = kp.x, y = kp.y, size = kp.z, angle = kp.w;
 
-    // rectifyBoxes, bad.cpp:115-147 (thread 0: double cos/sin as in bad.cpp:138-139)
-    if (tid == 0) {
+    // rectifyBoxes, bad.cpp:115-147 (one lane of the last wave: double cos/sin as in bad.cpp:138-139; the
+    // result is needed only after the integral image is built)
+    if (tid == 255) {
         Affine A;
         const float s = scale_factor * size / (0.5f * (float)(32 + 32));
         if (angle == -1) {
@@ -87,46 +90,99 @@ __global__ __launch_bounds__(256) void bad_kernel(
 
     int* I = reinterpret_cast<int*>(smem);                       // (S+1) x (S+1)
     const int IP = S + 1;
-    float* hb = reinterpret_cast<float*>(I + IP * IP);           // (S+6) x S
-    uint8_t* raw = reinterpret_cast<uint8_t*>(hb + (BLUR ? (S + 6) * S : 0));
-    const int RP = BLUR ? S + 6 : S;
+    const int G = (S + 7) >> 3, HP = G * 8;
+    const int RP = S + 6;                                        // raw rows / valid raw columns
+    const int RPB = ((S + 12 + 3) >> 2) << 2;                    // raw row pitch in bytes
+    uint8_t* raw = smem;                                         // aliases I (dead before I is written)
+    size_t ibytes = (size_t)IP * IP * 4;
+    if (BLUR && (size_t)RP * RPB > ibytes) ibytes = (size_t)RP * RPB;
+    float* hb = reinterpret_cast<float*>(smem + ((ibytes + 15) & ~(size_t)15));
 
     if (fits) {
         if (BLUR) {
-            // raw window with a 3-px apron, BORDER_REFLECT_101 at the image border (spec S6)
-            for (int i = tid; i < RP * RP; i += 256) {
-                const int r = i / RP, c = i % RP;
-                const int gy = reflect101(wy0 - 3 + r, rows), gx = reflect101(wx0 - 3 + c, cols);
-                raw[i] = img[(size_t)gy * pitch + gx];
+            // ---- raw window with a 3-px apron -> LDS.  Interior + 4-byte aligned images: aligned dword loads
+            //      (row start rounded down to 4, byte offset `off` kept); otherwise bytes with REFLECT_101.
+            const bool interior = (wx0 - 3 >= 0) && (wx0 + S + 3 <= cols) && (wy0 - 3 >= 0) && (wy0 + S + 3 <= rows);
+            const bool fastld = interior && ((((uintptr_t)img) | (uintptr_t)pitch) & 3u) == 0;
+            const int off = fastld ? ((wx0 - 3) & 3) : 0;
+            if (fastld) {
+                const int ndw = (off + RP + 3) >> 2;
+                const int sh = ndw <= 16 ? 4 : (ndw <= 32 ? 5 : 6);      // lanes per row: 16 / 32 / 64
+                const int j = tid & ((1 << sh) - 1), r0 = tid >> sh, rstep = 256 >> sh;
+                const uint8_t* base = img + (size_t)(wy0 - 3) * pitch + ((wx0 - 3) & ~3);
+                for (int jj = j; jj < ndw; jj += (1 << sh))
+                    for (int r = r0; r < RP; r += rstep)
+                        *reinterpret_cast<uint32_t*>(raw + r * RPB + 4 * jj) =
+                            *reinterpret_cast<const uint32_t*>(base + (size_t)r * pitch + 4 * jj);
+            } else {
+                for (int r = wid; r < RP; r += 4) {
+                    const int gy = reflect101(wy0 - 3 + r, rows);
+                    const uint8_t* src = img + (size_t)gy * pitch;
+                    for (int c = lane; c < RP; c += 64) raw[r * RPB + c] = src[reflect101(wx0 - 3 + c, cols)];
+                }
             }
             __syncthreads();
             const float tp[7] = { taps0, taps1, taps2, taps3, taps2, taps1, taps0 };
-            // row pass: u8 -> float, taps in order 0..6
-            for (int i = tid; i < RP * S; i += 256) {
-                const int r = i / S, c = i % S;
-                const uint8_t* p = raw + r * RP + c;
-                float acc = 0.f;
+            // ---- row pass (spec S6): u8 -> float, taps in order 0..6; 8 consecutive outputs per lane so that
+            //      every raw byte is read from LDS once (5 dwords) instead of 7 times
+            {
+                const int sh = G <= 8 ? 3 : (G <= 16 ? 4 : (G <= 32 ? 5 : 6));
+                const int g0 = tid & ((1 << sh) - 1), r0 = tid >> sh, rstep = 256 >> sh;
+                for (int g = g0; g < G; g += (1 << sh)) {
+                    for (int r = r0; r < RP; r += rstep) {
+                        const uint32_t* w = reinterpret_cast<const uint32_t*>(raw + r * RPB + 8 * g);
+                        const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4];
+                        const uint32_t b0 = __builtin_amdgcn_alignbyte(w1, w0, off), b1 = __builtin_amdgcn_alignbyte(w2, w1, off);
+                        const uint32_t b2 = __builtin_amdgcn_alignbyte(w3, w2, off), b3 = __builtin_amdgcn_alignbyte(w4, w3, off);
+                        float v[16];
 #pragma unroll
-                for (int j = 0; j < 7; j++) acc = acc + tp[j] * (float)p[j];
-                hb[i] = acc;
+                        for (int k = 0; k < 4; k++) {
+                            v[k] = (float)((b0 >> (8 * k)) & 0xff); v[4 + k] = (float)((b1 >> (8 * k)) & 0xff);
+                            v[8 + k] = (float)((b2 >> (8 * k)) & 0xff); v[12 + k] = (float)((b3 >> (8 * k)) & 0xff);
+                        }
+                        float o[8];
+#pragma unroll
+                        for (int i = 0; i < 8; i++) {
+                            float acc = tp[0] * v[i];                   // == 0.f + tp[0]*v[i] exactly
+#pragma unroll
+                            for (int jt = 1; jt < 7; jt++) acc = acc + tp[jt] * v[i + jt];
+                            o[i] = acc;
+                        }
+                        float4* dstp = reinterpret_cast<float4*>(hb + r * HP + 8 * g);
+                        dstp[0] = make_float4(o[0], o[1], o[2], o[3]);
+                        dstp[1] = make_float4(o[4], o[5], o[6], o[7]);
+                    }
+                }
             }
             __syncthreads();
-            // column pass: float -> u8 (round half even, saturate), stored as the integral's source
-            for (int i = tid; i < S * S; i += 256) {
-                const int r = i / S, c = i % S;
-                float acc = 0.f;
+            // ---- column pass: float -> u8 (round half even, saturate) -> source of the integral; one column
+            //      per lane, 8 consecutive rows per item (14 LDS reads instead of 56)
+            for (int c = lane; c < S; c += 64) {
+                const bool cin = (wx0 + c) < cols;
+                for (int rg = wid; rg < G; rg += 4) {
+                    float v[14];
 #pragma unroll
-                for (int j = 0; j < 7; j++) acc = acc + tp[j] * hb[(r + j) * S + c];
-                float v = rintf(acc);
-                v = v < 0.f ? 0.f : (v > 255.f ? 255.f : v);
-                const bool inside = (wy0 + r) < rows && (wx0 + c) < cols;
-                I[(r + 1) * IP + (c + 1)] = inside ? (int)v : 0;
+                    for (int k = 0; k < 14; k++) v[k] = hb[(8 * rg + k) * HP + c];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const int r = 8 * rg + i;
+                        float acc = tp[0] * v[i];
+#pragma unroll
+                        for (int jt = 1; jt < 7; jt++) acc = acc + tp[jt] * v[i + jt];
+                        float q = rintf(acc);
+                        q = q < 0.f ? 0.f : (q > 255.f ? 255.f : q);
+                        if (r < S) I[(r + 1) * IP + (c + 1)] = (cin && (wy0 + r) < rows) ? (int)q : 0;
+                    }
+                }
             }
         } else {
-            for (int i = tid; i < S * S; i += 256) {
-                const int r = i / S, c = i % S;
-                const int gy = wy0 + r, gx = wx0 + c;
-                I[(r + 1) * IP + (c + 1)] = (gy < rows && gx < cols) ? (int)img[(size_t)gy * pitch + gx] : 0;
+            for (int r = wid; r < S; r += 4) {
+                const int gy = wy0 + r;
+                const uint8_t* src = img + (size_t)(gy < rows ? gy : 0) * pitch;
+                for (int c = lane; c < S; c += 64) {
+                    const int gx = wx0 + c;
+                    I[(r + 1) * IP + (c + 1)] = (gy < rows && gx < cols) ? (int)src[gx] : 0;
+                }
             }
         }
         for (int i = tid; i <= S; i += 256) { I[i] = 0; I[i * IP] = 0; }
@@ -157,16 +213,16 @@ __global__ __launch_bounds__(256) void bad_kernel(
         const int b = b0 + tid;
         bool bit = false;
         if (b < nbits && fits) {
-            const int4 bx = P->box[b];
-            const float x1f = (float)(bx.x & 0xff), x2f = (float)(bx.x >> 8);
-            const float y1f = (float)(bx.y & 0xff), y2f = (float)(bx.y >> 8);
+            const uint2 bq = P->box[b];
+            const float x1f = (float)(bq.x & 31u), x2f = (float)((bq.x >> 5) & 31u);
+            const float y1f = (float)((bq.x >> 10) & 31u), y2f = (float)((bq.x >> 15) & 31u);
             // transform, bad.cpp:151-155: CV_ROUNDNUM(x) = (int)(x + 0.5f)
             const int cx1 = (int)((A.m00 * x1f + A.m01 * y1f + A.m02) + 0.5f);
             const int cy1 = (int)((A.m10 * x1f + A.m11 * y1f + A.m12) + 0.5f);
             const int cx2 = (int)((A.m00 * x2f + A.m01 * y2f + A.m02) + 0.5f);
             const int cy2 = (int)((A.m10 * x2f + A.m11 * y2f + A.m12) + 0.5f);
-            const int r = (int)((A.s * (float)bx.z) + 0.5f);
-            const float thr = P->thr[b];
+            const int r = (int)((A.s * (float)(bq.x >> 20)) + 0.5f);
+            const float thr = __uint_as_float(bq.y);
             if (border) {
                 // computeBadResponse, bad.cpp:166-251: boxes clamped to the frame, float means
                 int ax1 = cx1 - r; if (ax1 < 0) ax1 = 0; else if (ax1 >= fw - 1) ax1 = fw - 2;
@@ -205,7 +261,6 @@ __global__ __launch_bounds__(256) void bad_kernel(
         }
         // 8 consecutive box pairs -> one byte, MSB first (bad.cpp:349,368)
         const unsigned long long m = __ballot(bit);
-        const int lane = tid & 63;
         if ((lane & 7) == 0 && b < nbits) {
             const unsigned v = (unsigned)(m >> lane) & 0xffu;
             desc[(size_t)kid * desc_pitch + (b >> 3)] = (uint8_t)(__brev(v) >> 24);
@@ -240,7 +295,12 @@ hipError_t efx_launch_bad(const DescribeLaunch& a, const BadParamsDev* d_params,
     const float max_size = a.max_size > 0.f ? a.max_size : (float)EFX_PATCH_SIZE;
     const int S = bad_smax_for(max_size, a.scale_factor, reach);
     size_t lds = (size_t)(S + 1) * (S + 1) * 4;
-    if (a.blur) lds += (size_t)(S + 6) * S * 4 + (size_t)(S + 6) * (S + 6);
+    if (a.blur) {
+        const int G = (S + 7) >> 3, HP = G * 8, RP = S + 6, RPB = ((S + 12 + 3) >> 2) << 2;
+        if ((size_t)RP * RPB > lds) lds = (size_t)RP * RPB;
+        lds = (lds + 15) & ~(size_t)15;
+        lds += (size_t)(8 * G + 6) * HP * 4;
+    }
     lds = (lds + 15) & ~(size_t)15;
     if (lds > 160 * 1024 - 64) return hipErrorInvalidValue;    // keypoint window does not fit in LDS
     float t[7];

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void pyr_fast_kernel(
     const uint8_t* __restrict__ src, int spitch, int rows, int cols, int tiles_x, int tiles_y,
     uint8_t* __restrict__ dst, int dpitch, int drows, int dcols, float fx, float fy,
     int threshold, int do_fast,
-    Corner* __restrict__ cand, TileHdr* __restrict__ hdr, int* __restrict__ cand_total)
+    Corner* __restrict__ cand, unsigned cand_sub_cap, TileHdr* __restrict__ hdr, int* __restrict__ cand_total, int dbg)
 {
     __shared__ uint32_t s_tile[EFX_LT * (EFX_LT / 4)];
     __shared__ unsigned long long s_bitmap[EFX_TILE];
@@ -195,6 +195,7 @@ __global__ __launch_bounds__(256) void pyr_fast_kernel(
     __syncthreads();
 
     int total = 0;
+    if (dbg & 1) do_fast = 0;
     if (do_fast) {
         // ---- phase 1: FAST-9, lane = column, wave = 16 rows; one ballot per row = one bitmap row ----
         const int lane = tid & 63, wid = tid >> 6;
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(256) void pyr_fast_kernel(
             const int ly = wid * 16 + r;
             const int y = y0 + ly;
             bool corner = false;
-            if (xin && y >= EFX_HALF_PATCH && y < rows - EFX_HALF_PATCH)
+            if (xin && y >= EFX_HALF_PATCH && y < rows - EFX_HALF_PATCH && !(dbg & 2))
                 corner = fast9_lds<EFX_LT>(tb + (ly + EFX_HALO) * EFX_LT + lane + EFX_HALO, threshold);
             const unsigned long long m = __ballot(corner);
             if (lane == 0) s_bitmap[ly] = m;
@@ -226,18 +227,18 @@ __global__ __launch_bounds__(256) void pyr_fast_kernel(
             bits &= bits - 1;
             s_list[pos++] = (uint16_t)((cx * 16 + b) | (brow << 8));
         }
-        if (tid == 0) s_start = total > 0 ? atomicAdd(cand_total, total) : 0;
+        if (tid == 0) s_start = total > 0 ? atomicAdd(cand_total + (tile & (EFX_NSUB - 1)), total) : 0;
         __syncthreads();
 
         // ---- phase 3: Harris on the corners, append to the level's corner array ----
         const int start = s_start;
         for (int k = tid; k < total; k += 256) {
             const int lx = s_list[k] & 0xff, ly = s_list[k] >> 8;
-            const float resp = harris_lds<EFX_LT>(tb + (ly + EFX_HALO) * EFX_LT + lx + EFX_HALO);
+            const float resp = (dbg & 4) ? 1.f : harris_lds<EFX_LT>(tb + (ly + EFX_HALO) * EFX_LT + lx + EFX_HALO);
             Corner c;
             c.xy = (uint32_t)(x0 + lx) | ((uint32_t)(y0 + ly) << 16);
             c.resp = resp;
-            cand[(size_t)start + k] = c;
+            cand[(size_t)(tile & (EFX_NSUB - 1)) * cand_sub_cap + start + k] = c;
         }
         TileHdr* h = hdr + tile;
         if (tid <= EFX_CELLS_PER_TILE) h->cell_off[tid] = (uint16_t)s_celloff[tid];
@@ -245,31 +246,39 @@ __global__ __launch_bounds__(256) void pyr_fast_kernel(
     }
 
     // ---- phase 4: this tile's share of level s+1 (spec S5; cv::cuda::resize, .cpp:154) ----
-    if (dst != nullptr) {
+    if (dst != nullptr && !(dbg & 8)) {
         const int ox_b = first_ge(x0, fx, dcols);
         const int ox_e = (tx == tiles_x - 1) ? dcols : first_ge(x0 + EFX_TILE, fx, dcols);
         const int oy_b = first_ge(y0, fy, drows);
         const int oy_e = (ty == tiles_y - 1) ? drows : first_ge(y0 + EFX_TILE, fy, drows);
-        const int nx = ox_e - ox_b, ny = oy_e - oy_b;
-        if (nx > 0 && ny > 0) {
-            for (int i = tid; i < nx * ny; i += 256) {
-                const int oy = oy_b + i / nx, ox = ox_b + i % nx;
-                const float sx = (float)ox * fx, sy = (float)oy * fy;
-                int x1 = (int)floorf(sx), y1 = (int)floorf(sy);
-                if (x1 > cols - 1) x1 = cols - 1;
+        // lane = output column (its source column and x-weights are row-invariant), waves take rows in turn
+        const int lane4 = tid & 63, wid4 = tid >> 6;
+        for (int oxs = ox_b; oxs < ox_e; oxs += 64) {
+            const int ox = oxs + lane4;
+            const bool act = ox < ox_e;
+            const float sx = (float)ox * fx;
+            int x1 = (int)floorf(sx);
+            if (x1 > cols - 1) x1 = cols - 1;
+            const int x2 = x1 + 1;
+            const int x2r = x2 < cols - 1 ? x2 : cols - 1;
+            const float wx0 = (float)x2 - sx, wx1 = sx - (float)x1;
+            const int lc = act ? (x1 - x0 + EFX_HALO) : EFX_HALO;
+            const int dxr = act ? (x2r - x1) : 0;
+            for (int oy = oy_b + wid4; oy < oy_e; oy += 4) {
+                const float sy = (float)oy * fy;
+                int y1 = (int)floorf(sy);
                 if (y1 > rows - 1) y1 = rows - 1;
-                const int x2 = x1 + 1, y2 = y1 + 1;
-                const int x2r = x2 < cols - 1 ? x2 : cols - 1;
+                const int y2 = y1 + 1;
                 const int y2r = y2 < rows - 1 ? y2 : rows - 1;
-                const uint8_t* pa = tb + (y1 - y0 + EFX_HALO) * EFX_LT + (x1 - x0 + EFX_HALO);
-                const uint8_t* pb = tb + (y2r - y0 + EFX_HALO) * EFX_LT + (x1 - x0 + EFX_HALO);
-                const int dxr = x2r - x1;
+                const float wy0 = (float)y2 - sy, wy1 = sy - (float)y1;
+                const uint8_t* pa = tb + (y1 - y0 + EFX_HALO) * EFX_LT + lc;
+                const uint8_t* pb = tb + (y2r - y0 + EFX_HALO) * EFX_LT + lc;
                 float out = 0.f;
-                out = out + (float)pa[0] * (((float)x2 - sx) * ((float)y2 - sy));
-                out = out + (float)pa[dxr] * ((sx - (float)x1) * ((float)y2 - sy));
-                out = out + (float)pb[0] * (((float)x2 - sx) * (sy - (float)y1));
-                out = out + (float)pb[dxr] * ((sx - (float)x1) * (sy - (float)y1));
-                dst[(size_t)oy * dpitch + ox] = sat_u8_rne(out);
+                out = out + (float)pa[0] * (wx0 * wy0);
+                out = out + (float)pa[dxr] * (wx1 * wy0);
+                out = out + (float)pb[0] * (wx0 * wy1);
+                out = out + (float)pb[dxr] * (wx1 * wy1);
+                if (act) dst[(size_t)oy * dpitch + ox] = sat_u8_rne(out);
             }
         }
     }
@@ -308,25 +317,46 @@ __device__ __forceinline__ int level_of_tile(const LevelTable* T, int gt)
 
 // ================================================================================================
 // Kernel C: radius non-max suppression (radiusSuppressionKernel + IsMaxPoint, .cu:62-97, 202-216).
-// One workgroup per tile; every corner of the tile scans the corners of the cells within blockRadius.
-// Survivors are compacted in canonical order and appended to the level's survivor array.
+// One workgroup per tile.  The corners of the tile's cells plus a ring of blockRadius cells are staged in
+// LDS (coalesced copies of the neighbouring tiles' cell lists); every corner of the tile then scans the
+// (2*blockRadius+1)^2 cells around its own cell in LDS.  Survivors are compacted in canonical order
+// (two passes: flags + block scan, then one atomic chunk allocation and the writes) and appended to the
+// level's survivor array.  If the staged neighbourhood would not fit (huge radius / extreme density) the
+// comparison falls back to reading the neighbours from L2.
 // ================================================================================================
+#define NMS_LDS_ENTRIES 3072
+#define NMS_MAX_CELLS 64
+
 __global__ __launch_bounds__(256) void nms_kernel(const LevelTable* __restrict__ T, TileHdr* __restrict__ hdr,
                                                   const Corner* __restrict__ cand_all, Corner* __restrict__ surv_all,
-                                                  Counters* __restrict__ cnt, int radius)
+                                                  Counters* __restrict__ cnt, int radius, int dbg)
 {
-    __shared__ Corner s_surv[EFX_TILE * EFX_TILE];
+    __shared__ Corner s_nb[NMS_LDS_ENTRIES];
+    __shared__ int s_off[NMS_MAX_CELLS + 1];
+    __shared__ int s_cnt[NMS_MAX_CELLS];
+    __shared__ unsigned s_src[NMS_MAX_CELLS];
     __shared__ int s_scan[8];
+    __shared__ int s_round_base[17];
     __shared__ int s_start;
+    __shared__ Corner s_cmax[NMS_MAX_CELLS];
+    __shared__ Corner s_hme[256];
+    __shared__ int4 s_hbox[256];
+    __shared__ uint16_t s_hsrc[256];
+    __shared__ uint8_t s_hkeep[256];
+    __shared__ int s_wcnt[4];
 
     const int gt = blockIdx.x;
     const int l = level_of_tile(T, gt);
     const LevelDev& L = T->lv[l];
     if (!L.active) return;
     const int tile = gt - L.tile_base;
+    const int tx = tile % L.tiles_x, ty = tile / L.tiles_x;
     TileHdr* hl = hdr + L.tile_base;
     const TileHdr& h = hl[tile];
     const Corner* cand = cand_all + L.cand_base;
+    const int tid = threadIdx.x;
+
+    const Corner* own = cand + (size_t)(tile & (EFX_NSUB - 1)) * L.cand_sub_cap + h.cand_start;
 
     const int n_own = h.cell_off[EFX_CELLS_PER_TILE];
     int n_valid = L.cap - (int)h.cand_rank;            // cap in canonical order (spec S2; cuda_fast.cu:245)
@@ -336,13 +366,127 @@ __global__ __launch_bounds__(256) void nms_kernel(const LevelTable* __restrict__
     const int block_radius = (radius + EFX_CELL - 1) / EFX_CELL;   // cvCeil(radius / CELL_SIZE), .cu:292
     const int gw = (L.cols + EFX_CELL - 1) / EFX_CELL, gh = (L.rows + EFX_CELL - 1) / EFX_CELL;
 
+    if (dbg == 1) return;
+    // region of cells staged in LDS: the tile's 4x4 cells plus the ring, clipped to the grid
+    const int rcx0 = max(tx * 4 - block_radius, 0), rcy0 = max(ty * 4 - block_radius, 0);
+    const int rcx1 = min(tx * 4 + 4 + block_radius, gw), rcy1 = min(ty * 4 + 4 + block_radius, gh);
+    const int rw = rcx1 - rcx0, rh = rcy1 - rcy0;
+    const int ncells = rw * rh;
+    bool staged = ncells <= NMS_MAX_CELLS;
+    if (staged) {
+        if (tid < 64) {
+            int c = 0; unsigned src = 0;
+            if (tid < ncells) {
+                const int bx = rcx0 + tid % rw, by = rcy0 + tid / rw;
+                const TileHdr& nh = hl[(by >> 2) * L.tiles_x + (bx >> 2)];
+                const int ci = (by & 3) * 4 + (bx & 3);
+                const int nn = L.cap - (int)nh.cand_rank;           // valid corners of that tile
+                const int b = nh.cell_off[ci];
+                int e = nh.cell_off[ci + 1];
+                if (e > nn) e = nn;
+                c = e > b ? e - b : 0;
+                src = (unsigned)(((by >> 2) * L.tiles_x + (bx >> 2)) & (EFX_NSUB - 1)) * L.cand_sub_cap + nh.cand_start + (unsigned)b;
+            }
+            const int incl = wave_incl_scan(c);
+            if (tid < ncells) { s_off[tid] = incl - c; s_cnt[tid] = c; s_src[tid] = src; }
+            if (tid == 63) s_off[NMS_MAX_CELLS] = incl;
+        }
+        __syncthreads();
+        staged = s_off[NMS_MAX_CELLS] <= NMS_LDS_ENTRIES;
+        if (staged) {
+            const int lane = tid & 63, wid = tid >> 6;
+            for (int c = wid; c < ncells; c += 4) {
+                const int n = s_cnt[c], o = s_off[c];
+                const Corner* q = cand + s_src[c];
+                for (int j = lane; j < n; j += 64) s_nb[o + j] = q[j];
+            }
+        }
+        __syncthreads();
+    }
+
+    if (dbg == 2) return;
+    // per staged cell: its strongest corner.  Most corners are suppressed by the strongest corner of one of
+    // the neighbouring cells, so this is the quick test; the few that pass get the full scan below.
+    if (staged) {
+        if (tid < ncells) {
+            const Corner* q = s_nb + s_off[tid];
+            const int n = s_cnt[tid];
+            Corner best; best.xy = 0xffffffffu; best.resp = -3.0e38f;
+            for (int j = 0; j < n; j++) { const Corner o = q[j]; if (o.resp > best.resp) best = o; }
+            s_cmax[tid] = best;
+        }
+        __syncthreads();
+    }
+
+    // pass 1: survivor flags, one bit per 256-corner round
+    const int lane = tid & 63, wid = tid >> 6;
+    unsigned keepmask = 0;
     int nsurv = 0;
-    for (int k0 = 0; k0 < n_valid; k0 += 256) {
-        const int k = k0 + threadIdx.x;
+    int round = 0;
+    for (int k0 = 0; k0 < n_valid; k0 += 256, round++) {
+        const int k = k0 + tid;
         bool keep = false;
-        Corner me; me.xy = 0; me.resp = 0.f;
-        if (k < n_valid) {
-            me = cand[(size_t)h.cand_start + k];
+        if (staged) {
+            // phase A: one lane per corner, quick test against the 3x3 (or larger) cell maxima
+            bool hard = false;
+            Corner me; me.xy = 0; me.resp = 0.f;
+            int minx = 0, maxx = -1, miny = 0, maxy = -1;
+            if (k < n_valid) {
+                me = own[k];
+                const int mx = me.xy & 0xffff, my = me.xy >> 16;
+                const int bx1 = mx / EFX_CELL, by1 = my / EFX_CELL;
+                minx = max(bx1 - block_radius, 0) - rcx0; maxx = min(bx1 + block_radius, gw - 1) - rcx0;
+                miny = max(by1 - block_radius, 0) - rcy0; maxy = min(by1 + block_radius, gh - 1) - rcy0;
+                hard = true;
+                for (int by = miny; by <= maxy && hard; by++)
+                    for (int bx = minx; bx <= maxx; bx++) {
+                        const Corner o = s_cmax[by * rw + bx];
+                        const int dx = mx - (int)(o.xy & 0xffff), dy = my - (int)(o.xy >> 16);
+                        if (o.xy != me.xy && me.resp <= o.resp && dx * dx + dy * dy < image_radius) { hard = false; break; }
+                    }
+            }
+            // compact the corners that passed the quick test
+            const unsigned long long hm = __ballot(hard);
+            if (lane == 0) s_wcnt[wid] = __popcll(hm);
+            __syncthreads();
+            int hb = 0;
+            for (int w = 0; w < wid; w++) hb += s_wcnt[w];
+            const int nhard = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+            if (hard) {
+                const int pos = hb + __popcll(hm & ((1ull << lane) - 1ull));
+                s_hme[pos] = me;
+                s_hbox[pos] = make_int4(minx, maxx, miny, maxy);
+                s_hsrc[pos] = (uint16_t)tid;
+            }
+            s_hkeep[tid] = 0;
+            __syncthreads();
+            // phase B: 16 lanes per hard corner scan the staged neighbour cells together (IsMaxPoint, .cu:62-97)
+            const int grp = tid >> 4, sub = tid & 15;
+            for (int h0 = 0; h0 < nhard; h0 += 16) {
+                const int hi = h0 + grp;
+                bool kill = false;
+                if (hi < nhard) {
+                    const Corner m = s_hme[hi];
+                    const int4 bx4 = s_hbox[hi];
+                    const int mx = m.xy & 0xffff, my = m.xy >> 16;
+                    for (int by = bx4.z; by <= bx4.w; by++) {
+                        const int b = s_off[by * rw + bx4.x];
+                        const int e = s_off[by * rw + bx4.y] + s_cnt[by * rw + bx4.y];   // a row of cells is contiguous
+                        for (int j = b + sub; j < e; j += 16) {
+                            const Corner o = s_nb[j];
+                            const int dx = mx - (int)(o.xy & 0xffff), dy = my - (int)(o.xy >> 16);
+                            kill |= (o.xy != m.xy && m.resp <= o.resp && dx * dx + dy * dy < image_radius);
+                        }
+                    }
+                }
+                const unsigned long long km = __ballot(kill);
+                const unsigned gk = (unsigned)(km >> ((lane >> 4) * 16)) & 0xffffu;
+                if (hi < nhard && sub == 0) s_hkeep[s_hsrc[hi]] = gk == 0 ? 1 : 0;
+            }
+            __syncthreads();
+            keep = s_hkeep[tid] != 0;
+        } else if (k < n_valid) {
+            const Corner me = own[k];
             const int mx = me.xy & 0xffff, my = me.xy >> 16;
             const int bx1 = mx / EFX_CELL, by1 = my / EFX_CELL;
             const int minx = max(bx1 - block_radius, 0), maxx = min(bx1 + block_radius, gw - 1);
@@ -350,15 +494,15 @@ __global__ __launch_bounds__(256) void nms_kernel(const LevelTable* __restrict__
             keep = true;
             for (int by = miny; by <= maxy && keep; by++) {
                 for (int bx = minx; bx <= maxx && keep; bx++) {
-                    const int ntile = (by >> 2) * L.tiles_x + (bx >> 2);
-                    const TileHdr& nh = hl[ntile];
+                    const int nt = (by >> 2) * L.tiles_x + (bx >> 2);
+                    const TileHdr& nh = hl[nt];
                     const int c = (by & 3) * 4 + (bx & 3);
-                    int nn = L.cap - (int)nh.cand_rank;                 // valid corners of that tile
+                    const int nn = L.cap - (int)nh.cand_rank;
                     const int b = nh.cell_off[c];
                     int e = nh.cell_off[c + 1];
                     if (e > nn) e = nn;
-                    const Corner* q = cand + nh.cand_start;
-                    for (int j = b; j < e; j++) {
+                    const Corner* q = cand + (size_t)(nt & (EFX_NSUB - 1)) * L.cand_sub_cap + nh.cand_start + b;
+                    for (int j = 0; j < e - b; j++) {
                         const Corner o = q[j];
                         if (o.xy == me.xy) continue;                     // idx1 == idx2
                         const int dx = mx - (int)(o.xy & 0xffff), dy = my - (int)(o.xy >> 16);
@@ -368,16 +512,32 @@ __global__ __launch_bounds__(256) void nms_kernel(const LevelTable* __restrict__
             }
         }
         int tot;
-        const int pre = block_excl_scan<4>(keep ? 1 : 0, s_scan, &tot);
-        if (keep) s_surv[nsurv + pre] = me;
+        (void)block_excl_scan<4>(keep ? 1 : 0, s_scan, &tot);
+        if (keep) keepmask |= 1u << round;
+        if (tid == 0) s_round_base[round] = nsurv;
         nsurv += tot;
     }
-    if (threadIdx.x == 0) s_start = nsurv > 0 ? atomicAdd(&cnt->surv_total[l], nsurv) : 0;
+    if (dbg == 3) return;
+    if (tid == 0) s_start = nsurv > 0 ? atomicAdd(&cnt->surv_total[l][tile & (EFX_NSUB - 1)], nsurv) : 0;
     __syncthreads();
+    // pass 2: write the survivors in canonical order
     const int start = s_start;
-    Corner* surv = surv_all + L.surv_base;
-    for (int i = threadIdx.x; i < nsurv; i += 256) surv[(size_t)start + i] = s_surv[i];
-    if (threadIdx.x == 0) { hl[tile].surv_start = (uint32_t)start; hl[tile].surv_count = (uint32_t)nsurv; }
+    Corner* surv = surv_all + L.surv_base + (size_t)(tile & (EFX_NSUB - 1)) * L.surv_sub_cap;
+    round = 0;
+    for (int k0 = 0; k0 < n_valid; k0 += 256, round++) {
+        const int k = k0 + tid;
+        const bool keep = (keepmask >> round) & 1u;
+        const unsigned long long m = __ballot(keep);
+        // rank inside the round: waves before this one + lanes before this lane
+        if ((tid & 63) == 0) s_wcnt[tid >> 6] = __popcll(m);
+        __syncthreads();
+        int before = 0;
+        for (int w = 0; w < (tid >> 6); w++) before += s_wcnt[w];
+        const int rank = before + __popcll(m & ((1ull << (tid & 63)) - 1ull));
+        if (keep) surv[(size_t)start + s_round_base[round] + rank] = own[k];
+        __syncthreads();
+    }
+    if (tid == 0) { hl[tile].surv_start = (uint32_t)start; hl[tile].surv_count = (uint32_t)nsurv; }
 }
 
 // ================================================================================================
@@ -404,7 +564,9 @@ __global__ __launch_bounds__(1024) void select_kernel(const LevelTable* __restri
     // output base of this level: sum over lower levels of min(survivors, quota)  (.cpp:292-314)
     int base = 0, all = 0;
     for (int i = 0; i < T->nlevels; i++) {
-        const int k = T->lv[i].active ? min(cnt->surv_total[i], T->lv[i].quota) : 0;
+        int ns = 0;
+        for (int sub = 0; sub < EFX_NSUB; sub++) ns += cnt->surv_total[i][sub];
+        const int k = T->lv[i].active ? min(ns, T->lv[i].quota) : 0;
         if (i < l) base += k;
         all += k;
     }
@@ -415,7 +577,8 @@ __global__ __launch_bounds__(1024) void select_kernel(const LevelTable* __restri
     }
     if (!L.active) { if (tid == 0) { cnt->kept[l] = 0; cnt->thresh[l] = 0; } return; }
 
-    const int n = cnt->surv_total[l];
+    int n = 0;
+    for (int sub = 0; sub < EFX_NSUB; sub++) n += cnt->surv_total[l][sub];
     const Corner* surv = surv_all + L.surv_base;
     unsigned long long thresh = 0;
     if (n > L.quota) {
@@ -427,11 +590,15 @@ __global__ __launch_bounds__(1024) void select_kernel(const LevelTable* __restri
             const int shift = 64 - decided - width;
             for (int i = tid; i < SEL_BINS; i += 1024) s_hist[i] = 0;
             __syncthreads();
-            for (int i = tid; i < n; i += 1024) {
-                const Corner c = surv[i];
-                const unsigned long long k = efx_select_key(c.xy, c.resp);
-                const bool match = decided == 0 ? true : ((k >> (64 - decided)) == prefix);
-                if (match) atomicAdd(&s_hist[(int)((k >> shift) & ((1u << width) - 1))], 1);
+            for (int sub = 0; sub < EFX_NSUB; sub++) {
+                const Corner* q = surv + (size_t)sub * L.surv_sub_cap;
+                const int ns = cnt->surv_total[l][sub];
+                for (int i = tid; i < ns; i += 1024) {
+                    const Corner c = q[i];
+                    const unsigned long long k = efx_select_key(c.xy, c.resp);
+                    const bool match = decided == 0 ? true : ((k >> (64 - decided)) == prefix);
+                    if (match) atomicAdd(&s_hist[(int)((k >> shift) & ((1u << width) - 1))], 1);
+                }
             }
             __syncthreads();
             // walk the bins from the top: thread t owns bins [hi-4t-3, hi-4t]
@@ -470,7 +637,7 @@ __global__ __launch_bounds__(1024) void select_kernel(const LevelTable* __restri
         int c = 0;
         if (t < ntiles) {
             const int sc = (int)hl[t].surv_count;
-            const Corner* q = surv + hl[t].surv_start;
+            const Corner* q = surv + (size_t)(t & (EFX_NSUB - 1)) * L.surv_sub_cap + hl[t].surv_start;
             for (int j = 0; j < sc; j++) c += efx_select_key(q[j].xy, q[j].resp) >= thresh ? 1 : 0;
         }
         int tot;
@@ -508,32 +675,10 @@ __device__ __forceinline__ float atan2_deg(int m01, int m10)
     return (float)(a * (180.0 / PI));
 }
 
-// IC_Angle (cuda_efficient_features.cu:141-172): integer moments over the radius-15 disc
-__device__ __forceinline__ float ic_angle(const uint8_t* img, int pitch, int x, int y)
-{
-    const int U_MAX[16] = { 15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3 };
-    int m01 = 0, m10 = 0;
-    const uint8_t* c = img + (size_t)y * pitch + x;
-    for (int dx = -EFX_HALF_PATCH; dx <= EFX_HALF_PATCH; dx++) m10 += dx * (int)c[dx];
-    for (int dy = 1; dy <= EFX_HALF_PATCH; dy++) {
-        int ysum = 0;
-        const int d = U_MAX[dy];
-        const uint8_t* pt = c - (size_t)dy * pitch;
-        const uint8_t* pb = c + (size_t)dy * pitch;
-        for (int dx = -d; dx <= d; dx++) {
-            const int vT = pt[dx], vB = pb[dx];
-            ysum += (vB - vT);
-            m10 += dx * (vB + vT);
-        }
-        m01 += dy * ysum;
-    }
-    return atan2_deg(m01, m10);
-}
-
 // ================================================================================================
-// Kernel E: emit the selected survivors in canonical order: IC angle (calcAngles, .cu:376-390),
-// scalePoints (.cu:236-248), 5xN output rows, and the level-local float4 list for the describers
-// (convertKeypointsKernel, .cu:250-263).
+// Kernel E: emit the selected survivors in canonical order: scalePoints (.cu:236-248), 5xN output rows,
+// and the level-local float4 list for the describers (convertKeypointsKernel, .cu:250-263).
+// Kernel F (angle_kernel) then fills in the IC angle (calcAngles, .cu:376-390), one wave per keypoint.
 // ================================================================================================
 __global__ __launch_bounds__(64) void emit_kernel(const LevelTable* __restrict__ T, const TileHdr* __restrict__ hdr,
                                                   const Corner* __restrict__ surv_all, const Counters* __restrict__ cnt,
@@ -549,9 +694,7 @@ __global__ __launch_bounds__(64) void emit_kernel(const LevelTable* __restrict__
     const int sc = (int)h.surv_count;
     if (sc == 0) return;
     const unsigned long long thresh = cnt->thresh[l];
-    const Corner* q = surv_all + L.surv_base + h.surv_start;
-    const uint8_t* img = l == 0 ? img0 : pyramid + L.img_off;
-    const int pitch = l == 0 ? pitch0 : L.pitch;
+    const Corner* q = surv_all + L.surv_base + (size_t)((gt - L.tile_base) & (EFX_NSUB - 1)) * L.surv_sub_cap + h.surv_start;
     const int lane = threadIdx.x;
 
     int running = 0;
@@ -566,19 +709,62 @@ __global__ __launch_bounds__(64) void emit_kernel(const LevelTable* __restrict__
         running += __popcll(m);
         if (sel && out < capacity) {
             const int x = c.xy & 0xffff, y = c.xy >> 16;
-            const float angle = ic_angle(img, pitch, x, y);
             const short sx = (short)(L.scale * (float)x + 0.5f);
             const short sy = (short)(L.scale * (float)y + 0.5f);
             if (kps) {
                 *reinterpret_cast<uint32_t*>(kps + 0 * kps_pitch + 4 * (size_t)out) = (uint32_t)(uint16_t)sx | ((uint32_t)(uint16_t)sy << 16);
                 *reinterpret_cast<float*>(kps + 1 * kps_pitch + 4 * (size_t)out) = c.resp;
-                *reinterpret_cast<float*>(kps + 2 * kps_pitch + 4 * (size_t)out) = angle;
                 *reinterpret_cast<int*>(kps + 3 * kps_pitch + 4 * (size_t)out) = l;
                 *reinterpret_cast<float*>(kps + 4 * kps_pitch + 4 * (size_t)out) = L.scale * (float)EFX_PATCH_SIZE;
             }
-            kp4[out] = make_float4((float)x, (float)y, (float)EFX_PATCH_SIZE, angle);
+            kp4[out] = make_float4((float)x, (float)y, (float)EFX_PATCH_SIZE, 0.f);     // angle: angle_kernel
             kp_level[out] = l;
         }
+    }
+}
+
+// ================================================================================================
+// Kernel F: IC_Angle (cuda_efficient_features.cu:141-172), one wave per keypoint.  Lane = column dx of the
+// radius-15 disc (31 columns), loop over the 31 rows: every row is one coalesced 31-byte read.  The integer
+// moments are order-independent, the wave reduction gives exactly the reference's m_01 / m_10.
+// ================================================================================================
+__global__ __launch_bounds__(256) void angle_kernel(const LevelTable* __restrict__ T, const int* __restrict__ d_count, int capacity,
+                                                    const uint8_t* __restrict__ img0, int pitch0, const uint8_t* __restrict__ pyramid,
+                                                    float4* __restrict__ kp4, const int* __restrict__ kp_level,
+                                                    uint8_t* __restrict__ kps, size_t kps_pitch)
+{
+    const int lane = threadIdx.x & 63;
+    const int kid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int count = min(*d_count, capacity);
+    if (kid >= count) return;
+    const float4 kp = kp4[kid];
+    const int l = kp_level[kid];
+    const uint8_t* img = l == 0 ? img0 : pyramid + T->lv[l].img_off;
+    const int pitch = l == 0 ? pitch0 : T->lv[l].pitch;
+    const int x = (int)kp.x, y = (int)kp.y;
+    int m01 = 0, m10 = 0;
+    if (lane < 31) {
+        const int dx = lane - EFX_HALF_PATCH;
+        const int adx = dx < 0 ? -dx : dx;
+        const uint8_t* c = img + (size_t)y * pitch + x + dx;
+#pragma unroll
+        for (int dy = -EFX_HALF_PATCH; dy <= EFX_HALF_PATCH; dy++) {
+            // U_MAX, cuda_efficient_features.cu:143
+            const int U_MAX[16] = { 15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3 };
+            const int ady = dy < 0 ? -dy : dy;
+            if (adx <= U_MAX[ady]) {
+                const int v = c[dy * pitch];
+                m10 += dx * v;
+                m01 += dy * v;
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { m10 += __shfl_xor(m10, d, 64); m01 += __shfl_xor(m01, d, 64); }
+    if (lane == 0) {
+        const float angle = atan2_deg(m01, m10);
+        kp4[kid].w = angle;
+        if (kps) *reinterpret_cast<float*>(kps + 2 * kps_pitch + 4 * (size_t)kid) = angle;
     }
 }
 
@@ -627,24 +813,32 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
         const bool aligned = (((uintptr_t)src | (uintptr_t)spitch) & 3u) == 0;
         Corner* cand = a.cand + L.cand_base;
         TileHdr* hdr = a.hdr + L.tile_base;
-        int* ctot = &a.counters->cand_total[s];
+        int* ctot = &a.counters->cand_total[s][0];
         const bool prof = a.prof_count && *a.prof_count < a.prof_capacity;
         if (prof) (void)hipEventRecord(a.prof_start[*a.prof_count], stream);
         if (aligned)
             hipLaunchKernelGGL(pyr_fast_kernel<true>, dim3(ntiles), dim3(256), 0, stream, src, spitch, L.rows, L.cols,
-                               L.tiles_x, L.tiles_y, dst, dpitch, drows, dcols, fx, fy, a.threshold, do_fast, cand, hdr, ctot);
+                               L.tiles_x, L.tiles_y, dst, dpitch, drows, dcols, fx, fy, a.threshold, do_fast, cand, L.cand_sub_cap, hdr, ctot, a.dbg & 15);
         else
             hipLaunchKernelGGL(pyr_fast_kernel<false>, dim3(ntiles), dim3(256), 0, stream, src, spitch, L.rows, L.cols,
-                               L.tiles_x, L.tiles_y, dst, dpitch, drows, dcols, fx, fy, a.threshold, do_fast, cand, hdr, ctot);
+                               L.tiles_x, L.tiles_y, dst, dpitch, drows, dcols, fx, fy, a.threshold, do_fast, cand, L.cand_sub_cap, hdr, ctot, a.dbg & 15);
         if (prof) { (void)hipEventRecord(a.prof_stop[*a.prof_count], stream); a.prof_level[*a.prof_count] = s; ++*a.prof_count; }
     }
     hipLaunchKernelGGL(tile_rank_scan_kernel, dim3(H.nlevels), dim3(1024), 0, stream, a.d_table, a.hdr);
     hipLaunchKernelGGL(nms_kernel, dim3(H.total_tiles), dim3(256), 0, stream, a.d_table, a.hdr, a.cand, a.surv,
-                       a.counters, a.nonmax_radius);
+                       a.counters, a.nonmax_radius, a.dbg >> 4);
     hipLaunchKernelGGL(select_kernel, dim3(H.nlevels), dim3(1024), 0, stream, a.d_table, a.hdr, a.surv, a.counters,
                        a.capacity, a.d_count);
     hipLaunchKernelGGL(emit_kernel, dim3(H.total_tiles), dim3(64), 0, stream, a.d_table, a.hdr, a.surv, a.counters,
                        a.img0, a.pitch0, a.pyramid, (uint8_t*)a.d_keypoints, a.kps_pitch, a.capacity, a.kp4, a.kp_level);
+    if (a.capacity > 0) {
+        int nmax = 0;
+        for (int s = 0; s < H.nlevels; s++) if (H.lv[s].active) nmax += H.lv[s].quota;
+        if (nmax > a.capacity) nmax = a.capacity;
+        if (nmax > 0)
+            hipLaunchKernelGGL(angle_kernel, dim3((nmax + 3) / 4), dim3(256), 0, stream, a.d_table, a.d_count, a.capacity,
+                               a.img0, a.pitch0, a.pyramid, a.kp4, a.kp_level, (uint8_t*)a.d_keypoints, a.kps_pitch);
+    }
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (a.h_mirror) e = hipMemcpyAsync(a.h_mirror, a.counters, sizeof(Counters), hipMemcpyDeviceToHost, stream);

@@ -10,6 +10,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -89,8 +90,8 @@ int describer_init(Describer& d, int kind, int nbits, float scale)
         float reach = 0.f;
         for (int i = 0; i < nbits; i++) {
             const int x1 = boxes[5 * i + 0], x2 = boxes[5 * i + 1], y1 = boxes[5 * i + 2], y2 = boxes[5 * i + 3], r = boxes[5 * i + 4];
-            h->box[i] = make_int4(x1 | (x2 << 8), y1 | (y2 << 8), r, 0);
-            h->thr[i] = thr[i];
+            uint32_t tb; memcpy(&tb, &thr[i], 4);
+            h->box[i] = make_uint2((uint32_t)(x1 | (x2 << 5) | (y1 << 10) | (y2 << 15) | (r << 20)), tb);
             const float d1 = sqrtf((float)((x1 - 16) * (x1 - 16) + (y1 - 16) * (y1 - 16))) + (float)r;
             const float d2 = sqrtf((float)((x2 - 16) * (x2 - 16) + (y2 - 16) * (y2 - 16))) + (float)r;
             reach = fmaxf(reach, fmaxf(d1, d2));
@@ -258,7 +259,16 @@ int build_geometry(efx_context* c, int rows, int cols)
         }
         L.cand_base = ncand;
         L.surv_base = nsurv;
-        if (L.active) { ncand += (size_t)L.rows * L.cols; nsurv += (size_t)L.cap; }
+        if (L.active) {
+            // sub-array k holds the tiles with (tile & 7) == k; a 64x64 tile has at most 4096 corners
+            const size_t tiles_per_sub = ((size_t)L.tiles_x * L.tiles_y + EFX_NSUB - 1) / EFX_NSUB;
+            const size_t csub = tiles_per_sub * EFX_TILE * EFX_TILE;
+            const size_t ssub = csub < (size_t)L.cap ? csub : (size_t)L.cap;
+            L.cand_sub_cap = (unsigned)csub;
+            L.surv_sub_cap = (unsigned)ssub;
+            ncand += csub * EFX_NSUB;
+            nsurv += ssub * EFX_NSUB;
+        }
     }
     T.total_tiles = tiles;
     if (rows > 32767 || cols > 32767) return set_err(c->err, EFX_ERR_UNSUPPORTED, "image larger than 32767 (short2 coordinates)");
@@ -307,6 +317,7 @@ int detect_common(efx_context* c, const uint8_t* d_image, int rows, int cols, si
     a.threshold = c->p.fast_threshold;
     a.nonmax_radius = c->p.nonmax_radius;
     a.first_level = c->p.first_level;
+    { const char* e = getenv("EFX_DEBUG"); a.dbg = e ? atoi(e) : 0; }
     a.d_keypoints = d_keypoints; a.kps_pitch = kps_pitch; a.capacity = capacity;
     a.d_count = d_count ? d_count : static_cast<int*>(c->count.p);
     a.kp4 = static_cast<float4*>(c->kp4.p);
@@ -522,8 +533,11 @@ int efx_last_level_stats(const efx_context* ctx, efx_level_stats* stats, int max
     if (!ctx || !stats || !ctx->h_mirror || !ctx->has_frame) return EFX_ERR_BAD_ARG;
     const int nl = ctx->h_table.nlevels < max_levels ? ctx->h_table.nlevels : max_levels;
     for (int i = 0; i < nl; i++) {
-        stats[i].n_candidates = ctx->h_mirror->cand_total[i];
-        stats[i].n_after_nms = ctx->h_mirror->surv_total[i];
+        stats[i].n_candidates = 0; stats[i].n_after_nms = 0;
+        for (int sub = 0; sub < EFX_NSUB; sub++) {
+            stats[i].n_candidates += ctx->h_mirror->cand_total[i][sub];
+            stats[i].n_after_nms += ctx->h_mirror->surv_total[i][sub];
+        }
         stats[i].n_kept = ctx->h_mirror->kept[i];
     }
     if (nlevels) *nlevels = nl;
