@@ -158,9 +158,9 @@ __global__ __launch_bounds__(256) void pyr_fast_kernel(
     int threshold, int do_fast,
     Corner* __restrict__ cand, unsigned cand_sub_cap, TileHdr* __restrict__ hdr, int* __restrict__ cand_total, int dbg)
 {
-    __shared__ uint32_t s_tile[EFX_LT * (EFX_LT / 4)];
+    __shared__ __attribute__((aligned(16))) uint32_t s_tile[EFX_LT * (EFX_LP / 4)];
     __shared__ unsigned long long s_bitmap[EFX_TILE];
-    __shared__ uint16_t s_list[EFX_TILE * EFX_TILE];
+    __shared__ uint16_t s_list[EFX_TILE * EFX_TILE];     // phase 1-2: per-wave quick-test survivors; phase 3+: corner list
     __shared__ int s_scan[8];
     __shared__ int s_celloff[EFX_CELLS_PER_TILE + 1];
     __shared__ int s_start;
@@ -172,43 +172,89 @@ __global__ __launch_bounds__(256) void pyr_fast_kernel(
     const int x0 = tx * EFX_TILE, y0 = ty * EFX_TILE;
     const uint8_t* tb = reinterpret_cast<const uint8_t*>(s_tile);
 
-    // ---- phase 0: tile + halo -> LDS (coalesced dword loads when the image allows it) ----
-    for (int i = tid; i < EFX_LT * (EFX_LT / 4); i += 256) {
-        const int r = i / (EFX_LT / 4), c4 = i % (EFX_LT / 4);
+    // ---- phase 0: tile + halo -> LDS.  72 rows x 72 bytes as 9 x 8-byte pieces per row (the global address is
+    //      only 4-byte aligned: x0 - 4), LDS row pitch 80 B. ----
+    if (tid < EFX_TILE) s_bitmap[tid] = 0ull;
+    for (int i = tid; i < EFX_LT * 9; i += 256) {
+        const int r = i / 9, c8 = i - r * 9;
         const int gy = y0 - EFX_HALO + r;
-        const int gx = x0 - EFX_HALO + c4 * 4;
-        uint32_t v = 0;
+        const int gx = x0 - EFX_HALO + c8 * 8;
+        uint2 v = make_uint2(0u, 0u);
         if (gy >= 0 && gy < rows) {
             const uint8_t* p = src + (size_t)gy * spitch;
-            if (ALIGNED && gx >= 0 && gx + 4 <= cols) {
-                v = *reinterpret_cast<const uint32_t*>(p + gx);
+            if (ALIGNED && gx >= 0 && gx + 8 <= cols) {
+                v = *reinterpret_cast<const uint2*>(p + gx);
             } else {
 #pragma unroll
                 for (int b = 0; b < 4; b++) {
-                    const int x = gx + b;
-                    if (x >= 0 && x < cols) v |= (uint32_t)p[x] << (8 * b);
+                    const int xa = gx + b, xb = gx + 4 + b;
+                    if (xa >= 0 && xa < cols) v.x |= (uint32_t)p[xa] << (8 * b);
+                    if (xb >= 0 && xb < cols) v.y |= (uint32_t)p[xb] << (8 * b);
                 }
             }
         }
-        s_tile[i] = v;
+        *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(s_tile) + r * EFX_LP + c8 * 8) = v;
     }
     __syncthreads();
 
     int total = 0;
     if (dbg & 1) do_fast = 0;
     if (do_fast) {
-        // ---- phase 1: FAST-9, lane = column, wave = 16 rows; one ballot per row = one bitmap row ----
         const int lane = tid & 63, wid = tid >> 6;
-        const int x = x0 + lane;
-        const bool xin = x >= EFX_HALF_PATCH && x < cols - EFX_HALF_PATCH;     // mask, .cpp:176-182
-        for (int r = 0; r < 16; r++) {
-            const int ly = wid * 16 + r;
-            const int y = y0 + ly;
-            bool corner = false;
-            if (xin && y >= EFX_HALF_PATCH && y < rows - EFX_HALF_PATCH && !(dbg & 2))
-                corner = fast9_lds<EFX_LT>(tb + (ly + EFX_HALO) * EFX_LT + lane + EFX_HALO, threshold);
-            const unsigned long long m = __ballot(corner);
-            if (lane == 0) s_bitmap[ly] = m;
+        // ---- phase 1: quick test on all pixels.  A lane owns a 4x4 pixel block and pulls the 10 rows x 12 bytes
+        //      it needs as 30 dwords (1.9 LDS reads per pixel); every byte it compares is a static extract.  A
+        //      9-arc always contains two neighbouring compass points of the same polarity (cuda_fast.cu:193-197
+        //      has the weaker opposing-pair form); pixels that pass go to a per-wave list. ----
+        const int cg = lane & 15, rg = lane >> 4;
+        const int bx = cg * 4, by = wid * 16 + rg * 4;
+        unsigned qm = 0;
+        {
+            const uint32_t* trow = s_tile + (by + EFX_HALO - 3) * (EFX_LP / 4) + cg;
+            uint32_t R[10][3];
+#pragma unroll
+            for (int i = 0; i < 10; i++) {
+                R[i][0] = trow[i * (EFX_LP / 4) + 0]; R[i][1] = trow[i * (EFX_LP / 4) + 1]; R[i][2] = trow[i * (EFX_LP / 4) + 2];
+            }
+            const int gx0 = x0 + bx, gy0 = y0 + by;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const bool yin = (gy0 + j) >= EFX_HALF_PATCH && (gy0 + j) < rows - EFX_HALF_PATCH;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int p = (R[j + 3][1] >> (8 * i)) & 0xff;
+                    const int cn = (R[j][1] >> (8 * i)) & 0xff;                       // (x, y-3)   k = 8
+                    const int cs = (R[j + 6][1] >> (8 * i)) & 0xff;                   // (x, y+3)   k = 0
+                    const int ce = i == 0 ? (int)(R[j + 3][1] >> 24) : (int)((R[j + 3][2] >> (8 * (i - 1))) & 0xff);   // (x+3, y) k = 4
+                    const int cw = i == 3 ? (int)(R[j + 3][1] & 0xff) : (int)((R[j + 3][0] >> (8 * (i + 1))) & 0xff);  // (x-3, y) k = 12
+                    const int hi = p + threshold, lo = p - threshold;
+                    const bool bn = cn > hi, bs = cs > hi, be = ce > hi, bw = cw > hi;
+                    const bool dn = cn < lo, ds = cs < lo, de = ce < lo, dw = cw < lo;
+                    const bool pass = ((bs | bn) & (be | bw)) | ((ds | dn) & (de | dw));
+                    const bool xin = (gx0 + i) >= EFX_HALF_PATCH && (gx0 + i) < cols - EFX_HALF_PATCH;   // mask, .cpp:176-182
+                    if (pass && xin && yin && !(dbg & 2)) qm |= 1u << (j * 4 + i);
+                }
+            }
+        }
+        uint16_t* ql = s_list + wid * 1024;
+        const int qcnt = __popc(qm);
+        const int qincl = wave_incl_scan(qcnt);
+        const int nq = __shfl(qincl, 63, 64);
+        {
+            int pos = qincl - qcnt;
+            while (qm) {
+                const int b = __ffs(qm) - 1;
+                qm &= qm - 1;
+                ql[pos++] = (uint16_t)((bx + (b & 3)) | ((by + (b >> 2)) << 8));
+            }
+        }
+        __syncthreads();
+        // ---- phase 2: full 16-point segment test on the survivors, one lane per pixel; corners set their bit in
+        //      the 64x64 bitmap ----
+        for (int idx = lane; idx < nq; idx += 64) {
+            const int e = ql[idx];
+            const int lx = e & 0xff, ly = e >> 8;
+            if (fast9_lds<EFX_LP>(tb + (ly + EFX_HALO) * EFX_LP + lx + EFX_HALO, threshold))
+                atomicOr(reinterpret_cast<unsigned*>(s_bitmap) + ly * 2 + (lx >> 5), 1u << (lx & 31));
         }
         __syncthreads();
 
@@ -234,7 +280,7 @@ __global__ __launch_bounds__(256) void pyr_fast_kernel(
         const int start = s_start;
         for (int k = tid; k < total; k += 256) {
             const int lx = s_list[k] & 0xff, ly = s_list[k] >> 8;
-            const float resp = (dbg & 4) ? 1.f : harris_lds<EFX_LT>(tb + (ly + EFX_HALO) * EFX_LT + lx + EFX_HALO);
+            const float resp = (dbg & 4) ? 1.f : harris_lds<EFX_LP>(tb + (ly + EFX_HALO) * EFX_LP + lx + EFX_HALO);
             Corner c;
             c.xy = (uint32_t)(x0 + lx) | ((uint32_t)(y0 + ly) << 16);
             c.resp = resp;
@@ -271,8 +317,8 @@ __global__ __launch_bounds__(256) void pyr_fast_kernel(
                 const int y2 = y1 + 1;
                 const int y2r = y2 < rows - 1 ? y2 : rows - 1;
                 const float wy0 = (float)y2 - sy, wy1 = sy - (float)y1;
-                const uint8_t* pa = tb + (y1 - y0 + EFX_HALO) * EFX_LT + lc;
-                const uint8_t* pb = tb + (y2r - y0 + EFX_HALO) * EFX_LT + lc;
+                const uint8_t* pa = tb + (y1 - y0 + EFX_HALO) * EFX_LP + lc;
+                const uint8_t* pb = tb + (y2r - y0 + EFX_HALO) * EFX_LP + lc;
                 float out = 0.f;
                 out = out + (float)pa[0] * (wx0 * wy0);
                 out = out + (float)pa[dxr] * (wx1 * wy0);

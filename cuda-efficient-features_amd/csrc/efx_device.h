@@ -18,6 +18,7 @@
 #define EFX_CELLS_PER_TILE 16
 #define EFX_HALO 4             // FAST needs 3, Harris 7x7 of 3x3 Sobel needs 4, resize needs 1
 #define EFX_LT (EFX_TILE + 2 * EFX_HALO)   // LDS tile edge (72)
+#define EFX_LP 80               // LDS tile row pitch in bytes: 20 dwords, so rows 4 apart are 16 banks apart
 #define EFX_MAX_LEVELS 32
 #define EFX_HALF_PATCH 15      // cuda_efficient_features.cpp:34
 #define EFX_PATCH_SIZE 31      // cuda_efficient_features.cpp:33

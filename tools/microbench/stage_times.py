@@ -1,4 +1,5 @@
-"""Times detectAsync on one 8K frame for several EFX_DEBUG stage knobs (investigation helper)."""
+"""Times the pyramid+FAST launches (HIP events per launch) and the whole detect call on one 8K frame for several
+EFX_DEBUG stage knobs (investigation helper)."""
 import os, sys, time
 sys.path.insert(0, '.')
 import numpy as np, torch
@@ -10,11 +11,18 @@ kps = torch.zeros((5, 40000), dtype=torch.float32, device='cuda'); cnt = torch.z
 def run(dbg, reps=5):
     os.environ['EFX_DEBUG'] = str(dbg)
     det.detectAsync(img, kps, cnt); torch.cuda.synchronize()
+    det.profileEnable(reps * 8)
     a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(reps): det.detectAsync(img, kps, cnt)
     b.record(); torch.cuda.synchronize()
-    return a.elapsed_time(b) / reps * 1000
-for name, dbg in [('full', 0), ('pyr: no fast at all', 1), ('pyr: quick-reject all', 2), ('pyr: no harris', 4), ('pyr: no resize', 8),
-                  ('pyr: only load (1|8)', 9), ('nms: ret after hdr', 16), ('nms: ret after staging', 32), ('nms: ret after pass1', 48)]:
-    print(f'{name:28s} {run(dbg):9.1f} us', det.lastLevelStats()[0] if dbg == 0 else '')
+    ms, lvl = det.profileRead()
+    det.profileEnable(0)
+    per_level = [ms[lvl == l].mean() * 1000 for l in range(8)]
+    return a.elapsed_time(b) / reps * 1000, sum(per_level), per_level
+cases = [('full', 0), ('pyr: no fast at all', 1), ('pyr: quick-reject all', 2), ('pyr: no harris', 4), ('pyr: no resize', 8),
+         ('pyr: only load (1|8)', 9), ('pyr: quick only+resize', 2), ('nms: ret after hdr', 16), ('nms: ret after staging', 32), ('nms: ret after pass1', 48)]
+if len(sys.argv) > 1: cases = [(f'dbg {v}', int(v)) for v in sys.argv[1:]]
+for name, dbg in cases:
+    tot, pyr, pl = run(dbg)
+    print(f'{name:26s} detect {tot:8.1f} us | pyr_fast sum {pyr:7.1f} us | L0 {pl[0]:6.1f} L1 {pl[1]:6.1f} L7 {pl[7]:5.1f}')
