@@ -98,26 +98,43 @@ __device__ __forceinline__ bool fast9_lds(const uint8_t* c, int t)
 }
 
 // Harris response, spec S4 (cuda_efficient_features.cu:99-139): exact int32 sums of the 49 Sobel products,
-// then one fixed, uncontracted float formula.
+// then one fixed, uncontracted float formula.  The 9x9 footprint is pulled as 9 rows x 3 aligned dwords and
+// re-aligned with v_alignbyte (27 LDS reads instead of 81 byte reads); the Sobel sums share the pairwise row /
+// column sums, and the products use 24-bit multiplies (|d| <= 1020).
 template <int P>
 __device__ __forceinline__ float harris_lds(const uint8_t* c)
 {
+    const uint8_t* p0 = c - 4 * P - 4;                       // top-left byte of the footprint
+    const unsigned sh = (unsigned)(reinterpret_cast<uintptr_t>(p0) & 3u);
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(p0 - sh);
+    int px[9][9];
+#pragma unroll
+    for (int r = 0; r < 9; r++) {
+        const uint32_t w0 = w[r * (P / 4)], w1 = w[r * (P / 4) + 1], w2 = w[r * (P / 4) + 2];
+        const uint32_t a = __builtin_amdgcn_alignbyte(w1, w0, sh), b = __builtin_amdgcn_alignbyte(w2, w1, sh);
+        const uint32_t t = w2 >> (8 * sh);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { px[r][k] = (a >> (8 * k)) & 0xff; px[r][4 + k] = (b >> (8 * k)) & 0xff; }
+        px[r][8] = t & 0xff;
+    }
+    // vs[r][c] = px[r][c] + px[r+1][c] (vertical pair sums), hs[r][c] = px[r][c] + px[r][c+1] (horizontal)
     int sxx = 0, sxy = 0, syy = 0;
-    int r0[9], r1[9], r2[9];
 #pragma unroll
-    for (int i = 0; i < 9; i++) { r0[i] = c[-4 * P + i - 4]; r1[i] = c[-3 * P + i - 4]; }
+    for (int r = 1; r <= 7; r++) {
+        int V[9], H0[7], H2[7];
 #pragma unroll
-    for (int iy = -3; iy <= 3; iy++) {
-#pragma unroll
-        for (int i = 0; i < 9; i++) r2[i] = c[(iy + 1) * P + i - 4];
+        for (int cidx = 0; cidx < 9; cidx++) V[cidx] = (px[r - 1][cidx] + px[r][cidx]) + (px[r][cidx] + px[r + 1][cidx]);
 #pragma unroll
         for (int ix = 0; ix < 7; ix++) {
-            const int dx = (r0[ix + 2] + 2 * r1[ix + 2] + r2[ix + 2]) - (r0[ix] + 2 * r1[ix] + r2[ix]);
-            const int dy = (r2[ix] + 2 * r2[ix + 1] + r2[ix + 2]) - (r0[ix] + 2 * r0[ix + 1] + r0[ix + 2]);
-            sxx += dx * dx; sxy += dx * dy; syy += dy * dy;
+            H0[ix] = (px[r - 1][ix] + px[r - 1][ix + 1]) + (px[r - 1][ix + 1] + px[r - 1][ix + 2]);
+            H2[ix] = (px[r + 1][ix] + px[r + 1][ix + 1]) + (px[r + 1][ix + 1] + px[r + 1][ix + 2]);
         }
 #pragma unroll
-        for (int i = 0; i < 9; i++) { r0[i] = r1[i]; r1[i] = r2[i]; }
+        for (int ix = 0; ix < 7; ix++) {
+            const int dx = V[ix + 2] - V[ix];
+            const int dy = H2[ix] - H0[ix];
+            sxx += __mul24(dx, dx); sxy += __mul24(dx, dy); syy += __mul24(dy, dy);
+        }
     }
     const float SCALE = 1.f / (float)(4 * 7 * 255);
     const float K = SCALE * SCALE;
@@ -133,30 +150,90 @@ __device__ __forceinline__ uint8_t sat_u8_rne(float v)
     return (uint8_t)(r < 0.f ? 0.f : (r > 255.f ? 255.f : r));
 }
 
-// smallest ox >= 0 with floor(ox * f) >= v  (float product, monotone in ox)
-__device__ __forceinline__ int first_ge(int v, float f, int limit)
+// ================================================================================================
+// Kernel R: one 64x64 tile of pyramid level s+1 per workgroup, bilinear from level s (spec S5; the
+// cv::cuda::resize call of calcImagePyramid, cuda_efficient_features.cpp:154).  The source footprint of the
+// tile is staged in LDS with aligned dword loads; lane = output column (source column and x-weights are
+// row-invariant), the 4 waves take the rows in turn, every wave store is one full 64-byte row segment.
+// ================================================================================================
+__global__ __launch_bounds__(256) void resize_kernel(
+    const uint8_t* __restrict__ src, int spitch, int rows, int cols, int aligned,
+    uint8_t* __restrict__ dst, int dpitch, int drows, int dcols, float fx, float fy, int tiles_x, int tiles_y, int lpitch)
 {
-    if (v <= 0) return 0;
-    int e = (int)((float)v / f);
-    if (e > limit) e = limit;
-    while (e > 0 && (int)floorf((float)(e - 1) * f) >= v) e--;
-    while (e < limit && (int)floorf((float)e * f) < v) e++;
-    return e;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int tile = xcd_chunked(blockIdx.x, tiles_x * tiles_y);
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int ox0 = tx * EFX_TILE, oy0 = ty * EFX_TILE;
+    const int ox1 = min(ox0 + EFX_TILE, dcols), oy1 = min(oy0 + EFX_TILE, drows);
+    // source footprint [sx0, sx1] x [sy0, sy1] (inclusive, after the +1 neighbour and the clamps)
+    const int sx0 = min((int)floorf((float)ox0 * fx), cols - 1), sy0 = min((int)floorf((float)oy0 * fy), rows - 1);
+    const int sx1 = min(min((int)floorf((float)(ox1 - 1) * fx), cols - 1) + 1, cols - 1);
+    const int sy1 = min(min((int)floorf((float)(oy1 - 1) * fy), rows - 1) + 1, rows - 1);
+    const int ax0 = sx0 & ~3;                              // LDS column 0 <-> source column ax0
+    const int ndw = ((sx1 - ax0) >> 2) + 1, nrow = sy1 - sy0 + 1;
+    for (int i = tid; i < ndw * nrow; i += 256) {
+        const int r = i / ndw, c4 = i - r * ndw;
+        const int gx = ax0 + 4 * c4;
+        const uint8_t* p = src + (size_t)(sy0 + r) * spitch;
+        uint32_t v = 0;
+        if (aligned && gx + 4 <= cols) {
+            v = *reinterpret_cast<const uint32_t*>(p + gx);
+        } else {
+#pragma unroll
+            for (int b = 0; b < 4; b++) if (gx + b < cols) v |= (uint32_t)p[gx + b] << (8 * b);
+        }
+        *reinterpret_cast<uint32_t*>(smem + r * lpitch + 4 * c4) = v;
+    }
+    __syncthreads();
+    const int lane = tid & 63, wid = tid >> 6;
+    const int ox = ox0 + lane;
+    if (ox >= ox1) return;
+    const float sx = (float)ox * fx;
+    int x1 = (int)floorf(sx);
+    if (x1 > cols - 1) x1 = cols - 1;
+    const int x2 = x1 + 1;
+    const int x2r = x2 < cols - 1 ? x2 : cols - 1;
+    const float wx0 = (float)x2 - sx, wx1 = sx - (float)x1;
+    const int lc = x1 - ax0, dxr = x2r - x1;
+    for (int oy = oy0 + wid; oy < oy1; oy += 4) {
+        const float sy = (float)oy * fy;
+        int y1 = (int)floorf(sy);
+        if (y1 > rows - 1) y1 = rows - 1;
+        const int y2 = y1 + 1;
+        const int y2r = y2 < rows - 1 ? y2 : rows - 1;
+        const float wy0 = (float)y2 - sy, wy1 = sy - (float)y1;
+        const uint8_t* pa = smem + (y1 - sy0) * lpitch + lc;
+        const uint8_t* pb = smem + (y2r - sy0) * lpitch + lc;
+        float out = 0.f;
+        out = out + (float)pa[0] * (wx0 * wy0);
+        out = out + (float)pa[dxr] * (wx1 * wy0);
+        out = out + (float)pb[0] * (wx0 * wy1);
+        out = out + (float)pb[dxr] * (wx1 * wy1);
+        dst[(size_t)oy * dpitch + ox] = sat_u8_rne(out);
+    }
+}
+
+// level of a global tile index
+__device__ __forceinline__ int level_of_tile(const LevelTable* T, int gt)
+{
+    int l = 0;
+    for (int i = 1; i < T->nlevels; i++)
+        if (gt >= T->lv[i].tile_base) l = i;
+    return l;
 }
 
 // ================================================================================================
-// Kernel A: one 64x64 tile of level s per workgroup.
-//   load tile+halo -> LDS | FAST-9 -> corner bitmap (ballot) | canonical enumeration (cell-major)
-//   | Harris on the corners | append {xy, response} to the level's corner array + tile header
-//   | bilinear resize of the tile's share of level s+1 (spec S5)
-// Algorithmic HBM bytes: every level read once and every derived level written once.
+// Kernel A: FAST-9 + Harris for every 64x64 tile of every pyramid level in ONE launch (no per-level tails).
+//   tile+halo -> LDS | quick test on all pixels (register blocked) | full segment test on the survivors
+//   -> corner bitmap | canonical enumeration (cell-major) | Harris on the corners
+//   | append {xy, response} to the level's corner array + tile header
+// Algorithmic HBM bytes: every level is read once.
 // ================================================================================================
-template <bool ALIGNED>
-__global__ __launch_bounds__(256) void pyr_fast_kernel(
-    const uint8_t* __restrict__ src, int spitch, int rows, int cols, int tiles_x, int tiles_y,
-    uint8_t* __restrict__ dst, int dpitch, int drows, int dcols, float fx, float fy,
-    int threshold, int do_fast,
-    Corner* __restrict__ cand, unsigned cand_sub_cap, TileHdr* __restrict__ hdr, int* __restrict__ cand_total, int dbg)
+__global__ __launch_bounds__(256) void fast_kernel(
+    const LevelTable* __restrict__ T, const uint8_t* __restrict__ img0, int pitch0, int aligned0,
+    const uint8_t* __restrict__ pyramid, int threshold,
+    Corner* __restrict__ cand_all, TileHdr* __restrict__ hdr_all, Counters* __restrict__ cnt, int dbg)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_tile[EFX_LT * (EFX_LP / 4)];
     __shared__ unsigned long long s_bitmap[EFX_TILE];
@@ -166,11 +243,20 @@ __global__ __launch_bounds__(256) void pyr_fast_kernel(
     __shared__ int s_start;
 
     const int tid = threadIdx.x;
-    const int ntiles = tiles_x * tiles_y;
-    const int tile = xcd_chunked(blockIdx.x, ntiles);
-    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int gt = xcd_chunked(blockIdx.x, T->total_tiles);
+    const int l = level_of_tile(T, gt);
+    const LevelDev& L = T->lv[l];
+    if (!L.active) return;
+    const int tile = gt - L.tile_base;
+    const int rows = L.rows, cols = L.cols;
+    const uint8_t* src = l == 0 ? img0 : pyramid + L.img_off;
+    const int spitch = l == 0 ? pitch0 : L.pitch;
+    const bool aligned = l == 0 ? aligned0 != 0 : true;
+    const int tx = tile % L.tiles_x, ty = tile / L.tiles_x;
     const int x0 = tx * EFX_TILE, y0 = ty * EFX_TILE;
     const uint8_t* tb = reinterpret_cast<const uint8_t*>(s_tile);
+    Corner* cand = cand_all + L.cand_base;
+    TileHdr* hdr = hdr_all + L.tile_base;
 
     // ---- phase 0: tile + halo -> LDS.  72 rows x 72 bytes as 9 x 8-byte pieces per row (the global address is
     //      only 4-byte aligned: x0 - 4), LDS row pitch 80 B. ----
@@ -182,7 +268,7 @@ __global__ __launch_bounds__(256) void pyr_fast_kernel(
         uint2 v = make_uint2(0u, 0u);
         if (gy >= 0 && gy < rows) {
             const uint8_t* p = src + (size_t)gy * spitch;
-            if (ALIGNED && gx >= 0 && gx + 8 <= cols) {
+            if (aligned && gx >= 0 && gx + 8 <= cols) {
                 v = *reinterpret_cast<const uint2*>(p + gx);
             } else {
 #pragma unroll
@@ -198,8 +284,7 @@ __global__ __launch_bounds__(256) void pyr_fast_kernel(
     __syncthreads();
 
     int total = 0;
-    if (dbg & 1) do_fast = 0;
-    if (do_fast) {
+    {
         const int lane = tid & 63, wid = tid >> 6;
         // ---- phase 1: quick test on all pixels.  A lane owns a 4x4 pixel block and pulls the 10 rows x 12 bytes
         //      it needs as 30 dwords (1.9 LDS reads per pixel); every byte it compares is a static extract.  A
@@ -258,13 +343,13 @@ __global__ __launch_bounds__(256) void pyr_fast_kernel(
         }
         __syncthreads();
 
-        // ---- phase 2: canonical enumeration (spec S1): cell-major, raster inside the 16x16 cell ----
+        // ---- phase 3: canonical enumeration (spec S1): cell-major, raster inside the 16x16 cell ----
         const int cell = tid >> 4, rr = tid & 15;
         const int cy = cell >> 2, cx = cell & 3;
         const int brow = cy * 16 + rr;
         unsigned bits = (unsigned)(s_bitmap[brow] >> (cx * 16)) & 0xffffu;
-        const int cnt = __popc(bits);
-        const int pre = block_excl_scan<4>(cnt, s_scan, &total);
+        const int cntb = __popc(bits);
+        const int pre = block_excl_scan<4>(cntb, s_scan, &total);
         if (rr == 0) s_celloff[cell] = pre;
         if (tid == 0) s_celloff[EFX_CELLS_PER_TILE] = total;
         int pos = pre;
@@ -273,10 +358,10 @@ __global__ __launch_bounds__(256) void pyr_fast_kernel(
             bits &= bits - 1;
             s_list[pos++] = (uint16_t)((cx * 16 + b) | (brow << 8));
         }
-        if (tid == 0) s_start = total > 0 ? atomicAdd(cand_total + (tile & (EFX_NSUB - 1)), total) : 0;
+        if (tid == 0) s_start = total > 0 ? atomicAdd(&cnt->cand_total[l][tile & (EFX_NSUB - 1)], total) : 0;
         __syncthreads();
 
-        // ---- phase 3: Harris on the corners, append to the level's corner array ----
+        // ---- phase 4: Harris on the corners, append to the level's corner array ----
         const int start = s_start;
         for (int k = tid; k < total; k += 256) {
             const int lx = s_list[k] & 0xff, ly = s_list[k] >> 8;
@@ -284,49 +369,11 @@ __global__ __launch_bounds__(256) void pyr_fast_kernel(
             Corner c;
             c.xy = (uint32_t)(x0 + lx) | ((uint32_t)(y0 + ly) << 16);
             c.resp = resp;
-            cand[(size_t)(tile & (EFX_NSUB - 1)) * cand_sub_cap + start + k] = c;
+            cand[(size_t)(tile & (EFX_NSUB - 1)) * L.cand_sub_cap + start + k] = c;
         }
         TileHdr* h = hdr + tile;
         if (tid <= EFX_CELLS_PER_TILE) h->cell_off[tid] = (uint16_t)s_celloff[tid];
         if (tid == 32) { h->cand_start = (uint32_t)start; h->cand_rank = 0; h->surv_start = 0; h->surv_count = 0; h->out_off = 0; }
-    }
-
-    // ---- phase 4: this tile's share of level s+1 (spec S5; cv::cuda::resize, .cpp:154) ----
-    if (dst != nullptr && !(dbg & 8)) {
-        const int ox_b = first_ge(x0, fx, dcols);
-        const int ox_e = (tx == tiles_x - 1) ? dcols : first_ge(x0 + EFX_TILE, fx, dcols);
-        const int oy_b = first_ge(y0, fy, drows);
-        const int oy_e = (ty == tiles_y - 1) ? drows : first_ge(y0 + EFX_TILE, fy, drows);
-        // lane = output column (its source column and x-weights are row-invariant), waves take rows in turn
-        const int lane4 = tid & 63, wid4 = tid >> 6;
-        for (int oxs = ox_b; oxs < ox_e; oxs += 64) {
-            const int ox = oxs + lane4;
-            const bool act = ox < ox_e;
-            const float sx = (float)ox * fx;
-            int x1 = (int)floorf(sx);
-            if (x1 > cols - 1) x1 = cols - 1;
-            const int x2 = x1 + 1;
-            const int x2r = x2 < cols - 1 ? x2 : cols - 1;
-            const float wx0 = (float)x2 - sx, wx1 = sx - (float)x1;
-            const int lc = act ? (x1 - x0 + EFX_HALO) : EFX_HALO;
-            const int dxr = act ? (x2r - x1) : 0;
-            for (int oy = oy_b + wid4; oy < oy_e; oy += 4) {
-                const float sy = (float)oy * fy;
-                int y1 = (int)floorf(sy);
-                if (y1 > rows - 1) y1 = rows - 1;
-                const int y2 = y1 + 1;
-                const int y2r = y2 < rows - 1 ? y2 : rows - 1;
-                const float wy0 = (float)y2 - sy, wy1 = sy - (float)y1;
-                const uint8_t* pa = tb + (y1 - y0 + EFX_HALO) * EFX_LP + lc;
-                const uint8_t* pb = tb + (y2r - y0 + EFX_HALO) * EFX_LP + lc;
-                float out = 0.f;
-                out = out + (float)pa[0] * (wx0 * wy0);
-                out = out + (float)pa[dxr] * (wx1 * wy0);
-                out = out + (float)pb[0] * (wx0 * wy1);
-                out = out + (float)pb[dxr] * (wx1 * wy1);
-                if (act) dst[(size_t)oy * dpitch + ox] = sat_u8_rne(out);
-            }
-        }
     }
 }
 
@@ -350,15 +397,6 @@ __global__ __launch_bounds__(1024) void tile_rank_scan_kernel(const LevelTable* 
         if (t < n) h[t].cand_rank = (uint32_t)(running + pre);
         running += tot;
     }
-}
-
-// level of a global tile index
-__device__ __forceinline__ int level_of_tile(const LevelTable* T, int gt)
-{
-    int l = 0;
-    for (int i = 1; i < T->nlevels; i++)
-        if (gt >= T->lv[i].tile_base) l = i;
-    return l;
 }
 
 // ================================================================================================
@@ -843,32 +881,31 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
     hipError_t e = hipMemsetAsync(a.counters, 0, sizeof(Counters), stream);
     if (e != hipSuccess) return e;
 
-    for (int s = 0; s < H.nlevels; s++) {
+    // pyramid chain (calcImagePyramid, .cpp:136-157): level s+1 from level s
+    for (int s = 0; s + 1 < H.nlevels; s++) {
         const LevelDev& L = H.lv[s];
-        if (L.rows <= 0 || L.cols <= 0) continue;
+        const LevelDev& N = H.lv[s + 1];
+        if (L.rows <= 0 || L.cols <= 0 || N.rows <= 0 || N.cols <= 0) break;
         const uint8_t* src = s == 0 ? a.img0 : a.pyramid + L.img_off;
         const int spitch = s == 0 ? a.pitch0 : L.pitch;
-        uint8_t* dst = nullptr; int dpitch = 0, drows = 0, dcols = 0; float fx = 1.f, fy = 1.f;
-        if (s + 1 < H.nlevels && H.lv[s + 1].rows > 0 && H.lv[s + 1].cols > 0) {
-            const LevelDev& N = H.lv[s + 1];
-            dst = a.pyramid + N.img_off; dpitch = N.pitch; drows = N.rows; dcols = N.cols; fx = N.fx; fy = N.fy;
-        }
-        const int do_fast = L.active;
-        if (!do_fast && dst == nullptr) continue;
-        const int ntiles = L.tiles_x * L.tiles_y;
-        const bool aligned = (((uintptr_t)src | (uintptr_t)spitch) & 3u) == 0;
-        Corner* cand = a.cand + L.cand_base;
-        TileHdr* hdr = a.hdr + L.tile_base;
-        int* ctot = &a.counters->cand_total[s][0];
+        const int aligned = (((uintptr_t)src | (uintptr_t)spitch) & 3u) == 0;
+        const int sw = (int)ceilf((float)(EFX_TILE - 1) * N.fx) + 8, sh = (int)ceilf((float)(EFX_TILE - 1) * N.fy) + 3;
+        const int lpitch = (sw + 3) & ~3;
+        const size_t lds = (size_t)lpitch * sh;
+        if (lds > 64 * 1024) return hipErrorInvalidValue;
         const bool prof = a.prof_count && *a.prof_count < a.prof_capacity;
         if (prof) (void)hipEventRecord(a.prof_start[*a.prof_count], stream);
-        if (aligned)
-            hipLaunchKernelGGL(pyr_fast_kernel<true>, dim3(ntiles), dim3(256), 0, stream, src, spitch, L.rows, L.cols,
-                               L.tiles_x, L.tiles_y, dst, dpitch, drows, dcols, fx, fy, a.threshold, do_fast, cand, L.cand_sub_cap, hdr, ctot, a.dbg & 15);
-        else
-            hipLaunchKernelGGL(pyr_fast_kernel<false>, dim3(ntiles), dim3(256), 0, stream, src, spitch, L.rows, L.cols,
-                               L.tiles_x, L.tiles_y, dst, dpitch, drows, dcols, fx, fy, a.threshold, do_fast, cand, L.cand_sub_cap, hdr, ctot, a.dbg & 15);
-        if (prof) { (void)hipEventRecord(a.prof_stop[*a.prof_count], stream); a.prof_level[*a.prof_count] = s; ++*a.prof_count; }
+        hipLaunchKernelGGL(resize_kernel, dim3(N.tiles_x * N.tiles_y), dim3(256), lds, stream, src, spitch, L.rows, L.cols, aligned,
+                           a.pyramid + N.img_off, N.pitch, N.rows, N.cols, N.fx, N.fy, N.tiles_x, N.tiles_y, lpitch);
+        if (prof) { (void)hipEventRecord(a.prof_stop[*a.prof_count], stream); a.prof_level[*a.prof_count] = 100 + s; ++*a.prof_count; }
+    }
+    {
+        const int aligned0 = (((uintptr_t)a.img0 | (uintptr_t)a.pitch0) & 3u) == 0;
+        const bool prof = a.prof_count && *a.prof_count < a.prof_capacity;
+        if (prof) (void)hipEventRecord(a.prof_start[*a.prof_count], stream);
+        hipLaunchKernelGGL(fast_kernel, dim3(H.total_tiles), dim3(256), 0, stream, a.d_table, a.img0, a.pitch0, aligned0,
+                           a.pyramid, a.threshold, a.cand, a.hdr, a.counters, a.dbg & 15);
+        if (prof) { (void)hipEventRecord(a.prof_stop[*a.prof_count], stream); a.prof_level[*a.prof_count] = 0; ++*a.prof_count; }
     }
     hipLaunchKernelGGL(tile_rank_scan_kernel, dim3(H.nlevels), dim3(1024), 0, stream, a.d_table, a.hdr);
     hipLaunchKernelGGL(nms_kernel, dim3(H.total_tiles), dim3(256), 0, stream, a.d_table, a.hdr, a.cand, a.surv,

@@ -18,11 +18,11 @@ def run(dbg, reps=5):
     b.record(); torch.cuda.synchronize()
     ms, lvl = det.profileRead()
     det.profileEnable(0)
-    per_level = [ms[lvl == l].mean() * 1000 for l in range(8)]
-    return a.elapsed_time(b) / reps * 1000, sum(per_level), per_level
-cases = [('full', 0), ('pyr: no fast at all', 1), ('pyr: quick-reject all', 2), ('pyr: no harris', 4), ('pyr: no resize', 8),
-         ('pyr: only load (1|8)', 9), ('pyr: quick only+resize', 2), ('nms: ret after hdr', 16), ('nms: ret after staging', 32), ('nms: ret after pass1', 48)]
+    fast = ms[lvl == 0].mean() * 1000
+    chain = ms[lvl >= 100].sum() * 1000 / reps
+    return a.elapsed_time(b) / reps * 1000, fast, chain
+cases = [('full', 0), ('fast: quick-reject all', 2), ('fast: no harris', 4), ('nms: ret after hdr', 16), ('nms: ret after staging', 32), ('nms: ret after pass1', 48)]
 if len(sys.argv) > 1: cases = [(f'dbg {v}', int(v)) for v in sys.argv[1:]]
 for name, dbg in cases:
-    tot, pyr, pl = run(dbg)
-    print(f'{name:26s} detect {tot:8.1f} us | pyr_fast sum {pyr:7.1f} us | L0 {pl[0]:6.1f} L1 {pl[1]:6.1f} L7 {pl[7]:5.1f}')
+    tot, fast, chain = run(dbg)
+    print(f'{name:26s} detect {tot:8.1f} us | fast_kernel {fast:7.1f} us | resize chain {chain:6.1f} us')
