@@ -63,7 +63,9 @@ def main():
 
     F = args.frames_per_step
     # per-rank frames: global frame k = rank * F + i uses seed 1000 + k
-    frames = [torch.from_numpy(synth.synth_frame(ROWS, COLS, seed=1000 + rank * F + i)).cuda() for i in range(F)]
+    sharding = cef_loader.load_submodule("sharding")
+    frames = [torch.from_numpy(synth.synth_frame(ROWS, COLS, seed=1000 + k)).cuda()
+              for k in sharding.frames_for_rank(F, rank, world)]
 
     det = cef.EfficientFeatures.create(NFEATURES, 1.2, 8, 0, 20, 15, cef.EfficientFeatures.BAD_512)
     kps = [torch.zeros((5, NFEATURES), dtype=torch.float32, device="cuda") for _ in range(F)]
@@ -93,13 +95,9 @@ def main():
     ms, lvl = det.profileRead()
 
     nkp = int(sum(int(c.item()) for c in cnt))      # keypoints per step on this rank
-    t_max = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    kp_sum = torch.tensor([nkp], dtype=torch.float64, device="cuda")
-    if dist is not None:
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-        dist.all_reduce(kp_sum, op=dist.ReduceOp.SUM)
-    t_max = float(t_max.item())
-    kp_total = float(kp_sum.item()) * args.steps     # keypoints all ranks processed in the timed region
+    # RCCL over xGMI only for the counters: MAX of the time, SUM of the keypoints
+    t_max, kp_step, _ = sharding.reduce_counters(dist, "cuda", dt, nkp, F)
+    kp_total = kp_step * args.steps                  # keypoints all ranks processed in the timed region
 
     if rank == 0:
         px, bytes_frame = detect_algorithmic_bytes(det, ROWS, COLS)

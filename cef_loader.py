@@ -16,3 +16,10 @@ def load():
     sys.modules["cef_amd"] = mod
     spec.loader.exec_module(mod)
     return mod
+
+
+def load_submodule(name):
+    """Imports cuda-efficient-features_amd/<name>.py as cef_amd.<name>."""
+    load()
+    import importlib
+    return importlib.import_module("cef_amd." + name)
