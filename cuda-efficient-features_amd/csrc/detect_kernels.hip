@@ -233,8 +233,9 @@ __device__ __forceinline__ int level_of_tile(const LevelTable* T, int gt)
 __global__ __launch_bounds__(256) void fast_kernel(
     const LevelTable* __restrict__ T, const uint8_t* __restrict__ img0, int pitch0, int aligned0,
     const uint8_t* __restrict__ pyramid, int threshold,
-    Corner* __restrict__ cand_all, TileHdr* __restrict__ hdr_all, Counters* __restrict__ cnt, int dbg)
+    Corner* __restrict__ cand_all, Corner* __restrict__ cmax_all, TileHdr* __restrict__ hdr_all, Counters* __restrict__ cnt, int dbg)
 {
+    __shared__ unsigned long long s_cellmax[EFX_CELLS_PER_TILE];
     __shared__ __attribute__((aligned(16))) uint32_t s_tile[EFX_LT * (EFX_LP / 4)];
     __shared__ unsigned long long s_bitmap[EFX_TILE];
     __shared__ uint16_t s_list[EFX_TILE * EFX_TILE];     // phase 1-2: per-wave quick-test survivors; phase 3+: corner list
@@ -261,6 +262,7 @@ __global__ __launch_bounds__(256) void fast_kernel(
     // ---- phase 0: tile + halo -> LDS.  72 rows x 72 bytes as 9 x 8-byte pieces per row (the global address is
     //      only 4-byte aligned: x0 - 4), LDS row pitch 80 B. ----
     if (tid < EFX_TILE) s_bitmap[tid] = 0ull;
+    if (tid < EFX_CELLS_PER_TILE) s_cellmax[tid] = 0ull;
     for (int i = tid; i < EFX_LT * 9; i += 256) {
         const int r = i / 9, c8 = i - r * 9;
         const int gy = y0 - EFX_HALO + r;
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(256) void fast_kernel(
             bits &= bits - 1;
             s_list[pos++] = (uint16_t)((cx * 16 + b) | (brow << 8));
         }
-        if (tid == 0) s_start = total > 0 ? atomicAdd(&cnt->cand_total[l][tile & (EFX_NSUB - 1)], total) : 0;
+        if (tid == 0) s_start = total > 0 ? atomicAdd(&cnt->cand_total[l][tile & (EFX_NSUB - 1)].v, total) : 0;
         __syncthreads();
 
         // ---- phase 4: Harris on the corners, append to the level's corner array ----
@@ -370,6 +372,19 @@ __global__ __launch_bounds__(256) void fast_kernel(
             c.xy = (uint32_t)(x0 + lx) | ((uint32_t)(y0 + ly) << 16);
             c.resp = resp;
             cand[(size_t)(tile & (EFX_NSUB - 1)) * L.cand_sub_cap + start + k] = c;
+            // strongest corner of the 16x16 cell (quick test of the NMS kernel): 64-bit max of (response key, xy)
+            atomicMax(&s_cellmax[(ly >> 4) * 4 + (lx >> 4)], (efx_select_key(0u, resp) & 0xffffffff00000000ull) | c.xy);
+        }
+        __syncthreads();
+        if (tid < EFX_CELLS_PER_TILE) {
+            const unsigned long long m = s_cellmax[tid];
+            Corner best; best.xy = 0xffffffffu; best.resp = -3.0e38f;
+            if (m != 0ull) {
+                uint32_t u = (uint32_t)(m >> 32);
+                u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;          // inverse of the order-preserving map
+                best.resp = __uint_as_float(u); best.xy = (uint32_t)m;
+            }
+            cmax_all[L.cmax_base + (size_t)(ty * 4 + (tid >> 2)) * (L.tiles_x * 4) + tx * 4 + (tid & 3)] = best;
         }
         TileHdr* h = hdr + tile;
         if (tid <= EFX_CELLS_PER_TILE) h->cell_off[tid] = (uint16_t)s_celloff[tid];
@@ -401,227 +416,184 @@ __global__ __launch_bounds__(1024) void tile_rank_scan_kernel(const LevelTable* 
 
 // ================================================================================================
 // Kernel C: radius non-max suppression (radiusSuppressionKernel + IsMaxPoint, .cu:62-97, 202-216).
-// One workgroup per tile.  The corners of the tile's cells plus a ring of blockRadius cells are staged in
-// LDS (coalesced copies of the neighbouring tiles' cell lists); every corner of the tile then scans the
-// (2*blockRadius+1)^2 cells around its own cell in LDS.  Survivors are compacted in canonical order
-// (two passes: flags + block scan, then one atomic chunk allocation and the writes) and appended to the
-// level's survivor array.  If the staged neighbourhood would not fit (huge radius / extreme density) the
-// comparison falls back to reading the neighbours from L2.
+// The work is latency bound (a few dozen corners per tile, dependent look-ups), so it is laid out for
+// maximum waves in flight: ONE WAVE per 64x64 tile, no barriers, 1.5 KB of LDS.
+//   phase A  one lane per corner: quick test against the strongest corner of each neighbouring cell (the
+//            per-cell maxima are written by fast_kernel); this suppresses most corners with 9 loads;
+//   phase B  the corners that pass are scanned exactly: 16 lanes per corner walk the corner lists of the
+//            (2*blockRadius+1)^2 neighbouring cells together (IsMaxPoint);
+//   survivors are compacted by ballot in canonical order and appended to the level's survivor array.
 // ================================================================================================
-#define NMS_LDS_ENTRIES 3072
-#define NMS_MAX_CELLS 64
-
-__global__ __launch_bounds__(256) void nms_kernel(const LevelTable* __restrict__ T, TileHdr* __restrict__ hdr,
-                                                  const Corner* __restrict__ cand_all, Corner* __restrict__ surv_all,
-                                                  Counters* __restrict__ cnt, int radius, int dbg)
+__global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ T, TileHdr* __restrict__ hdr,
+                                                 const Corner* __restrict__ cand_all, const Corner* __restrict__ cmax_all,
+                                                 Corner* __restrict__ surv_all, Counters* __restrict__ cnt, int radius, int dbg)
 {
-    __shared__ Corner s_nb[NMS_LDS_ENTRIES];
-    __shared__ int s_off[NMS_MAX_CELLS + 1];
-    __shared__ int s_cnt[NMS_MAX_CELLS];
-    __shared__ unsigned s_src[NMS_MAX_CELLS];
-    __shared__ int s_scan[8];
-    __shared__ int s_round_base[17];
-    __shared__ int s_start;
-    __shared__ Corner s_cmax[NMS_MAX_CELLS];
-    __shared__ Corner s_hme[256];
-    __shared__ int4 s_hbox[256];
-    __shared__ uint16_t s_hsrc[256];
-    __shared__ uint8_t s_hkeep[256];
-    __shared__ int s_wcnt[4];
+    __shared__ Corner s_hme[64];
+    __shared__ uint8_t s_hsrc[64];
+    __shared__ uint8_t s_hkeep[64];
 
     const int gt = blockIdx.x;
     const int l = level_of_tile(T, gt);
     const LevelDev& L = T->lv[l];
     if (!L.active) return;
     const int tile = gt - L.tile_base;
-    const int tx = tile % L.tiles_x, ty = tile / L.tiles_x;
     TileHdr* hl = hdr + L.tile_base;
     const TileHdr& h = hl[tile];
     const Corner* cand = cand_all + L.cand_base;
-    const int tid = threadIdx.x;
-
     const Corner* own = cand + (size_t)(tile & (EFX_NSUB - 1)) * L.cand_sub_cap + h.cand_start;
+    const int lane = threadIdx.x;
 
     const int n_own = h.cell_off[EFX_CELLS_PER_TILE];
     int n_valid = L.cap - (int)h.cand_rank;            // cap in canonical order (spec S2; cuda_fast.cu:245)
     n_valid = n_valid < 0 ? 0 : (n_valid > n_own ? n_own : n_valid);
+    if (dbg == 1) return;
 
     const int image_radius = radius * radius;           // cvCeil(radius * radius), .cu:291
     const int block_radius = (radius + EFX_CELL - 1) / EFX_CELL;   // cvCeil(radius / CELL_SIZE), .cu:292
     const int gw = (L.cols + EFX_CELL - 1) / EFX_CELL, gh = (L.rows + EFX_CELL - 1) / EFX_CELL;
+    const int gwp = L.tiles_x * 4;                      // row pitch of the per-cell maxima table
+    const Corner* cmax = cmax_all + L.cmax_base;
+    // the per-cell maxima include corners beyond the cap; when the cap is active (pathological frames) the
+    // quick test is skipped and every corner takes the exact scan
+    int lvl_total = 0;
+    for (int sub = 0; sub < EFX_NSUB; sub++) lvl_total += cnt->cand_total[l][sub].v;
+    const bool quick_ok = lvl_total <= L.cap && block_radius <= 2;
+    const int span = 2 * block_radius + 1;
 
-    if (dbg == 1) return;
-    // region of cells staged in LDS: the tile's 4x4 cells plus the ring, clipped to the grid
-    const int rcx0 = max(tx * 4 - block_radius, 0), rcy0 = max(ty * 4 - block_radius, 0);
-    const int rcx1 = min(tx * 4 + 4 + block_radius, gw), rcy1 = min(ty * 4 + 4 + block_radius, gh);
-    const int rw = rcx1 - rcx0, rh = rcy1 - rcy0;
-    const int ncells = rw * rh;
-    bool staged = ncells <= NMS_MAX_CELLS;
-    if (staged) {
-        if (tid < 64) {
-            int c = 0; unsigned src = 0;
-            if (tid < ncells) {
-                const int bx = rcx0 + tid % rw, by = rcy0 + tid / rw;
-                const TileHdr& nh = hl[(by >> 2) * L.tiles_x + (bx >> 2)];
-                const int ci = (by & 3) * 4 + (bx & 3);
-                const int nn = L.cap - (int)nh.cand_rank;           // valid corners of that tile
-                const int b = nh.cell_off[ci];
-                int e = nh.cell_off[ci + 1];
-                if (e > nn) e = nn;
-                c = e > b ? e - b : 0;
-                src = (unsigned)(((by >> 2) * L.tiles_x + (bx >> 2)) & (EFX_NSUB - 1)) * L.cand_sub_cap + nh.cand_start + (unsigned)b;
-            }
-            const int incl = wave_incl_scan(c);
-            if (tid < ncells) { s_off[tid] = incl - c; s_cnt[tid] = c; s_src[tid] = src; }
-            if (tid == 63) s_off[NMS_MAX_CELLS] = incl;
-        }
-        __syncthreads();
-        staged = s_off[NMS_MAX_CELLS] <= NMS_LDS_ENTRIES;
-        if (staged) {
-            const int lane = tid & 63, wid = tid >> 6;
-            for (int c = wid; c < ncells; c += 4) {
-                const int n = s_cnt[c], o = s_off[c];
-                const Corner* q = cand + s_src[c];
-                for (int j = lane; j < n; j += 64) s_nb[o + j] = q[j];
-            }
-        }
-        __syncthreads();
-    }
-
-    if (dbg == 2) return;
-    // per staged cell: its strongest corner.  Most corners are suppressed by the strongest corner of one of
-    // the neighbouring cells, so this is the quick test; the few that pass get the full scan below.
-    if (staged) {
-        if (tid < ncells) {
-            const Corner* q = s_nb + s_off[tid];
-            const int n = s_cnt[tid];
-            Corner best; best.xy = 0xffffffffu; best.resp = -3.0e38f;
-            for (int j = 0; j < n; j++) { const Corner o = q[j]; if (o.resp > best.resp) best = o; }
-            s_cmax[tid] = best;
-        }
-        __syncthreads();
-    }
-
-    // pass 1: survivor flags, one bit per 256-corner round
-    const int lane = tid & 63, wid = tid >> 6;
-    unsigned keepmask = 0;
     int nsurv = 0;
+    // survivors are written after the count is known: remember the flags of up to 64 rounds (4096 corners)
+    unsigned long long keepbits[1] = { 0ull };
+    (void)keepbits;
+    // first pass: flags per round kept in LDS-free form: one 64-bit ballot per round, stored by lane `round`
+    unsigned long long my_round_mask = 0ull;            // lane r holds the survivor ballot of round r
     int round = 0;
-    for (int k0 = 0; k0 < n_valid; k0 += 256, round++) {
-        const int k = k0 + tid;
-        bool keep = false;
-        if (staged) {
-            // phase A: one lane per corner, quick test against the 3x3 (or larger) cell maxima
-            bool hard = false;
-            Corner me; me.xy = 0; me.resp = 0.f;
-            int minx = 0, maxx = -1, miny = 0, maxy = -1;
-            if (k < n_valid) {
-                me = own[k];
-                const int mx = me.xy & 0xffff, my = me.xy >> 16;
-                const int bx1 = mx / EFX_CELL, by1 = my / EFX_CELL;
-                minx = max(bx1 - block_radius, 0) - rcx0; maxx = min(bx1 + block_radius, gw - 1) - rcx0;
-                miny = max(by1 - block_radius, 0) - rcy0; maxy = min(by1 + block_radius, gh - 1) - rcy0;
-                hard = true;
-                for (int by = miny; by <= maxy && hard; by++)
-                    for (int bx = minx; bx <= maxx; bx++) {
-                        const Corner o = s_cmax[by * rw + bx];
-                        const int dx = mx - (int)(o.xy & 0xffff), dy = my - (int)(o.xy >> 16);
-                        if (o.xy != me.xy && me.resp <= o.resp && dx * dx + dy * dy < image_radius) { hard = false; break; }
-                    }
-            }
-            // compact the corners that passed the quick test
-            const unsigned long long hm = __ballot(hard);
-            if (lane == 0) s_wcnt[wid] = __popcll(hm);
-            __syncthreads();
-            int hb = 0;
-            for (int w = 0; w < wid; w++) hb += s_wcnt[w];
-            const int nhard = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
-            if (hard) {
-                const int pos = hb + __popcll(hm & ((1ull << lane) - 1ull));
-                s_hme[pos] = me;
-                s_hbox[pos] = make_int4(minx, maxx, miny, maxy);
-                s_hsrc[pos] = (uint16_t)tid;
-            }
-            s_hkeep[tid] = 0;
-            __syncthreads();
-            // phase B: 16 lanes per hard corner scan the staged neighbour cells together (IsMaxPoint, .cu:62-97)
-            const int grp = tid >> 4, sub = tid & 15;
-            for (int h0 = 0; h0 < nhard; h0 += 16) {
-                const int hi = h0 + grp;
-                bool kill = false;
-                if (hi < nhard) {
-                    const Corner m = s_hme[hi];
-                    const int4 bx4 = s_hbox[hi];
-                    const int mx = m.xy & 0xffff, my = m.xy >> 16;
-                    for (int by = bx4.z; by <= bx4.w; by++) {
-                        const int b = s_off[by * rw + bx4.x];
-                        const int e = s_off[by * rw + bx4.y] + s_cnt[by * rw + bx4.y];   // a row of cells is contiguous
-                        for (int j = b + sub; j < e; j += 16) {
-                            const Corner o = s_nb[j];
-                            const int dx = mx - (int)(o.xy & 0xffff), dy = my - (int)(o.xy >> 16);
-                            kill |= (o.xy != m.xy && m.resp <= o.resp && dx * dx + dy * dy < image_radius);
-                        }
-                    }
-                }
-                const unsigned long long km = __ballot(kill);
-                const unsigned gk = (unsigned)(km >> ((lane >> 4) * 16)) & 0xffffu;
-                if (hi < nhard && sub == 0) s_hkeep[s_hsrc[hi]] = gk == 0 ? 1 : 0;
-            }
-            __syncthreads();
-            keep = s_hkeep[tid] != 0;
-        } else if (k < n_valid) {
-            const Corner me = own[k];
+    for (int k0 = 0; k0 < n_valid; k0 += 64, round++) {
+        const int k = k0 + lane;
+        bool hard = false;
+        Corner me; me.xy = 0; me.resp = 0.f;
+        int minx = 0, maxx = -1, miny = 0, maxy = -1;
+        if (k < n_valid) {
+            me = own[k];
             const int mx = me.xy & 0xffff, my = me.xy >> 16;
             const int bx1 = mx / EFX_CELL, by1 = my / EFX_CELL;
-            const int minx = max(bx1 - block_radius, 0), maxx = min(bx1 + block_radius, gw - 1);
-            const int miny = max(by1 - block_radius, 0), maxy = min(by1 + block_radius, gh - 1);
-            keep = true;
-            for (int by = miny; by <= maxy && keep; by++) {
-                for (int bx = minx; bx <= maxx && keep; bx++) {
+            minx = max(bx1 - block_radius, 0); maxx = min(bx1 + block_radius, gw - 1);
+            miny = max(by1 - block_radius, 0); maxy = min(by1 + block_radius, gh - 1);
+            hard = true;
+            if (quick_ok) {
+                if (block_radius == 1) {
+                    // all 9 loads are issued before the first compare (no load-compare-branch chains)
+                    Corner o[9];
+#pragma unroll
+                    for (int q = 0; q < 9; q++) {
+                        const int bx = min(max(bx1 - 1 + (q % 3), 0), gw - 1), by = min(max(by1 - 1 + (q / 3), 0), gh - 1);
+                        o[q] = cmax[by * gwp + bx];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 9; q++) {
+                        const int dx = mx - (int)(o[q].xy & 0xffff), dy = my - (int)(o[q].xy >> 16);
+                        if (o[q].xy != me.xy && me.resp <= o[q].resp && dx * dx + dy * dy < image_radius) hard = false;
+                    }
+                } else {
+                    for (int by = miny; by <= maxy; by++)
+                        for (int bx = minx; bx <= maxx; bx++) {
+                            const Corner o = cmax[by * gwp + bx];
+                            const int dx = mx - (int)(o.xy & 0xffff), dy = my - (int)(o.xy >> 16);
+                            if (o.xy != me.xy && me.resp <= o.resp && dx * dx + dy * dy < image_radius) hard = false;
+                        }
+                }
+            }
+        }
+        const unsigned long long hm = __ballot(hard);
+        const int nhard = __popcll(hm);
+        if (hard) {
+            const int pos = __popcll(hm & ((1ull << lane) - 1ull));
+            s_hme[pos] = me;
+            s_hsrc[pos] = (uint8_t)lane;
+        }
+        s_hkeep[lane] = 0;
+        __builtin_amdgcn_wave_barrier();
+        // phase B: 16 lanes per hard corner
+        const int grp = lane >> 4, sub = lane & 15;
+        if (dbg == 6 && lane == 0) atomicAdd(&cnt->sum.dbg, nhard);
+        for (int h0 = 0; h0 < (dbg == 2 ? 0 : nhard); h0 += 4) {
+            const int hi = h0 + grp;
+            const bool act = hi < nhard;
+            Corner m; m.xy = 0; m.resp = 0.f;
+            if (act) m = s_hme[hi];
+            const int mx = m.xy & 0xffff, my = m.xy >> 16;
+            const int bx1 = mx / EFX_CELL, by1 = my / EFX_CELL;
+            const int cx0 = max(bx1 - block_radius, 0), cx1 = min(bx1 + block_radius, gw - 1);
+            const int cy0 = max(by1 - block_radius, 0), cy1 = min(by1 + block_radius, gh - 1);
+            bool kill = false;
+            // cells of the neighbourhood in chunks of 16: lane `sub` fetches the list range of cell c0+sub,
+            // then the 16 lanes walk every list together
+            for (int c0 = 0; c0 < span * span; c0 += 16) {
+                const int ci = c0 + sub;
+                const int oy = ci / span, ox = ci - oy * span;
+                const int bx = bx1 - block_radius + ox, by = by1 - block_radius + oy;
+                int lb = 0, le = 0; unsigned lbase = 0;
+                if (act && ci < span * span && bx >= cx0 && bx <= cx1 && by >= cy0 && by <= cy1) {
                     const int nt = (by >> 2) * L.tiles_x + (bx >> 2);
                     const TileHdr& nh = hl[nt];
                     const int c = (by & 3) * 4 + (bx & 3);
                     const int nn = L.cap - (int)nh.cand_rank;
-                    const int b = nh.cell_off[c];
-                    int e = nh.cell_off[c + 1];
-                    if (e > nn) e = nn;
-                    const Corner* q = cand + (size_t)(nt & (EFX_NSUB - 1)) * L.cand_sub_cap + nh.cand_start + b;
-                    for (int j = 0; j < e - b; j++) {
-                        const Corner o = q[j];
-                        if (o.xy == me.xy) continue;                     // idx1 == idx2
+                    lb = nh.cell_off[c];
+                    le = nh.cell_off[c + 1];
+                    if (le > nn) le = nn;
+                    lbase = (unsigned)(nt & (EFX_NSUB - 1)) * L.cand_sub_cap + nh.cand_start;
+                }
+                // first 16 entries of every cell: all loads in flight before the first compare
+                Corner e[16]; bool ev[16]; int nb[16], ne[16]; unsigned nbase[16];
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const int src = (lane & 48) + i;
+                    nb[i] = __shfl(lb, src, 64); ne[i] = __shfl(le, src, 64);
+                    nbase[i] = (unsigned)__shfl((int)lbase, src, 64);
+                    ev[i] = nb[i] + sub < ne[i];
+                    e[i].xy = m.xy; e[i].resp = 0.f;
+                    if (ev[i]) e[i] = cand[(size_t)nbase[i] + nb[i] + sub];
+                }
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const int dx = mx - (int)(e[i].xy & 0xffff), dy = my - (int)(e[i].xy >> 16);
+                    kill |= (ev[i] && e[i].xy != m.xy && m.resp <= e[i].resp && dx * dx + dy * dy < image_radius);
+                }
+                // cells with more than 16 corners (dense regions)
+#pragma unroll 1
+                for (int i = 0; i < 16; i++) {
+                    for (int j = nb[i] + sub + 16; j < ne[i]; j += 16) {
+                        const Corner o = cand[(size_t)nbase[i] + j];
                         const int dx = mx - (int)(o.xy & 0xffff), dy = my - (int)(o.xy >> 16);
-                        if (me.resp <= o.resp && dx * dx + dy * dy < image_radius) { keep = false; break; }
+                        kill |= (o.xy != m.xy && m.resp <= o.resp && dx * dx + dy * dy < image_radius);
                     }
                 }
             }
+            const unsigned long long km = __ballot(kill);
+            const unsigned gk = (unsigned)(km >> (grp * 16)) & 0xffffu;
+            if (act && sub == 0) s_hkeep[s_hsrc[hi]] = gk == 0 ? 1 : 0;
         }
-        int tot;
-        (void)block_excl_scan<4>(keep ? 1 : 0, s_scan, &tot);
-        if (keep) keepmask |= 1u << round;
-        if (tid == 0) s_round_base[round] = nsurv;
-        nsurv += tot;
+        __builtin_amdgcn_wave_barrier();
+        const bool keep = s_hkeep[lane] != 0;
+        const unsigned long long km2 = __ballot(keep);
+        if (lane == round) my_round_mask = km2;
+        nsurv += __popcll(km2);
+        __builtin_amdgcn_wave_barrier();
     }
     if (dbg == 3) return;
-    if (tid == 0) s_start = nsurv > 0 ? atomicAdd(&cnt->surv_total[l][tile & (EFX_NSUB - 1)], nsurv) : 0;
-    __syncthreads();
-    // pass 2: write the survivors in canonical order
-    const int start = s_start;
+    int start = 0;
+    if (lane == 0 && nsurv > 0 && dbg != 4) start = atomicAdd(&cnt->surv_total[l][tile & (EFX_NSUB - 1)].v, nsurv);
+    start = __shfl(start, 0, 64);
+    // second pass: write the survivors in canonical order
     Corner* surv = surv_all + L.surv_base + (size_t)(tile & (EFX_NSUB - 1)) * L.surv_sub_cap;
+    int base = 0;
     round = 0;
-    for (int k0 = 0; k0 < n_valid; k0 += 256, round++) {
-        const int k = k0 + tid;
-        const bool keep = (keepmask >> round) & 1u;
-        const unsigned long long m = __ballot(keep);
-        // rank inside the round: waves before this one + lanes before this lane
-        if ((tid & 63) == 0) s_wcnt[tid >> 6] = __popcll(m);
-        __syncthreads();
-        int before = 0;
-        for (int w = 0; w < (tid >> 6); w++) before += s_wcnt[w];
-        const int rank = before + __popcll(m & ((1ull << (tid & 63)) - 1ull));
-        if (keep) surv[(size_t)start + s_round_base[round] + rank] = own[k];
-        __syncthreads();
+    for (int k0 = 0; k0 < n_valid && dbg != 5; k0 += 64, round++) {
+        const unsigned long long m = (unsigned long long)(unsigned)__shfl((int)(my_round_mask & 0xffffffffu), round, 64) |
+                                     ((unsigned long long)(unsigned)__shfl((int)(my_round_mask >> 32), round, 64) << 32);
+        if ((m >> lane) & 1ull) surv[(size_t)start + base + __popcll(m & ((1ull << lane) - 1ull))] = own[k0 + lane];
+        base += __popcll(m);
     }
-    if (tid == 0) { hl[tile].surv_start = (uint32_t)start; hl[tile].surv_count = (uint32_t)nsurv; }
+    if (lane == 0) { hl[tile].surv_start = (uint32_t)start; hl[tile].surv_count = (uint32_t)nsurv; }
 }
 
 // ================================================================================================
@@ -649,7 +621,7 @@ __global__ __launch_bounds__(1024) void select_kernel(const LevelTable* __restri
     int base = 0, all = 0;
     for (int i = 0; i < T->nlevels; i++) {
         int ns = 0;
-        for (int sub = 0; sub < EFX_NSUB; sub++) ns += cnt->surv_total[i][sub];
+        for (int sub = 0; sub < EFX_NSUB; sub++) ns += cnt->surv_total[i][sub].v;
         const int k = T->lv[i].active ? min(ns, T->lv[i].quota) : 0;
         if (i < l) base += k;
         all += k;
@@ -657,12 +629,12 @@ __global__ __launch_bounds__(1024) void select_kernel(const LevelTable* __restri
     if (tid == 0) {
         cnt->level_out_base[l] = base;
         if (l == T->nlevels - 1) cnt->level_out_base[T->nlevels] = all;
-        if (l == 0) { const int n = all < capacity ? all : capacity; cnt->n_out = n; if (d_count) *d_count = n; }
+        if (l == 0) { const int n = all < capacity ? all : capacity; cnt->sum.n_out = n; if (d_count) *d_count = n; }
     }
-    if (!L.active) { if (tid == 0) { cnt->kept[l] = 0; cnt->thresh[l] = 0; } return; }
+    if (!L.active) { if (tid == 0) { cnt->sum.kept[l] = 0; cnt->thresh[l] = 0; } return; }
 
     int n = 0;
-    for (int sub = 0; sub < EFX_NSUB; sub++) n += cnt->surv_total[l][sub];
+    for (int sub = 0; sub < EFX_NSUB; sub++) n += cnt->surv_total[l][sub].v;
     const Corner* surv = surv_all + L.surv_base;
     unsigned long long thresh = 0;
     if (n > L.quota) {
@@ -676,7 +648,7 @@ __global__ __launch_bounds__(1024) void select_kernel(const LevelTable* __restri
             __syncthreads();
             for (int sub = 0; sub < EFX_NSUB; sub++) {
                 const Corner* q = surv + (size_t)sub * L.surv_sub_cap;
-                const int ns = cnt->surv_total[l][sub];
+                const int ns = cnt->surv_total[l][sub].v;
                 for (int i = tid; i < ns; i += 1024) {
                     const Corner c = q[i];
                     const unsigned long long k = efx_select_key(c.xy, c.resp);
@@ -729,7 +701,13 @@ __global__ __launch_bounds__(1024) void select_kernel(const LevelTable* __restri
         if (t < ntiles) hl[t].out_off = (uint32_t)(base + running + pre);
         running += tot;
     }
-    if (tid == 0) cnt->kept[l] = running;
+    if (tid == 0) {
+        cnt->sum.kept[l] = running;
+        cnt->sum.surv[l] = n;
+        int nc = 0;
+        for (int sub = 0; sub < EFX_NSUB; sub++) nc += cnt->cand_total[l][sub].v;
+        cnt->sum.cand[l] = nc;
+    }
 }
 
 // Spec S7: deterministic double-precision atan2 (octant reduction + odd Taylor series), the same
@@ -904,11 +882,11 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
         const bool prof = a.prof_count && *a.prof_count < a.prof_capacity;
         if (prof) (void)hipEventRecord(a.prof_start[*a.prof_count], stream);
         hipLaunchKernelGGL(fast_kernel, dim3(H.total_tiles), dim3(256), 0, stream, a.d_table, a.img0, a.pitch0, aligned0,
-                           a.pyramid, a.threshold, a.cand, a.hdr, a.counters, a.dbg & 15);
+                           a.pyramid, a.threshold, a.cand, a.cmax, a.hdr, a.counters, a.dbg & 15);
         if (prof) { (void)hipEventRecord(a.prof_stop[*a.prof_count], stream); a.prof_level[*a.prof_count] = 0; ++*a.prof_count; }
     }
     hipLaunchKernelGGL(tile_rank_scan_kernel, dim3(H.nlevels), dim3(1024), 0, stream, a.d_table, a.hdr);
-    hipLaunchKernelGGL(nms_kernel, dim3(H.total_tiles), dim3(256), 0, stream, a.d_table, a.hdr, a.cand, a.surv,
+    hipLaunchKernelGGL(nms_kernel, dim3(H.total_tiles), dim3(64), 0, stream, a.d_table, a.hdr, a.cand, a.cmax, a.surv,
                        a.counters, a.nonmax_radius, a.dbg >> 4);
     hipLaunchKernelGGL(select_kernel, dim3(H.nlevels), dim3(1024), 0, stream, a.d_table, a.hdr, a.surv, a.counters,
                        a.capacity, a.d_count);
@@ -924,7 +902,7 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
     }
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    if (a.h_mirror) e = hipMemcpyAsync(a.h_mirror, a.counters, sizeof(Counters), hipMemcpyDeviceToHost, stream);
+    if (a.h_mirror) e = hipMemcpyAsync(a.h_mirror, &a.counters->sum, sizeof(Summary), hipMemcpyDeviceToHost, stream);
     return e;
 }
 

@@ -178,8 +178,8 @@ struct efx_context {
     int g_rows = -1, g_cols = -1;
     efx_params g_p;
     LevelTable h_table;
-    DevBuf d_table, pyramid, hdr, cand, surv, counters, kp4, kp_level, img, kps, descout, count;
-    Counters* h_mirror = nullptr;   // pinned
+    DevBuf d_table, pyramid, hdr, cand, cmax, surv, counters, kp4, kp_level, img, kps, descout, count;
+    Summary* h_mirror = nullptr;    // pinned
     bool has_frame = false;
     const uint8_t* last_img0 = nullptr; int last_pitch0 = 0;
     // per-launch timing of the pyramid+FAST kernel (efx_profile_*)
@@ -189,7 +189,7 @@ struct efx_context {
 
     ~efx_context()
     {
-        d_table.release(); pyramid.release(); hdr.release(); cand.release(); surv.release(); counters.release();
+        d_table.release(); pyramid.release(); hdr.release(); cand.release(); cmax.release(); surv.release(); counters.release();
         kp4.release(); kp_level.release(); img.release(); kps.release(); descout.release(); count.release();
         if (h_mirror) (void)hipHostFree(h_mirror);
         for (hipEvent_t e : prof_start) (void)hipEventDestroy(e);
@@ -229,7 +229,7 @@ int build_geometry(efx_context* c, int rows, int cols)
         quota[p.nlevels - 1] = p.nfeatures - sum > 0 ? p.nfeatures - sum : 0;
     }
     float scale = 1.f;
-    size_t pyr = 0, ncand = 0, nsurv = 0;
+    size_t pyr = 0, ncand = 0, nsurv = 0, ncmax = 0;
     int tiles = 0;
     for (int s = 0; s < p.nlevels; s++) {
         LevelDev& L = T.lv[s];
@@ -259,6 +259,8 @@ int build_geometry(efx_context* c, int rows, int cols)
         }
         L.cand_base = ncand;
         L.surv_base = nsurv;
+        L.cmax_base = ncmax;
+        ncmax += (size_t)L.tiles_x * 4 * L.tiles_y * 4;
         if (L.active) {
             // sub-array k holds the tiles with (tile & 7) == k; a 64x64 tile has at most 4096 corners
             const size_t tiles_per_sub = ((size_t)L.tiles_x * L.tiles_y + EFX_NSUB - 1) / EFX_NSUB;
@@ -278,9 +280,10 @@ int build_geometry(efx_context* c, int rows, int cols)
     HIP_TRY(c->err, c->hdr.reserve((size_t)(tiles + 1) * sizeof(TileHdr)));
     HIP_TRY(c->err, c->cand.reserve((ncand + 1) * sizeof(Corner)));
     HIP_TRY(c->err, c->surv.reserve((nsurv + 1) * sizeof(Corner)));
+    HIP_TRY(c->err, c->cmax.reserve((ncmax + 1) * sizeof(Corner)));
     HIP_TRY(c->err, c->counters.reserve(sizeof(Counters)));
     HIP_TRY(c->err, c->count.reserve(sizeof(int)));
-    if (!c->h_mirror) HIP_TRY(c->err, hipHostMalloc(reinterpret_cast<void**>(&c->h_mirror), sizeof(Counters), hipHostMallocDefault));
+    if (!c->h_mirror) HIP_TRY(c->err, hipHostMalloc(reinterpret_cast<void**>(&c->h_mirror), sizeof(Summary), hipHostMallocDefault));
     // synchronous upload: geometry changes are rare (first frame / size or parameter change)
     HIP_TRY(c->err, hipMemcpy(c->d_table.p, &T, sizeof(LevelTable), hipMemcpyHostToDevice));
     c->g_rows = rows; c->g_cols = cols; c->g_p = p;
@@ -313,6 +316,7 @@ int detect_common(efx_context* c, const uint8_t* d_image, int rows, int cols, si
     a.hdr = static_cast<TileHdr*>(c->hdr.p);
     a.cand = static_cast<Corner*>(c->cand.p);
     a.surv = static_cast<Corner*>(c->surv.p);
+    a.cmax = static_cast<Corner*>(c->cmax.p);
     a.counters = static_cast<Counters*>(c->counters.p);
     a.threshold = c->p.fast_threshold;
     a.nonmax_radius = c->p.nonmax_radius;
@@ -533,12 +537,10 @@ int efx_last_level_stats(const efx_context* ctx, efx_level_stats* stats, int max
     if (!ctx || !stats || !ctx->h_mirror || !ctx->has_frame) return EFX_ERR_BAD_ARG;
     const int nl = ctx->h_table.nlevels < max_levels ? ctx->h_table.nlevels : max_levels;
     for (int i = 0; i < nl; i++) {
-        stats[i].n_candidates = 0; stats[i].n_after_nms = 0;
-        for (int sub = 0; sub < EFX_NSUB; sub++) {
-            stats[i].n_candidates += ctx->h_mirror->cand_total[i][sub];
-            stats[i].n_after_nms += ctx->h_mirror->surv_total[i][sub];
-        }
+        stats[i].n_candidates = ctx->h_mirror->cand[i];
+        stats[i].n_after_nms = ctx->h_mirror->surv[i];
         stats[i].n_kept = ctx->h_mirror->kept[i];
+        if (i == 0 && ctx->h_mirror->dbg) stats[i].n_kept = ctx->h_mirror->dbg;   // EFX_DEBUG=96 probe
     }
     if (nlevels) *nlevels = nl;
     return EFX_OK;

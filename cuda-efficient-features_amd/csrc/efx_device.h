@@ -38,6 +38,7 @@ struct LevelDev {
     unsigned long long img_off; // byte offset of the level in the pyramid buffer (levels >= 1)
     unsigned long long cand_base;   // entry offset of the level in the cand array
     unsigned long long surv_base;   // entry offset of the level in the surv array
+    unsigned long long cmax_base;   // entry offset of the level in the per-cell maxima table (tiles_x*4 x tiles_y*4)
     unsigned int cand_sub_cap;      // each level's arrays are split into EFX_NSUB sub-arrays (tile & 7) so that
     unsigned int surv_sub_cap;      // chunk allocation contends on 8 counters instead of 1 (11.5 ns per same-word atomic)
 };
@@ -59,13 +60,21 @@ struct __attribute__((aligned(64))) TileHdr {
 };
 static_assert(sizeof(TileHdr) == 64, "TileHdr must be 64 bytes");
 
-struct Counters {               // zeroed at the start of every frame
-    int cand_total[EFX_MAX_LEVELS][EFX_NSUB];
-    int surv_total[EFX_MAX_LEVELS][EFX_NSUB];
+struct __attribute__((aligned(128))) PaddedCounter { int v; int pad[31]; };   // one allocation counter per 128-B line:
+                                                    // same-line atomics serialise (11.5 ns each) even on different words
+struct Summary {                // what the host mirror receives (written by select_kernel)
+    int cand[EFX_MAX_LEVELS];
+    int surv[EFX_MAX_LEVELS];
     int kept[EFX_MAX_LEVELS];           // after quota
+    int n_out;                          // N written to the caller
+    int dbg;
+};
+struct Counters {               // zeroed at the start of every frame
+    PaddedCounter cand_total[EFX_MAX_LEVELS][EFX_NSUB];
+    PaddedCounter surv_total[EFX_MAX_LEVELS][EFX_NSUB];
     int level_out_base[EFX_MAX_LEVELS + 1];
     unsigned long long thresh[EFX_MAX_LEVELS];   // selection threshold key per level
-    int n_out;                          // N written to the caller
+    Summary sum;
 };
 
 // one FAST corner / survivor
@@ -101,6 +110,7 @@ struct DetectLaunch {
     const LevelTable* h_table;  // host copy (same contents)
     TileHdr* hdr;
     Corner* cand;
+    Corner* cmax;               // strongest corner of every 16x16 cell (quick test of the NMS)
     Corner* surv;
     Counters* counters;
     int threshold;

@@ -25,4 +25,4 @@ cases = [('full', 0), ('fast: quick-reject all', 2), ('fast: no harris', 4), ('n
 if len(sys.argv) > 1: cases = [(f'dbg {v}', int(v)) for v in sys.argv[1:]]
 for name, dbg in cases:
     tot, fast, chain = run(dbg)
-    print(f'{name:26s} detect {tot:8.1f} us | fast_kernel {fast:7.1f} us | resize chain {chain:6.1f} us')
+    print(f'{name:26s} detect {tot:8.1f} us | fast_kernel {fast:7.1f} us | resize chain {chain:6.1f} us', det.lastLevelStats()[:1])
