@@ -85,7 +85,9 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    det.profileEnable(args.steps * F * 8)          # one HIP event pair per pyramid+FAST launch of the timed region
+    # HIP event pairs around the fast_kernel / resize launches of every F-th frame of the timed region (each pair
+    # costs a few microseconds of stream idle time, so not on every frame)
+    det.profileEnable(args.steps * 8 + 8, stride=F)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):

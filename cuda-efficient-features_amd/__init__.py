@@ -38,7 +38,7 @@ ABI_SYMBOLS = [
     "efx_bad_create", "efx_hashsift_create", "efx_describer_destroy", "efx_describer_descriptor_size",
     "efx_describer_last_error", "efx_describer_compute_kp4_async", "efx_describer_compute_async",
     "efx_describer_compute", "efx_describer_hashsift_debug_async",
-    "efx_profile_enable", "efx_profile_read",
+    "efx_profile_enable", "efx_profile_set_stride", "efx_profile_read",
     "efx_level_geometry", "efx_copy_level_async",
 ]
 
@@ -116,6 +116,7 @@ def lib():
         L.efx_describer_hashsift_debug_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p,
                                                          C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
         L.efx_profile_enable.argtypes = [C.c_void_p, C.c_int]
+        L.efx_profile_set_stride.argtypes = [C.c_void_p, C.c_int]
         L.efx_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]
         L.efx_level_geometry.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                          C.POINTER(C.c_float)]
@@ -255,8 +256,9 @@ class EfficientFeatures:
         return [dict(n_candidates=st[i].n_candidates, n_after_nms=st[i].n_after_nms, n_kept=st[i].n_kept)
                 for i in range(nl.value)]
 
-    def profileEnable(self, max_launches):
+    def profileEnable(self, max_launches, stride=1):
         self._check(lib().efx_profile_enable(self._h, int(max_launches)))
+        self._check(lib().efx_profile_set_stride(self._h, int(stride)))
 
     def profileRead(self, capacity=65536):
         """(ms, level) arrays of the recorded pyramid+FAST launches; call after synchronising the stream."""

@@ -22,16 +22,7 @@ __device__ __forceinline__ int lane_id()
 }
 
 // inclusive scan across the 64 lanes of a wave
-__device__ __forceinline__ int wave_incl_scan(int v)
-{
-    const int lane = lane_id();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int t = __shfl_up(v, d, 64);
-        if (lane >= d) v += t;
-    }
-    return v;
-}
+__device__ __forceinline__ int wave_incl_scan(int v) { return efx_wave_incl_scan(v); }
 
 // exclusive scan over a block of NW waves; `scratch` holds NW+1 ints of LDS. Returns the exclusive prefix,
 // *total receives the block sum. Contains two barriers.
@@ -675,10 +666,13 @@ __global__ __launch_bounds__(1024) void select_kernel(const LevelTable* __restri
                 before += loc[j];
             }
             __syncthreads();
+            const int in_bin = s_hist[s_bin];
             prefix = (prefix << width) | (unsigned long long)s_bin;
             remaining = s_rem;
             decided += width;
             __syncthreads();
+            // every key of the chosen bin is wanted: the threshold is the bin's lower edge, no more passes
+            if (remaining == in_bin) { prefix = decided < 64 ? (prefix << (64 - decided)) : prefix; decided = 64; }
         }
         thresh = prefix;                     // exactly `quota` keys are >= thresh (keys are unique)
     }

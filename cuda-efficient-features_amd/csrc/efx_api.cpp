@@ -186,6 +186,7 @@ struct efx_context {
     std::vector<hipEvent_t> prof_start, prof_stop;
     std::vector<int> prof_level;
     int prof_count = 0;
+    int prof_stride = 1, prof_calls = 0;   // record events on every prof_stride-th detect call only
 
     ~efx_context()
     {
@@ -327,7 +328,7 @@ int detect_common(efx_context* c, const uint8_t* d_image, int rows, int cols, si
     a.kp4 = static_cast<float4*>(c->kp4.p);
     a.kp_level = static_cast<int*>(c->kp_level.p);
     a.h_mirror = reinterpret_cast<int*>(c->h_mirror);
-    if (!c->prof_start.empty()) {
+    if (!c->prof_start.empty() && (c->prof_calls++ % c->prof_stride) == 0) {
         a.prof_start = c->prof_start.data(); a.prof_stop = c->prof_stop.data(); a.prof_level = c->prof_level.data();
         a.prof_count = &c->prof_count; a.prof_capacity = (int)c->prof_start.size();
     }
@@ -668,9 +669,17 @@ int efx_describer_hashsift_debug_async(efx_describer* d, const uint8_t* d_image,
                            nullptr, 0, d_responses, d_T, (hipStream_t)stream);
 }
 
+int efx_profile_set_stride(efx_context* ctx, int stride)
+{
+    if (!ctx || stride < 1) return EFX_ERR_BAD_ARG;
+    ctx->prof_stride = stride; ctx->prof_calls = 0;
+    return EFX_OK;
+}
+
 int efx_profile_enable(efx_context* ctx, int max_launches)
 {
     if (!ctx || max_launches < 0 || max_launches > 65536) return EFX_ERR_BAD_ARG;
+    ctx->prof_calls = 0;
     for (hipEvent_t e : ctx->prof_start) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->prof_stop) (void)hipEventDestroy(e);
     ctx->prof_start.clear(); ctx->prof_stop.clear(); ctx->prof_level.clear(); ctx->prof_count = 0;

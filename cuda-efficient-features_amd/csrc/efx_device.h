@@ -101,6 +101,21 @@ struct BadParamsDev {           // per-context copy of the learned tables (no pr
     uint2 box[512];             // {x1 | x2<<5 | y1<<10 | y2<<15 | radius<<20, threshold bits}: 8 B per box pair
 };
 
+#if defined(__HIPCC__)
+// Inclusive scan across the 64 lanes of a wave with DPP moves only (6 VALU ops, no LDS crossbar):
+// row_shr 1/2/4/8 inside the 16-lane rows, then row_bcast15 / row_bcast31 across rows (gfx9 / CDNA DPP controls).
+__device__ __forceinline__ int efx_wave_incl_scan(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);     // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);     // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);     // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);     // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);     // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);     // row_bcast:31 -> rows 2, 3
+    return v;
+}
+#endif
+
 // ---- launchers (host side, defined in the .hip files) ----
 struct DetectLaunch {
     const uint8_t* img0;        // level 0 (caller's image)

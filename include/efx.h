@@ -201,6 +201,8 @@ int efx_describer_hashsift_debug_async(efx_describer* d, const uint8_t* d_image,
  * stream was synchronised) returns the elapsed milliseconds and the pyramid level of each recorded launch and
  * rewinds the recorder. */
 int efx_profile_enable(efx_context* ctx, int max_launches);
+/* Record events only on every `stride`-th detect call (an event pair costs a few microseconds of stream idle time). */
+int efx_profile_set_stride(efx_context* ctx, int stride);
 int efx_profile_read(efx_context* ctx, float* ms, int* level, int capacity, int* n);
 
 /* Geometry of pyramid level `level` for a rows x cols frame with the context's parameters
