@@ -41,6 +41,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames-per-step", type=int, default=8)
+    ap.add_argument("--streams", type=int, default=1,
+                    help="independent frames in flight per GPU: one context + one HIP stream each (a context is not "
+                         "re-entrant, like the reference's EfficientFeaturesImpl; frames are independent)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -67,14 +70,17 @@ def main():
     frames = [torch.from_numpy(synth.synth_frame(ROWS, COLS, seed=1000 + k)).cuda()
               for k in sharding.frames_for_rank(F, rank, world)]
 
-    det = cef.EfficientFeatures.create(NFEATURES, 1.2, 8, 0, 20, 15, cef.EfficientFeatures.BAD_512)
+    NS = max(1, min(args.streams, F))
+    dets = [cef.EfficientFeatures.create(NFEATURES, 1.2, 8, 0, 20, 15, cef.EfficientFeatures.BAD_512) for _ in range(NS)]
+    streams = [torch.cuda.Stream() for _ in range(NS)]
+    det = dets[0]
     kps = [torch.zeros((5, NFEATURES), dtype=torch.float32, device="cuda") for _ in range(F)]
     desc = [torch.zeros((NFEATURES, 64), dtype=torch.uint8, device="cuda") for _ in range(F)]
     cnt = [torch.zeros(1, dtype=torch.int32, device="cuda") for _ in range(F)]
 
     def step():
         for i in range(F):
-            det.detectAndComputeAsync(frames[i], kps[i], desc[i], cnt[i], capacity=NFEATURES)
+            dets[i % NS].detectAndComputeAsync(frames[i], kps[i], desc[i], cnt[i], capacity=NFEATURES, stream=streams[i % NS])
 
     def barrier():
         torch.cuda.synchronize()
@@ -141,7 +147,7 @@ def main():
                "data": "synthetic",
                "config": {"workload": "detectAndCompute BAD512 on 8K (7680x4320) synthetic frames, nfeatures=40000, "
                                       "8 levels, scale 1.2, FAST threshold 20, NMS radius 15 (BASELINE.json configs[4])",
-                          "frames_per_step_per_gpu": F, "frames_per_step": F * world,
+                          "frames_per_step_per_gpu": F, "frames_per_step": F * world, "streams_per_gpu": NS,
                           "keypoints_per_frame": round(nkp / F, 1), "parallelism": f"frames sharded over {world} GPU(s)"},
                "roofline": roof}
 

@@ -31,7 +31,9 @@ struct Affine { float m00, m01, m02, m10, m11, m12, s; };
 
 // LDS plan (dynamic): [ I: (S+1)^2 int32, aliased by raw: (S+6) x RPB u8 | hb: (8G+6) x HP float ]
 //   G = ceil(S/8) groups of 8 outputs, HP = 8G, RPB = 4*ceil((S+12)/4) (room for the dword-alignment slack)
-template <bool BLUR>
+// SF != 0: every keypoint is known to need exactly an SF x SF window (size 31, scale 1 -> 52: the detector's
+// keypoints), so all index arithmetic and loop bounds fold to constants.
+template <bool BLUR, int SF>
 __global__ __launch_bounds__(256) void bad_kernel(
     const uint8_t* __restrict__ img0, int pitch0, int rows0, int cols0,
     const uint8_t* __restrict__ pyramid, const LevelTable* __restrict__ T,
@@ -80,10 +82,10 @@ __global__ __launch_bounds__(256) void bad_kernel(
 
     // window geometry: every (clamped) box coordinate of this keypoint lies in [wx0, wx0+S] x [wy0, wy0+S]
     const float sg = scale_factor * size / 32.f;
-    int R = (int)floorf(fabsf(sg) * P->reach + 4.f);
-    int S = 2 * R + 2;
-    const bool fits = S <= smax && S > 0;
-    if (!fits) S = smax;                        // keypoint larger than the caller's max_size: zero descriptor
+    const int R = (int)floorf(fabsf(sg) * P->reach + 4.f);
+    const int Srt = 2 * R + 2;
+    const bool fits = SF ? (Srt == SF) : (Srt <= smax && Srt > 0);
+    const int S = SF ? SF : (fits ? Srt : smax);  // keypoint larger than the caller's max_size: zero descriptor
     const int ix = (int)floorf(x), iy = (int)floorf(y);
     const int wx0 = min(max(ix - R, 0), max(cols - S, 0));
     const int wy0 = min(max(iy - R, 0), max(rows - S, 0));
@@ -306,13 +308,27 @@ hipError_t efx_launch_bad(const DescribeLaunch& a, const BadParamsDev* d_params,
     float t[7];
     efx_gaussian_taps_host(t);
     if (a.blur) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bad_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(bad_kernel<true>, dim3(a.n), dim3(256), lds, stream, a.img0, a.pitch0, a.rows0, a.cols0, a.pyramid,
+        if (S == 52 && a.uniform_size) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bad_kernel<true, 52>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((bad_kernel<true, 52>), dim3(a.n), dim3(256), lds, stream, a.img0, a.pitch0, a.rows0, a.cols0, a.pyramid,
+                               a.d_table, a.kp4, a.kp_level, a.d_count, a.n, a.scale_factor, S, d_params, t[0], t[1], t[2], t[3],
+                               a.desc, a.desc_pitch);
+            return hipGetLastError();
+        }
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bad_kernel<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((bad_kernel<true, 0>), dim3(a.n), dim3(256), lds, stream, a.img0, a.pitch0, a.rows0, a.cols0, a.pyramid,
                            a.d_table, a.kp4, a.kp_level, a.d_count, a.n, a.scale_factor, S, d_params, t[0], t[1], t[2], t[3],
                            a.desc, a.desc_pitch);
     } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bad_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(bad_kernel<false>, dim3(a.n), dim3(256), lds, stream, a.img0, a.pitch0, a.rows0, a.cols0, a.pyramid,
+        if (S == 52 && a.uniform_size) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bad_kernel<false, 52>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((bad_kernel<false, 52>), dim3(a.n), dim3(256), lds, stream, a.img0, a.pitch0, a.rows0, a.cols0, a.pyramid,
+                               a.d_table, a.kp4, a.kp_level, a.d_count, a.n, a.scale_factor, S, d_params, t[0], t[1], t[2], t[3],
+                               a.desc, a.desc_pitch);
+            return hipGetLastError();
+        }
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bad_kernel<false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((bad_kernel<false, 0>), dim3(a.n), dim3(256), lds, stream, a.img0, a.pitch0, a.rows0, a.cols0, a.pyramid,
                            a.d_table, a.kp4, a.kp_level, a.d_count, a.n, a.scale_factor, S, d_params, t[0], t[1], t[2], t[3],
                            a.desc, a.desc_pitch);
     }

@@ -387,11 +387,15 @@ __global__ __launch_bounds__(256) void fast_kernel(
 // Kernel B: canonical rank of every tile's first corner = exclusive scan of the tile counts in tile
 // order (needed to apply the 10% cap deterministically, spec S2).  One workgroup per level.
 // ================================================================================================
-__global__ __launch_bounds__(1024) void tile_rank_scan_kernel(const LevelTable* __restrict__ T, TileHdr* __restrict__ hdr)
+__global__ __launch_bounds__(1024) void tile_rank_scan_kernel(const LevelTable* __restrict__ T, TileHdr* __restrict__ hdr, const Counters* __restrict__ cnt)
 {
     __shared__ int s_scan[20];
     const LevelDev& L = T->lv[blockIdx.x];
     if (!L.active) return;
+    // the ranks are only consulted when the level has more corners than its cap (pathological frames)
+    int lvl_total = 0;
+    for (int sub = 0; sub < EFX_NSUB; sub++) lvl_total += cnt->cand_total[blockIdx.x][sub].v;
+    if (lvl_total <= L.cap) return;
     const int n = L.tiles_x * L.tiles_y;
     TileHdr* h = hdr + L.tile_base;
     int running = 0;
@@ -434,8 +438,13 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
     const Corner* own = cand + (size_t)(tile & (EFX_NSUB - 1)) * L.cand_sub_cap + h.cand_start;
     const int lane = threadIdx.x;
 
+    // the per-cell maxima include corners beyond the cap; when the cap is active (pathological frames) the
+    // quick test is skipped and every corner takes the exact scan
+    int lvl_total = 0;
+    for (int sub = 0; sub < EFX_NSUB; sub++) lvl_total += cnt->cand_total[l][sub].v;
+    const bool capped = lvl_total > L.cap;              // only then the canonical ranks were computed
     const int n_own = h.cell_off[EFX_CELLS_PER_TILE];
-    int n_valid = L.cap - (int)h.cand_rank;            // cap in canonical order (spec S2; cuda_fast.cu:245)
+    int n_valid = capped ? L.cap - (int)h.cand_rank : n_own;   // cap in canonical order (spec S2; cuda_fast.cu:245)
     n_valid = n_valid < 0 ? 0 : (n_valid > n_own ? n_own : n_valid);
     if (dbg == 1) return;
 
@@ -444,11 +453,7 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
     const int gw = (L.cols + EFX_CELL - 1) / EFX_CELL, gh = (L.rows + EFX_CELL - 1) / EFX_CELL;
     const int gwp = L.tiles_x * 4;                      // row pitch of the per-cell maxima table
     const Corner* cmax = cmax_all + L.cmax_base;
-    // the per-cell maxima include corners beyond the cap; when the cap is active (pathological frames) the
-    // quick test is skipped and every corner takes the exact scan
-    int lvl_total = 0;
-    for (int sub = 0; sub < EFX_NSUB; sub++) lvl_total += cnt->cand_total[l][sub].v;
-    const bool quick_ok = lvl_total <= L.cap && block_radius <= 2;
+    const bool quick_ok = !capped && block_radius <= 2;
     const int span = 2 * block_radius + 1;
 
     int nsurv = 0;
@@ -527,7 +532,7 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
                     const int nt = (by >> 2) * L.tiles_x + (bx >> 2);
                     const TileHdr& nh = hl[nt];
                     const int c = (by & 3) * 4 + (bx & 3);
-                    const int nn = L.cap - (int)nh.cand_rank;
+                    const int nn = capped ? L.cap - (int)nh.cand_rank : 65536;
                     lb = nh.cell_off[c];
                     le = nh.cell_off[c + 1];
                     if (le > nn) le = nn;
@@ -803,16 +808,19 @@ __global__ __launch_bounds__(256) void angle_kernel(const LevelTable* __restrict
         const int dx = lane - EFX_HALF_PATCH;
         const int adx = dx < 0 ? -dx : dx;
         const uint8_t* c = img + (size_t)y * pitch + x + dx;
+        // all 31 row loads are issued first (the disc test only masks the accumulation), so one memory round trip
+        int v[31];
 #pragma unroll
-        for (int dy = -EFX_HALF_PATCH; dy <= EFX_HALF_PATCH; dy++) {
+        for (int i = 0; i < 31; i++) v[i] = c[(i - EFX_HALF_PATCH) * pitch];
+#pragma unroll
+        for (int i = 0; i < 31; i++) {
             // U_MAX, cuda_efficient_features.cu:143
             const int U_MAX[16] = { 15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3 };
+            const int dy = i - EFX_HALF_PATCH;
             const int ady = dy < 0 ? -dy : dy;
-            if (adx <= U_MAX[ady]) {
-                const int v = c[dy * pitch];
-                m10 += dx * v;
-                m01 += dy * v;
-            }
+            const int vv = adx <= U_MAX[ady] ? v[i] : 0;
+            m10 += dx * vv;
+            m01 += dy * vv;
         }
     }
 #pragma unroll
@@ -879,7 +887,7 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
                            a.pyramid, a.threshold, a.cand, a.cmax, a.hdr, a.counters, a.dbg & 15);
         if (prof) { (void)hipEventRecord(a.prof_stop[*a.prof_count], stream); a.prof_level[*a.prof_count] = 0; ++*a.prof_count; }
     }
-    hipLaunchKernelGGL(tile_rank_scan_kernel, dim3(H.nlevels), dim3(1024), 0, stream, a.d_table, a.hdr);
+    hipLaunchKernelGGL(tile_rank_scan_kernel, dim3(H.nlevels), dim3(1024), 0, stream, a.d_table, a.hdr, a.counters);
     hipLaunchKernelGGL(nms_kernel, dim3(H.total_tiles), dim3(64), 0, stream, a.d_table, a.hdr, a.cand, a.cmax, a.surv,
                        a.counters, a.nonmax_radius, a.dbg >> 4);
     hipLaunchKernelGGL(select_kernel, dim3(H.nlevels), dim3(1024), 0, stream, a.d_table, a.hdr, a.surv, a.counters,

@@ -346,6 +346,7 @@ int detect_common(efx_context* c, const uint8_t* d_image, int rows, int cols, si
         dl.n = capacity < c->p.nfeatures ? capacity : c->p.nfeatures;
         dl.blur = 1;
         dl.max_size = (float)EFX_PATCH_SIZE;
+        dl.uniform_size = 1;
         dl.desc = d_desc; dl.desc_pitch = desc_pitch;
         rc = describer_run(c->desc, c->err, dl, nullptr, nullptr, stream);
         if (rc) return rc;
@@ -355,7 +356,7 @@ int detect_common(efx_context* c, const uint8_t* d_image, int rows, int cols, si
 
 int describe_single(Describer& d, std::string& err, const uint8_t* d_image, int rows, int cols, size_t pitch,
                     const float4* kp4, int n, float max_size, uint8_t* d_desc, size_t desc_pitch,
-                    float* dbg_resp, float* dbg_T, hipStream_t stream)
+                    float* dbg_resp, float* dbg_T, hipStream_t stream, int uniform_size = 0)
 {
     if (!d_image || rows <= 0 || cols <= 0 || pitch < (size_t)cols) return set_err(err, EFX_ERR_BAD_ARG, "bad image arguments");
     if (n < 0) return set_err(err, EFX_ERR_BAD_ARG, "n must be >= 0");
@@ -365,7 +366,7 @@ int describe_single(Describer& d, std::string& err, const uint8_t* d_image, int 
     DescribeLaunch dl;
     memset(&dl, 0, sizeof(dl));
     dl.img0 = d_image; dl.pitch0 = (int)pitch; dl.rows0 = rows; dl.cols0 = cols;
-    dl.kp4 = kp4; dl.n = n; dl.blur = 0; dl.max_size = max_size;
+    dl.kp4 = kp4; dl.n = n; dl.blur = 0; dl.max_size = max_size; dl.uniform_size = uniform_size;
     dl.desc = d_desc; dl.desc_pitch = desc_pitch;
     return describer_run(d, err, dl, dbg_resp, dbg_T, stream);
 }
@@ -380,7 +381,7 @@ int describe_5xn(Describer& d, std::string& err, const uint8_t* d_image, int row
     hipError_t e = efx_launch_convert_keypoints(d_keypoints, kps_pitch, n, static_cast<float4*>(d.kp4.p), stream);
     if (e != hipSuccess) return set_err(err, EFX_ERR_HIP, "convertKeypoints failed: %s", hipGetErrorString(e));
     return describe_single(d, err, d_image, rows, cols, pitch, static_cast<const float4*>(d.kp4.p), n, (float)EFX_PATCH_SIZE,
-                           d_desc, desc_pitch, nullptr, nullptr, stream);
+                           d_desc, desc_pitch, nullptr, nullptr, stream, 1);
 }
 
 int describe_host(Describer& d, std::string& err, const uint8_t* h_image, int rows, int cols, size_t pitch,

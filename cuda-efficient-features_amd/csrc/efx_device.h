@@ -151,6 +151,7 @@ struct DescribeLaunch {
     int blur;                                              // 1: 7x7 sigma-2 Gaussian first (detectAndCompute)
     float scale_factor;                                    // BAD scaleFactor / HashSIFT croppingScale
     float max_size;                                        // upper bound of keypoint size (LDS window)
+    int uniform_size;                                      // 1: every keypoint has size == max_size (detector output)
     uint8_t* desc; size_t desc_pitch;
 };
 
