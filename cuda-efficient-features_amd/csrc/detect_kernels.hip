@@ -144,10 +144,13 @@ __device__ __forceinline__ uint8_t sat_u8_rne(float v)
 // ================================================================================================
 // Kernel R: one 64x64 tile of pyramid level s+1 per workgroup, bilinear from level s (spec S5; the
 // cv::cuda::resize call of calcImagePyramid, cuda_efficient_features.cpp:154).  The source footprint of the
-// tile is staged in LDS with aligned dword loads; lane = output column (source column and x-weights are
-// row-invariant), the 4 waves take the rows in turn, every wave store is one full 64-byte row segment.
+// tile is staged in LDS with aligned dword loads.  A lane produces 4 horizontally adjacent outputs (their
+// source columns and x-weights are row-invariant and stay in registers), 16 lanes cover a row, the 256
+// threads cover 16 rows per pass; v_cvt_pk_u8_f32 rounds (half to even), saturates and packs, so a lane
+// stores one dword per row.
 // ================================================================================================
-__global__ __launch_bounds__(256) void resize_kernel(
+template <int NT>
+__global__ __launch_bounds__(NT) void resize_kernel(
     const uint8_t* __restrict__ src, int spitch, int rows, int cols, int aligned,
     uint8_t* __restrict__ dst, int dpitch, int drows, int dcols, float fx, float fy, int tiles_x, int tiles_y, int lpitch)
 {
@@ -163,45 +166,64 @@ __global__ __launch_bounds__(256) void resize_kernel(
     const int sy1 = min(min((int)floorf((float)(oy1 - 1) * fy), rows - 1) + 1, rows - 1);
     const int ax0 = sx0 & ~3;                              // LDS column 0 <-> source column ax0
     const int ndw = ((sx1 - ax0) >> 2) + 1, nrow = sy1 - sy0 + 1;
-    for (int i = tid; i < ndw * nrow; i += 256) {
-        const int r = i / ndw, c4 = i - r * ndw;
-        const int gx = ax0 + 4 * c4;
-        const uint8_t* p = src + (size_t)(sy0 + r) * spitch;
-        uint32_t v = 0;
-        if (aligned && gx + 4 <= cols) {
-            v = *reinterpret_cast<const uint32_t*>(p + gx);
-        } else {
+    {   // 32 lanes per source row (ndw <= 32 for scale factors up to ~1.9), 8 rows per pass; wider rows loop
+        const int j0 = tid & 31, r0 = tid >> 5;
+        for (int j = j0; j < ndw; j += 32) {
+            const int gx = ax0 + 4 * j;
+            for (int r = r0; r < nrow; r += NT / 32) {
+                const uint8_t* p = src + (size_t)(sy0 + r) * spitch;
+                uint32_t v = 0;
+                if (aligned && gx + 4 <= cols) {
+                    v = *reinterpret_cast<const uint32_t*>(p + gx);
+                } else {
 #pragma unroll
-            for (int b = 0; b < 4; b++) if (gx + b < cols) v |= (uint32_t)p[gx + b] << (8 * b);
+                    for (int b = 0; b < 4; b++) if (gx + b < cols) v |= (uint32_t)p[gx + b] << (8 * b);
+                }
+                *reinterpret_cast<uint32_t*>(smem + r * lpitch + 4 * j) = v;
+            }
         }
-        *reinterpret_cast<uint32_t*>(smem + r * lpitch + 4 * c4) = v;
     }
     __syncthreads();
-    const int lane = tid & 63, wid = tid >> 6;
-    const int ox = ox0 + lane;
-    if (ox >= ox1) return;
-    const float sx = (float)ox * fx;
-    int x1 = (int)floorf(sx);
-    if (x1 > cols - 1) x1 = cols - 1;
-    const int x2 = x1 + 1;
-    const int x2r = x2 < cols - 1 ? x2 : cols - 1;
-    const float wx0 = (float)x2 - sx, wx1 = sx - (float)x1;
-    const int lc = x1 - ax0, dxr = x2r - x1;
-    for (int oy = oy0 + wid; oy < oy1; oy += 4) {
+    const int cq = tid & 15, rq = tid >> 4;               // 16 lanes x 4 outputs per row, 16 rows per pass
+    const int oxq = ox0 + 4 * cq;
+    if (oxq >= ox1) return;
+    float wx0[4], wx1[4]; int lc[4], dxr[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int ox = min(oxq + k, dcols - 1);
+        const float sx = (float)ox * fx;
+        int x1 = (int)floorf(sx);
+        if (x1 > cols - 1) x1 = cols - 1;
+        const int x2 = x1 + 1;
+        const int x2r = x2 < cols - 1 ? x2 : cols - 1;
+        wx0[k] = (float)x2 - sx; wx1[k] = sx - (float)x1;
+        lc[k] = x1 - ax0; dxr[k] = x2r - x1;
+    }
+    const bool full4 = oxq + 4 <= ox1 && ((((uintptr_t)dst) | (uintptr_t)dpitch) & 3u) == 0;
+    for (int oy = oy0 + rq; oy < oy1; oy += NT / 16) {
         const float sy = (float)oy * fy;
         int y1 = (int)floorf(sy);
         if (y1 > rows - 1) y1 = rows - 1;
         const int y2 = y1 + 1;
         const int y2r = y2 < rows - 1 ? y2 : rows - 1;
         const float wy0 = (float)y2 - sy, wy1 = sy - (float)y1;
-        const uint8_t* pa = smem + (y1 - sy0) * lpitch + lc;
-        const uint8_t* pb = smem + (y2r - sy0) * lpitch + lc;
-        float out = 0.f;
-        out = out + (float)pa[0] * (wx0 * wy0);
-        out = out + (float)pa[dxr] * (wx1 * wy0);
-        out = out + (float)pb[0] * (wx0 * wy1);
-        out = out + (float)pb[dxr] * (wx1 * wy1);
-        dst[(size_t)oy * dpitch + ox] = sat_u8_rne(out);
+        const uint8_t* ra = smem + (y1 - sy0) * lpitch;
+        const uint8_t* rb = smem + (y2r - sy0) * lpitch;
+        uint32_t packed = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint8_t* pa = ra + lc[k];
+            const uint8_t* pb = rb + lc[k];
+            float out = (float)pa[0] * (wx0[k] * wy0);                  // == 0.f + ... exactly
+            out = out + (float)pa[dxr[k]] * (wx1[k] * wy0);
+            out = out + (float)pb[0] * (wx0[k] * wy1);
+            out = out + (float)pb[dxr[k]] * (wx1[k] * wy1);
+            packed = __builtin_amdgcn_cvt_pk_u8_f32(out, k, packed);     // rint (half even) + saturate + pack
+        }
+        uint8_t* d = dst + (size_t)oy * dpitch + oxq;
+        if (full4) *reinterpret_cast<uint32_t*>(d) = packed;
+        else
+            for (int k = 0; k < 4; k++) if (oxq + k < ox1) d[k] = (uint8_t)(packed >> (8 * k));
     }
 }
 
@@ -875,7 +897,7 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
         if (lds > 64 * 1024) return hipErrorInvalidValue;
         const bool prof = a.prof_count && *a.prof_count < a.prof_capacity;
         if (prof) (void)hipEventRecord(a.prof_start[*a.prof_count], stream);
-        hipLaunchKernelGGL(resize_kernel, dim3(N.tiles_x * N.tiles_y), dim3(256), lds, stream, src, spitch, L.rows, L.cols, aligned,
+        hipLaunchKernelGGL((resize_kernel<256>), dim3(N.tiles_x * N.tiles_y), dim3(256), lds, stream, src, spitch, L.rows, L.cols, aligned,
                            a.pyramid + N.img_off, N.pitch, N.rows, N.cols, N.fx, N.fy, N.tiles_x, N.tiles_y, lpitch);
         if (prof) { (void)hipEventRecord(a.prof_stop[*a.prof_count], stream); a.prof_level[*a.prof_count] = 100 + s; ++*a.prof_count; }
     }
