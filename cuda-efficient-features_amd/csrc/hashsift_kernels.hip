@@ -19,6 +19,7 @@
 //     binarize pass as in cuda_hash_sift.cu:414-435).
 
 #include "efx_device.h"
+#include <stdlib.h>
 
 #define HS_KPAD 132   // 129 padded to a multiple of 4 floats
 
@@ -40,19 +41,20 @@ struct AffineF { float m00, m01, m02, m10, m11, m12, pad0, pad1; };
 
 // LDS plan (dynamic, BLUR only): [ hblur (S+6)*S float | raw (S+6)^2 u8 | win S*S u8 ]
 template <bool BLUR>
-__global__ __launch_bounds__(256) void patch_sift_kernel(
+#define HS_NT 384    // 6 waves: one lane per histogram bin (6 x 6 x 10 = 360) in the accumulation phase
+__global__ __launch_bounds__(HS_NT) void patch_sift_kernel(
     const uint8_t* __restrict__ img0, int pitch0, int rows0, int cols0,
     const uint8_t* __restrict__ pyramid, const LevelTable* __restrict__ T,
     const float4* __restrict__ kp4, const int* __restrict__ kp_level, const int* __restrict__ d_count, int n,
     float crop_scale, int smax, const float* __restrict__ mag_scale /*30*30*/, const float* __restrict__ obin_lut /*511*511*/,
     float taps0, float taps1, float taps2, float taps3,
-    float* __restrict__ responses /* n x HS_KPAD */, float* __restrict__ dbg_responses /* n x 129 or null */)
+    float* __restrict__ responses /* n x HS_KPAD */, float* __restrict__ dbg_responses /* n x 129 or null */, int dbg)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ AffineF s_aff;
     __shared__ uint8_t s_patch[32 * 32];
-    __shared__ float s_mag[900];
-    __shared__ float s_of[900];
+    __shared__ float s_B0[4 * 900];
+    __shared__ float s_B1[4 * 900];
     __shared__ uint8_t s_oi[900];
     __shared__ float s_hist[6 * 6 * 10];
     __shared__ float s_desc[128];
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(256) void patch_sift_kernel(
         s_ri[i] = bi; s_rf[i] = bin - (float)bi;
         s_ci[i] = bi; s_cf[i] = bin - (float)bi;       // cellw == cellh, same formula for columns
     }
-    for (int i = tid; i < 360; i += 256) s_hist[i] = 0.f;
+
 
     // window the patch can touch
     const float sg = fabsf(crop_scale * size / 32.f);
@@ -117,14 +119,14 @@ __global__ __launch_bounds__(256) void patch_sift_kernel(
     uint8_t* win = raw + RP * RP;
 
     if (BLUR && fits) {
-        for (int i = tid; i < RP * RP; i += 256) {
+        for (int i = tid; i < RP * RP; i += HS_NT) {
             const int r = i / RP, c = i % RP;
             const int gy = reflect101(wy0 - 3 + r, rows), gx = reflect101(wx0 - 3 + c, cols);
             raw[i] = img[(size_t)gy * pitch + gx];
         }
         __syncthreads();
         const float tp[7] = { taps0, taps1, taps2, taps3, taps2, taps1, taps0 };
-        for (int i = tid; i < RP * S; i += 256) {
+        for (int i = tid; i < RP * S; i += HS_NT) {
             const int r = i / S, c = i % S;
             const uint8_t* p = raw + r * RP + c;
             float acc = 0.f;
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(256) void patch_sift_kernel(
             hb[i] = acc;
         }
         __syncthreads();
-        for (int i = tid; i < S * S; i += 256) {
+        for (int i = tid; i < S * S; i += HS_NT) {
             const int r = i / S, c = i % S;
             float acc = 0.f;
 #pragma unroll
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(256) void patch_sift_kernel(
     // warpAffineLinear, hash_sift.cpp:68-109
     {
         const AffineF A = s_aff;
-        for (int i = tid; i < 1024; i += 256) {
+        for (int i = tid; i < 1024; i += HS_NT) {
             const int y = i >> 5, x = i & 31;
             const float u = A.m00 * (float)x + A.m01 * (float)y + A.m02;
             const float v = A.m10 * (float)x + A.m11 * (float)y + A.m12;
@@ -177,9 +179,10 @@ __global__ __launch_bounds__(256) void patch_sift_kernel(
     }
     __syncthreads();
 
+    if (dbg == 1) return;
     // gradients, magnitude, orientation of the 30x30 interior (hash_sift.cpp:244-260)
     {
-        for (int i = tid; i < 900; i += 256) {
+        for (int i = tid; i < 900; i += HS_NT) {
             const int y = i / 30, x = i % 30;           // patch pixel (x+1, y+1)
             const uint8_t* pc = s_patch + (y + 1) * 32 + (x + 1);
             const int idx = (int)pc[1] - (int)pc[-1], idy = (int)pc[-32] - (int)pc[32];
@@ -192,40 +195,65 @@ __global__ __launch_bounds__(256) void patch_sift_kernel(
             const float of = obin - (float)oi;
             if (oi < 0) oi += 8;
             if (oi >= 8) oi -= 8;
-            s_mag[i] = mag; s_of[i] = of; s_oi[i] = (uint8_t)oi;
-        }
-    }
-    __syncthreads();
-
-    // trilinear histogram, one lane per spatial bin, pixels in raster order (hash_sift.cpp:233-290)
-    if (tid < 36) {
-        const int RB = tid / 6, CB = tid % 6;
-        float* h = s_hist + tid * 10;
-        for (int y = 1; y <= 30; y++) {
-            const int ri = s_ri[y];
-            const int rsel = (ri + 1 == RB) ? 0 : ((ri + 2 == RB) ? 1 : -1);
-            if (rsel < 0) continue;
-            const float rf = s_rf[y];
-            for (int x = 1; x <= 30; x++) {
-                const int ci = s_ci[x];
-                const int csel = (ci + 1 == CB) ? 0 : ((ci + 2 == CB) ? 1 : -1);
-                if (csel < 0) continue;
-                const int i = (y - 1) * 30 + (x - 1);
-                const float mag = s_mag[i];
-                const float v1 = rf * mag, v0 = mag - v1;             // distribute along r
-                const float a = rsel ? v1 : v0;
-                const float cf = s_cf[x];
-                const float a1 = cf * a, a0 = a - a1;                 // distribute along c
-                const float b = csel ? a1 : a0;
-                const float of = s_of[i];
-                const float b1 = of * b, b0 = b - b1;                 // distribute along o
-                const int oi = s_oi[i];
-                h[oi] += b0;
-                h[oi + 1] += b1;
+            s_oi[i] = (uint8_t)oi;
+            // distribute (hash_sift.cpp:193-198, 262-273) for the four (row-bin, column-bin) neighbours of the pixel:
+            // sel = 2*rsel + csel; B0 goes to orientation bin oi, B1 to oi+1
+            const float rf = s_rf[y + 1], cf = s_cf[x + 1];
+            const float v1 = rf * mag, v0 = mag - v1;
+            const float v01 = cf * v0, v00 = v0 - v01;
+            const float v11 = cf * v1, v10 = v1 - v11;
+            const float a4[4] = { v00, v01, v10, v11 };
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float b1 = of * a4[q];
+                s_B1[q * 900 + i] = b1;
+                s_B0[q * 900 + i] = a4[q] - b1;
             }
         }
     }
     __syncthreads();
+
+    if (dbg == 2) return;
+    // trilinear histogram without atomics: one lane per bin (R, C, o), accumulating in a register while walking
+    // the pixels of its spatial neighbourhood in raster order -- every bin therefore receives its additions in
+    // exactly the order of the serial CPU loop (hash_sift.cpp:233-290)
+    if (tid < 360) {
+        const int RB = tid / 60, CB = (tid / 10) % 6, OB = tid % 10;
+        float acc = 0.f;
+        // rows / columns whose lower bin is RB-2 or RB-1 (CB-2 or CB-1): the bin index is monotone in the
+        // coordinate, so they form one contiguous range (16 pixels, fewer at the patch border)
+        int ylo = 31, yhi = 0, xlo = 31, xhi = 0;
+        for (int t = 1; t <= 30; t++) {
+            const int ri = s_ri[t], ci = s_ci[t];
+            if (ri + 2 == RB || ri + 1 == RB) { ylo = min(ylo, t); yhi = max(yhi, t); }
+            if (ci + 2 == CB || ci + 1 == CB) { xlo = min(xlo, t); xhi = max(xhi, t); }
+        }
+        // branch-free walk over the (at most) 16 x 16 pixels: the loads do not depend on the running sum, so they
+        // pipeline; a pixel that does not vote for this orientation bin adds +0.f (exact: acc >= 0)
+        int xoff[16], xcol[16]; bool xok[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int x = xlo + j;
+            xok[j] = x <= xhi;
+            const int xc = xok[j] ? x : xlo;
+            xcol[j] = xc - 1;
+            xoff[j] = ((s_ci[xc] + 1 == CB) ? 0 : 900) + (xc - 1);
+        }
+        for (int y = ylo; y <= yhi; y++) {
+            const int rbase = ((s_ri[y] + 1 == RB) ? 0 : 1800) + (y - 1) * 30;
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int i = (y - 1) * 30 + xcol[j];
+                const int oi = s_oi[i];
+                const float b0 = s_B0[rbase + xoff[j]], b1 = s_B1[rbase + xoff[j]];
+                const float w = (oi == OB) ? b0 : ((oi + 1 == OB) ? b1 : 0.f);
+                acc += xok[j] ? w : 0.f;
+            }
+        }
+        s_hist[tid] = acc;
+    }
+    __syncthreads();
+    if (dbg == 3) return;
     // circular fold + copy (hash_sift.cpp:293-308)
     if (tid < 16) {
         const int r = tid >> 2, c = tid & 3;
@@ -253,6 +281,7 @@ __global__ __launch_bounds__(256) void patch_sift_kernel(
         }
         __syncthreads();
     }
+    if (dbg == 4) return;
     float* out = responses + (size_t)kid * HS_KPAD;
     if (tid < 128) {
         float v = rintf(512.f * s_desc[tid]);                           // saturate_cast<uchar>: cvRound + clamp
@@ -338,17 +367,19 @@ hipError_t efx_launch_hashsift(const DescribeLaunch& a, const HashSiftDev& h, hi
     }
     float t[7];
     efx_gaussian_taps_host(t);
+    const char* dbge = getenv("EFX_DEBUG_HS");
+    const int dbg = dbge ? atoi(dbge) : 0;
     const float* mag = h.W + (size_t)h.nbits * HS_KPAD;    // the 30x30 weight table is stored behind W
     const float* lut = mag + 900;                          // followed by the 511x511 orientation-bin table
     if (a.blur) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_sift_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(patch_sift_kernel<true>, dim3(a.n), dim3(256), lds, stream, a.img0, a.pitch0, a.rows0, a.cols0,
+        hipLaunchKernelGGL(patch_sift_kernel<true>, dim3(a.n), dim3(HS_NT), lds, stream, a.img0, a.pitch0, a.rows0, a.cols0,
                            a.pyramid, a.d_table, a.kp4, a.kp_level, a.d_count, a.n, a.scale_factor, S, mag, lut,
-                           t[0], t[1], t[2], t[3], h.responses, h.dbg_responses);
+                           t[0], t[1], t[2], t[3], h.responses, h.dbg_responses, dbg);
     } else {
-        hipLaunchKernelGGL(patch_sift_kernel<false>, dim3(a.n), dim3(256), 0, stream, a.img0, a.pitch0, a.rows0, a.cols0,
+        hipLaunchKernelGGL(patch_sift_kernel<false>, dim3(a.n), dim3(HS_NT), 0, stream, a.img0, a.pitch0, a.rows0, a.cols0,
                            a.pyramid, a.d_table, a.kp4, a.kp_level, a.d_count, a.n, a.scale_factor, S, mag, lut,
-                           t[0], t[1], t[2], t[3], h.responses, h.dbg_responses);
+                           t[0], t[1], t[2], t[3], h.responses, h.dbg_responses, dbg);
     }
     if (a.desc || h.dbg_T) {
         hipLaunchKernelGGL(project_sign_kernel, dim3((a.n + 127) / 128, h.nbits / 64), dim3(256), 0, stream,

@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Measures the BASELINE.json configurations next to the headline metric (which bench.py owns):
+  C2  4K detect-only                                   (README.md:52-54 protocol)
+  C3  4K, 40k keypoints, compute-only BAD256 / BAD512  (README.md:60-62; sample_benchmark.cpp:132-141)
+  C4  4K, 40k keypoints, compute-only HashSIFT256/512
+  plus detect / detectAndCompute on FHD, 4K and 8K for all four descriptor types.
+Protocol of samples/sample_benchmark.cpp:39-52: 1 warm-up + N timed iterations of the async call followed by a
+stream synchronise, input resident on the device.  Prints one JSON object; --out writes it to a file."""
+import argparse
+import json
+import sys
+import time
+
+sys.path.insert(0, ".")
+import numpy as np
+import torch
+
+import cef_loader
+from tools import synth
+
+cef = cef_loader.load()
+EF = cef.EfficientFeatures
+
+
+def perf(fn, iters):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+        torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters * 1e3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--out", default="")
+    ap.add_argument("--sizes", default="fhd,4k,8k")
+    args = ap.parse_args()
+    res = {"protocol": "1 warm-up + %d iterations, async call + stream sync, input on device, nfeatures=40000" % args.iters,
+           "device": torch.cuda.get_device_name(0), "rows": []}
+    for size in args.sizes.split(","):
+        rows, cols = synth.SIZES[size]
+        img = torch.from_numpy(synth.synth_frame(rows, cols, seed=1000)).cuda()
+        px = rows * cols
+        kps = torch.zeros((5, 40000), dtype=torch.float32, device="cuda")
+        cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+        det = EF.create(40000, dtype=EF.BAD_256)
+        ms = perf(lambda: det.detectAsync(img, kps, cnt), args.iters)
+        n = int(cnt.item())
+        # algorithmic bytes of detect: (2F-1) P
+        lv = [det.levelGeometry(rows, cols, l) for l in range(8)]
+        P = [r * c for r, c, _ in lv]
+        bytes_detect = sum(P) + sum(P[1:])
+        res["rows"].append({"size": size, "mode": "detect", "ms": round(ms, 4), "keypoints": n,
+                            "Mkeypoints_per_s": round(n / ms / 1e3, 2),
+                            "algorithmic_MB": round(bytes_detect / 1e6, 1),
+                            "achieved_GBps": round(bytes_detect / ms / 1e6, 1), "frac_of_8TBps": round(bytes_detect / ms / 1e6 / 8000, 4)})
+        for name, dt, nbytes in (("BAD256", EF.BAD_256, 32), ("BAD512", EF.BAD_512, 64),
+                                 ("HashSIFT256", EF.HASH_SIFT_256, 32), ("HashSIFT512", EF.HASH_SIFT_512, 64)):
+            d = EF.create(40000, dtype=dt)
+            desc = torch.zeros((40000, nbytes), dtype=torch.uint8, device="cuda")
+            d.detectAsync(img, kps, cnt); torch.cuda.synchronize()
+            n = int(cnt.item())
+            ms_c = perf(lambda: d.computeAsync(img, kps, n=n, descriptors=desc), args.iters)
+            ms_dc = perf(lambda: d.detectAndComputeAsync(img, kps, desc, cnt), args.iters)
+            row = {"size": size, "descriptor": name, "keypoints": n, "compute_ms": round(ms_c, 4),
+                   "Mdescriptors_per_s": round(n / ms_c / 1e3, 2), "detectAndCompute_ms": round(ms_dc, 4),
+                   "detectAndCompute_Mkeypoints_per_s": round(n / ms_dc / 1e3, 2)}
+            if name.startswith("BAD"):
+                # SURVEY 8d BAD compute: P + 2*4(W+1)(H+1) + 16N + N*nbits/8 (the reference's global-integral design)
+                b = px + 8 * (rows + 1) * (cols + 1) + 16 * n + n * nbytes
+                row["survey_algorithmic_MB"] = round(b / 1e6, 1)
+                row["compute_frac_of_8TBps_vs_survey_bytes"] = round(b / ms_c / 1e6 / 8000, 4)
+            else:
+                flop = 2.0 * 129 * (nbytes * 8) * n
+                row["projection_GFLOP"] = round(flop / 1e9, 3)
+            res["rows"].append(row)
+    s = json.dumps(res, indent=1)
+    print(s)
+    if args.out:
+        open(args.out, "w").write(s)
+
+
+if __name__ == "__main__":
+    main()
