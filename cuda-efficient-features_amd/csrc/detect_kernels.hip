@@ -257,7 +257,8 @@ __global__ __launch_bounds__(256) void fast_kernel(
     __shared__ int s_start;
 
     const int tid = threadIdx.x;
-    const int gt = xcd_chunked(blockIdx.x, T->total_tiles);
+    // heaviest tiles first: the upper pyramid levels have the densest corners, so they must not form the tail
+    const int gt = T->total_tiles - 1 - xcd_chunked(blockIdx.x, T->total_tiles);
     const int l = level_of_tile(T, gt);
     const LevelDev& L = T->lv[l];
     if (!L.active) return;
@@ -449,7 +450,7 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
     __shared__ uint8_t s_hsrc[64];
     __shared__ uint8_t s_hkeep[64];
 
-    const int gt = blockIdx.x;
+    const int gt = T->total_tiles - 1 - blockIdx.x;      // densest (upper-level) tiles first
     const int l = level_of_tile(T, gt);
     const LevelDev& L = T->lv[l];
     if (!L.active) return;
