@@ -317,9 +317,15 @@ __global__ __launch_bounds__(256) void fast_kernel(
                 R[i][0] = trow[i * (EFX_LP / 4) + 0]; R[i][1] = trow[i * (EFX_LP / 4) + 1]; R[i][2] = trow[i * (EFX_LP / 4) + 2];
             }
             const int gx0 = x0 + bx, gy0 = y0 + by;
+            // validity of the 16 pixels of the block (border mask, .cpp:176-182) as one 16-bit mask
+            unsigned xm = 0, ym = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if ((gx0 + i) >= EFX_HALF_PATCH && (gx0 + i) < cols - EFX_HALF_PATCH) xm |= 0x1111u << i;
+                if ((gy0 + i) >= EFX_HALF_PATCH && (gy0 + i) < rows - EFX_HALF_PATCH) ym |= 0xfu << (4 * i);
+            }
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const bool yin = (gy0 + j) >= EFX_HALF_PATCH && (gy0 + j) < rows - EFX_HALF_PATCH;
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const int p = (R[j + 3][1] >> (8 * i)) & 0xff;
@@ -327,14 +333,16 @@ __global__ __launch_bounds__(256) void fast_kernel(
                     const int cs = (R[j + 6][1] >> (8 * i)) & 0xff;                   // (x, y+3)   k = 0
                     const int ce = i == 0 ? (int)(R[j + 3][1] >> 24) : (int)((R[j + 3][2] >> (8 * (i - 1))) & 0xff);   // (x+3, y) k = 4
                     const int cw = i == 3 ? (int)(R[j + 3][1] & 0xff) : (int)((R[j + 3][0] >> (8 * (i + 1))) & 0xff);  // (x-3, y) k = 12
-                    const int hi = p + threshold, lo = p - threshold;
-                    const bool bn = cn > hi, bs = cs > hi, be = ce > hi, bw = cw > hi;
-                    const bool dn = cn < lo, ds = cs < lo, de = ce < lo, dw = cw < lo;
-                    const bool pass = ((bs | bn) & (be | bw)) | ((ds | dn) & (de | dw));
-                    const bool xin = (gx0 + i) >= EFX_HALF_PATCH && (gx0 + i) < cols - EFX_HALF_PATCH;   // mask, .cpp:176-182
-                    if (pass && xin && yin && !(dbg & 2)) qm |= 1u << (j * 4 + i);
+                    // two neighbouring compass points brighter than p+t  <=>  min(max(N,S), max(E,W)) > p+t,
+                    // and the mirrored form for darker: 6 min/max + 2 compares per pixel
+                    const int bright = min(max(cs, cn), max(ce, cw));
+                    const int dark = max(min(cs, cn), min(ce, cw));
+                    const bool pass = (bright > p + threshold) | (dark < p - threshold);
+                    qm |= (pass ? 1u : 0u) << (j * 4 + i);
                 }
             }
+            qm &= xm & ym;
+            if (dbg & 2) qm = 0;
         }
         uint16_t* ql = s_list + wid * 1024;
         const int qcnt = __popc(qm);
