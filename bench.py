@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames-per-step", type=int, default=8)
-    ap.add_argument("--streams", type=int, default=1,
+    ap.add_argument("--streams", type=int, default=2,
                     help="independent frames in flight per GPU: one context + one HIP stream each (a context is not "
                          "re-entrant, like the reference's EfficientFeaturesImpl; frames are independent)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -126,11 +126,24 @@ def main():
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                 "algorithmic_bytes_per_launch": fast_bytes, "avg_launch_ms": round(avg_ms, 5),
-                "launches_timed": int(nl),
+                "launches_timed": int(nl), "concurrent_streams": NS,
                 "pyramid_plus_fast_pass": {"algorithmic_bytes_per_frame": bytes_frame,
                                            "resize_chain_ms_per_frame": round(chain_per_frame_ms, 5),
                                            "ms_per_frame": round(pass_ms, 5),
                                            "achieved": round(bytes_frame / (pass_ms * 1e-3) / 1e9, 1) if nl else None}}
+        if NS > 1:
+            # the live events above see the kernel sharing the GPU with the other stream's kernels; for reference,
+            # the same kernel with nothing else running (4 frames on one stream, after the timed region)
+            det.profileEnable(64, stride=1)
+            for i in range(min(4, F)):
+                det.detectAndComputeAsync(frames[i], kps[i], desc[i], cnt[i], capacity=NFEATURES)
+            torch.cuda.synchronize()
+            ms2, lvl2 = det.profileRead()
+            iso = ms2[lvl2 == 0]
+            if len(iso):
+                roof["isolated"] = {"avg_launch_ms": round(float(iso.mean()), 5),
+                                    "achieved": round(fast_bytes / (float(iso.mean()) * 1e-3) / 1e9, 1),
+                                    "frac": round(fast_bytes / (float(iso.mean()) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         tr_path = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tr_path):
             try:
