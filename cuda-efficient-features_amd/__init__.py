@@ -38,6 +38,8 @@ ABI_SYMBOLS = [
     "efx_bad_create", "efx_hashsift_create", "efx_describer_destroy", "efx_describer_descriptor_size",
     "efx_describer_last_error", "efx_describer_compute_kp4_async", "efx_describer_compute_async",
     "efx_describer_compute", "efx_describer_hashsift_debug_async",
+    "efx_matcher_create", "efx_matcher_destroy", "efx_matcher_last_error", "efx_match_knn2_async",
+    "efx_match_crosscheck_async",
     "efx_profile_enable", "efx_profile_set_stride", "efx_profile_read",
     "efx_level_geometry", "efx_copy_level_async",
 ]
@@ -115,6 +117,13 @@ def lib():
                                             C.c_void_p, C.c_size_t]
         L.efx_describer_hashsift_debug_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p,
                                                          C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.efx_matcher_create.argtypes = [C.POINTER(C.c_void_p)]
+        L.efx_matcher_destroy.argtypes = [C.c_void_p]
+        L.efx_matcher_last_error.restype = C.c_char_p
+        L.efx_matcher_last_error.argtypes = [C.c_void_p]
+        for name in ("efx_match_knn2_async", "efx_match_crosscheck_async"):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int,
+                                         C.c_void_p, C.c_void_p, C.c_void_p]
         L.efx_profile_enable.argtypes = [C.c_void_p, C.c_int]
         L.efx_profile_set_stride.argtypes = [C.c_void_p, C.c_int]
         L.efx_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]
@@ -416,6 +425,73 @@ class HashSIFT(_Describer):
             self._h, image.data_ptr(), image.shape[0], image.shape[1], image.stride(0), k.data_ptr(), n,
             C.c_float(max_size), resp.data_ptr(), T.data_ptr(), _stream_ptr(stream)))
         return resp[:n], T[:n]
+
+
+class BFMatcher:
+    """cv::BFMatcher(NORM_HAMMING[, crossCheck]) on the device (samples/sample_feature_matching.cpp:99-101,
+    samples/sample_image_sequence.cpp:81,114-115).  Descriptors are N x 32 / N x 64 uint8 CUDA tensors."""
+    NORM_HAMMING = 6
+
+    def __init__(self, normType=6, crossCheck=False):
+        if normType != 6:
+            raise EfxError(-2, "only NORM_HAMMING is supported")
+        self.crossCheck = bool(crossCheck)
+        self._h = C.c_void_p()
+        rc = lib().efx_matcher_create(C.byref(self._h))
+        if rc != EFX_OK:
+            self._h = C.c_void_p()
+            raise EfxError(rc, lib().efx_matcher_last_error(None).decode())
+
+    @staticmethod
+    def create(normType=6, crossCheck=False):
+        return BFMatcher(normType, crossCheck)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                lib().efx_matcher_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != EFX_OK:
+            raise EfxError(rc, lib().efx_matcher_last_error(self._h).decode())
+
+    @staticmethod
+    def _desc(t):
+        import torch
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.uint8 and t.dim() == 2 and t.stride(1) == 1
+                and t.shape[1] in (32, 64)):
+            raise EfxError(-1, "descriptors must be an N x 32 or N x 64 uint8 CUDA tensor")
+        return t
+
+    def knnMatch(self, query, train, k=2, stream=None):
+        """Returns (idx, dist): nq x 2 int32 CUDA tensors, nearest first (distance = differing bits)."""
+        import torch
+        if k != 2:
+            raise EfxError(-2, "k must be 2")
+        q, t = self._desc(query), self._desc(train)
+        if q.shape[1] != t.shape[1]:
+            raise EfxError(-1, "query and train descriptors differ in size")
+        idx = torch.full((max(q.shape[0], 1), 2), -1, dtype=torch.int32, device=q.device)
+        dist = torch.full((max(q.shape[0], 1), 2), -1, dtype=torch.int32, device=q.device)
+        self._check(lib().efx_match_knn2_async(self._h, q.data_ptr(), q.stride(0), q.shape[0], t.data_ptr(), t.stride(0),
+                                               t.shape[0], q.shape[1], idx.data_ptr(), dist.data_ptr(), _stream_ptr(stream)))
+        return idx[:q.shape[0]], dist[:q.shape[0]]
+
+    def match(self, query, train, stream=None):
+        """crossCheck matcher: (trainIdx per query or -1, distance).  Without crossCheck: the nearest neighbour."""
+        import torch
+        q, t = self._desc(query), self._desc(train)
+        if not self.crossCheck:
+            idx, dist = self.knnMatch(q, t, 2, stream)
+            return idx[:, 0].contiguous(), dist[:, 0].contiguous()
+        m = torch.full((max(q.shape[0], 1),), -1, dtype=torch.int32, device=q.device)
+        d = torch.full((max(q.shape[0], 1),), -1, dtype=torch.int32, device=q.device)
+        self._check(lib().efx_match_crosscheck_async(self._h, q.data_ptr(), q.stride(0), q.shape[0], t.data_ptr(), t.stride(0),
+                                                     t.shape[0], q.shape[1], m.data_ptr(), d.data_ptr(), _stream_ptr(stream)))
+        return m[:q.shape[0]], d[:q.shape[0]]
 
 
 def unpack_keypoints(kps):

@@ -169,6 +169,12 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct efx_describer { Describer d; };
 
+struct efx_matcher {
+    DevBuf scratch, a_idx, a_dist, b_idx, b_dist;
+    std::string err;
+    ~efx_matcher() { scratch.release(); a_idx.release(); a_dist.release(); b_idx.release(); b_dist.release(); }
+};
+
 struct efx_context {
     efx_params p;
     Describer desc;                 // describer_ (cuda_efficient_features.cpp:402), rebuilt by setDescriptorType
@@ -706,6 +712,80 @@ int efx_profile_read(efx_context* ctx, float* ms, int* level, int capacity, int*
     }
     *n = cnt;
     ctx->prof_count = 0;
+    return EFX_OK;
+}
+
+// ---- brute-force Hamming matcher ----
+int efx_matcher_create(efx_matcher** out)
+{
+    if (!out) return set_err(g_create_error, EFX_ERR_BAD_ARG, "null output handle");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return set_err(g_create_error, EFX_ERR_NO_DEVICE, "no HIP device: the matcher has no CPU fallback");
+    efx_matcher* m = new (std::nothrow) efx_matcher;
+    if (!m) return set_err(g_create_error, EFX_ERR_NOMEM, "out of host memory");
+    *out = m;
+    return EFX_OK;
+}
+int efx_matcher_destroy(efx_matcher* m) { delete m; return EFX_OK; }
+const char* efx_matcher_last_error(const efx_matcher* m) { return m ? m->err.c_str() : g_create_error.c_str(); }
+
+static int match_args_ok(efx_matcher* m, const uint8_t* q, size_t qp, int nq, const uint8_t* t, size_t tp, int nt, int db)
+{
+    if (db != 32 && db != 64) return set_err(m->err, EFX_ERR_BAD_ARG, "descriptor size must be 32 or 64 bytes");
+    if (nq < 0 || nt < 0) return set_err(m->err, EFX_ERR_BAD_ARG, "negative row count");
+    if ((nq > 0 && !q) || (nt > 0 && !t)) return set_err(m->err, EFX_ERR_BAD_ARG, "null descriptors");
+    if (qp < (size_t)db || tp < (size_t)db || ((qp | tp | (uintptr_t)q | (uintptr_t)t) & 3u))
+        return set_err(m->err, EFX_ERR_BAD_ARG, "descriptor rows must be 4-byte aligned and at least desc_bytes apart");
+    return EFX_OK;
+}
+
+static int knn2_run(efx_matcher* m, const uint8_t* q, size_t qp, int nq, const uint8_t* t, size_t tp, int nt, int db,
+                    int* idx, int* dist, hipStream_t stream)
+{
+    if (nq == 0) return EFX_OK;
+    // enough (query block, train chunk) pairs to fill the chip: ~4 workgroups per CU
+    int nchunks = 1024 / ((nq + 255) / 256);
+    if (nchunks < 1) nchunks = 1;
+    if (nchunks > 64) nchunks = 64;
+    if (nchunks > nt) nchunks = nt > 0 ? nt : 1;
+    HIP_TRY(m->err, m->scratch.reserve((size_t)nchunks * nq * 16));
+    hipError_t e = efx_launch_knn2(q, qp, nq, t, tp, nt, db, m->scratch.p, nchunks, idx, dist, stream);
+    if (e != hipSuccess) return set_err(m->err, EFX_ERR_HIP, "knn launch failed: %s", hipGetErrorString(e));
+    return EFX_OK;
+}
+
+int efx_match_knn2_async(efx_matcher* m, const uint8_t* d_query, size_t q_pitch, int nq, const uint8_t* d_train, size_t t_pitch, int nt,
+                         int desc_bytes, int* d_idx, int* d_dist, void* stream)
+{
+    if (!m) return EFX_ERR_BAD_ARG;
+    int rc = match_args_ok(m, d_query, q_pitch, nq, d_train, t_pitch, nt, desc_bytes);
+    if (rc) return rc;
+    if (nq > 0 && (!d_idx || !d_dist)) return set_err(m->err, EFX_ERR_BAD_ARG, "null outputs");
+    return knn2_run(m, d_query, q_pitch, nq, d_train, t_pitch, nt, desc_bytes, d_idx, d_dist, (hipStream_t)stream);
+}
+
+int efx_match_crosscheck_async(efx_matcher* m, const uint8_t* d_query, size_t q_pitch, int nq, const uint8_t* d_train, size_t t_pitch, int nt,
+                               int desc_bytes, int* d_match, int* d_dist, void* stream)
+{
+    if (!m) return EFX_ERR_BAD_ARG;
+    int rc = match_args_ok(m, d_query, q_pitch, nq, d_train, t_pitch, nt, desc_bytes);
+    if (rc) return rc;
+    if (nq == 0) return EFX_OK;
+    if (!d_match) return set_err(m->err, EFX_ERR_BAD_ARG, "null outputs");
+    HIP_TRY(m->err, m->a_idx.reserve((size_t)nq * 8)); HIP_TRY(m->err, m->a_dist.reserve((size_t)nq * 8));
+    HIP_TRY(m->err, m->b_idx.reserve((size_t)(nt > 0 ? nt : 1) * 8)); HIP_TRY(m->err, m->b_dist.reserve((size_t)(nt > 0 ? nt : 1) * 8));
+    rc = knn2_run(m, d_query, q_pitch, nq, d_train, t_pitch, nt, desc_bytes, (int*)m->a_idx.p, (int*)m->a_dist.p, (hipStream_t)stream);
+    if (rc) return rc;
+    rc = knn2_run(m, d_train, t_pitch, nt, d_query, q_pitch, nq, desc_bytes, (int*)m->b_idx.p, (int*)m->b_dist.p, (hipStream_t)stream);
+    if (rc) return rc;
+    hipError_t e = efx_launch_crosscheck((const int*)m->a_idx.p, (const int*)m->b_idx.p, nq, d_match, (hipStream_t)stream);
+    if (e != hipSuccess) return set_err(m->err, EFX_ERR_HIP, "crosscheck launch failed: %s", hipGetErrorString(e));
+    if (d_dist) {
+        // distance of the kept pairs = first column of the query->train result
+        HIP_TRY(m->err, hipMemcpy2DAsync(d_dist, 4, m->a_dist.p, 8, 4, (size_t)nq, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    }
     return EFX_OK;
 }
 

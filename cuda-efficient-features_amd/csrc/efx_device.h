@@ -171,3 +171,8 @@ hipError_t efx_launch_convert_keypoints(const void* d_keypoints, size_t kps_pitc
 hipError_t efx_launch_copy2d(const uint8_t* src, size_t spitch, uint8_t* dst, size_t dpitch, int rows, int cols, hipStream_t stream);
 
 void efx_gaussian_taps_host(float taps[7]);
+
+// brute-force Hamming matcher (match_kernels.hip); scratch: nchunks * nq * 16 bytes
+hipError_t efx_launch_knn2(const uint8_t* query, size_t q_pitch, int nq, const uint8_t* train, size_t t_pitch, int nt,
+                           int desc_bytes, void* scratch, int nchunks, int* idx, int* dist, hipStream_t stream);
+hipError_t efx_launch_crosscheck(const int* q2t, const int* t2q, int nq, int* match, hipStream_t stream);

@@ -193,6 +193,28 @@ int efx_describer_hashsift_debug_async(efx_describer* d, const uint8_t* d_image,
                                        float* d_responses, float* d_T, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ */
+/* brute-force Hamming matcher: cv::BFMatcher(NORM_HAMMING) as the samples use it   */
+
+typedef struct efx_matcher efx_matcher;      /* owns the scratch buffers; one per (thread, stream) */
+int efx_matcher_create(efx_matcher** out);
+int efx_matcher_destroy(efx_matcher* m);
+const char* efx_matcher_last_error(const efx_matcher* m);
+
+/* knnMatch(query, train, matches, 2) (samples/sample_image_sequence.cpp:114-115).  Descriptors are device
+ * matrices of desc_bytes (32 or 64) per row.  d_idx / d_dist: nq x 2 ints, nearest first; the distance is the
+ * number of differing bits; ties go to the lower train index; -1 where fewer than two train rows exist. */
+int efx_match_knn2_async(efx_matcher* m, const uint8_t* d_query, size_t q_pitch, int nq,
+                         const uint8_t* d_train, size_t t_pitch, int nt, int desc_bytes,
+                         int* d_idx, int* d_dist, void* stream);
+
+/* BFMatcher::create(NORM_HAMMING, crossCheck = true)->match (samples/sample_feature_matching.cpp:99-101):
+ * d_match[i] = j if train j is query i's nearest and query i is train j's nearest, else -1;
+ * d_dist[i] (may be NULL) = their distance. */
+int efx_match_crosscheck_async(efx_matcher* m, const uint8_t* d_query, size_t q_pitch, int nq,
+                               const uint8_t* d_train, size_t t_pitch, int nt, int desc_bytes,
+                               int* d_match, int* d_dist, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ */
 /* introspection used by the parity tests (no reference equivalent)                                  */
 
 /* Per-launch timing of the dominant kernel (pyramid + FAST + Harris, one launch per level) with HIP events on

@@ -301,3 +301,51 @@ def test_determinism(cef, torch_mod):
         n = int(cnt.item())
         outs.append((n, kps[:, :n].cpu().numpy().tobytes(), desc[:n].cpu().numpy().tobytes()))
     assert outs[0] == outs[1] == outs[2]
+
+
+# ---- brute-force Hamming matcher ----
+@pytest.mark.parametrize("nbytes", [32, 64])
+@pytest.mark.parametrize("nq,nt", [(1000, 1300), (257, 3), (5, 1), (300, 300)])
+def test_matcher_knn2_and_crosscheck(cef, torch_mod, nbytes, nq, nt):
+    """knnMatch(k=2) and crossCheck match are exact (integer distances, ties to the lower train index)."""
+    from oracle import matcher_oracle as MO
+    rng = np.random.default_rng(nq * 7 + nt + nbytes)
+    q = rng.integers(0, 256, size=(nq, nbytes), dtype=np.uint8)
+    t = rng.integers(0, 256, size=(nt, nbytes), dtype=np.uint8)
+    k = min(nq, nt) // 2
+    t[:k] = q[:k]                                     # exact matches
+    if nt > k + 4:
+        t[k:k + 4] = t[0]                             # duplicates: distance ties between train rows
+    t[nt // 2, 0] ^= 1
+    m = cef.BFMatcher.create(cef.BFMatcher.NORM_HAMMING)
+    idx, dist = m.knnMatch(_dev(torch_mod, q), _dev(torch_mod, t), 2)
+    torch_mod.cuda.synchronize()
+    widx, wdist = MO.knn2(q, t)
+    assert np.array_equal(dist.cpu().numpy(), wdist)
+    assert np.array_equal(idx.cpu().numpy(), widx)
+    mc = cef.BFMatcher.create(cef.BFMatcher.NORM_HAMMING, True)
+    mm, md = mc.match(_dev(torch_mod, q), _dev(torch_mod, t))
+    torch_mod.cuda.synchronize()
+    wm, wd = MO.crosscheck(q, t)
+    assert np.array_equal(mm.cpu().numpy(), wm) and np.array_equal(md.cpu().numpy(), wd)
+
+
+def test_matcher_on_detected_descriptors(cef, torch_mod):
+    """Two views of one scene (shifted crop): cross-checked BAD256 matches are mostly the true correspondences."""
+    from oracle import matcher_oracle as MO
+    big = synth.synth_frame(700, 900, seed=33)
+    a, b = np.ascontiguousarray(big[:600, :800]), np.ascontiguousarray(big[40:640, 60:860])
+    det = cef.EfficientFeatures.create(1500, nlevels=1, dtype=cef.EfficientFeatures.BAD_256)
+    ka, da = det.detectAndCompute(a)
+    kb, db = det.detectAndCompute(b)
+    m = cef.BFMatcher.create(cef.BFMatcher.NORM_HAMMING, True)
+    mm, md = m.match(_dev(torch_mod, da), _dev(torch_mod, db))
+    torch_mod.cuda.synchronize()
+    mm = mm.cpu().numpy()
+    wm, _ = MO.crosscheck(da, db)
+    assert np.array_equal(mm, wm)
+    ok = mm >= 0
+    dx = ka["x"][ok] - kb["x"][mm[ok]]
+    dy = ka["y"][ok] - kb["y"][mm[ok]]
+    good = (np.abs(dx - 60) <= 1) & (np.abs(dy - 40) <= 1)
+    assert ok.sum() > 100 and good.mean() > 0.8
