@@ -74,6 +74,10 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise EfxError(-4, f"{LIB_PATH} is missing: build it with __graft_entry__.build() "
                                "(make -C cuda-efficient-features_amd/csrc); there is no CPU fallback")
+        try:
+            import torch  # noqa: F401  -- must come first: the library then binds to the HIP runtime torch loaded,
+        except ImportError:   # so that torch tensors and libefx_hip.so share one runtime instance (devices, streams)
+            pass
         L = C.CDLL(LIB_PATH)
         L.efx_last_error.restype = C.c_char_p
         L.efx_last_error.argtypes = [C.c_void_p]

@@ -484,7 +484,13 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
     const int gw = (L.cols + EFX_CELL - 1) / EFX_CELL, gh = (L.rows + EFX_CELL - 1) / EFX_CELL;
     const int gwp = L.tiles_x * 4;                      // row pitch of the per-cell maxima table
     const Corner* cmax = cmax_all + L.cmax_base;
-    const bool quick_ok = !capped && block_radius <= 2;
+    const bool quick_ok = block_radius <= 2;
+    // under an active cap a cell maximum is a valid suppressor only if its whole tile lies below the cap
+    auto usable = [&](int bx, int by) -> bool {
+        if (!capped) return true;
+        const TileHdr& nh = hl[(by >> 2) * L.tiles_x + (bx >> 2)];
+        return (int)nh.cand_rank + (int)nh.cell_off[EFX_CELLS_PER_TILE] <= L.cap;
+    };
     const int span = 2 * block_radius + 1;
 
     int nsurv = 0;
@@ -518,14 +524,15 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
 #pragma unroll
                     for (int q = 0; q < 9; q++) {
                         const int dx = mx - (int)(o[q].xy & 0xffff), dy = my - (int)(o[q].xy >> 16);
-                        if (o[q].xy != me.xy && me.resp <= o[q].resp && dx * dx + dy * dy < image_radius) hard = false;
+                        if (o[q].xy != me.xy && me.resp <= o[q].resp && dx * dx + dy * dy < image_radius &&
+                            usable(min(max(bx1 - 1 + (q % 3), 0), gw - 1), min(max(by1 - 1 + (q / 3), 0), gh - 1))) hard = false;
                     }
                 } else {
                     for (int by = miny; by <= maxy; by++)
                         for (int bx = minx; bx <= maxx; bx++) {
                             const Corner o = cmax[by * gwp + bx];
                             const int dx = mx - (int)(o.xy & 0xffff), dy = my - (int)(o.xy >> 16);
-                            if (o.xy != me.xy && me.resp <= o.resp && dx * dx + dy * dy < image_radius) hard = false;
+                            if (o.xy != me.xy && me.resp <= o.resp && dx * dx + dy * dy < image_radius && usable(bx, by)) hard = false;
                         }
                 }
             }
@@ -568,6 +575,8 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
                     le = nh.cell_off[c + 1];
                     if (le > nn) le = nn;
                     lbase = (unsigned)(nt & (EFX_NSUB - 1)) * L.cand_sub_cap + nh.cand_start;
+                    // a cell whose strongest corner is weaker than this corner cannot suppress it: skip the cell
+                    if (quick_ok && cmax[by * gwp + bx].resp < m.resp) le = lb;
                 }
                 // first 16 entries of every cell: all loads in flight before the first compare
                 Corner e[16]; bool ev[16]; int nb[16], ne[16]; unsigned nbase[16];

@@ -79,6 +79,9 @@ int main(int argc, char** argv)
             ms = perf(niter, [&] { feature->computeAsync(img, d_keypoints, n, d_descriptors, stream); (void)hipStreamSynchronize(stream); });
         }
         printf("%5d keypoints found.\nprocessing time: %.3f[milli sec]\n", feature->lastCount(), ms);
+        efx_level_stats st[32]; int nl = 0;
+        if (efx_last_level_stats(feature->handle(), st, 32, &nl) == EFX_OK)
+            for (int l = 0; l < nl; l++) printf("level %d: %d FAST corners, %d after NMS, %d kept\n", l, st[l].n_candidates, st[l].n_after_nms, st[l].n_kept);
     } catch (const efx::Exception& e) {
         fprintf(stderr, "efx error %d: %s\n", e.code, e.what());
         return 2;
