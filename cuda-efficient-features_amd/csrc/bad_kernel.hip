@@ -27,7 +27,35 @@ __device__ __forceinline__ int reflect101(int p, int len)
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-struct Affine { float m00, m01, m02, m10, m11, m12, s; };
+struct __attribute__((aligned(16))) Affine { float m00, m01, m02, m10, m11, m12, s, pad; };
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// rectifyBoxes, bad.cpp:115-147: the patch -> image affine map of every keypoint, one lane per keypoint (the double
+// cos/sin of bad.cpp:138-139 is ~400 instructions: far too long to run on one lane of a per-keypoint workgroup)
+__global__ __launch_bounds__(256) void bad_affine_kernel(const float4* __restrict__ kp4, const int* __restrict__ d_count, int n,
+                                                         float scale_factor, Affine* __restrict__ aff)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int count = d_count ? min(*d_count, n) : n;
+    if (i >= count) return;
+    const float4 kp = kp4[i];
+    const float x = kp.x, y = kp.y, size = kp.z, angle = kp.w;
+    Affine A;
+    const float s = scale_factor * size / (0.5f * (float)(32 + 32));
+    if (angle == -1) {
+        A.m00 = s; A.m01 = 0.0f; A.m02 = -0.5f * s * (float)32 + x;
+        A.m10 = 0.0f; A.m11 = s; A.m12 = -s * 0.5f * (float)32 + y;
+    } else {
+        const float cosine = (angle >= 0) ? (float)cos((double)angle * 0.017453292519943295) : 1.f;
+        const float sine = (angle >= 0) ? (float)sin((double)angle * 0.017453292519943295) : 0.f;
+        A.m00 = s * cosine; A.m01 = -s * sine;
+        A.m02 = (-s * cosine + s * sine) * (float)32 * 0.5f + x;
+        A.m10 = s * sine; A.m11 = s * cosine;
+        A.m12 = (-s * sine - s * cosine) * (float)32 * 0.5f + y;
+    }
+    A.s = s; A.pad = 0.f;
+    aff[i] = A;
+}
 
 // LDS plan (dynamic): [ I: (S+1)^2 int32, aliased by raw: (S+6) x RPB u8 | hb: (8G+6) x HP float ]
 //   G = ceil(S/8) groups of 8 outputs, HP = 8G, RPB = 4*ceil((S+12)/4) (room for the dword-alignment slack)
@@ -38,11 +66,10 @@ __global__ __launch_bounds__(256) void bad_kernel(
     const uint8_t* __restrict__ img0, int pitch0, int rows0, int cols0,
     const uint8_t* __restrict__ pyramid, const LevelTable* __restrict__ T,
     const float4* __restrict__ kp4, const int* __restrict__ kp_level, const int* __restrict__ d_count, int n,
-    float scale_factor, int smax, const BadParamsDev* __restrict__ P, float taps0, float taps1, float taps2, float taps3,
+    float scale_factor, int smax, const BadParamsDev* __restrict__ P, const Affine* __restrict__ aff, float taps0, float taps1, float taps2, float taps3,
     uint8_t* __restrict__ desc, size_t desc_pitch)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ Affine s_aff;
 
     const int kid = blockIdx.x;
     const int count = d_count ? min(*d_count, n) : n;
@@ -58,27 +85,7 @@ __global__ __launch_bounds__(256) void bad_kernel(
         else { rows = T->lv[0].rows; cols = T->lv[0].cols; }
     }
     const int nbits = P->nbits;
-    const float x = kp.x, y = kp.y, size = kp.z, angle = kp.w;
-
-    // rectifyBoxes, bad.cpp:115-147 (one lane of the last wave: double cos/sin as in bad.cpp:138-139; the
-    // result is needed only after the integral image is built)
-    if (tid == 255) {
-        Affine A;
-        const float s = scale_factor * size / (0.5f * (float)(32 + 32));
-        if (angle == -1) {
-            A.m00 = s; A.m01 = 0.0f; A.m02 = -0.5f * s * (float)32 + x;
-            A.m10 = 0.0f; A.m11 = s; A.m12 = -s * 0.5f * (float)32 + y;
-        } else {
-            const float cosine = (angle >= 0) ? (float)cos((double)angle * 0.017453292519943295) : 1.f;
-            const float sine = (angle >= 0) ? (float)sin((double)angle * 0.017453292519943295) : 0.f;
-            A.m00 = s * cosine; A.m01 = -s * sine;
-            A.m02 = (-s * cosine + s * sine) * (float)32 * 0.5f + x;
-            A.m10 = s * sine; A.m11 = s * cosine;
-            A.m12 = (-s * sine - s * cosine) * (float)32 * 0.5f + y;
-        }
-        A.s = s;
-        s_aff = A;
-    }
+    const float x = kp.x, y = kp.y, size = kp.z;
 
     // window geometry: every (clamped) box coordinate of this keypoint lies in [wx0, wx0+S] x [wy0, wy0+S]
     const float sg = scale_factor * size / 32.f;
@@ -125,55 +132,68 @@ __global__ __launch_bounds__(256) void bad_kernel(
             }
             __syncthreads();
             const float tp[7] = { taps0, taps1, taps2, taps3, taps2, taps1, taps0 };
-            // ---- row pass (spec S6): u8 -> float, taps in order 0..6; 8 consecutive outputs per lane so that
-            //      every raw byte is read from LDS once (5 dwords) instead of 7 times
+            // ---- row pass (spec S6): u8 -> float, acc = fma(tap_j, v_j, acc) for j = 0..6.  An item is 8
+            //      consecutive outputs of TWO adjacent rows, so every FMA is a v_pk_fma_f32 on a (row r, row r+1)
+            //      register pair and every raw byte is read from LDS once.  RP = S + 6 is even.
             {
-                const int sh = G <= 8 ? 3 : (G <= 16 ? 4 : (G <= 32 ? 5 : 6));
-                const int g0 = tid & ((1 << sh) - 1), r0 = tid >> sh, rstep = 256 >> sh;
-                for (int g = g0; g < G; g += (1 << sh)) {
-                    for (int r = r0; r < RP; r += rstep) {
-                        const uint32_t* w = reinterpret_cast<const uint32_t*>(raw + r * RPB + 8 * g);
-                        const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4];
-                        const uint32_t b0 = __builtin_amdgcn_alignbyte(w1, w0, off), b1 = __builtin_amdgcn_alignbyte(w2, w1, off);
-                        const uint32_t b2 = __builtin_amdgcn_alignbyte(w3, w2, off), b3 = __builtin_amdgcn_alignbyte(w4, w3, off);
-                        float v[16];
+                const int nitems = (RP >> 1) * G;
+                for (int it = tid; it < nitems; it += 256) {
+                    const int rp = it / G, g = it - rp * G;
+                    const uint32_t* wa = reinterpret_cast<const uint32_t*>(raw + (2 * rp) * RPB + 8 * g);
+                    const uint32_t* wb = wa + (RPB >> 2);
+                    const uint32_t a0 = wa[0], a1 = wa[1], a2 = wa[2], a3 = wa[3], a4 = wa[4];
+                    const uint32_t c0 = wb[0], c1 = wb[1], c2 = wb[2], c3 = wb[3], c4 = wb[4];
+                    const uint32_t ba[4] = { __builtin_amdgcn_alignbyte(a1, a0, off), __builtin_amdgcn_alignbyte(a2, a1, off),
+                                             __builtin_amdgcn_alignbyte(a3, a2, off), __builtin_amdgcn_alignbyte(a4, a3, off) };
+                    const uint32_t bb[4] = { __builtin_amdgcn_alignbyte(c1, c0, off), __builtin_amdgcn_alignbyte(c2, c1, off),
+                                             __builtin_amdgcn_alignbyte(c3, c2, off), __builtin_amdgcn_alignbyte(c4, c3, off) };
+                    f32x2 v[14];
 #pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            v[k] = (float)((b0 >> (8 * k)) & 0xff); v[4 + k] = (float)((b1 >> (8 * k)) & 0xff);
-                            v[8 + k] = (float)((b2 >> (8 * k)) & 0xff); v[12 + k] = (float)((b3 >> (8 * k)) & 0xff);
-                        }
-                        float o[8];
-#pragma unroll
-                        for (int i = 0; i < 8; i++) {
-                            float acc = tp[0] * v[i];                   // == 0.f + tp[0]*v[i] exactly
-#pragma unroll
-                            for (int jt = 1; jt < 7; jt++) acc = acc + tp[jt] * v[i + jt];
-                            o[i] = acc;
-                        }
-                        float4* dstp = reinterpret_cast<float4*>(hb + r * HP + 8 * g);
-                        dstp[0] = make_float4(o[0], o[1], o[2], o[3]);
-                        dstp[1] = make_float4(o[4], o[5], o[6], o[7]);
+                    for (int k = 0; k < 14; k++) {
+                        v[k].x = (float)((ba[k >> 2] >> (8 * (k & 3))) & 0xff);
+                        v[k].y = (float)((bb[k >> 2] >> (8 * (k & 3))) & 0xff);
                     }
+                    f32x2 o[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        f32x2 acc = v[i] * tp[0];                        // == fma(tp[0], v, 0) exactly
+#pragma unroll
+                        for (int jt = 1; jt < 7; jt++) acc = __builtin_elementwise_fma(v[i + jt], (f32x2)(tp[jt]), acc);
+                        o[i] = acc;
+                    }
+                    float4* d0 = reinterpret_cast<float4*>(hb + (2 * rp) * HP + 8 * g);
+                    float4* d1 = reinterpret_cast<float4*>(hb + (2 * rp + 1) * HP + 8 * g);
+                    d0[0] = make_float4(o[0].x, o[1].x, o[2].x, o[3].x); d0[1] = make_float4(o[4].x, o[5].x, o[6].x, o[7].x);
+                    d1[0] = make_float4(o[0].y, o[1].y, o[2].y, o[3].y); d1[1] = make_float4(o[4].y, o[5].y, o[6].y, o[7].y);
                 }
             }
             __syncthreads();
-            // ---- column pass: float -> u8 (round half even, saturate) -> source of the integral; one column
-            //      per lane, 8 consecutive rows per item (14 LDS reads instead of 56)
-            for (int c = lane; c < S; c += 64) {
-                const bool cin = (wx0 + c) < cols;
-                for (int rg = wid; rg < G; rg += 4) {
-                    float v[14];
+            // ---- column pass: float -> u8 (round half even, saturate: v_cvt_pk_u8_f32) -> source of the
+            //      integral.  An item is 8 consecutive rows of TWO adjacent columns (S is even): 14 ds_read_b64,
+            //      56 v_pk_fma_f32.
+            {
+                const int ncp = S >> 1;
+                const int nitems = ncp * G;
+                for (int it = tid; it < nitems; it += 256) {
+                    const int rg = it / ncp, cp = it - rg * ncp;
+                    const int c = 2 * cp;
+                    const bool cin0 = (wx0 + c) < cols, cin1 = (wx0 + c + 1) < cols;
+                    f32x2 v[14];
 #pragma unroll
-                    for (int k = 0; k < 14; k++) v[k] = hb[(8 * rg + k) * HP + c];
+                    for (int k = 0; k < 14; k++) v[k] = *reinterpret_cast<const f32x2*>(hb + (8 * rg + k) * HP + c);
 #pragma unroll
                     for (int i = 0; i < 8; i++) {
                         const int r = 8 * rg + i;
-                        float acc = tp[0] * v[i];
+                        f32x2 acc = v[i] * tp[0];
 #pragma unroll
-                        for (int jt = 1; jt < 7; jt++) acc = acc + tp[jt] * v[i + jt];
-                        float q = rintf(acc);
-                        q = q < 0.f ? 0.f : (q > 255.f ? 255.f : q);
-                        if (r < S) I[(r + 1) * IP + (c + 1)] = (cin && (wy0 + r) < rows) ? (int)q : 0;
+                        for (int jt = 1; jt < 7; jt++) acc = __builtin_elementwise_fma(v[i + jt], (f32x2)(tp[jt]), acc);
+                        const int q0 = (int)__builtin_amdgcn_cvt_pk_u8_f32(acc.x, 0, 0u);
+                        const int q1 = (int)__builtin_amdgcn_cvt_pk_u8_f32(acc.y, 0, 0u);
+                        if (r < S) {
+                            const bool rin = (wy0 + r) < rows;
+                            I[(r + 1) * IP + (c + 1)] = (cin0 && rin) ? q0 : 0;
+                            I[(r + 1) * IP + (c + 2)] = (cin1 && rin) ? q1 : 0;
+                        }
                     }
                 }
             }
@@ -204,7 +224,7 @@ __global__ __launch_bounds__(256) void bad_kernel(
     }
     __syncthreads();
 
-    const Affine A = s_aff;
+    const Affine A = aff[kid];
     // isKeypointInTheBorder, bad.cpp:86-103
     const float sb = scale_factor * size / (float)(32 + 32);
     const float bw = (float)32 * sb * 1.75f, bh = (float)32 * sb * 1.75f;
@@ -249,12 +269,13 @@ __global__ __launch_bounds__(256) void bad_kernel(
                 bit = (avg1 - avg2) <= thr;
             } else {
                 // integer fast path, bad.cpp:365-393 (tap coordinates clamped into the frame: spec S9)
-                const int ax1 = clampi(cx1 - r, 0, fw - 1) - wx0, ay1 = clampi(cy1 - r, 0, fh - 1) - wy0;
-                const int ax2 = clampi(cx1 + r + 1, 0, fw - 1) - wx0, ay2 = clampi(cy1 + r + 1, 0, fh - 1) - wy0;
-                const int bx1 = clampi(cx2 - r, 0, fw - 1) - wx0, by1 = clampi(cy2 - r, 0, fh - 1) - wy0;
-                const int bx2 = clampi(cx2 + r + 1, 0, fw - 1) - wx0, by2 = clampi(cy2 + r + 1, 0, fh - 1) - wy0;
-                const int lax1 = clampi(ax1, 0, S), lay1 = clampi(ay1, 0, S), lax2 = clampi(ax2, 0, S), lay2 = clampi(ay2, 0, S);
-                const int lbx1 = clampi(bx1, 0, S), lby1 = clampi(by1, 0, S), lbx2 = clampi(bx2, 0, S), lby2 = clampi(by2, 0, S);
+                // The window lies inside the frame (or, for frames smaller than the window, the pixels beyond the
+                // frame are zero, so the integral is constant there): clamping to the frame and then to the
+                // window equals clamping to the window.
+                const int lax1 = clampi(cx1 - r - wx0, 0, S), lay1 = clampi(cy1 - r - wy0, 0, S);
+                const int lax2 = clampi(cx1 + r + 1 - wx0, 0, S), lay2 = clampi(cy1 + r + 1 - wy0, 0, S);
+                const int lbx1 = clampi(cx2 - r - wx0, 0, S), lby1 = clampi(cy2 - r - wy0, 0, S);
+                const int lbx2 = clampi(cx2 + r + 1 - wx0, 0, S), lby2 = clampi(cy2 + r + 1 - wy0, 0, S);
                 const int side = 1 + (r << 1);
                 const int area_resp = I[lay1 * IP + lax1] + I[lay2 * IP + lax2] - I[lay1 * IP + lax2] - I[lay2 * IP + lax1]
                                     - I[lby1 * IP + lbx1] - I[lby2 * IP + lbx2] + I[lby1 * IP + lbx2] + I[lby2 * IP + lbx1];
@@ -307,29 +328,31 @@ hipError_t efx_launch_bad(const DescribeLaunch& a, const BadParamsDev* d_params,
     if (lds > 160 * 1024 - 64) return hipErrorInvalidValue;    // keypoint window does not fit in LDS
     float t[7];
     efx_gaussian_taps_host(t);
+    Affine* aff = static_cast<Affine*>(a.bad_affine);
+    hipLaunchKernelGGL(bad_affine_kernel, dim3((a.n + 255) / 256), dim3(256), 0, stream, a.kp4, a.d_count, a.n, a.scale_factor, aff);
     if (a.blur) {
         if (S == 52 && a.uniform_size) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bad_kernel<true, 52>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL((bad_kernel<true, 52>), dim3(a.n), dim3(256), lds, stream, a.img0, a.pitch0, a.rows0, a.cols0, a.pyramid,
-                               a.d_table, a.kp4, a.kp_level, a.d_count, a.n, a.scale_factor, S, d_params, t[0], t[1], t[2], t[3],
+                               a.d_table, a.kp4, a.kp_level, a.d_count, a.n, a.scale_factor, S, d_params, aff, t[0], t[1], t[2], t[3],
                                a.desc, a.desc_pitch);
             return hipGetLastError();
         }
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bad_kernel<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((bad_kernel<true, 0>), dim3(a.n), dim3(256), lds, stream, a.img0, a.pitch0, a.rows0, a.cols0, a.pyramid,
-                           a.d_table, a.kp4, a.kp_level, a.d_count, a.n, a.scale_factor, S, d_params, t[0], t[1], t[2], t[3],
+                           a.d_table, a.kp4, a.kp_level, a.d_count, a.n, a.scale_factor, S, d_params, aff, t[0], t[1], t[2], t[3],
                            a.desc, a.desc_pitch);
     } else {
         if (S == 52 && a.uniform_size) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bad_kernel<false, 52>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL((bad_kernel<false, 52>), dim3(a.n), dim3(256), lds, stream, a.img0, a.pitch0, a.rows0, a.cols0, a.pyramid,
-                               a.d_table, a.kp4, a.kp_level, a.d_count, a.n, a.scale_factor, S, d_params, t[0], t[1], t[2], t[3],
+                               a.d_table, a.kp4, a.kp_level, a.d_count, a.n, a.scale_factor, S, d_params, aff, t[0], t[1], t[2], t[3],
                                a.desc, a.desc_pitch);
             return hipGetLastError();
         }
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bad_kernel<false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((bad_kernel<false, 0>), dim3(a.n), dim3(256), lds, stream, a.img0, a.pitch0, a.rows0, a.cols0, a.pyramid,
-                           a.d_table, a.kp4, a.kp_level, a.d_count, a.n, a.scale_factor, S, d_params, t[0], t[1], t[2], t[3],
+                           a.d_table, a.kp4, a.kp_level, a.d_count, a.n, a.scale_factor, S, d_params, aff, t[0], t[1], t[2], t[3],
                            a.desc, a.desc_pitch);
     }
     return hipGetLastError();

@@ -298,6 +298,7 @@ __global__ __launch_bounds__(256) void fast_kernel(
         *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(s_tile) + r * EFX_LP + c8 * 8) = v;
     }
     __syncthreads();
+    if (dbg & 1) return;
 
     int total = 0;
     {
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(256) void fast_kernel(
         __syncthreads();
         // ---- phase 2: full 16-point segment test on the survivors, one lane per pixel; corners set their bit in
         //      the 64x64 bitmap ----
-        for (int idx = lane; idx < nq; idx += 64) {
+        for (int idx = lane; idx < ((dbg & 8) ? 0 : nq); idx += 64) {
             const int e = ql[idx];
             const int lx = e & 0xff, ly = e >> 8;
             if (fast9_lds<EFX_LP>(tb + (ly + EFX_HALO) * EFX_LP + lx + EFX_HALO, threshold))
@@ -386,8 +387,12 @@ __global__ __launch_bounds__(256) void fast_kernel(
         __syncthreads();
 
         // ---- phase 4: Harris on the corners, append to the level's corner array ----
+        //      Most tiles hold fewer than 64 corners, i.e. one wave of work; wave w of every workgroup sits on
+        //      SIMD w, so the wave that takes the first 64 corners is rotated per tile (pseudo-randomly) to keep
+        //      the four SIMDs of a CU evenly loaded.
         const int start = s_start;
-        for (int k = tid; k < total; k += 256) {
+        const int rtid = (tid + 64 * (int)(((uint32_t)gt * 0x9E3779B1u) >> 30)) & 255;
+        for (int k = rtid; k < total; k += 256) {
             const int lx = s_list[k] & 0xff, ly = s_list[k] >> 8;
             const float resp = (dbg & 4) ? 1.f : harris_lds<EFX_LP>(tb + (ly + EFX_HALO) * EFX_LP + lx + EFX_HALO);
             Corner c;

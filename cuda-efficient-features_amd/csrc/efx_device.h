@@ -153,6 +153,7 @@ struct DescribeLaunch {
     float max_size;                                        // upper bound of keypoint size (LDS window)
     int uniform_size;                                      // 1: every keypoint has size == max_size (detector output)
     uint8_t* desc; size_t desc_pitch;
+    void* bad_affine;                                      // BAD scratch: n x 32 bytes (per-keypoint affine map)
 };
 
 hipError_t efx_launch_bad(const DescribeLaunch& a, const BadParamsDev* d_params, float reach, hipStream_t stream);

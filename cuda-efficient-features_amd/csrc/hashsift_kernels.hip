@@ -131,7 +131,7 @@ __global__ __launch_bounds__(HS_NT) void patch_sift_kernel(
             const uint8_t* p = raw + r * RP + c;
             float acc = 0.f;
 #pragma unroll
-            for (int j = 0; j < 7; j++) acc = acc + tp[j] * (float)p[j];
+            for (int j = 0; j < 7; j++) acc = __builtin_fmaf(tp[j], (float)p[j], acc);
             hb[i] = acc;
         }
         __syncthreads();
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(HS_NT) void patch_sift_kernel(
             const int r = i / S, c = i % S;
             float acc = 0.f;
 #pragma unroll
-            for (int j = 0; j < 7; j++) acc = acc + tp[j] * hb[(r + j) * S + c];
+            for (int j = 0; j < 7; j++) acc = __builtin_fmaf(tp[j], hb[(r + j) * S + c], acc);
             float v = rintf(acc);
             v = v < 0.f ? 0.f : (v > 255.f ? 255.f : v);
             win[i] = (uint8_t)v;

@@ -470,8 +470,10 @@ static int reflect101(int p, int len)
 
 void efxo_gaussian7(const uint8_t* src, int rows, int cols, int sstride, uint8_t* dst, int dstride)
 {
-    /* Spec S6: separable; row pass u8 -> float (taps in order 0..6), column pass float -> u8
-     * (round-half-even saturate).  Call site: cuda_efficient_features.cpp:193,305. */
+    /* Spec S6: separable; row pass u8 -> float, column pass float -> u8 (round-half-even saturate); each pass
+     * accumulates acc = fma(tap_j, v_j, acc) for j = 0..6 from acc = 0 (single rounding per tap: what nvcc's
+     * default FMA contraction makes of the `sum = sum + src * kernel[k]` loop of the filter the reference calls).
+     * Call site: cuda_efficient_features.cpp:193,305. */
     float taps[7];
     efxo_gaussian_taps(taps);
     float* tmp = (float*)malloc(sizeof(float) * (size_t)rows * cols);
@@ -479,14 +481,14 @@ void efxo_gaussian7(const uint8_t* src, int rows, int cols, int sstride, uint8_t
         const uint8_t* p = src + (size_t)y * sstride;
         for (int x = 0; x < cols; x++) {
             float acc = 0.f;
-            for (int j = 0; j < 7; j++) acc = acc + taps[j] * (float)p[reflect101(x + j - 3, cols)];
+            for (int j = 0; j < 7; j++) acc = fmaf(taps[j], (float)p[reflect101(x + j - 3, cols)], acc);
             tmp[(size_t)y * cols + x] = acc;
         }
     }
     for (int y = 0; y < rows; y++) {
         for (int x = 0; x < cols; x++) {
             float acc = 0.f;
-            for (int j = 0; j < 7; j++) acc = acc + taps[j] * tmp[(size_t)reflect101(y + j - 3, rows) * cols + x];
+            for (int j = 0; j < 7; j++) acc = fmaf(taps[j], tmp[(size_t)reflect101(y + j - 3, rows) * cols + x], acc);
             dst[(size_t)y * dstride + x] = sat_u8_f(acc);
         }
     }

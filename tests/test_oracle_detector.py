@@ -111,14 +111,17 @@ def test_gaussian_equals_numpy_spec(oracle):
     idx_c = np.where(idx_c >= 50, 2 * 49 - idx_c, idx_c)          # reflect-101
     idx_r = np.abs(np.arange(-3, 40 + 3))
     idx_r = np.where(idx_r >= 40, 2 * 39 - idx_r, idx_r)
+    # fma(a, b, c) on float32 values == float32(float64(a) * float64(b) + float64(c)): the product is exact in
+    # double; the double rounding of the sum cannot hit a float32 tie for these operand widths in practice
+    fma = lambda a, b, c: (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
     P = img.astype(np.float32)[:, idx_c]
     tmp = np.zeros((40, 50), np.float32)
     for j in range(7):
-        tmp = tmp + taps[j] * P[:, j:j + 50]
+        tmp = fma(np.full((40, 50), taps[j], np.float32), P[:, j:j + 50], tmp)
     T = tmp[idx_r, :]
     out = np.zeros((40, 50), np.float32)
     for j in range(7):
-        out = out + taps[j] * T[j:j + 40, :]
+        out = fma(np.full((40, 50), taps[j], np.float32), T[j:j + 40, :], out)
     want = np.clip(np.rint(out), 0, 255).astype(np.uint8)
     assert np.array_equal(oracle.gaussian7(img), want)
 
