@@ -92,41 +92,8 @@ __device__ __forceinline__ bool fast9_lds(const uint8_t* c, int t)
 // then one fixed, uncontracted float formula.  The 9x9 footprint is pulled as 9 rows x 3 aligned dwords and
 // re-aligned with v_alignbyte (27 LDS reads instead of 81 byte reads); the Sobel sums share the pairwise row /
 // column sums, and the products use 24-bit multiplies (|d| <= 1020).
-template <int P>
-__device__ __forceinline__ float harris_lds(const uint8_t* c)
+__device__ __forceinline__ float harris_from_sums(int sxx, int sxy, int syy)
 {
-    const uint8_t* p0 = c - 4 * P - 4;                       // top-left byte of the footprint
-    const unsigned sh = (unsigned)(reinterpret_cast<uintptr_t>(p0) & 3u);
-    const uint32_t* w = reinterpret_cast<const uint32_t*>(p0 - sh);
-    int px[9][9];
-#pragma unroll
-    for (int r = 0; r < 9; r++) {
-        const uint32_t w0 = w[r * (P / 4)], w1 = w[r * (P / 4) + 1], w2 = w[r * (P / 4) + 2];
-        const uint32_t a = __builtin_amdgcn_alignbyte(w1, w0, sh), b = __builtin_amdgcn_alignbyte(w2, w1, sh);
-        const uint32_t t = w2 >> (8 * sh);
-#pragma unroll
-        for (int k = 0; k < 4; k++) { px[r][k] = (a >> (8 * k)) & 0xff; px[r][4 + k] = (b >> (8 * k)) & 0xff; }
-        px[r][8] = t & 0xff;
-    }
-    // vs[r][c] = px[r][c] + px[r+1][c] (vertical pair sums), hs[r][c] = px[r][c] + px[r][c+1] (horizontal)
-    int sxx = 0, sxy = 0, syy = 0;
-#pragma unroll
-    for (int r = 1; r <= 7; r++) {
-        int V[9], H0[7], H2[7];
-#pragma unroll
-        for (int cidx = 0; cidx < 9; cidx++) V[cidx] = (px[r - 1][cidx] + px[r][cidx]) + (px[r][cidx] + px[r + 1][cidx]);
-#pragma unroll
-        for (int ix = 0; ix < 7; ix++) {
-            H0[ix] = (px[r - 1][ix] + px[r - 1][ix + 1]) + (px[r - 1][ix + 1] + px[r - 1][ix + 2]);
-            H2[ix] = (px[r + 1][ix] + px[r + 1][ix + 1]) + (px[r + 1][ix + 1] + px[r + 1][ix + 2]);
-        }
-#pragma unroll
-        for (int ix = 0; ix < 7; ix++) {
-            const int dx = V[ix + 2] - V[ix];
-            const int dy = H2[ix] - H0[ix];
-            sxx += __mul24(dx, dx); sxy += __mul24(dx, dy); syy += __mul24(dy, dy);
-        }
-    }
     const float SCALE = 1.f / (float)(4 * 7 * 255);
     const float K = SCALE * SCALE;
     const float a = (float)sxx * K, b = (float)syy * K, cc = (float)sxy * K;
@@ -134,6 +101,85 @@ __device__ __forceinline__ float harris_lds(const uint8_t* c)
     const float tr = a + b;
     return det - 0.04f * tr * tr;
 }
+
+// same sums from byte loads (level-0 images whose base or pitch is not 4-byte aligned)
+__device__ __forceinline__ float harris_bytes(const uint8_t* c, int P)
+{
+    int sxx = 0, sxy = 0, syy = 0;
+    for (int iy = -3; iy <= 3; iy++)
+        for (int ix = -3; ix <= 3; ix++) {
+            const uint8_t* q = c + iy * P + ix;
+            const int dx = ((int)q[-P + 1] + 2 * (int)q[1] + (int)q[P + 1]) - ((int)q[-P - 1] + 2 * (int)q[-1] + (int)q[P - 1]);
+            const int dy = ((int)q[P - 1] + 2 * (int)q[P] + (int)q[P + 1]) - ((int)q[-P - 1] + 2 * (int)q[-P] + (int)q[-P + 1]);
+            sxx += dx * dx; sxy += dx * dy; syy += dy * dy;
+        }
+    return harris_from_sums(sxx, sxy, syy);
+}
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+
+// Harris response of the 7x7 window around a corner (calcResponse, cuda_efficient_features.cu:99-139).
+// p0 = top-left byte of the 9x9 footprint, row pitch P bytes; both 4-byte aligned up to the offset sh.
+__device__ __forceinline__ float harris_rows(const uint8_t* p0, int P)
+{
+    // 9x9 footprint.  All intermediate sums fit 16 bits (|dx|, |dy| <= 1020), so the Sobel arithmetic runs on
+    // packed pairs of neighbouring columns (v_pk_add_u16 / v_pk_sub_i16) and the three moment sums are
+    // v_dot2_i32_i16 accumulations: exact integers, same values as the scalar form.
+    const unsigned sh = (unsigned)(reinterpret_cast<uintptr_t>(p0) & 3u);
+    const uint8_t* wb = p0 - sh;
+    // Row by row (rolling, to keep the live register set small): E[j] = columns (2j, 2j+1) for j < 4,
+    // E[4] = (8, 7); O[j] = columns (2j+1, 2j+2); H[j] = horizontal 1-2-1 sums at columns (2j+1, 2j+2);
+    // S = E(row-1) + E(row) vertical pair sums; V = S(r-1) + S(r) vertical 1-2-1 sums.
+    u16x2 Hm2[4], Hm1[4], Sm1[5], Em1[5];      // H(row-2), H(row-1), S(row-1), E(row-1)
+    int sxx = 0, sxy = 0, syy = 0;
+#pragma unroll
+    for (int row = 0; row < 9; row++) {
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(wb + (size_t)row * P);
+        const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+        const uint32_t a = __builtin_amdgcn_alignbyte(w1, w0, sh), b = __builtin_amdgcn_alignbyte(w2, w1, sh);
+        const uint32_t t = w2 >> (8 * sh);
+        u16x2 E[5], O[4], H[4], S[5];
+        E[0] = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(b, a, 0x0c010c00u));
+        E[1] = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(b, a, 0x0c030c02u));
+        E[2] = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(b, a, 0x0c050c04u));
+        E[3] = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(b, a, 0x0c070c06u));
+        E[4] = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(t, b, 0x0c030c04u));
+        O[0] = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(b, a, 0x0c020c01u));
+        O[1] = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(b, a, 0x0c040c03u));
+        O[2] = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(b, a, 0x0c060c05u));
+        O[3] = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(t, b, 0x0c040c03u));
+#pragma unroll
+        for (int j = 0; j < 4; j++) H[j] = (E[j] + E[j + 1]) + (O[j] + O[j]);
+        if (row >= 1) {
+#pragma unroll
+            for (int j = 0; j < 5; j++) S[j] = Em1[j] + E[j];
+        }
+        if (row >= 2) {
+            // output row r = row - 1: dx = V[ix+2] - V[ix] (the high half of the j == 3 pair is V7 - V7 = 0),
+            // dy = H(r+1) - H(r-1)
+            u16x2 V[5];
+#pragma unroll
+            for (int j = 0; j < 5; j++) V[j] = Sm1[j] + S[j];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const i16x2 dx = __builtin_bit_cast(i16x2, (u16x2)(V[j + 1] - V[j]));
+                uint32_t dyu = __builtin_bit_cast(uint32_t, (u16x2)(H[j] - Hm2[j]));
+                if (j == 3) dyu &= 0xffffu;                      // ix = 7 does not exist
+                const i16x2 dy = __builtin_bit_cast(i16x2, dyu);
+                sxx = __builtin_amdgcn_sdot2(dx, dx, sxx, false);
+                sxy = __builtin_amdgcn_sdot2(dx, dy, sxy, false);
+                syy = __builtin_amdgcn_sdot2(dy, dy, syy, false);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) { Hm2[j] = Hm1[j]; Hm1[j] = H[j]; }
+#pragma unroll
+        for (int j = 0; j < 5; j++) { Sm1[j] = S[j]; Em1[j] = E[j]; }
+    }
+    return harris_from_sums(sxx, sxy, syy);
+}
+
 
 __device__ __forceinline__ uint8_t sat_u8_rne(float v)
 {
@@ -227,6 +273,34 @@ __global__ __launch_bounds__(NT) void resize_kernel(
     }
 }
 
+// tile + halo -> LDS: 72 rows x 72 bytes as 9 x 8-byte pieces per row (the global address is only 4-byte
+// aligned: x0 - 4), LDS row pitch 80 B; pixels outside the image read as 0
+template <int NT>
+__device__ __forceinline__ void load_tile_lds(uint32_t* s_tile, const uint8_t* __restrict__ src, int spitch, int rows, int cols,
+                                              bool aligned, int x0, int y0, int tid)
+{
+    for (int i = tid; i < EFX_LT * 9; i += NT) {
+        const int r = i / 9, c8 = i - r * 9;
+        const int gy = y0 - EFX_HALO + r;
+        const int gx = x0 - EFX_HALO + c8 * 8;
+        uint2 v = make_uint2(0u, 0u);
+        if (gy >= 0 && gy < rows) {
+            const uint8_t* p = src + (size_t)gy * spitch;
+            if (aligned && gx >= 0 && gx + 8 <= cols) {
+                v = *reinterpret_cast<const uint2*>(p + gx);
+            } else {
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const int xa = gx + b, xb = gx + 4 + b;
+                    if (xa >= 0 && xa < cols) v.x |= (uint32_t)p[xa] << (8 * b);
+                    if (xb >= 0 && xb < cols) v.y |= (uint32_t)p[xb] << (8 * b);
+                }
+            }
+        }
+        *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(s_tile) + r * EFX_LP + c8 * 8) = v;
+    }
+}
+
 // level of a global tile index
 __device__ __forceinline__ int level_of_tile(const LevelTable* T, int gt)
 {
@@ -246,9 +320,8 @@ __device__ __forceinline__ int level_of_tile(const LevelTable* T, int gt)
 __global__ __launch_bounds__(256) void fast_kernel(
     const LevelTable* __restrict__ T, const uint8_t* __restrict__ img0, int pitch0, int aligned0,
     const uint8_t* __restrict__ pyramid, int threshold,
-    Corner* __restrict__ cand_all, Corner* __restrict__ cmax_all, TileHdr* __restrict__ hdr_all, Counters* __restrict__ cnt, int dbg)
+    Corner* __restrict__ cand_all, TileHdr* __restrict__ hdr_all, Counters* __restrict__ cnt, int dbg)
 {
-    __shared__ unsigned long long s_cellmax[EFX_CELLS_PER_TILE];
     __shared__ __attribute__((aligned(16))) uint32_t s_tile[EFX_LT * (EFX_LP / 4)];
     __shared__ unsigned long long s_bitmap[EFX_TILE];
     __shared__ uint16_t s_list[EFX_TILE * EFX_TILE];     // phase 1-2: per-wave quick-test survivors; phase 3+: corner list
@@ -276,27 +349,7 @@ __global__ __launch_bounds__(256) void fast_kernel(
     // ---- phase 0: tile + halo -> LDS.  72 rows x 72 bytes as 9 x 8-byte pieces per row (the global address is
     //      only 4-byte aligned: x0 - 4), LDS row pitch 80 B. ----
     if (tid < EFX_TILE) s_bitmap[tid] = 0ull;
-    if (tid < EFX_CELLS_PER_TILE) s_cellmax[tid] = 0ull;
-    for (int i = tid; i < EFX_LT * 9; i += 256) {
-        const int r = i / 9, c8 = i - r * 9;
-        const int gy = y0 - EFX_HALO + r;
-        const int gx = x0 - EFX_HALO + c8 * 8;
-        uint2 v = make_uint2(0u, 0u);
-        if (gy >= 0 && gy < rows) {
-            const uint8_t* p = src + (size_t)gy * spitch;
-            if (aligned && gx >= 0 && gx + 8 <= cols) {
-                v = *reinterpret_cast<const uint2*>(p + gx);
-            } else {
-#pragma unroll
-                for (int b = 0; b < 4; b++) {
-                    const int xa = gx + b, xb = gx + 4 + b;
-                    if (xa >= 0 && xa < cols) v.x |= (uint32_t)p[xa] << (8 * b);
-                    if (xb >= 0 && xb < cols) v.y |= (uint32_t)p[xb] << (8 * b);
-                }
-            }
-        }
-        *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(s_tile) + r * EFX_LP + c8 * 8) = v;
-    }
+    load_tile_lds<256>(s_tile, src, spitch, rows, cols, aligned, x0, y0, tid);
     __syncthreads();
     if (dbg & 1) return;
 
@@ -386,36 +439,64 @@ __global__ __launch_bounds__(256) void fast_kernel(
         if (tid == 0) s_start = total > 0 ? atomicAdd(&cnt->cand_total[l][tile & (EFX_NSUB - 1)].v, total) : 0;
         __syncthreads();
 
-        // ---- phase 4: Harris on the corners, append to the level's corner array ----
-        //      Most tiles hold fewer than 64 corners, i.e. one wave of work; wave w of every workgroup sits on
-        //      SIMD w, so the wave that takes the first 64 corners is rotated per tile (pseudo-randomly) to keep
-        //      the four SIMDs of a CU evenly loaded.
+        // ---- phase 4: append the corner coordinates to the level's corner array (responses: harris_kernel) ----
         const int start = s_start;
-        const int rtid = (tid + 64 * (int)(((uint32_t)gt * 0x9E3779B1u) >> 30)) & 255;
-        for (int k = rtid; k < total; k += 256) {
+        for (int k = tid; k < total; k += 256) {
             const int lx = s_list[k] & 0xff, ly = s_list[k] >> 8;
-            const float resp = (dbg & 4) ? 1.f : harris_lds<EFX_LP>(tb + (ly + EFX_HALO) * EFX_LP + lx + EFX_HALO);
-            Corner c;
-            c.xy = (uint32_t)(x0 + lx) | ((uint32_t)(y0 + ly) << 16);
-            c.resp = resp;
-            cand[(size_t)(tile & (EFX_NSUB - 1)) * L.cand_sub_cap + start + k] = c;
-            // strongest corner of the 16x16 cell (quick test of the NMS kernel): 64-bit max of (response key, xy)
-            atomicMax(&s_cellmax[(ly >> 4) * 4 + (lx >> 4)], (efx_select_key(0u, resp) & 0xffffffff00000000ull) | c.xy);
-        }
-        __syncthreads();
-        if (tid < EFX_CELLS_PER_TILE) {
-            const unsigned long long m = s_cellmax[tid];
-            Corner best; best.xy = 0xffffffffu; best.resp = -3.0e38f;
-            if (m != 0ull) {
-                uint32_t u = (uint32_t)(m >> 32);
-                u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;          // inverse of the order-preserving map
-                best.resp = __uint_as_float(u); best.xy = (uint32_t)m;
-            }
-            cmax_all[L.cmax_base + (size_t)(ty * 4 + (tid >> 2)) * (L.tiles_x * 4) + tx * 4 + (tid & 3)] = best;
+            cand[(size_t)(tile & (EFX_NSUB - 1)) * L.cand_sub_cap + start + k].xy = (uint32_t)(x0 + lx) | ((uint32_t)(y0 + ly) << 16);
         }
         TileHdr* h = hdr + tile;
         if (tid <= EFX_CELLS_PER_TILE) h->cell_off[tid] = (uint16_t)s_celloff[tid];
         if (tid == 32) { h->cand_start = (uint32_t)start; h->cand_rank = 0; h->surv_start = 0; h->surv_count = 0; h->out_off = 0; }
+    }
+}
+
+// ================================================================================================
+// Kernel A2: Harris responses.  One wave per tile; a lane takes one corner and gathers its 9x9 footprint
+// straight from the level image (L2 / Infinity Cache hits: fast_kernel has just read it) as one 12-byte load per
+// row -- measured faster than staging the tile in LDS again (117 vs 130 us per 8K frame).
+// Also leaves the strongest corner of every 16x16 cell (the quick test of the NMS kernel).
+// ================================================================================================
+__global__ __launch_bounds__(64) void harris_kernel(
+    const LevelTable* __restrict__ T, const uint8_t* __restrict__ img0, int pitch0, int aligned0,
+    const uint8_t* __restrict__ pyramid, Corner* __restrict__ cand_all, Corner* __restrict__ cmax_all,
+    const TileHdr* __restrict__ hdr_all, int dbg)
+{
+    __shared__ unsigned long long s_cellmax[EFX_CELLS_PER_TILE];
+    const int lane = threadIdx.x;
+    const int gt = T->total_tiles - 1 - xcd_chunked(blockIdx.x, T->total_tiles);      // densest tiles first
+    const int l = level_of_tile(T, gt);
+    const LevelDev& L = T->lv[l];
+    if (!L.active) return;
+    const int tile = gt - L.tile_base;
+    const uint8_t* src = l == 0 ? img0 : pyramid + L.img_off;
+    const int spitch = l == 0 ? pitch0 : L.pitch;
+    const bool aligned = l == 0 ? aligned0 != 0 : true;
+    const int tx = tile % L.tiles_x, ty = tile / L.tiles_x;
+    const TileHdr& h = hdr_all[L.tile_base + tile];
+    const int total = h.cell_off[EFX_CELLS_PER_TILE];
+    Corner* cand = cand_all + L.cand_base + (size_t)(tile & (EFX_NSUB - 1)) * L.cand_sub_cap + h.cand_start;
+    if (lane < EFX_CELLS_PER_TILE) s_cellmax[lane] = 0ull;
+    __syncthreads();
+    for (int k = lane; k < total; k += 64) {
+        const uint32_t xy = cand[k].xy;
+        const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
+        const uint8_t* c = src + (size_t)y * spitch + x;
+        const float resp = (dbg & 4) ? 1.f : (aligned ? harris_rows(c - 4 * spitch - 4, spitch) : harris_bytes(c, spitch));
+        cand[k].resp = resp;
+        // strongest corner of the 16x16 cell: 64-bit max of (response key, xy)
+        atomicMax(&s_cellmax[((y >> 4) & 3) * 4 + ((x >> 4) & 3)], (efx_select_key(0u, resp) & 0xffffffff00000000ull) | xy);
+    }
+    __syncthreads();
+    if (lane < EFX_CELLS_PER_TILE) {
+        const unsigned long long m = s_cellmax[lane];
+        Corner best; best.xy = 0xffffffffu; best.resp = -3.0e38f;
+        if (m != 0ull) {
+            uint32_t u = (uint32_t)(m >> 32);
+            u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;          // inverse of the order-preserving map
+            best.resp = __uint_as_float(u); best.xy = (uint32_t)m;
+        }
+        cmax_all[L.cmax_base + (size_t)(ty * 4 + (lane >> 2)) * (L.tiles_x * 4) + tx * 4 + (lane & 3)] = best;
     }
 }
 
@@ -929,8 +1010,10 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
         const bool prof = a.prof_count && *a.prof_count < a.prof_capacity;
         if (prof) (void)hipEventRecord(a.prof_start[*a.prof_count], stream);
         hipLaunchKernelGGL(fast_kernel, dim3(H.total_tiles), dim3(256), 0, stream, a.d_table, a.img0, a.pitch0, aligned0,
-                           a.pyramid, a.threshold, a.cand, a.cmax, a.hdr, a.counters, a.dbg & 15);
+                           a.pyramid, a.threshold, a.cand, a.hdr, a.counters, a.dbg & 15);
         if (prof) { (void)hipEventRecord(a.prof_stop[*a.prof_count], stream); a.prof_level[*a.prof_count] = 0; ++*a.prof_count; }
+        hipLaunchKernelGGL(harris_kernel, dim3(H.total_tiles), dim3(64), 0, stream, a.d_table, a.img0, a.pitch0, aligned0, a.pyramid,
+                           a.cand, a.cmax, a.hdr, a.dbg & 15);
     }
     hipLaunchKernelGGL(tile_rank_scan_kernel, dim3(H.nlevels), dim3(1024), 0, stream, a.d_table, a.hdr, a.counters);
     hipLaunchKernelGGL(nms_kernel, dim3(H.total_tiles), dim3(64), 0, stream, a.d_table, a.hdr, a.cand, a.cmax, a.surv,
