@@ -9,8 +9,8 @@ A "step" is one pass of the hot path over one batch of FRAMES_PER_STEP independe
 (seeds 1000+k, BASELINE.json configs[4]: 64 frames over 8 GPUs = 8 per GPU).  Frames shard across ranks with
 no data-path collective (weak scaling); RCCL is used only to reduce the timing / keypoint counters.
 
-Output: ONE JSON line on rank 0 (driver contract) with `roofline` (dominant kernel = FAST+Harris over all pyramid levels,
-HBM bound, timed live with HIP events on the launch stream) and `cpu_baseline` (the oracle timed on the
+Output: ONE JSON line on rank 0 (driver contract) with `roofline` (the kernel with the longest average launch among
+fast / harris / nms / bad, against the HBM roofline, timed live with HIP events on the launch stream) and `cpu_baseline` (the oracle timed on the
 host cores, rank 0, N=1 only, one 8K frame).
 """
 import argparse
@@ -91,9 +91,9 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    # HIP event pairs around the fast_kernel / resize launches of every F-th frame of the timed region (each pair
-    # costs a few microseconds of stream idle time, so not on every frame)
-    det.profileEnable(args.steps * 8 + 8, stride=F)
+    # HIP event pairs around the kernels of one frame per step on context 0 (each pair costs a few microseconds of
+    # stream idle time, so not on every frame)
+    det.profileEnable(args.steps * 12 + 12, stride=max(1, F // NS))
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -109,45 +109,67 @@ def main():
 
     if rank == 0:
         px, bytes_frame = detect_algorithmic_bytes(det, ROWS, COLS)
-        # dominant kernel: fast_kernel (FAST-9 + Harris over every tile of every pyramid level, ONE launch per
-        # frame).  Algorithmic bytes per launch = every level read once = sum_s P_s (3.096 B per input
-        # pixel); duration per launch = mean of the HIP-event pairs recorded in the timed region.  The pyramid
-        # chain (7 resize launches per frame, level read once + level written once) is reported next to it; the two
-        # together are the "pyramid+FAST pass" of SURVEY 8d ((2F-1) P = 5.19 B per input pixel).
-        fast_ms = ms[lvl == 0]
+        stats = dets[0].lastLevelStats()
+        n_corners = float(sum(s["n_candidates"] for s in stats))      # FAST corners of the last frame of context 0
+        n_kp = nkp / F
+        # Algorithmic HBM bytes per launch: what any implementation of the stage must move.
+        #   fast_kernel    every pyramid level read once (sum_s P_s = 3.096 B per input pixel) + 4 B per corner out
+        #   harris_kernel  9x9 footprints lie inside the levels (read once more) + 4 B in / 4 B out per corner
+        #   nms_kernel     8 B per corner in, 8 B per survivor out (per-cell maxima are cache traffic)
+        #   bad_kernel     the (blur-extended) windows lie inside the levels: sum_s P_s + 16 B in + 64 B out per keypoint
+        #                  (the reference design -- per-level blur + global integral images, SURVEY 8d -- moves
+        #                  2 F P + 5 sum P_s + gathers ~ 1.06 GB for the same stage; reported as survey_design_bytes)
+        sumP = float(sum(px))
+        kinfo = {0: ("fast_kernel", sumP + 4 * n_corners), 1: ("harris_kernel", sumP + 8 * n_corners),
+                 2: ("nms_kernel", 8 * n_corners + 8 * 60000.0), 10: ("bad_kernel<blur,52>", sumP + 80 * n_kp)}
+
+        def table(ms_, lvl_):
+            t = {}
+            for code, (name, nbytes) in kinfo.items():
+                m = ms_[lvl_ == code]
+                if len(m):
+                    avg = float(m.mean())
+                    t[name] = {"avg_launch_ms": round(avg, 5), "launches_timed": int(len(m)), "algorithmic_bytes": nbytes,
+                               "achieved": round(nbytes / (avg * 1e-3) / 1e9, 1), "frac": round(nbytes / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            return t
+
+        live = table(ms, lvl)
         chain_ms = ms[lvl >= 100]
-        nl = len(fast_ms)
-        fast_bytes = float(sum(px))
-        avg_ms = float(fast_ms.mean()) if nl else float("nan")
-        achieved = fast_bytes / (avg_ms * 1e-3) / 1e9 if nl else float("nan")
-        chain_per_frame_ms = float(chain_ms.sum()) / max(nl, 1)
-        pass_ms = avg_ms + chain_per_frame_ms
-        roof = {"bound": "hbm", "kernel": "fast_kernel (FAST-9 + Harris, all pyramid levels, one launch per frame)",
-                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                "algorithmic_bytes_per_launch": fast_bytes, "avg_launch_ms": round(avg_ms, 5),
-                "launches_timed": int(nl), "concurrent_streams": NS,
-                "pyramid_plus_fast_pass": {"algorithmic_bytes_per_frame": bytes_frame,
-                                           "resize_chain_ms_per_frame": round(chain_per_frame_ms, 5),
-                                           "ms_per_frame": round(pass_ms, 5),
-                                           "achieved": round(bytes_frame / (pass_ms * 1e-3) / 1e9, 1) if nl else None}}
+        nl = max(1, int((lvl == 0).sum()))
+        chain_per_frame_ms = float(chain_ms.sum()) / nl
+        dom = max(live, key=lambda k: live[k]["avg_launch_ms"]) if live else None
+        roof = {"bound": "hbm", "kernel": dom, "achieved": live[dom]["achieved"] if dom else None, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": live[dom]["frac"] if dom else None, "traffic": None,
+                "algorithmic_bytes_per_launch": live[dom]["algorithmic_bytes"] if dom else None,
+                "avg_launch_ms": live[dom]["avg_launch_ms"] if dom else None,
+                "launches_timed": live[dom]["launches_timed"] if dom else 0, "concurrent_streams": NS,
+                "note": "dominant kernel = longest average launch among the timed kernels; every kernel of this pipeline "
+                        "is VALU-issue bound on MI355X (DESIGN.md section 5), so the HBM fraction is small by construction",
+                "kernels_live": live,
+                "resize_chain_ms_per_frame": round(chain_per_frame_ms, 5),
+                "whole_frame": {"survey_8d_bytes_per_frame": 0.9e9, "ms_per_frame": round(t_max / args.steps / F * 1e3, 4),
+                                "achieved": round(0.9e9 / (t_max / args.steps / F) / 1e9, 1),
+                                "frac": round(0.9e9 / (t_max / args.steps / F) / 1e9 / HBM_PEAK_GBS, 4)}}
+        if dom and dom.startswith("bad"):
+            roof["survey_design_bytes"] = 2 * sumP + 5 * sumP + 338e6 + 80 * n_kp
         if NS > 1:
-            # the live events above see the kernel sharing the GPU with the other stream's kernels; for reference,
-            # the same kernel with nothing else running (4 frames on one stream, after the timed region)
-            det.profileEnable(64, stride=1)
+            # the live events above see each kernel sharing the GPU with the other stream's kernels; for reference,
+            # the same kernels with nothing else running (4 frames on one stream, after the timed region)
+            det.profileEnable(256, stride=1)
             for i in range(min(4, F)):
                 det.detectAndComputeAsync(frames[i], kps[i], desc[i], cnt[i], capacity=NFEATURES)
             torch.cuda.synchronize()
             ms2, lvl2 = det.profileRead()
-            iso = ms2[lvl2 == 0]
-            if len(iso):
-                roof["isolated"] = {"avg_launch_ms": round(float(iso.mean()), 5),
-                                    "achieved": round(fast_bytes / (float(iso.mean()) * 1e-3) / 1e9, 1),
-                                    "frac": round(fast_bytes / (float(iso.mean()) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            iso = table(ms2, lvl2)
+            roof["kernels_isolated"] = iso
+            if dom in iso:
+                roof["isolated"] = {k: iso[dom][k] for k in ("avg_launch_ms", "achieved", "frac")}
         tr_path = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tr_path):
             try:
-                roof["traffic"] = json.load(open(tr_path)).get("fast_kernel_bytes_per_launch")
+                pk = json.load(open(tr_path)).get("per_kernel", {})
+                hit = [v for k, v in pk.items() if k.split("<")[0] == (dom or "").split("<")[0]]
+                roof["traffic"] = hit[0]["bytes_per_launch"] if hit else None
             except Exception:
                 pass
 

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void bad_kernel(
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-    const int kid = blockIdx.x;
+    const int kid = xcd_chunked(blockIdx.x, gridDim.x);   // neighbouring keypoints on the same XCD: windows share L2 lines
     const int count = d_count ? min(*d_count, n) : n;
     if (kid >= count) return;
     const int tid = threadIdx.x;

@@ -47,15 +47,6 @@ __device__ __forceinline__ int block_excl_scan(int v, int* scratch, int* total)
     return r;
 }
 
-// XCD-aware block -> tile mapping: workgroup b runs on XCD b % 8 (observed dispatch order), so give every
-// XCD one contiguous run of tiles; neighbouring tiles then share halo lines in the same L2.
-__device__ __forceinline__ int xcd_chunked(int bid, int n)
-{
-    const int q = n / EFX_NXCD, r = n % EFX_NXCD;
-    const int xcd = bid % EFX_NXCD, idx = bid / EFX_NXCD;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-}
-
 // ------------------------------------------------------------------------------------------------
 // FAST-9 segment test on an LDS tile (cuda_fast.cu:33-222).  c points at the centre pixel, P = LDS pitch.
 // Circle order as cuda_fast.cu:179-207: k=0 at (0,+3) walking towards +x.
@@ -921,7 +912,8 @@ __global__ __launch_bounds__(256) void angle_kernel(const LevelTable* __restrict
                                                     uint8_t* __restrict__ kps, size_t kps_pitch)
 {
     const int lane = threadIdx.x & 63;
-    const int kid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // neighbouring keypoints (canonical order) on the same XCD: their patches share L2 lines
+    const int kid = xcd_chunked(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
     const int count = min(*d_count, capacity);
     if (kid >= count) return;
     const float4 kp = kp4[kid];
@@ -999,25 +991,28 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
         const int lpitch = (sw + 3) & ~3;
         const size_t lds = (size_t)lpitch * sh;
         if (lds > 64 * 1024) return hipErrorInvalidValue;
-        const bool prof = a.prof_count && *a.prof_count < a.prof_capacity;
-        if (prof) (void)hipEventRecord(a.prof_start[*a.prof_count], stream);
+        const bool prof = a.prof.begin(stream);
         hipLaunchKernelGGL((resize_kernel<256>), dim3(N.tiles_x * N.tiles_y), dim3(256), lds, stream, src, spitch, L.rows, L.cols, aligned,
                            a.pyramid + N.img_off, N.pitch, N.rows, N.cols, N.fx, N.fy, N.tiles_x, N.tiles_y, lpitch);
-        if (prof) { (void)hipEventRecord(a.prof_stop[*a.prof_count], stream); a.prof_level[*a.prof_count] = 100 + s; ++*a.prof_count; }
+        a.prof.end(prof, 100 + s, stream);
     }
     {
         const int aligned0 = (((uintptr_t)a.img0 | (uintptr_t)a.pitch0) & 3u) == 0;
-        const bool prof = a.prof_count && *a.prof_count < a.prof_capacity;
-        if (prof) (void)hipEventRecord(a.prof_start[*a.prof_count], stream);
+        bool prof = a.prof.begin(stream);
         hipLaunchKernelGGL(fast_kernel, dim3(H.total_tiles), dim3(256), 0, stream, a.d_table, a.img0, a.pitch0, aligned0,
                            a.pyramid, a.threshold, a.cand, a.hdr, a.counters, a.dbg & 15);
-        if (prof) { (void)hipEventRecord(a.prof_stop[*a.prof_count], stream); a.prof_level[*a.prof_count] = 0; ++*a.prof_count; }
+        a.prof.end(prof, 0, stream);
+        prof = a.prof.begin(stream);
         hipLaunchKernelGGL(harris_kernel, dim3(H.total_tiles), dim3(64), 0, stream, a.d_table, a.img0, a.pitch0, aligned0, a.pyramid,
                            a.cand, a.cmax, a.hdr, a.dbg & 15);
+        a.prof.end(prof, 1, stream);
     }
     hipLaunchKernelGGL(tile_rank_scan_kernel, dim3(H.nlevels), dim3(1024), 0, stream, a.d_table, a.hdr, a.counters);
+    bool prof = a.prof.begin(stream);
     hipLaunchKernelGGL(nms_kernel, dim3(H.total_tiles), dim3(64), 0, stream, a.d_table, a.hdr, a.cand, a.cmax, a.surv,
                        a.counters, a.nonmax_radius, a.dbg >> 4);
+    a.prof.end(prof, 2, stream);
+    prof = a.prof.begin(stream);
     hipLaunchKernelGGL(select_kernel, dim3(H.nlevels), dim3(1024), 0, stream, a.d_table, a.hdr, a.surv, a.counters,
                        a.capacity, a.d_count);
     hipLaunchKernelGGL(emit_kernel, dim3(H.total_tiles), dim3(64), 0, stream, a.d_table, a.hdr, a.surv, a.counters,
@@ -1030,6 +1025,7 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
             hipLaunchKernelGGL(angle_kernel, dim3((nmax + 3) / 4), dim3(256), 0, stream, a.d_table, a.d_count, a.capacity,
                                a.img0, a.pitch0, a.pyramid, a.kp4, a.kp_level, (uint8_t*)a.d_keypoints, a.kps_pitch);
     }
+    a.prof.end(prof, 3, stream);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (a.h_mirror) e = hipMemcpyAsync(a.h_mirror, &a.counters->sum, sizeof(Summary), hipMemcpyDeviceToHost, stream);

@@ -140,6 +140,8 @@ int describer_run(Describer& d, std::string& err, DescribeLaunch a, float* dbg_r
 {
     a.scale_factor = d.scale;
     if (a.n <= 0) return EFX_OK;
+    const bool prof = a.prof.begin(stream);
+    struct ProfEnd { const ProfRec& p; bool on; hipStream_t st; ~ProfEnd() { p.end(on, 10, st); } } prof_end{a.prof, prof, stream};
     if (d.kind == 0) {
         HIP_TRY(err, d.responses.reserve((size_t)a.n * 32));
         a.bad_affine = d.responses.p;
@@ -337,8 +339,8 @@ int detect_common(efx_context* c, const uint8_t* d_image, int rows, int cols, si
     a.kp_level = static_cast<int*>(c->kp_level.p);
     a.h_mirror = reinterpret_cast<int*>(c->h_mirror);
     if (!c->prof_start.empty() && (c->prof_calls++ % c->prof_stride) == 0) {
-        a.prof_start = c->prof_start.data(); a.prof_stop = c->prof_stop.data(); a.prof_level = c->prof_level.data();
-        a.prof_count = &c->prof_count; a.prof_capacity = (int)c->prof_start.size();
+        a.prof.start = c->prof_start.data(); a.prof.stop = c->prof_stop.data(); a.prof.code = c->prof_level.data();
+        a.prof.count = &c->prof_count; a.prof.capacity = (int)c->prof_start.size();
     }
     hipError_t e = efx_launch_detect(a, stream);
     if (e != hipSuccess) return set_err(c->err, EFX_ERR_HIP, "detect launch failed: %s", hipGetErrorString(e));
@@ -356,6 +358,7 @@ int detect_common(efx_context* c, const uint8_t* d_image, int rows, int cols, si
         dl.max_size = (float)EFX_PATCH_SIZE;
         dl.uniform_size = 1;
         dl.desc = d_desc; dl.desc_pitch = desc_pitch;
+        dl.prof = a.prof;
         rc = describer_run(c->desc, c->err, dl, nullptr, nullptr, stream);
         if (rc) return rc;
     }

@@ -117,6 +117,37 @@ __device__ __forceinline__ int efx_wave_incl_scan(int v)
 #endif
 
 // ---- launchers (host side, defined in the .hip files) ----
+#ifdef __HIPCC__
+// XCD-aware block -> tile mapping: workgroup b runs on XCD b % 8 (observed dispatch order), so give every
+// XCD one contiguous run of tiles; neighbouring tiles then share halo lines in the same L2.
+__device__ __forceinline__ int xcd_chunked(int bid, int n)
+{
+    const int q = n / EFX_NXCD, r = n % EFX_NXCD;
+    const int xcd = bid % EFX_NXCD, idx = bid / EFX_NXCD;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+#endif
+
+// Optional per-launch timing (efx_profile_*): one HIP-event pair around a launch, tagged with a code:
+// 0 fast_kernel, 1 harris_kernel, 2 nms_kernel, 3 select+emit+angle, 10 describe (BAD / HashSIFT), 100+s resize of level s+1
+struct ProfRec {
+    hipEvent_t* start; hipEvent_t* stop; int* code; int* count; int capacity;
+    bool begin(hipStream_t st) const
+    {
+        if (!count || *count >= capacity) return false;
+        (void)hipEventRecord(start[*count], st);
+        return true;
+    }
+    void end(bool on, int c, hipStream_t st) const
+    {
+        if (!on) return;
+        (void)hipEventRecord(stop[*count], st);
+        code[*count] = c;
+        ++*count;
+    }
+};
+
 struct DetectLaunch {
     const uint8_t* img0;        // level 0 (caller's image)
     int pitch0;
@@ -137,7 +168,7 @@ struct DetectLaunch {
     float4* kp4; int* kp_level;
     int* h_mirror;              // pinned host mirror of Counters (may be null)
     // optional per-launch timing of the pyramid+FAST kernel (bench roofline): event pairs + their level
-    hipEvent_t* prof_start; hipEvent_t* prof_stop; int* prof_level; int* prof_count; int prof_capacity;
+    ProfRec prof;                                          // optional HIP-event pairs around the launches
 };
 
 hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream);
@@ -154,6 +185,7 @@ struct DescribeLaunch {
     int uniform_size;                                      // 1: every keypoint has size == max_size (detector output)
     uint8_t* desc; size_t desc_pitch;
     void* bad_affine;                                      // BAD scratch: n x 32 bytes (per-keypoint affine map)
+    ProfRec prof;
 };
 
 hipError_t efx_launch_bad(const DescribeLaunch& a, const BadParamsDev* d_params, float reach, hipStream_t stream);

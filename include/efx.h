@@ -217,11 +217,12 @@ int efx_match_crosscheck_async(efx_matcher* m, const uint8_t* d_query, size_t q_
 /* ------------------------------------------------------------------------------------------------ */
 /* introspection used by the parity tests (no reference equivalent)                                  */
 
-/* Per-launch timing of the dominant kernel (pyramid + FAST + Harris, one launch per level) with HIP events on
- * the caller's stream: efx_profile_enable allocates `max_launches` event pairs (0 disables); every following
- * detect call records one pair per level launch until the pairs are used up.  efx_profile_read (after the
- * stream was synchronised) returns the elapsed milliseconds and the pyramid level of each recorded launch and
- * rewinds the recorder. */
+/* Per-launch timing of the pipeline's kernels with HIP events on the caller's stream: efx_profile_enable
+ * allocates `max_launches` event pairs (0 disables); every following detect / detectAndCompute call records one
+ * pair per timed launch until the pairs are used up.  efx_profile_read (after the stream was synchronised)
+ * returns the elapsed milliseconds and a code for each recorded launch and rewinds the recorder.  Codes:
+ * 0 fast_kernel, 1 harris_kernel, 2 nms_kernel, 3 select + emit + angle kernels, 10 describe stage (BAD or
+ * HashSIFT kernels), 100+s resize of pyramid level s+1. */
 int efx_profile_enable(efx_context* ctx, int max_launches);
 /* Record events only on every `stride`-th detect call (an event pair costs a few microseconds of stream idle time). */
 int efx_profile_set_stride(efx_context* ctx, int stride);
