@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void fast_kernel(
 
     const int tid = threadIdx.x;
     // heaviest tiles first: the upper pyramid levels have the densest corners, so they must not form the tail
-    const int gt = T->total_tiles - 1 - xcd_chunked(blockIdx.x, T->total_tiles);
+    const int gt = T->total_tiles - 1 - xcd_interleaved(blockIdx.x, T->total_tiles);
     const int l = level_of_tile(T, gt);
     const LevelDev& L = T->lv[l];
     if (!L.active) return;
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(64) void harris_kernel(
 {
     __shared__ unsigned long long s_cellmax[EFX_CELLS_PER_TILE];
     const int lane = threadIdx.x;
-    const int gt = T->total_tiles - 1 - xcd_chunked(blockIdx.x, T->total_tiles);      // densest tiles first
+    const int gt = T->total_tiles - 1 - xcd_interleaved(blockIdx.x, T->total_tiles);      // densest tiles first
     const int l = level_of_tile(T, gt);
     const LevelDev& L = T->lv[l];
     if (!L.active) return;
@@ -535,7 +535,7 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
     __shared__ uint8_t s_hsrc[64];
     __shared__ uint8_t s_hkeep[64];
 
-    const int gt = T->total_tiles - 1 - blockIdx.x;      // densest (upper-level) tiles first
+    const int gt = T->total_tiles - 1 - xcd_interleaved(blockIdx.x, T->total_tiles);      // densest (upper-level) tiles first
     const int l = level_of_tile(T, gt);
     const LevelDev& L = T->lv[l];
     if (!L.active) return;

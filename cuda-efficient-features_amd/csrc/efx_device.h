@@ -127,6 +127,18 @@ __device__ __forceinline__ int xcd_chunked(int bid, int n)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+
+// The same idea for work whose cost varies along the index (tiles ordered densest level first): runs of
+// EFX_XCD_RUN consecutive items go round-robin over the XCDs, so every XCD sees the same mix of levels while
+// neighbouring tiles still share an L2.
+#define EFX_XCD_RUN 32
+__device__ __forceinline__ int xcd_interleaved(int bid, int n)
+{
+    const int S = EFX_NXCD * EFX_XCD_RUN;
+    if (bid >= (n / S) * S) return bid;
+    const int xcd = bid % EFX_NXCD, i = bid / EFX_NXCD;
+    return ((i / EFX_XCD_RUN) * EFX_NXCD + xcd) * EFX_XCD_RUN + (i % EFX_XCD_RUN);
+}
 #endif
 
 // Optional per-launch timing (efx_profile_*): one HIP-event pair around a launch, tagged with a code:
