@@ -520,20 +520,25 @@ __global__ __launch_bounds__(1024) void tile_rank_scan_kernel(const LevelTable* 
 // ================================================================================================
 // Kernel C: radius non-max suppression (radiusSuppressionKernel + IsMaxPoint, .cu:62-97, 202-216).
 // The work is latency bound (a few dozen corners per tile, dependent look-ups), so it is laid out for
-// maximum waves in flight: ONE WAVE per 64x64 tile, no barriers, 1.5 KB of LDS.
+// maximum waves in flight and short dependency chains: ONE WAVE per 64x64 tile, ~3 KB of LDS.
+//   prologue the headers of the 3x3 neighbouring tiles go to LDS (every later list look-up reads them there);
 //   phase A  one lane per corner: quick test against the strongest corner of each neighbouring cell (the
-//            per-cell maxima are written by fast_kernel); this suppresses most corners with 9 loads;
-//   phase B  the corners that pass are scanned exactly: 16 lanes per corner walk the corner lists of the
-//            (2*blockRadius+1)^2 neighbouring cells together (IsMaxPoint);
+//            per-cell maxima are written by harris_kernel); this suppresses ~95 % of the corners with 9 loads;
+//            the corners that pass ("hard") are collected in an LDS list across rounds;
+//   phase B  the hard corners are scanned exactly, 8 lanes per corner, 8 corners at a time: the lanes walk the
+//            corner lists of those neighbouring cells whose strongest corner is not weaker (IsMaxPoint);
 //   survivors are compacted by ballot in canonical order and appended to the level's survivor array.
 // ================================================================================================
+#define NMS_HCAP 256
+
 __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ T, TileHdr* __restrict__ hdr,
                                                  const Corner* __restrict__ cand_all, const Corner* __restrict__ cmax_all,
                                                  Corner* __restrict__ surv_all, Counters* __restrict__ cnt, int radius, int dbg)
 {
-    __shared__ Corner s_hme[64];
-    __shared__ uint8_t s_hsrc[64];
-    __shared__ uint8_t s_hkeep[64];
+    __shared__ Corner s_hme[NMS_HCAP];
+    __shared__ uint16_t s_hidx[NMS_HCAP];
+    __shared__ unsigned long long s_keep[64];            // survivor bits of round r (64 rounds = 4096 corners = a full tile)
+    __shared__ __attribute__((aligned(64))) uint32_t s_nb[9][16];   // TileHdr of the 3x3 neighbouring tiles
 
     const int gt = T->total_tiles - 1 - xcd_interleaved(blockIdx.x, T->total_tiles);      // densest (upper-level) tiles first
     const int l = level_of_tile(T, gt);
@@ -541,13 +546,32 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
     if (!L.active) return;
     const int tile = gt - L.tile_base;
     TileHdr* hl = hdr + L.tile_base;
-    const TileHdr& h = hl[tile];
     const Corner* cand = cand_all + L.cand_base;
-    const Corner* own = cand + (size_t)(tile & (EFX_NSUB - 1)) * L.cand_sub_cap + h.cand_start;
     const int lane = threadIdx.x;
+    const int tx = tile % L.tiles_x, ty = tile / L.tiles_x;
 
-    // the per-cell maxima include corners beyond the cap; when the cap is active (pathological frames) the
-    // quick test is skipped and every corner takes the exact scan
+    s_keep[lane] = 0ull;
+    for (int i = lane; i < 9 * 16; i += 64) {
+        const int t = i >> 4, w = i & 15;
+        const int ntx = tx - 1 + (t % 3), nty = ty - 1 + (t / 3);
+        uint32_t v = 0u;
+        if (ntx >= 0 && ntx < L.tiles_x && nty >= 0 && nty < L.tiles_y)
+            v = reinterpret_cast<const uint32_t*>(&hl[nty * L.tiles_x + ntx])[w];
+        s_nb[t][w] = v;
+    }
+    __syncthreads();
+    // header of the tile that holds cell (bx, by): the LDS copy when it is a neighbour (always, up to radius 64)
+    auto nhdr = [&](int bx, int by) -> const TileHdr* {
+        const int ntx = bx >> 2, nty = by >> 2;
+        const int dx = ntx - tx, dy = nty - ty;
+        if (dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1) return reinterpret_cast<const TileHdr*>(&s_nb[(dy + 1) * 3 + dx + 1][0]);
+        return &hl[nty * L.tiles_x + ntx];
+    };
+    const TileHdr& h = *reinterpret_cast<const TileHdr*>(&s_nb[4][0]);
+    const Corner* own = cand + (size_t)(tile & (EFX_NSUB - 1)) * L.cand_sub_cap + h.cand_start;
+
+    // the per-cell maxima include corners beyond the cap; when the cap is active (pathological frames) a cell
+    // maximum is a valid suppressor only if its whole tile lies below the cap
     int lvl_total = 0;
     for (int sub = 0; sub < EFX_NSUB; sub++) lvl_total += cnt->cand_total[l][sub].v;
     const bool capped = lvl_total > L.cap;              // only then the canonical ranks were computed
@@ -562,32 +586,87 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
     const int gwp = L.tiles_x * 4;                      // row pitch of the per-cell maxima table
     const Corner* cmax = cmax_all + L.cmax_base;
     const bool quick_ok = block_radius <= 2;
-    // under an active cap a cell maximum is a valid suppressor only if its whole tile lies below the cap
     auto usable = [&](int bx, int by) -> bool {
         if (!capped) return true;
-        const TileHdr& nh = hl[(by >> 2) * L.tiles_x + (bx >> 2)];
-        return (int)nh.cand_rank + (int)nh.cell_off[EFX_CELLS_PER_TILE] <= L.cap;
+        const TileHdr* nh = nhdr(bx, by);
+        return (int)nh->cand_rank + (int)nh->cell_off[EFX_CELLS_PER_TILE] <= L.cap;
     };
     const int span = 2 * block_radius + 1;
+    const int ncell = span * span;
+    const int grp = lane >> 3, sub = lane & 7;
 
-    int nsurv = 0;
-    // survivors are written after the count is known: remember the flags of up to 64 rounds (4096 corners)
-    unsigned long long keepbits[1] = { 0ull };
-    (void)keepbits;
-    // first pass: flags per round kept in LDS-free form: one 64-bit ballot per round, stored by lane `round`
-    unsigned long long my_round_mask = 0ull;            // lane r holds the survivor ballot of round r
-    int round = 0;
-    for (int k0 = 0; k0 < n_valid; k0 += 64, round++) {
+    // phase B over the hard corners collected so far
+    auto scan_hard = [&](int nh) {
+        for (int h0 = 0; h0 < nh; h0 += 8) {
+            const int hi = h0 + grp;
+            const bool act = hi < nh;
+            Corner m; m.xy = 0; m.resp = 0.f;
+            if (act) m = s_hme[hi];
+            const int mx = m.xy & 0xffff, my = m.xy >> 16;
+            const int bx1 = mx / EFX_CELL, by1 = my / EFX_CELL;
+            const int cx0 = max(bx1 - block_radius, 0), cx1 = min(bx1 + block_radius, gw - 1);
+            const int cy0 = max(by1 - block_radius, 0), cy1 = min(by1 + block_radius, gh - 1);
+            bool kill = false;
+            // cells of the neighbourhood in chunks of 16: lane `sub` fetches the list ranges of cells c0+sub and
+            // c0+8+sub, then the 8 lanes walk every list that is left together
+            for (int c0 = 0; c0 < ncell; c0 += 16) {
+                int lb[2] = { 0, 0 }, le[2] = { 0, 0 }; unsigned lbase[2] = { 0u, 0u };
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const int ci = c0 + 8 * q + sub;
+                    const int oy = ci / span, ox = ci - oy * span;
+                    const int bx = bx1 - block_radius + ox, by = by1 - block_radius + oy;
+                    if (act && ci < ncell && bx >= cx0 && bx <= cx1 && by >= cy0 && by <= cy1) {
+                        const TileHdr* nh2 = nhdr(bx, by);
+                        const int nt = (by >> 2) * L.tiles_x + (bx >> 2);
+                        const int c = (by & 3) * 4 + (bx & 3);
+                        const int nn = capped ? L.cap - (int)nh2->cand_rank : 65536;
+                        lb[q] = nh2->cell_off[c];
+                        le[q] = nh2->cell_off[c + 1];
+                        if (le[q] > nn) le[q] = nn;
+                        lbase[q] = (unsigned)(nt & (EFX_NSUB - 1)) * L.cand_sub_cap + nh2->cand_start;
+                        // a cell whose strongest corner is weaker than this corner cannot suppress it: skip the cell
+                        if (quick_ok && le[q] > lb[q] && cmax[by * gwp + bx].resp < m.resp) le[q] = lb[q];
+                    }
+                }
+                // bit i of gneed <-> cell c0+i still has a list to walk (group-uniform)
+                unsigned gneed = ((unsigned)(__ballot(le[0] > lb[0]) >> (grp * 8)) & 0xffu) |
+                                 (((unsigned)(__ballot(le[1] > lb[1]) >> (grp * 8)) & 0xffu) << 8);
+                while (__ballot(gneed != 0u) != 0ull) {
+                    const int i = gneed ? __ffs(gneed) - 1 : 0;
+                    const int src = (lane & 56) + (i & 7);
+                    const int b0 = __shfl(lb[0], src, 64), b1 = __shfl(lb[1], src, 64);
+                    const int e0 = __shfl(le[0], src, 64), e1 = __shfl(le[1], src, 64);
+                    const unsigned a0 = (unsigned)__shfl((int)lbase[0], src, 64), a1 = (unsigned)__shfl((int)lbase[1], src, 64);
+                    const int nb = i < 8 ? b0 : b1, ne = i < 8 ? e0 : e1;
+                    const unsigned nbase = i < 8 ? a0 : a1;
+                    if (gneed) {
+                        for (int j = nb + sub; j < ne; j += 8) {
+                            const Corner o = cand[(size_t)nbase + j];
+                            const int dx = mx - (int)(o.xy & 0xffff), dy = my - (int)(o.xy >> 16);
+                            kill |= (o.xy != m.xy && m.resp <= o.resp && dx * dx + dy * dy < image_radius);
+                        }
+                    }
+                    gneed &= gneed - 1u;
+                }
+            }
+            const unsigned gk = (unsigned)(__ballot(kill) >> (grp * 8)) & 0xffu;
+            if (act && sub == 0 && gk == 0u) {
+                const int idx = s_hidx[hi];
+                atomicOr(&s_keep[idx >> 6], 1ull << (idx & 63));
+            }
+        }
+    };
+
+    int nh = 0;
+    for (int k0 = 0; k0 < n_valid; k0 += 64) {
         const int k = k0 + lane;
         bool hard = false;
         Corner me; me.xy = 0; me.resp = 0.f;
-        int minx = 0, maxx = -1, miny = 0, maxy = -1;
         if (k < n_valid) {
             me = own[k];
             const int mx = me.xy & 0xffff, my = me.xy >> 16;
             const int bx1 = mx / EFX_CELL, by1 = my / EFX_CELL;
-            minx = max(bx1 - block_radius, 0); maxx = min(bx1 + block_radius, gw - 1);
-            miny = max(by1 - block_radius, 0); maxy = min(by1 + block_radius, gh - 1);
             hard = true;
             if (quick_ok) {
                 if (block_radius == 1) {
@@ -605,6 +684,8 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
                             usable(min(max(bx1 - 1 + (q % 3), 0), gw - 1), min(max(by1 - 1 + (q / 3), 0), gh - 1))) hard = false;
                     }
                 } else {
+                    const int minx = max(bx1 - block_radius, 0), maxx = min(bx1 + block_radius, gw - 1);
+                    const int miny = max(by1 - block_radius, 0), maxy = min(by1 + block_radius, gh - 1);
                     for (int by = miny; by <= maxy; by++)
                         for (int bx = minx; bx <= maxx; bx++) {
                             const Corner o = cmax[by * gwp + bx];
@@ -615,92 +696,30 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
             }
         }
         const unsigned long long hm = __ballot(hard);
-        const int nhard = __popcll(hm);
         if (hard) {
-            const int pos = __popcll(hm & ((1ull << lane) - 1ull));
+            const int pos = nh + __popcll(hm & ((1ull << lane) - 1ull));
             s_hme[pos] = me;
-            s_hsrc[pos] = (uint8_t)lane;
+            s_hidx[pos] = (uint16_t)k;
         }
-        s_hkeep[lane] = 0;
-        __builtin_amdgcn_wave_barrier();
-        // phase B: 16 lanes per hard corner
-        const int grp = lane >> 4, sub = lane & 15;
-        if (dbg == 6 && lane == 0) atomicAdd(&cnt->sum.dbg, nhard);
-        for (int h0 = 0; h0 < (dbg == 2 ? 0 : nhard); h0 += 4) {
-            const int hi = h0 + grp;
-            const bool act = hi < nhard;
-            Corner m; m.xy = 0; m.resp = 0.f;
-            if (act) m = s_hme[hi];
-            const int mx = m.xy & 0xffff, my = m.xy >> 16;
-            const int bx1 = mx / EFX_CELL, by1 = my / EFX_CELL;
-            const int cx0 = max(bx1 - block_radius, 0), cx1 = min(bx1 + block_radius, gw - 1);
-            const int cy0 = max(by1 - block_radius, 0), cy1 = min(by1 + block_radius, gh - 1);
-            bool kill = false;
-            // cells of the neighbourhood in chunks of 16: lane `sub` fetches the list range of cell c0+sub,
-            // then the 16 lanes walk every list together
-            for (int c0 = 0; c0 < span * span; c0 += 16) {
-                const int ci = c0 + sub;
-                const int oy = ci / span, ox = ci - oy * span;
-                const int bx = bx1 - block_radius + ox, by = by1 - block_radius + oy;
-                int lb = 0, le = 0; unsigned lbase = 0;
-                if (act && ci < span * span && bx >= cx0 && bx <= cx1 && by >= cy0 && by <= cy1) {
-                    const int nt = (by >> 2) * L.tiles_x + (bx >> 2);
-                    const TileHdr& nh = hl[nt];
-                    const int c = (by & 3) * 4 + (bx & 3);
-                    const int nn = capped ? L.cap - (int)nh.cand_rank : 65536;
-                    lb = nh.cell_off[c];
-                    le = nh.cell_off[c + 1];
-                    if (le > nn) le = nn;
-                    lbase = (unsigned)(nt & (EFX_NSUB - 1)) * L.cand_sub_cap + nh.cand_start;
-                    // a cell whose strongest corner is weaker than this corner cannot suppress it: skip the cell
-                    if (quick_ok && cmax[by * gwp + bx].resp < m.resp) le = lb;
-                }
-                // first 16 entries of every cell: all loads in flight before the first compare
-                Corner e[16]; bool ev[16]; int nb[16], ne[16]; unsigned nbase[16];
-#pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    const int src = (lane & 48) + i;
-                    nb[i] = __shfl(lb, src, 64); ne[i] = __shfl(le, src, 64);
-                    nbase[i] = (unsigned)__shfl((int)lbase, src, 64);
-                    ev[i] = nb[i] + sub < ne[i];
-                    e[i].xy = m.xy; e[i].resp = 0.f;
-                    if (ev[i]) e[i] = cand[(size_t)nbase[i] + nb[i] + sub];
-                }
-#pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    const int dx = mx - (int)(e[i].xy & 0xffff), dy = my - (int)(e[i].xy >> 16);
-                    kill |= (ev[i] && e[i].xy != m.xy && m.resp <= e[i].resp && dx * dx + dy * dy < image_radius);
-                }
-                // cells with more than 16 corners (dense regions)
-#pragma unroll 1
-                for (int i = 0; i < 16; i++) {
-                    for (int j = nb[i] + sub + 16; j < ne[i]; j += 16) {
-                        const Corner o = cand[(size_t)nbase[i] + j];
-                        const int dx = mx - (int)(o.xy & 0xffff), dy = my - (int)(o.xy >> 16);
-                        kill |= (o.xy != m.xy && m.resp <= o.resp && dx * dx + dy * dy < image_radius);
-                    }
-                }
-            }
-            const unsigned long long km = __ballot(kill);
-            const unsigned gk = (unsigned)(km >> (grp * 16)) & 0xffffu;
-            if (act && sub == 0) s_hkeep[s_hsrc[hi]] = gk == 0 ? 1 : 0;
+        nh += __popcll(hm);
+        if (nh > NMS_HCAP - 64 || k0 + 64 >= n_valid) {
+            __syncthreads();
+            if (dbg != 2) scan_hard(nh);
+            nh = 0;
+            __syncthreads();
         }
-        __builtin_amdgcn_wave_barrier();
-        const bool keep = s_hkeep[lane] != 0;
-        const unsigned long long km2 = __ballot(keep);
-        if (lane == round) my_round_mask = km2;
-        nsurv += __popcll(km2);
-        __builtin_amdgcn_wave_barrier();
     }
     if (dbg == 3) return;
+    // lane r holds the survivor ballot of round r
+    const unsigned long long my_round_mask = s_keep[lane];
+    const int nsurv = __shfl(wave_incl_scan(__popcll(my_round_mask)), 63, 64);
     int start = 0;
-    if (lane == 0 && nsurv > 0 && dbg != 4) start = atomicAdd(&cnt->surv_total[l][tile & (EFX_NSUB - 1)].v, nsurv);
+    if (lane == 0 && nsurv > 0) start = atomicAdd(&cnt->surv_total[l][tile & (EFX_NSUB - 1)].v, nsurv);
     start = __shfl(start, 0, 64);
     // second pass: write the survivors in canonical order
     Corner* surv = surv_all + L.surv_base + (size_t)(tile & (EFX_NSUB - 1)) * L.surv_sub_cap;
-    int base = 0;
-    round = 0;
-    for (int k0 = 0; k0 < n_valid && dbg != 5; k0 += 64, round++) {
+    int base = 0, round = 0;
+    for (int k0 = 0; k0 < n_valid; k0 += 64, round++) {
         const unsigned long long m = (unsigned long long)(unsigned)__shfl((int)(my_round_mask & 0xffffffffu), round, 64) |
                                      ((unsigned long long)(unsigned)__shfl((int)(my_round_mask >> 32), round, 64) << 32);
         if ((m >> lane) & 1ull) surv[(size_t)start + base + __popcll(m & ((1ull << lane) - 1ull))] = own[k0 + lane];

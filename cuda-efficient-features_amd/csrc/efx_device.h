@@ -131,7 +131,9 @@ __device__ __forceinline__ int xcd_chunked(int bid, int n)
 // The same idea for work whose cost varies along the index (tiles ordered densest level first): runs of
 // EFX_XCD_RUN consecutive items go round-robin over the XCDs, so every XCD sees the same mix of levels while
 // neighbouring tiles still share an L2.
+#ifndef EFX_XCD_RUN
 #define EFX_XCD_RUN 32
+#endif
 __device__ __forceinline__ int xcd_interleaved(int bid, int n)
 {
     const int S = EFX_NXCD * EFX_XCD_RUN;
