@@ -40,6 +40,8 @@ ABI_SYMBOLS = [
     "efx_describer_compute", "efx_describer_hashsift_debug_async",
     "efx_matcher_create", "efx_matcher_destroy", "efx_matcher_last_error", "efx_match_knn2_async",
     "efx_match_crosscheck_async",
+    "efx_cvt_gray_async", "efx_host_alloc", "efx_host_free", "efx_uploader_create", "efx_uploader_destroy",
+    "efx_uploader_last_error", "efx_upload_gray_async", "efx_describer_compute_color",
     "efx_profile_enable", "efx_profile_set_stride", "efx_profile_read",
     "efx_level_geometry", "efx_copy_level_async",
 ]
@@ -128,6 +130,17 @@ def lib():
         for name in ("efx_match_knn2_async", "efx_match_crosscheck_async"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int,
                                          C.c_void_p, C.c_void_p, C.c_void_p]
+        L.efx_cvt_gray_async.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.efx_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+        L.efx_host_free.argtypes = [C.c_void_p]
+        L.efx_uploader_create.argtypes = [C.POINTER(C.c_void_p)]
+        L.efx_uploader_destroy.argtypes = [C.c_void_p]
+        L.efx_uploader_last_error.restype = C.c_char_p
+        L.efx_uploader_last_error.argtypes = [C.c_void_p]
+        L.efx_upload_gray_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int,
+                                            C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_void_p]
+        L.efx_describer_compute_color.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_void_p,
+                                                  C.c_int, C.c_void_p, C.c_size_t]
         L.efx_profile_enable.argtypes = [C.c_void_p, C.c_int]
         L.efx_profile_set_stride.argtypes = [C.c_void_p, C.c_int]
         L.efx_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]
@@ -364,8 +377,12 @@ class _Describer:
     def defaultNorm(self): return 6
 
     def compute(self, image, keypoints):
-        """image: host uint8; keypoints: KEYPOINT_DTYPE records or (n,4) float32 {x,y,size,angle}."""
-        img = _host_image(image)
+        """image: host uint8, H x W (8UC1), H x W x 3 (BGR) or H x W x 4 (BGRA) as the CPU describers accept
+        (bad.cpp:268-281); keypoints: KEYPOINT_DTYPE records or (n,4) float32 {x,y,size,angle}."""
+        img = np.ascontiguousarray(image)
+        if img.dtype != np.uint8 or not (img.ndim == 2 or (img.ndim == 3 and img.shape[2] in (1, 3, 4))):
+            raise EfxError(-1, "Image should be 8UC1, 8UC3 or 8UC4")
+        channels = 1 if img.ndim == 2 else img.shape[2]
         kps = np.asarray(keypoints)
         if kps.dtype != KEYPOINT_DTYPE:
             k4 = np.ascontiguousarray(kps, dtype=np.float32).reshape(-1, 4)
@@ -373,8 +390,8 @@ class _Describer:
             kps["x"], kps["y"], kps["size"], kps["angle"] = k4[:, 0], k4[:, 1], k4[:, 2], k4[:, 3]
         kps = np.ascontiguousarray(kps)
         desc = np.zeros((max(len(kps), 1), self.descriptorSize()), dtype=np.uint8)
-        self._check(lib().efx_describer_compute(self._h, img.ctypes.data, img.shape[0], img.shape[1], img.strides[0],
-                                                kps.ctypes.data, len(kps), desc.ctypes.data, desc.strides[0]))
+        self._check(lib().efx_describer_compute_color(self._h, img.ctypes.data, img.shape[0], img.shape[1], img.strides[0], channels,
+                                                      kps.ctypes.data, len(kps), desc.ctypes.data, desc.strides[0]))
         return desc[:len(kps)]
 
     def computeAsync(self, image, keypoints, n=None, descriptors=None, max_size=0.0, stream=None):
@@ -429,6 +446,78 @@ class HashSIFT(_Describer):
             self._h, image.data_ptr(), image.shape[0], image.shape[1], image.stride(0), k.data_ptr(), n,
             C.c_float(max_size), resp.data_ptr(), T.data_ptr(), _stream_ptr(stream)))
         return resp[:n], T[:n]
+
+
+
+def cvtGray(image, out=None, stream=None):
+    """cv::cvtColor(BGR2GRAY / BGRA2GRAY) on the device: H x W x 3|4 uint8 CUDA tensor -> H x W uint8 CUDA tensor."""
+    import torch
+    if not (isinstance(image, torch.Tensor) and image.is_cuda and image.dtype == torch.uint8 and image.dim() == 3
+            and image.shape[2] in (3, 4) and image.stride(2) == 1 and image.stride(1) == image.shape[2]):
+        raise EfxError(-1, "Image should be 8UC3 or 8UC4 (H x W x C uint8 CUDA tensor, packed pixels)")
+    rows, cols, ch = image.shape
+    if out is None:
+        out = torch.empty((rows, cols), dtype=torch.uint8, device=image.device)
+    rc = lib().efx_cvt_gray_async(image.data_ptr(), rows, cols, image.stride(0), ch, out.data_ptr(), out.stride(0), _stream_ptr(stream))
+    if rc != EFX_OK:
+        raise EfxError(rc, lib().efx_last_error(None).decode())
+    return out
+
+
+def host_alloc(shape):
+    """uint8 numpy array in page-locked host memory (cv::cuda::HostMem); keep the returned array alive while in use."""
+    nbytes = int(np.prod(shape))
+    p = C.c_void_p()
+    rc = lib().efx_host_alloc(nbytes, C.byref(p))
+    if rc != EFX_OK:
+        raise EfxError(rc, lib().efx_last_error(None).decode())
+    buf = (C.c_uint8 * nbytes).from_address(p.value)
+    arr = np.frombuffer(buf, dtype=np.uint8).reshape(shape)
+    _PINNED[arr.__array_interface__["data"][0]] = p
+    return arr
+
+
+def host_free(arr):
+    p = _PINNED.pop(arr.__array_interface__["data"][0], None)
+    if p is not None:
+        lib().efx_host_free(p)
+
+
+_PINNED = {}
+
+
+class Uploader:
+    """Double-buffered host -> device input stage (getInputMat upload, cuda_efficient_features.cpp:71-84)."""
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        rc = lib().efx_uploader_create(C.byref(self._h))
+        if rc != EFX_OK:
+            self._h = C.c_void_p()
+            raise EfxError(rc, lib().efx_uploader_last_error(None).decode())
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                lib().efx_uploader_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    def upload(self, image, stream=None):
+        """host uint8 H x W [x 3|4] -> (device pointer, pitch, rows, cols) of the gray frame, ordered on `stream`."""
+        img = image
+        if img.dtype != np.uint8 or not (img.ndim == 2 or (img.ndim == 3 and img.shape[2] in (3, 4))) or img.strides[-1] != 1:
+            raise EfxError(-1, "Image should be 8UC1, 8UC3 or 8UC4")
+        ch = 1 if img.ndim == 2 else img.shape[2]
+        if img.ndim == 3 and img.strides[1] != ch:
+            raise EfxError(-1, "pixels must be packed")
+        d = C.c_void_p(); pitch = C.c_size_t()
+        rc = lib().efx_upload_gray_async(self._h, img.ctypes.data, img.shape[0], img.shape[1], img.strides[0], ch,
+                                         C.byref(d), C.byref(pitch), _stream_ptr(stream))
+        if rc != EFX_OK:
+            raise EfxError(rc, lib().efx_uploader_last_error(self._h).decode())
+        return d.value, pitch.value, img.shape[0], img.shape[1]
 
 
 class BFMatcher:

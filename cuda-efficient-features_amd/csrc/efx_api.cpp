@@ -14,6 +14,7 @@
 #include <string.h>
 
 #include <new>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -679,6 +680,152 @@ int efx_describer_hashsift_debug_async(efx_describer* d, const uint8_t* d_image,
     if (d->d.kind != 1) return set_err(d->d.err, EFX_ERR_BAD_ARG, "not a HashSIFT describer");
     return describe_single(d->d, d->d.err, d_image, rows, cols, pitch, reinterpret_cast<const float4*>(d_kp4), n, max_size,
                            nullptr, 0, d_responses, d_T, (hipStream_t)stream);
+}
+
+// ---- input stage ----
+int efx_cvt_gray_async(const uint8_t* d_src, int rows, int cols, size_t src_pitch, int channels,
+                       uint8_t* d_gray, size_t gray_pitch, void* stream)
+{
+    if (!d_src || !d_gray || rows <= 0 || cols <= 0 || (channels != 3 && channels != 4) || src_pitch < (size_t)cols * channels ||
+        gray_pitch < (size_t)cols)
+        return set_err(g_create_error, EFX_ERR_BAD_ARG, "Image should be 8UC3 or 8UC4 with valid pitches");   // bad.cpp:279
+    hipError_t e = efx_launch_cvt_gray(d_src, src_pitch, rows, cols, channels, d_gray, gray_pitch, (hipStream_t)stream);
+    if (e != hipSuccess) return set_err(g_create_error, EFX_ERR_HIP, "cvt_gray launch failed: %s", hipGetErrorString(e));
+    return EFX_OK;
+}
+
+int efx_host_alloc(size_t bytes, void** out)
+{
+    if (!out || bytes == 0) return EFX_ERR_BAD_ARG;
+    *out = nullptr;
+    hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) return set_err(g_create_error, EFX_ERR_NOMEM, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    return EFX_OK;
+}
+
+int efx_host_free(void* p) { return (!p || hipHostFree(p) == hipSuccess) ? EFX_OK : EFX_ERR_HIP; }
+
+struct efx_uploader {
+    static constexpr int NSLOT = 2, NCHUNK = 4;
+    static constexpr size_t CHUNK = 4u << 20;
+    DevBuf raw[NSLOT], gray[NSLOT];
+    hipStream_t copy = nullptr;
+    hipEvent_t uploaded[NSLOT] = {}, consumed[NSLOT] = {}, chunk_done[NCHUNK] = {};
+    void* staging[NCHUNK] = {};
+    bool chunk_busy[NCHUNK] = {};
+    bool slot_used[NSLOT] = {};
+    unsigned long long frame = 0;
+    std::string err;
+    ~efx_uploader()
+    {
+        if (copy) (void)hipStreamSynchronize(copy);
+        for (int i = 0; i < NSLOT; i++) {
+            raw[i].release(); gray[i].release();
+            if (uploaded[i]) (void)hipEventDestroy(uploaded[i]);
+            if (consumed[i]) (void)hipEventDestroy(consumed[i]);
+        }
+        for (int i = 0; i < NCHUNK; i++) {
+            if (chunk_done[i]) (void)hipEventDestroy(chunk_done[i]);
+            if (staging[i]) (void)hipHostFree(staging[i]);
+        }
+        if (copy) (void)hipStreamDestroy(copy);
+    }
+};
+
+int efx_uploader_create(efx_uploader** out)
+{
+    if (!out) return set_err(g_create_error, EFX_ERR_BAD_ARG, "null output handle");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return set_err(g_create_error, EFX_ERR_NO_DEVICE, "no HIP device");
+    efx_uploader* u = new (std::nothrow) efx_uploader;
+    if (!u) return set_err(g_create_error, EFX_ERR_NOMEM, "out of host memory");
+    hipError_t e = hipStreamCreateWithFlags(&u->copy, hipStreamNonBlocking);
+    for (int i = 0; i < efx_uploader::NSLOT && e == hipSuccess; i++) {
+        e = hipEventCreateWithFlags(&u->uploaded[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&u->consumed[i], hipEventDisableTiming);
+    }
+    for (int i = 0; i < efx_uploader::NCHUNK && e == hipSuccess; i++) e = hipEventCreateWithFlags(&u->chunk_done[i], hipEventDisableTiming);
+    if (e != hipSuccess) { set_err(g_create_error, EFX_ERR_HIP, "uploader setup failed: %s", hipGetErrorString(e)); delete u; return EFX_ERR_HIP; }
+    *out = u;
+    return EFX_OK;
+}
+
+int efx_uploader_destroy(efx_uploader* u) { delete u; return EFX_OK; }
+const char* efx_uploader_last_error(const efx_uploader* u) { return u ? u->err.c_str() : g_create_error.c_str(); }
+
+int efx_upload_gray_async(efx_uploader* u, const uint8_t* h_image, int rows, int cols, size_t pitch, int channels,
+                          const uint8_t** d_gray, size_t* gray_pitch, void* stream_)
+{
+    if (!u) return EFX_ERR_BAD_ARG;
+    if (!h_image || rows <= 0 || cols <= 0 || (channels != 1 && channels != 3 && channels != 4) || pitch < (size_t)cols * channels ||
+        !d_gray || !gray_pitch)
+        return set_err(u->err, EFX_ERR_BAD_ARG, "Image should be 8UC1, 8UC3 or 8UC4");               // bad.cpp:279
+    hipStream_t stream = (hipStream_t)stream_;
+    const int slot = (int)(u->frame % efx_uploader::NSLOT);
+    const int prev = (int)((u->frame + efx_uploader::NSLOT - 1) % efx_uploader::NSLOT);
+    // everything enqueued on `stream` so far includes the consumers of the previous frame (slot `prev`)
+    if (u->frame > 0) HIP_TRY(u->err, hipEventRecord(u->consumed[prev], stream));
+    // this slot was last used by frame - NSLOT, whose consumers were covered by the event recorded one call ago
+    if (u->slot_used[slot]) HIP_TRY(u->err, hipStreamWaitEvent(u->copy, u->consumed[slot], 0));
+    const size_t row_bytes = (size_t)cols * channels;
+    const size_t dpitch = align_up(row_bytes, 256);
+    HIP_TRY(u->err, u->raw[slot].reserve(dpitch * rows));
+    hipPointerAttribute_t attr;
+    const bool pinned = hipPointerGetAttributes(&attr, h_image) == hipSuccess && attr.type == hipMemoryTypeHost;
+    if (!pinned) (void)hipGetLastError();
+    if (pinned) {
+        HIP_TRY(u->err, hipMemcpy2DAsync(u->raw[slot].p, dpitch, h_image, pitch, row_bytes, rows, hipMemcpyHostToDevice, u->copy));
+    } else {
+        // pageable memory: row blocks through a ring of pinned chunks; the host copy of block i+1 overlaps the DMA of block i
+        const int rows_per_chunk = (int)std::max<size_t>(1, efx_uploader::CHUNK / row_bytes);
+        if (row_bytes > efx_uploader::CHUNK) return set_err(u->err, EFX_ERR_UNSUPPORTED, "image row larger than the staging chunk");
+        int c = 0;
+        for (int r0 = 0; r0 < rows; r0 += rows_per_chunk, c = (c + 1) % efx_uploader::NCHUNK) {
+            const int nr = std::min(rows_per_chunk, rows - r0);
+            if (!u->staging[c]) HIP_TRY(u->err, hipHostMalloc(&u->staging[c], efx_uploader::CHUNK, hipHostMallocDefault));
+            if (u->chunk_busy[c]) HIP_TRY(u->err, hipEventSynchronize(u->chunk_done[c]));
+            uint8_t* st = static_cast<uint8_t*>(u->staging[c]);
+            for (int r = 0; r < nr; r++) memcpy(st + (size_t)r * row_bytes, h_image + (size_t)(r0 + r) * pitch, row_bytes);
+            HIP_TRY(u->err, hipMemcpy2DAsync(static_cast<uint8_t*>(u->raw[slot].p) + (size_t)r0 * dpitch, dpitch, st, row_bytes, row_bytes, nr,
+                                             hipMemcpyHostToDevice, u->copy));
+            HIP_TRY(u->err, hipEventRecord(u->chunk_done[c], u->copy));
+            u->chunk_busy[c] = true;
+        }
+    }
+    HIP_TRY(u->err, hipEventRecord(u->uploaded[slot], u->copy));
+    HIP_TRY(u->err, hipStreamWaitEvent(stream, u->uploaded[slot], 0));
+    u->slot_used[slot] = true;
+    u->frame++;
+    if (channels == 1) {
+        *d_gray = static_cast<const uint8_t*>(u->raw[slot].p); *gray_pitch = dpitch;
+        return EFX_OK;
+    }
+    const size_t gpitch = align_up((size_t)cols, 256);
+    HIP_TRY(u->err, u->gray[slot].reserve(gpitch * rows));
+    hipError_t e = efx_launch_cvt_gray(static_cast<const uint8_t*>(u->raw[slot].p), dpitch, rows, cols, channels,
+                                       static_cast<uint8_t*>(u->gray[slot].p), gpitch, stream);
+    if (e != hipSuccess) return set_err(u->err, EFX_ERR_HIP, "cvt_gray launch failed: %s", hipGetErrorString(e));
+    *d_gray = static_cast<const uint8_t*>(u->gray[slot].p); *gray_pitch = gpitch;
+    return EFX_OK;
+}
+
+int efx_describer_compute_color(efx_describer* d, const uint8_t* h_image, int rows, int cols, size_t pitch, int channels,
+                                const efx_keypoint* keypoints, int n, uint8_t* h_descriptors, size_t desc_pitch)
+{
+    if (!d) return EFX_ERR_BAD_ARG;
+    if (channels == 1) return describe_host(d->d, d->d.err, h_image, rows, cols, pitch, keypoints, n, h_descriptors, desc_pitch);
+    if ((channels != 3 && channels != 4) || !h_image || rows <= 0 || cols <= 0 || pitch < (size_t)cols * channels)
+        return set_err(d->d.err, EFX_ERR_BAD_ARG, "Image should be 8UC1, 8UC3 or 8UC4");             // bad.cpp:279
+    // convertToGray on the host side of the describer (bad.cpp:268-281): spec S11, same integers as the device kernel
+    std::vector<uint8_t> gray((size_t)rows * cols);
+    for (int y = 0; y < rows; y++) {
+        const uint8_t* s = h_image + (size_t)y * pitch;
+        uint8_t* g = gray.data() + (size_t)y * cols;
+        for (int x = 0; x < cols; x++, s += channels) g[x] = (uint8_t)((3735u * s[0] + 19235u * s[1] + 9798u * s[2] + 16384u) >> 15);
+    }
+    return describe_host(d->d, d->d.err, gray.data(), rows, cols, (size_t)cols, keypoints, n, h_descriptors, desc_pitch);
 }
 
 int efx_profile_set_stride(efx_context* ctx, int stride)

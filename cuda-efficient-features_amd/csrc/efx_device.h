@@ -219,6 +219,10 @@ hipError_t efx_launch_copy2d(const uint8_t* src, size_t spitch, uint8_t* dst, si
 
 void efx_gaussian_taps_host(float taps[7]);
 
+// BGR / BGRA -> gray (input_kernels.hip, spec S11)
+hipError_t efx_launch_cvt_gray(const uint8_t* src, size_t spitch, int rows, int cols, int channels, uint8_t* dst, size_t dpitch,
+                               hipStream_t stream);
+
 // brute-force Hamming matcher (match_kernels.hip); scratch: nchunks * nq * 16 bytes
 hipError_t efx_launch_knn2(const uint8_t* query, size_t q_pitch, int nq, const uint8_t* train, size_t t_pitch, int nt,
                            int desc_bytes, void* scratch, int nchunks, int* idx, int* dist, hipStream_t stream);

@@ -215,6 +215,37 @@ int efx_match_crosscheck_async(efx_matcher* m, const uint8_t* d_query, size_t q_
                                int* d_match, int* d_dist, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ */
+/* input stage: colour -> gray and host -> device upload overlapped with compute   */
+
+/* cv::cvtColor(COLOR_BGR2GRAY / COLOR_BGRA2GRAY) of an 8-bit image already on the device: what the CPU describers
+ * (bad.cpp:268-281, hash_sift.cpp:51-66) and the samples (sample_common.cpp:35-45) do on the host before calling
+ * the GPU class, which itself only takes CV_8UC1 (cuda_efficient_features.cpp:228).  channels = 3 (BGR) or 4 (BGRA);
+ * gray = (3735 B + 19235 G + 9798 R + 16384) >> 15 (OpenCV's 8-bit fixed-point form, DESIGN.md spec S11). */
+int efx_cvt_gray_async(const uint8_t* d_src, int rows, int cols, size_t src_pitch, int channels,
+                       uint8_t* d_gray, size_t gray_pitch, void* stream);
+
+/* Page-locked host memory (cv::cuda::HostMem): frames decoded into it upload by DMA without a staging copy. */
+int efx_host_alloc(size_t bytes, void** out);
+int efx_host_free(void* p);
+
+/* getInputMat's upload (cuda_efficient_features.cpp:71-84) as a double-buffered stage: efx_upload_gray_async copies a
+ * host frame (1, 3 or 4 channels, 8 bit) to one of two device slots on an internal copy stream and makes `stream` wait
+ * for it (plus the colour conversion, which runs on `stream`); *d_gray / *gray_pitch is the device gray frame, valid
+ * for work enqueued on `stream` until the second-next upload on this uploader.  Upload k+1 overlaps with whatever was
+ * enqueued on `stream` for frame k.  Pageable host memory is staged through pinned chunks (host memcpy bound);
+ * memory from efx_host_alloc goes by DMA directly. */
+typedef struct efx_uploader efx_uploader;
+int efx_uploader_create(efx_uploader** out);
+int efx_uploader_destroy(efx_uploader* u);
+const char* efx_uploader_last_error(const efx_uploader* u);
+int efx_upload_gray_async(efx_uploader* u, const uint8_t* h_image, int rows, int cols, size_t pitch, int channels,
+                          const uint8_t** d_gray, size_t* gray_pitch, void* stream);
+
+/* EfficientDescriptors::compute with a colour host image (bad.cpp:268-281 accepts 8UC1 / 8UC3 / 8UC4). */
+int efx_describer_compute_color(efx_describer* d, const uint8_t* h_image, int rows, int cols, size_t pitch, int channels,
+                                const efx_keypoint* keypoints, int n, uint8_t* h_descriptors, size_t desc_pitch);
+
+/* ------------------------------------------------------------------------------------------------ */
 /* introspection used by the parity tests (no reference equivalent)                                  */
 
 /* Per-launch timing of the pipeline's kernels with HIP events on the caller's stream: efx_profile_enable

@@ -816,3 +816,16 @@ int efxo_detect_and_compute(const uint8_t* img, int rows, int cols, int stride,
     for (int s = 0; s < nl; s++) free(pyr[s]);
     return total;
 }
+
+/* Spec S11: cv::cvtColor(COLOR_BGR2GRAY / COLOR_BGRA2GRAY) for 8-bit images as OpenCV >= 3.4 computes it
+ * (fixed point, BY15 = 3735, GY15 = 19235, RY15 = 9798, shift 15, + 1 << 14): third-party arithmetic behind
+ * bad.cpp:268-281, hash_sift.cpp:51-66 and samples/sample_common.cpp:35-45.  channels = 3 or 4. */
+void efxo_bgr2gray(const uint8_t* src, int rows, int cols, int sstride, int channels, uint8_t* dst, int dstride)
+{
+    for (int y = 0; y < rows; y++) {
+        const uint8_t* s = src + (size_t)y * sstride;
+        uint8_t* d = dst + (size_t)y * dstride;
+        for (int x = 0; x < cols; x++, s += channels)
+            d[x] = (uint8_t)((3735u * s[0] + 19235u * s[1] + 9798u * s[2] + 16384u) >> 15);
+    }
+}

@@ -132,6 +132,9 @@ int efxo_detect_and_compute(const uint8_t* img, int rows, int cols, int stride,
 int efxo_pyramid_level(const uint8_t* img, int rows, int cols, int stride, float scale_factor, int level,
                        uint8_t* dst);
 
+/* spec S11: BGR / BGRA -> gray (cv::cvtColor 8-bit fixed point) */
+void efxo_bgr2gray(const uint8_t* src, int rows, int cols, int sstride, int channels, uint8_t* dst, int dstride);
+
 #ifdef __cplusplus
 }
 #endif

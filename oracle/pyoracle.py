@@ -124,6 +124,14 @@ def hashsift_compute(img, kps, nbits, crop_scale=1.0):
     return hashsift_project(resp, nbits)[1]
 
 
+def bgr2gray(img):
+    """H x W x 3|4 uint8 -> H x W uint8 (spec S11)."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    out = np.zeros(img.shape[:2], dtype=np.uint8)
+    lib().efxo_bgr2gray(_p(img), img.shape[0], img.shape[1], img.strides[0], img.shape[2], _p(out), out.strides[0])
+    return out
+
+
 def pyramid_geometry(rows, cols, scale_factor=1.2, nlevels=8):
     lr = (C.c_int * nlevels)()
     lc = (C.c_int * nlevels)()
