@@ -40,6 +40,7 @@ ABI_SYMBOLS = [
     "efx_describer_compute", "efx_describer_hashsift_debug_async",
     "efx_matcher_create", "efx_matcher_destroy", "efx_matcher_last_error", "efx_match_knn2_async",
     "efx_match_crosscheck_async",
+    "efx_detect_and_compute_masked_async", "efx_compute_provided_async", "efx_detect_and_compute_ex",
     "efx_cvt_gray_async", "efx_host_alloc", "efx_host_free", "efx_uploader_create", "efx_uploader_destroy",
     "efx_uploader_last_error", "efx_upload_gray_async", "efx_describer_compute_color",
     "efx_profile_enable", "efx_profile_set_stride", "efx_profile_read",
@@ -130,6 +131,12 @@ def lib():
         for name in ("efx_match_knn2_async", "efx_match_crosscheck_async"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int,
                                          C.c_void_p, C.c_void_p, C.c_void_p]
+        L.efx_detect_and_compute_masked_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t,
+                                                          C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+        L.efx_compute_provided_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t,
+                                                 C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.efx_detect_and_compute_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t,
+                                                C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_int), C.c_int]
         L.efx_cvt_gray_async.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
         L.efx_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
         L.efx_host_free.argtypes = [C.c_void_p]
@@ -240,16 +247,39 @@ class EfficientFeatures:
                                            _stream_ptr(stream)))
         return keypoints, count
 
-    def detectAndComputeAsync(self, image, keypoints=None, descriptors=None, count=None, capacity=None, stream=None):
+    def detectAndComputeAsync(self, image, keypoints=None, descriptors=None, count=None, capacity=None, stream=None,
+                              mask=None, useProvidedKeypoints=False, n=None, want_descriptors=True):
+        """detectAndComputeAsync(image, mask, keypoints, descriptors, useProvidedKeypoints, stream)
+        (cuda_efficient_features.h:66-73).  mask: H x W uint8 CUDA tensor (spec S12); useProvidedKeypoints: `keypoints`
+        (5 x N, first `n` columns) are described as detectAndCompute would have (spec S13) and only descriptors return."""
         import torch
         image = _dev_image(image)
+        if useProvidedKeypoints:
+            if keypoints is None or keypoints.dim() != 2 or keypoints.shape[0] != 5 or keypoints.dtype != torch.float32:
+                raise EfxError(-1, "keypoints must be a 5 x N float32 matrix")
+            n = keypoints.shape[1] if n is None else int(n)
+            if descriptors is None:
+                descriptors = torch.zeros((max(n, 1), self.descriptorSize()), dtype=torch.uint8, device=image.device)
+            self._check(lib().efx_compute_provided_async(
+                self._h, image.data_ptr(), image.shape[0], image.shape[1], image.stride(0), keypoints.data_ptr(),
+                keypoints.stride(0) * 4, n, descriptors.data_ptr(), descriptors.stride(0), _stream_ptr(stream)))
+            return descriptors[:n]
         capacity = self.getMaxFeatures() if capacity is None else int(capacity)
         if keypoints is None:
             keypoints = torch.zeros((5, max(capacity, 1)), dtype=torch.float32, device=image.device)
-        if descriptors is None:
+        if descriptors is None and want_descriptors:
             descriptors = torch.zeros((max(capacity, 1), self.descriptorSize()), dtype=torch.uint8, device=image.device)
         if count is None:
             count = torch.zeros(1, dtype=torch.int32, device=image.device)
+        if mask is not None:
+            mask = _dev_image(mask)
+            if tuple(mask.shape) != tuple(image.shape):
+                raise EfxError(-1, "mask must have the size of the image")
+            self._check(lib().efx_detect_and_compute_masked_async(
+                self._h, image.data_ptr(), image.shape[0], image.shape[1], image.stride(0), mask.data_ptr(), mask.stride(0),
+                keypoints.data_ptr(), keypoints.stride(0) * 4, descriptors.data_ptr() if descriptors is not None else None,
+                descriptors.stride(0) if descriptors is not None else 0, capacity, count.data_ptr(), _stream_ptr(stream)))
+            return keypoints, descriptors, count
         self._check(lib().efx_detect_and_compute_async(
             self._h, image.data_ptr(), image.shape[0], image.shape[1], image.stride(0), keypoints.data_ptr(),
             keypoints.stride(0) * 4, descriptors.data_ptr(), descriptors.stride(0), capacity, count.data_ptr(),
@@ -324,16 +354,29 @@ class EfficientFeatures:
                                       kps.ctypes.data, len(kps), desc.ctypes.data, desc.strides[0]))
         return desc[:len(kps)]
 
-    def detectAndCompute(self, image, capacity=None, useProvidedKeypoints=False):
-        if useProvidedKeypoints:
-            raise EfxError(-1, "useProvidedKeypoints is not supported")     # CV_Assert(!useProvidedKeypoints), .cpp:229
+    def detectAndCompute(self, image, capacity=None, useProvidedKeypoints=False, mask=None, keypoints=None):
+        """Feature2D::detectAndCompute(image, mask, keypoints, descriptors, useProvidedKeypoints) on host arrays."""
         img = _host_image(image)
         capacity = self.getMaxFeatures() if capacity is None else int(capacity)
-        kps = keypoints_array(max(capacity, 1))
-        desc = np.zeros((max(capacity, 1), self.descriptorSize()), dtype=np.uint8)
-        n = C.c_int(0)
-        self._check(lib().efx_detect_and_compute(self._h, img.ctypes.data, img.shape[0], img.shape[1], img.strides[0],
-                                                 kps.ctypes.data, desc.ctypes.data, desc.strides[0], capacity, C.byref(n)))
+        m = None
+        if mask is not None:
+            m = _host_image(mask)
+            if m.shape != img.shape:
+                raise EfxError(-1, "mask must have the size of the image")
+        if useProvidedKeypoints:
+            if keypoints is None:
+                raise EfxError(-1, "useProvidedKeypoints needs keypoints")
+            kps = np.ascontiguousarray(keypoints, dtype=KEYPOINT_DTYPE)
+            n = C.c_int(len(kps))
+            desc = np.zeros((max(len(kps), 1), self.descriptorSize()), dtype=np.uint8)
+        else:
+            kps = keypoints_array(max(capacity, 1))
+            n = C.c_int(0)
+            desc = np.zeros((max(capacity, 1), self.descriptorSize()), dtype=np.uint8)
+        self._check(lib().efx_detect_and_compute_ex(self._h, img.ctypes.data, img.shape[0], img.shape[1], img.strides[0],
+                                                    m.ctypes.data if m is not None else None, m.strides[0] if m is not None else 0,
+                                                    kps.ctypes.data, desc.ctypes.data, desc.strides[0], capacity, C.byref(n),
+                                                    1 if useProvidedKeypoints else 0))
         return kps[:n.value].copy(), desc[:n.value].copy()
 
     @staticmethod

@@ -310,7 +310,7 @@ __device__ __forceinline__ int level_of_tile(const LevelTable* T, int gt)
 // ================================================================================================
 __global__ __launch_bounds__(256) void fast_kernel(
     const LevelTable* __restrict__ T, const uint8_t* __restrict__ img0, int pitch0, int aligned0,
-    const uint8_t* __restrict__ pyramid, int threshold,
+    const uint8_t* __restrict__ pyramid, int threshold, const uint8_t* __restrict__ mask, int mask_pitch,
     Corner* __restrict__ cand_all, TileHdr* __restrict__ hdr_all, Counters* __restrict__ cnt, int dbg)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_tile[EFX_LT * (EFX_LP / 4)];
@@ -407,7 +407,14 @@ __global__ __launch_bounds__(256) void fast_kernel(
         for (int idx = lane; idx < ((dbg & 8) ? 0 : nq); idx += 64) {
             const int e = ql[idx];
             const int lx = e & 0xff, ly = e >> 8;
-            if (fast9_lds<EFX_LP>(tb + (ly + EFX_HALO) * EFX_LP + lx + EFX_HALO, threshold))
+            bool corner = fast9_lds<EFX_LP>(tb + (ly + EFX_HALO) * EFX_LP + lx + EFX_HALO, threshold);
+            if (corner && mask) {
+                // spec S12: the level-0 mask is sampled where the keypoint will be reported (scalePoints, .cu:236-248)
+                const int sx = min((int)(short)(L.scale * (float)(x0 + lx) + 0.5f), T->lv[0].cols - 1);
+                const int sy = min((int)(short)(L.scale * (float)(y0 + ly) + 0.5f), T->lv[0].rows - 1);
+                corner = mask[(size_t)sy * mask_pitch + sx] != 0;
+            }
+            if (corner)
                 atomicOr(reinterpret_cast<unsigned*>(s_bitmap) + ly * 2 + (lx >> 5), 1u << (lx & 31));
         }
         __syncthreads();
@@ -980,6 +987,32 @@ __global__ void convert_keypoints_kernel(const uint8_t* __restrict__ kps, size_t
     kp4[i] = make_float4((float)x, (float)y, (float)EFX_PATCH_SIZE, ang);
 }
 
+__global__ void provided_keypoints_kernel(const LevelTable* __restrict__ T, const uint8_t* __restrict__ kps, size_t kps_pitch, int n,
+                                         float4* __restrict__ kp4, int* __restrict__ kp_level)
+{
+    // spec S13: inverse of scalePoints (cuda_efficient_features.cu:236-248) for scale >= 1
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t loc = *reinterpret_cast<const uint32_t*>(kps + 4 * (size_t)i);
+    const float ang = *reinterpret_cast<const float*>(kps + 2 * kps_pitch + 4 * (size_t)i);
+    const int oct = *reinterpret_cast<const int*>(kps + 3 * kps_pitch + 4 * (size_t)i);
+    const short x = (short)(loc & 0xffff), y = (short)(loc >> 16);
+    const bool ok = oct >= 0 && oct < T->nlevels && T->lv[oct].rows > 0 && T->lv[oct].cols > 0;
+    const float sc = ok ? T->lv[oct].scale : 1.f;
+    kp4[i] = make_float4((float)(int)((float)x / sc + 0.5f), (float)(int)((float)y / sc + 0.5f), (float)EFX_PATCH_SIZE, ang);
+    kp_level[i] = ok ? oct : 0;
+}
+
+__global__ void zero_invalid_descriptors_kernel(const LevelTable* __restrict__ T, const uint8_t* __restrict__ kps, size_t kps_pitch, int n,
+                                                uint8_t* __restrict__ desc, size_t desc_pitch, int nbytes)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int oct = *reinterpret_cast<const int*>(kps + 3 * kps_pitch + 4 * (size_t)i);
+    const bool ok = oct >= 0 && oct < T->nlevels && T->lv[oct].rows > 0 && T->lv[oct].cols > 0;
+    if (!ok) for (int b = 0; b < nbytes; b++) desc[(size_t)i * desc_pitch + b] = 0;
+}
+
 __global__ void copy2d_kernel(const uint8_t* __restrict__ src, size_t spitch, uint8_t* __restrict__ dst, size_t dpitch, int rows, int cols)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1015,11 +1048,12 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
                            a.pyramid + N.img_off, N.pitch, N.rows, N.cols, N.fx, N.fy, N.tiles_x, N.tiles_y, lpitch);
         a.prof.end(prof, 100 + s, stream);
     }
+    if (a.pyramid_only) return hipGetLastError();
     {
         const int aligned0 = (((uintptr_t)a.img0 | (uintptr_t)a.pitch0) & 3u) == 0;
         bool prof = a.prof.begin(stream);
         hipLaunchKernelGGL(fast_kernel, dim3(H.total_tiles), dim3(256), 0, stream, a.d_table, a.img0, a.pitch0, aligned0,
-                           a.pyramid, a.threshold, a.cand, a.hdr, a.counters, a.dbg & 15);
+                           a.pyramid, a.threshold, a.mask, a.mask_pitch, a.cand, a.hdr, a.counters, a.dbg & 15);
         a.prof.end(prof, 0, stream);
         prof = a.prof.begin(stream);
         hipLaunchKernelGGL(harris_kernel, dim3(H.total_tiles), dim3(64), 0, stream, a.d_table, a.img0, a.pitch0, aligned0, a.pyramid,
@@ -1056,6 +1090,24 @@ hipError_t efx_launch_convert_keypoints(const void* d_keypoints, size_t kps_pitc
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(convert_keypoints_kernel, dim3((n + 255) / 256), dim3(256), 0, stream,
                        (const uint8_t*)d_keypoints, kps_pitch, n, kp4);
+    return hipGetLastError();
+}
+
+hipError_t efx_launch_provided_keypoints(const LevelTable* d_table, const void* d_keypoints, size_t kps_pitch, int n, float4* kp4,
+                                         int* kp_level, hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(provided_keypoints_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, d_table, (const uint8_t*)d_keypoints,
+                       kps_pitch, n, kp4, kp_level);
+    return hipGetLastError();
+}
+
+hipError_t efx_launch_zero_invalid_descriptors(const LevelTable* d_table, const void* d_keypoints, size_t kps_pitch, int n,
+                                               uint8_t* desc, size_t desc_pitch, int nbytes, hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(zero_invalid_descriptors_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, d_table,
+                       (const uint8_t*)d_keypoints, kps_pitch, n, desc, desc_pitch, nbytes);
     return hipGetLastError();
 }
 

@@ -189,7 +189,7 @@ struct efx_context {
     int g_rows = -1, g_cols = -1;
     efx_params g_p;
     LevelTable h_table;
-    DevBuf d_table, pyramid, hdr, cand, cmax, surv, counters, kp4, kp_level, img, kps, descout, count;
+    DevBuf d_table, pyramid, hdr, cand, cmax, surv, counters, kp4, kp_level, img, kps, descout, count, maskbuf;
     Summary* h_mirror = nullptr;    // pinned
     bool has_frame = false;
     const uint8_t* last_img0 = nullptr; int last_pitch0 = 0;
@@ -202,7 +202,7 @@ struct efx_context {
     ~efx_context()
     {
         d_table.release(); pyramid.release(); hdr.release(); cand.release(); cmax.release(); surv.release(); counters.release();
-        kp4.release(); kp_level.release(); img.release(); kps.release(); descout.release(); count.release();
+        kp4.release(); kp_level.release(); img.release(); kps.release(); descout.release(); count.release(); maskbuf.release();
         if (h_mirror) (void)hipHostFree(h_mirror);
         for (hipEvent_t e : prof_start) (void)hipEventDestroy(e);
         for (hipEvent_t e : prof_stop) (void)hipEventDestroy(e);
@@ -304,8 +304,9 @@ int build_geometry(efx_context* c, int rows, int cols)
 
 int detect_common(efx_context* c, const uint8_t* d_image, int rows, int cols, size_t pitch,
                   void* d_keypoints, size_t kps_pitch, uint8_t* d_desc, size_t desc_pitch,
-                  int capacity, int* d_count, hipStream_t stream)
+                  int capacity, int* d_count, hipStream_t stream, const uint8_t* d_mask = nullptr, size_t mask_pitch = 0)
 {
+    if (d_mask && mask_pitch < (size_t)cols) return set_err(c->err, EFX_ERR_BAD_ARG, "mask must be an 8-bit image of the frame size");
     // CV_Assert(_image.type() == CV_8U) etc. (.cpp:228-229)
     if (!d_image || rows <= 0 || cols <= 0 || pitch < (size_t)cols) return set_err(c->err, EFX_ERR_BAD_ARG, "bad image arguments");
     if (capacity < 0) return set_err(c->err, EFX_ERR_BAD_ARG, "capacity must be >= 0");
@@ -334,6 +335,7 @@ int detect_common(efx_context* c, const uint8_t* d_image, int rows, int cols, si
     a.nonmax_radius = c->p.nonmax_radius;
     a.first_level = c->p.first_level;
     { const char* e = getenv("EFX_DEBUG"); a.dbg = e ? atoi(e) : 0; }
+    a.mask = d_mask; a.mask_pitch = (int)mask_pitch;
     a.d_keypoints = d_keypoints; a.kps_pitch = kps_pitch; a.capacity = capacity;
     a.d_count = d_count ? d_count : static_cast<int*>(c->count.p);
     a.kp4 = static_cast<float4*>(c->kp4.p);
@@ -363,6 +365,48 @@ int detect_common(efx_context* c, const uint8_t* d_image, int rows, int cols, si
         rc = describer_run(c->desc, c->err, dl, nullptr, nullptr, stream);
         if (rc) return rc;
     }
+    return EFX_OK;
+}
+
+// detectAndCompute(useProvidedKeypoints = true), spec S13: pyramid only, then blur + describe on the keypoints' levels
+int compute_provided(efx_context* c, const uint8_t* d_image, int rows, int cols, size_t pitch,
+                     const void* d_keypoints, size_t kps_pitch, int n, uint8_t* d_desc, size_t desc_pitch, hipStream_t stream)
+{
+    if (!d_image || rows <= 0 || cols <= 0 || pitch < (size_t)cols) return set_err(c->err, EFX_ERR_BAD_ARG, "bad image arguments");
+    if (n < 0) return set_err(c->err, EFX_ERR_BAD_ARG, "n must be >= 0");
+    if (n == 0) return EFX_OK;
+    if (!d_keypoints || kps_pitch < (size_t)n * 4 || (kps_pitch & 3)) return set_err(c->err, EFX_ERR_BAD_ARG, "bad keypoint matrix");
+    if (!d_desc || desc_pitch < (size_t)efx_descriptor_size(c)) return set_err(c->err, EFX_ERR_BAD_ARG, "bad descriptor buffer");
+    int rc = validate_params(c->p, c->err);
+    if (rc) return rc;
+    rc = build_geometry(c, rows, cols);
+    if (rc) return rc;
+    HIP_TRY(c->err, c->kp4.reserve((size_t)n * sizeof(float4)));
+    HIP_TRY(c->err, c->kp_level.reserve((size_t)n * sizeof(int)));
+    DetectLaunch a;
+    memset(&a, 0, sizeof(a));
+    a.img0 = d_image; a.pitch0 = (int)pitch;
+    a.pyramid = static_cast<uint8_t*>(c->pyramid.p);
+    a.d_table = static_cast<const LevelTable*>(c->d_table.p);
+    a.h_table = &c->h_table;
+    a.counters = static_cast<Counters*>(c->counters.p);
+    a.pyramid_only = 1;
+    hipError_t e = efx_launch_detect(a, stream);
+    if (e == hipSuccess)
+        e = efx_launch_provided_keypoints(a.d_table, d_keypoints, kps_pitch, n, static_cast<float4*>(c->kp4.p), static_cast<int*>(c->kp_level.p), stream);
+    if (e != hipSuccess) return set_err(c->err, EFX_ERR_HIP, "provided-keypoints launch failed: %s", hipGetErrorString(e));
+    c->has_frame = true; c->last_img0 = d_image; c->last_pitch0 = (int)pitch;
+    DescribeLaunch dl;
+    memset(&dl, 0, sizeof(dl));
+    dl.img0 = d_image; dl.pitch0 = (int)pitch; dl.rows0 = rows; dl.cols0 = cols;
+    dl.pyramid = a.pyramid; dl.d_table = a.d_table;
+    dl.kp4 = static_cast<const float4*>(c->kp4.p); dl.kp_level = static_cast<const int*>(c->kp_level.p); dl.d_count = nullptr;
+    dl.n = n; dl.blur = 1; dl.max_size = (float)EFX_PATCH_SIZE; dl.uniform_size = 1;
+    dl.desc = d_desc; dl.desc_pitch = desc_pitch;
+    rc = describer_run(c->desc, c->err, dl, nullptr, nullptr, stream);
+    if (rc) return rc;
+    e = efx_launch_zero_invalid_descriptors(a.d_table, d_keypoints, kps_pitch, n, d_desc, desc_pitch, efx_descriptor_size(c), stream);
+    if (e != hipSuccess) return set_err(c->err, EFX_ERR_HIP, "launch failed: %s", hipGetErrorString(e));
     return EFX_OK;
 }
 
@@ -524,6 +568,22 @@ int efx_detect_and_compute_async(efx_context* ctx, const uint8_t* d_image, int r
     return detect_common(ctx, d_image, rows, cols, pitch, d_keypoints, kps_pitch, d_descriptors, desc_pitch, capacity, d_count, (hipStream_t)stream);
 }
 
+int efx_detect_and_compute_masked_async(efx_context* ctx, const uint8_t* d_image, int rows, int cols, size_t pitch,
+                                        const uint8_t* d_mask, size_t mask_pitch, void* d_keypoints, size_t kps_pitch,
+                                        uint8_t* d_descriptors, size_t desc_pitch, int capacity, int* d_count, void* stream)
+{
+    if (!ctx) return EFX_ERR_BAD_ARG;
+    return detect_common(ctx, d_image, rows, cols, pitch, d_keypoints, kps_pitch, d_descriptors, desc_pitch, capacity, d_count,
+                         (hipStream_t)stream, d_mask, mask_pitch);
+}
+
+int efx_compute_provided_async(efx_context* ctx, const uint8_t* d_image, int rows, int cols, size_t pitch,
+                               const void* d_keypoints, size_t kps_pitch, int n, uint8_t* d_descriptors, size_t desc_pitch, void* stream)
+{
+    if (!ctx) return EFX_ERR_BAD_ARG;
+    return compute_provided(ctx, d_image, rows, cols, pitch, d_keypoints, kps_pitch, n, d_descriptors, desc_pitch, (hipStream_t)stream);
+}
+
 int efx_compute_async(efx_context* ctx, const uint8_t* d_image, int rows, int cols, size_t pitch,
                       const void* d_keypoints, size_t kps_pitch, int n, uint8_t* d_descriptors, size_t desc_pitch, void* stream)
 {
@@ -580,7 +640,8 @@ int efx_convert(const void* h_keypoints, size_t kps_pitch, int n, efx_keypoint* 
 }
 
 static int host_detect_impl(efx_context* ctx, const uint8_t* h_image, int rows, int cols, size_t pitch,
-                            efx_keypoint* keypoints, uint8_t* h_desc, size_t desc_pitch, int capacity, int* n, bool want_desc)
+                            efx_keypoint* keypoints, uint8_t* h_desc, size_t desc_pitch, int capacity, int* n, bool want_desc,
+                            const uint8_t* h_mask = nullptr, size_t mask_pitch = 0)
 {
     if (!ctx) return EFX_ERR_BAD_ARG;
     if (!h_image || rows <= 0 || cols <= 0 || pitch < (size_t)cols) return set_err(ctx->err, EFX_ERR_BAD_ARG, "bad image arguments");
@@ -593,8 +654,14 @@ static int host_detect_impl(efx_context* ctx, const uint8_t* h_image, int rows, 
     HIP_TRY(ctx->err, ctx->kps.reserve(kpitch * EFX_ROWS_COUNT));
     if (want_desc) HIP_TRY(ctx->err, ctx->descout.reserve((size_t)(capacity > 0 ? capacity : 1) * nbytes));
     HIP_TRY(ctx->err, hipMemcpy2D(ctx->img.p, ipitch, h_image, pitch, cols, rows, hipMemcpyHostToDevice));   // getInputMat upload, .cpp:75-77
+    if (h_mask) {
+        if (mask_pitch < (size_t)cols) return set_err(ctx->err, EFX_ERR_BAD_ARG, "mask must be an 8-bit image of the frame size");
+        HIP_TRY(ctx->err, ctx->maskbuf.reserve(ipitch * rows));
+        HIP_TRY(ctx->err, hipMemcpy2D(ctx->maskbuf.p, ipitch, h_mask, mask_pitch, cols, rows, hipMemcpyHostToDevice));
+    }
     int rc = detect_common(ctx, static_cast<const uint8_t*>(ctx->img.p), rows, cols, ipitch, ctx->kps.p, kpitch,
-                           want_desc ? static_cast<uint8_t*>(ctx->descout.p) : nullptr, nbytes, capacity, nullptr, nullptr);
+                           want_desc ? static_cast<uint8_t*>(ctx->descout.p) : nullptr, nbytes, capacity, nullptr, nullptr,
+                           h_mask ? static_cast<const uint8_t*>(ctx->maskbuf.p) : nullptr, ipitch);
     if (rc) return rc;
     HIP_TRY(ctx->err, hipStreamSynchronize(nullptr));
     const int cnt = ctx->h_mirror->n_out;
@@ -618,6 +685,44 @@ int efx_detect_and_compute(efx_context* ctx, const uint8_t* h_image, int rows, i
                            efx_keypoint* keypoints, uint8_t* h_descriptors, size_t desc_pitch, int capacity, int* n)
 {
     return host_detect_impl(ctx, h_image, rows, cols, pitch, keypoints, h_descriptors, desc_pitch, capacity, n, true);
+}
+
+// Feature2D::detectAndCompute with its full argument list: (image, mask, keypoints, descriptors, useProvidedKeypoints)
+int efx_detect_and_compute_ex(efx_context* ctx, const uint8_t* h_image, int rows, int cols, size_t pitch,
+                              const uint8_t* h_mask, size_t mask_pitch, efx_keypoint* keypoints, uint8_t* h_descriptors, size_t desc_pitch,
+                              int capacity, int* n, int use_provided_keypoints)
+{
+    if (!ctx) return EFX_ERR_BAD_ARG;
+    if (!use_provided_keypoints)
+        return host_detect_impl(ctx, h_image, rows, cols, pitch, keypoints, h_descriptors, desc_pitch, capacity, n, h_descriptors != nullptr,
+                                h_mask, mask_pitch);
+    // spec S13: *n keypoints are given; only the descriptors are written
+    if (!h_image || rows <= 0 || cols <= 0 || pitch < (size_t)cols) return set_err(ctx->err, EFX_ERR_BAD_ARG, "bad image arguments");
+    if (!n || *n < 0 || (*n > 0 && (!keypoints || !h_descriptors))) return set_err(ctx->err, EFX_ERR_BAD_ARG, "bad keypoint / descriptor arguments");
+    const int cnt = *n, nbytes = efx_descriptor_size(ctx);
+    if (cnt == 0) return EFX_OK;
+    if (desc_pitch < (size_t)nbytes) return set_err(ctx->err, EFX_ERR_BAD_ARG, "desc_pitch smaller than the descriptor");
+    const size_t ipitch = align_up((size_t)cols, 256), kpitch = align_up((size_t)cnt * 4, 256);
+    HIP_TRY(ctx->err, ctx->img.reserve(ipitch * rows));
+    HIP_TRY(ctx->err, ctx->kps.reserve(kpitch * EFX_ROWS_COUNT));
+    HIP_TRY(ctx->err, ctx->descout.reserve((size_t)cnt * nbytes));
+    std::vector<unsigned char> tmp(kpitch * EFX_ROWS_COUNT, 0);
+    for (int i = 0; i < cnt; i++) {
+        const uint32_t loc = (uint32_t)(uint16_t)(int16_t)keypoints[i].x | ((uint32_t)(uint16_t)(int16_t)keypoints[i].y << 16);
+        memcpy(&tmp[0 * kpitch + 4 * (size_t)i], &loc, 4);
+        memcpy(&tmp[1 * kpitch + 4 * (size_t)i], &keypoints[i].response, 4);
+        memcpy(&tmp[2 * kpitch + 4 * (size_t)i], &keypoints[i].angle, 4);
+        memcpy(&tmp[3 * kpitch + 4 * (size_t)i], &keypoints[i].octave, 4);
+        memcpy(&tmp[4 * kpitch + 4 * (size_t)i], &keypoints[i].size, 4);
+    }
+    HIP_TRY(ctx->err, hipMemcpy2D(ctx->img.p, ipitch, h_image, pitch, cols, rows, hipMemcpyHostToDevice));
+    HIP_TRY(ctx->err, hipMemcpy(ctx->kps.p, tmp.data(), tmp.size(), hipMemcpyHostToDevice));
+    int rc = compute_provided(ctx, static_cast<const uint8_t*>(ctx->img.p), rows, cols, ipitch, ctx->kps.p, kpitch, cnt,
+                              static_cast<uint8_t*>(ctx->descout.p), nbytes, nullptr);
+    if (rc) return rc;
+    HIP_TRY(ctx->err, hipStreamSynchronize(nullptr));
+    HIP_TRY(ctx->err, hipMemcpy2D(h_descriptors, desc_pitch, ctx->descout.p, nbytes, nbytes, cnt, hipMemcpyDeviceToHost));
+    return EFX_OK;
 }
 
 int efx_compute(efx_context* ctx, const uint8_t* h_image, int rows, int cols, size_t pitch,

@@ -177,6 +177,8 @@ struct DetectLaunch {
     int nonmax_radius;
     int first_level;
     int dbg;                    // EFX_DEBUG stage knob (investigation only, 0 in production)
+    const uint8_t* mask; int mask_pitch;   // optional level-0 mask (spec S12), null = none
+    int pyramid_only;           // 1: build the pyramid and stop (detectAndCompute with provided keypoints)
     // outputs
     void* d_keypoints; size_t kps_pitch; int capacity; int* d_count;
     float4* kp4; int* kp_level;
@@ -215,6 +217,12 @@ hipError_t efx_launch_hashsift(const DescribeLaunch& a, const HashSiftDev& h, hi
 
 // 5xN keypoint matrix -> float4 {x, y, 31, angle} (convertKeypointsKernel, cuda_efficient_features.cu:250-263)
 hipError_t efx_launch_convert_keypoints(const void* d_keypoints, size_t kps_pitch, int n, float4* kp4, hipStream_t stream);
+// 5xN keypoint matrix -> level coordinates {x / scale, y / scale, 31, angle} + level (spec S13); descriptors of
+// keypoints whose octave is out of range are zeroed afterwards
+hipError_t efx_launch_provided_keypoints(const LevelTable* d_table, const void* d_keypoints, size_t kps_pitch, int n, float4* kp4,
+                                         int* kp_level, hipStream_t stream);
+hipError_t efx_launch_zero_invalid_descriptors(const LevelTable* d_table, const void* d_keypoints, size_t kps_pitch, int n,
+                                               uint8_t* desc, size_t desc_pitch, int nbytes, hipStream_t stream);
 hipError_t efx_launch_copy2d(const uint8_t* src, size_t spitch, uint8_t* dst, size_t dpitch, int rows, int cols, hipStream_t stream);
 
 void efx_gaussian_taps_host(float taps[7]);

@@ -215,6 +215,29 @@ int efx_match_crosscheck_async(efx_matcher* m, const uint8_t* d_query, size_t q_
                                int* d_match, int* d_dist, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ */
+/* mask and useProvidedKeypoints: arguments the reference accepts but ignores / asserts  */
+
+/* detectAsync / detectAndComputeAsync honouring `mask` (cuda_efficient_features.cpp:225-250 takes `_mask` and never
+ * reads it).  d_mask: 8-bit, rows x cols, non-zero = allowed, NULL = no mask.  A FAST corner of pyramid level s at level
+ * coordinates (x, y) exists only if the mask is non-zero at the pixel the keypoint is reported at,
+ * ((short)(scale_s x + 0.5f), (short)(scale_s y + 0.5f)) (DESIGN.md spec S12).  d_descriptors may be NULL (detect only). */
+int efx_detect_and_compute_masked_async(efx_context* ctx, const uint8_t* d_image, int rows, int cols, size_t pitch,
+                                        const uint8_t* d_mask, size_t mask_pitch, void* d_keypoints, size_t kps_pitch,
+                                        uint8_t* d_descriptors, size_t desc_pitch, int capacity, int* d_count, void* stream);
+/* detectAndComputeAsync(useProvidedKeypoints = true) (the reference asserts it is false, :229): no detection; the n
+ * keypoints of the 5xN matrix are described exactly as detectAndCompute would have described them -- on the blurred
+ * pyramid level `octave`, at level coordinates (int)(x / scale + 0.5f), size 31, angle as given (DESIGN.md spec S13).
+ * Keypoints whose octave is not a pyramid level get a zero descriptor. */
+int efx_compute_provided_async(efx_context* ctx, const uint8_t* d_image, int rows, int cols, size_t pitch,
+                               const void* d_keypoints, size_t kps_pitch, int n,
+                               uint8_t* d_descriptors, size_t desc_pitch, void* stream);
+/* Feature2D::detectAndCompute(image, mask, keypoints, descriptors, useProvidedKeypoints) on host buffers
+ * (cuda_efficient_features.cpp:208-213).  use_provided_keypoints: *n keypoints are read, only descriptors are written. */
+int efx_detect_and_compute_ex(efx_context* ctx, const uint8_t* h_image, int rows, int cols, size_t pitch,
+                              const uint8_t* h_mask, size_t mask_pitch, efx_keypoint* keypoints,
+                              uint8_t* h_descriptors, size_t desc_pitch, int capacity, int* n, int use_provided_keypoints);
+
+/* ------------------------------------------------------------------------------------------------ */
 /* input stage: colour -> gray and host -> device upload overlapped with compute   */
 
 /* cv::cvtColor(COLOR_BGR2GRAY / COLOR_BGRA2GRAY) of an 8-bit image already on the device: what the CPU describers

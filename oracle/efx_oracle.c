@@ -708,6 +708,29 @@ int efxo_detect_and_compute(const uint8_t* img, int rows, int cols, int stride,
                             float* kps_out, uint8_t* desc_out, int16_t* lvl_xy_out, int capacity,
                             efxo_stats* stats)
 {
+    return efxo_detect_and_compute_masked(img, rows, cols, stride, NULL, 0, p, desc_type, params_a, params_b, kps_out, desc_out,
+                                          lvl_xy_out, capacity, stats);
+}
+
+/* Spec S12 (the reference accepts `mask` and ignores it, cuda_efficient_features.cpp:225-250): a FAST corner at level
+ * coordinates (x, y) of level s exists only if the level-0 mask is non-zero at the pixel the keypoint will be reported
+ * at, ((short)(scale_s x + 0.5f), (short)(scale_s y + 0.5f)) (scalePoints, cuda_efficient_features.cu:236-248), clamped
+ * into the mask.  Masked corners do not take part in the cap, the NMS or the quota. */
+static int mask_allows(const uint8_t* mask, int mstride, int rows, int cols, float scale, int x, int y)
+{
+    if (!mask) return 1;
+    int sx = (int16_t)(scale * (float)x + 0.5f), sy = (int16_t)(scale * (float)y + 0.5f);
+    if (sx > cols - 1) sx = cols - 1;
+    if (sy > rows - 1) sy = rows - 1;
+    return mask[(size_t)sy * mstride + sx] != 0;
+}
+
+int efxo_detect_and_compute_masked(const uint8_t* img, int rows, int cols, int stride, const uint8_t* mask, int mstride,
+                                   const efxo_params* p, int desc_type,
+                                   const void* params_a, const void* params_b,
+                                   float* kps_out, uint8_t* desc_out, int16_t* lvl_xy_out, int capacity,
+                                   efxo_stats* stats)
+{
     if (!img || !p || p->nlevels < 1 || p->nlevels > EFXO_MAX_LEVELS || p->first_level < 0 || capacity < 0) return -1;
     if (desc_type < -1 || desc_type > 3) return -1;
     const int nl = p->nlevels;
@@ -748,9 +771,15 @@ int efxo_detect_and_compute(const uint8_t* img, int rows, int cols, int stride,
             efxo_fast9_detect(L, h, w, w, p->fast_threshold, EFXO_HALF_PATCH, xy, ncand);
         }
         cand_t* c = (cand_t*)malloc(sizeof(cand_t) * (size_t)(ncand > 0 ? ncand : 1));
-        for (int i = 0; i < ncand; i++) {
-            c[i].x = xy[2 * i]; c[i].y = xy[2 * i + 1];
-            c[i].key = canon_key(c[i].x, c[i].y, tiles_x);
+        {
+            int kept = 0;
+            for (int i = 0; i < ncand; i++) {
+                if (!mask_allows(mask, mstride, rows, cols, sc[s], xy[2 * i], xy[2 * i + 1])) continue;       /* spec S12 */
+                c[kept].x = xy[2 * i]; c[kept].y = xy[2 * i + 1];
+                c[kept].key = canon_key(c[kept].x, c[kept].y, tiles_x);
+                kept++;
+            }
+            ncand = kept;
         }
         qsort(c, (size_t)ncand, sizeof(cand_t), cmp_cand);
         int n = ncand < cap ? ncand : cap;                          /* cuda_fast.cu:245 */
@@ -828,4 +857,65 @@ void efxo_bgr2gray(const uint8_t* src, int rows, int cols, int sstride, int chan
         for (int x = 0; x < cols; x++, s += channels)
             d[x] = (uint8_t)((3735u * s[0] + 19235u * s[1] + 9798u * s[2] + 16384u) >> 15);
     }
+}
+
+/* Spec S13 (the reference asserts !useProvidedKeypoints, cuda_efficient_features.cpp:229): detectAndCompute with
+ * useProvidedKeypoints = true skips detection and describes the given keypoints exactly as detectAndCompute would
+ * have: on the blurred pyramid level `octave`, at level coordinates ((int)(x / scale + 0.5f), (int)(y / scale + 0.5f))
+ * -- the inverse of scalePoints (cuda_efficient_features.cu:236-248) for scale >= 1 --, size 31, angle as given
+ * (cuda_efficient_features.cpp:302-307).  kps: the 5 x n matrix (rows `capacity` floats apart).  Keypoints whose
+ * octave is outside [0, nlevels) get an all-zero descriptor. */
+int efxo_compute_provided(const uint8_t* img, int rows, int cols, int stride, const efxo_params* p, int desc_type,
+                          const void* params_a, const void* params_b, const float* kps, int capacity, int n, uint8_t* desc_out)
+{
+    if (!img || !p || p->nlevels < 1 || p->nlevels > EFXO_MAX_LEVELS || desc_type < 0 || desc_type > 3 || n < 0) return -1;
+    const int nl = p->nlevels;
+    int lr[EFXO_MAX_LEVELS], lc[EFXO_MAX_LEVELS];
+    float sc[EFXO_MAX_LEVELS];
+    efxo_pyramid_geometry(rows, cols, p->scale_factor, nl, lr, lc, sc);
+    const int nbits = (desc_type == 0 || desc_type == 2) ? 256 : 512;
+    const int nbytes = nbits / 8;
+    memset(desc_out, 0, (size_t)n * nbytes);
+    uint8_t* prev = (uint8_t*)malloc((size_t)rows * cols);
+    for (int y = 0; y < rows; y++) memcpy(prev + (size_t)y * cols, img + (size_t)y * stride, (size_t)cols);
+    for (int s = 0; s < nl; s++) {
+        uint8_t* L = prev;
+        if (s > 0) {
+            L = (uint8_t*)malloc((size_t)(lr[s] > 0 ? lr[s] : 1) * (lc[s] > 0 ? lc[s] : 1));
+            if (lr[s] > 0 && lc[s] > 0 && lr[s - 1] > 0 && lc[s - 1] > 0)
+                efxo_resize_linear(prev, lr[s - 1], lc[s - 1], lc[s - 1], L, lr[s], lc[s], lc[s]);
+            free(prev);
+            prev = L;
+        }
+        const int w = lc[s], h = lr[s];
+        if (w <= 0 || h <= 0) continue;
+        int m = 0;
+        for (int i = 0; i < n; i++) { int32_t o; memcpy(&o, &kps[3 * (size_t)capacity + i], 4); if (o == s) m++; }
+        if (!m) continue;
+        float* kp4 = (float*)malloc(sizeof(float) * 4 * (size_t)m);
+        int* idx = (int*)malloc(sizeof(int) * (size_t)m);
+        m = 0;
+        for (int i = 0; i < n; i++) {
+            int32_t o; memcpy(&o, &kps[3 * (size_t)capacity + i], 4);
+            if (o != s) continue;
+            uint32_t packed; memcpy(&packed, &kps[i], 4);
+            const int16_t x = (int16_t)(packed & 0xffffu), y = (int16_t)(packed >> 16);
+            kp4[4 * m + 0] = (float)(int)((float)x / sc[s] + 0.5f);
+            kp4[4 * m + 1] = (float)(int)((float)y / sc[s] + 0.5f);
+            kp4[4 * m + 2] = (float)EFXO_PATCH_SIZE;
+            kp4[4 * m + 3] = kps[2 * (size_t)capacity + i];
+            idx[m++] = i;
+        }
+        uint8_t* blur = (uint8_t*)malloc((size_t)w * h);
+        uint8_t* d = (uint8_t*)malloc((size_t)m * nbytes);
+        efxo_gaussian7(L, h, w, w, blur, w);
+        if (desc_type <= 1)
+            efxo_bad_compute(blur, h, w, w, kp4, m, 1.f, (const int32_t*)params_a, (const float*)params_b, nbits, d);
+        else
+            efxo_hashsift_compute(blur, h, w, w, kp4, m, 1.f, (const float*)params_a, nbits, d);
+        for (int j = 0; j < m; j++) memcpy(desc_out + (size_t)idx[j] * nbytes, d + (size_t)j * nbytes, (size_t)nbytes);
+        free(blur); free(d); free(kp4); free(idx);
+    }
+    free(prev);
+    return 0;
 }

@@ -132,6 +132,16 @@ int efxo_detect_and_compute(const uint8_t* img, int rows, int cols, int stride,
 int efxo_pyramid_level(const uint8_t* img, int rows, int cols, int stride, float scale_factor, int level,
                        uint8_t* dst);
 
+/* spec S12: detectAndCompute honouring a level-0 mask (NULL = no mask) */
+int efxo_detect_and_compute_masked(const uint8_t* img, int rows, int cols, int stride, const uint8_t* mask, int mstride,
+                                   const efxo_params* p, int desc_type,
+                                   const void* params_a, const void* params_b,
+                                   float* kps_out, uint8_t* desc_out, int16_t* lvl_xy_out, int capacity,
+                                   efxo_stats* stats);
+/* spec S13: detectAndCompute(useProvidedKeypoints = true): describe the given 5 x n keypoint matrix */
+int efxo_compute_provided(const uint8_t* img, int rows, int cols, int stride, const efxo_params* p, int desc_type,
+                          const void* params_a, const void* params_b, const float* kps, int capacity, int n, uint8_t* desc_out);
+
 /* spec S11: BGR / BGRA -> gray (cv::cvtColor 8-bit fixed point) */
 void efxo_bgr2gray(const uint8_t* src, int rows, int cols, int sstride, int channels, uint8_t* dst, int dstride);
 

@@ -199,7 +199,7 @@ def atan2_deg(m01, m10):
 
 
 def detect_and_compute(img, nfeatures=5000, scale_factor=1.2, nlevels=8, first_level=0, fast_threshold=20,
-                       nonmax_radius=15, desc_type=-1, capacity=None):
+                       nonmax_radius=15, desc_type=-1, capacity=None, mask=None):
     """Returns dict(kps=(5,N) float32 raw rows, desc=(N,nbytes) or None, lvl_xy=(2,N) int16, stats)."""
     img = _u8(img)
     if capacity is None:
@@ -218,15 +218,39 @@ def detect_and_compute(img, nfeatures=5000, scale_factor=1.2, nlevels=8, first_l
         nbits = 256 if desc_type == HASH_SIFT_256 else 512
         a = load_hashsift_weights(nbits)
         desc = np.zeros((capacity, nbits // 8), dtype=np.uint8)
-    n = lib().efxo_detect_and_compute(_p(img), img.shape[0], img.shape[1], img.strides[0], C.byref(p), desc_type,
-                                      _p(a) if a is not None else None, _p(b) if b is not None else None,
-                                      _p(kps), _p(desc) if desc is not None else None, _p(lvl), capacity,
-                                      C.byref(st))
+    if mask is not None:
+        mask = _u8(mask)
+        assert mask.shape == img.shape
+    n = lib().efxo_detect_and_compute_masked(_p(img), img.shape[0], img.shape[1], img.strides[0],
+                                             _p(mask) if mask is not None else None, mask.strides[0] if mask is not None else 0,
+                                             C.byref(p), desc_type,
+                                             _p(a) if a is not None else None, _p(b) if b is not None else None,
+                                             _p(kps), _p(desc) if desc is not None else None, _p(lvl), capacity,
+                                             C.byref(st))
     if n < 0:
         raise ValueError("efxo_detect_and_compute: bad arguments")
     stats = {k: list(getattr(st, k))[:nlevels] for k in ("n_candidates", "n_after_cap", "n_after_nms", "n_kept")}
     return dict(n=n, kps=kps[:, :n].copy(), desc=None if desc is None else desc[:n].copy(),
                 lvl_xy=lvl[:, :n].copy(), stats=stats)
+
+
+def compute_provided(img, kps, desc_type, scale_factor=1.2, nlevels=8):
+    """detectAndCompute(useProvidedKeypoints=True), spec S13: kps is the (5, N) raw float32 matrix."""
+    img = _u8(img)
+    kps = np.ascontiguousarray(kps, dtype=np.float32)
+    n = kps.shape[1]
+    nbits = 256 if desc_type in (BAD_256, HASH_SIFT_256) else 512
+    if desc_type in (BAD_256, BAD_512):
+        a, b = load_bad_params(nbits)
+    else:
+        a, b = load_hashsift_weights(nbits), None
+    desc = np.zeros((max(n, 1), nbits // 8), dtype=np.uint8)
+    p = Params(0, scale_factor, nlevels, 0, 20, 15)
+    rc = lib().efxo_compute_provided(_p(img), img.shape[0], img.shape[1], img.strides[0], C.byref(p), desc_type,
+                                     _p(a), _p(b) if b is not None else None, _p(kps), kps.shape[1], n, _p(desc))
+    if rc:
+        raise ValueError("efxo_compute_provided: bad arguments")
+    return desc[:n]
 
 
 def unpack_keypoints(kps):
