@@ -41,6 +41,7 @@ ABI_SYMBOLS = [
     "efx_matcher_create", "efx_matcher_destroy", "efx_matcher_last_error", "efx_match_knn2_async",
     "efx_match_crosscheck_async",
     "efx_detect_and_compute_masked_async", "efx_compute_provided_async", "efx_detect_and_compute_ex",
+    "efx_ic_angles_async", "efx_ic_angles", "efx_descriptors_to_csv",
     "efx_cvt_gray_async", "efx_host_alloc", "efx_host_free", "efx_uploader_create", "efx_uploader_destroy",
     "efx_uploader_last_error", "efx_upload_gray_async", "efx_describer_compute_color",
     "efx_profile_enable", "efx_profile_set_stride", "efx_profile_read",
@@ -137,6 +138,10 @@ def lib():
                                                  C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
         L.efx_detect_and_compute_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t,
                                                 C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_int), C.c_int]
+        L.efx_ic_angles_async.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.efx_ic_angles.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.c_int]
+        L.efx_descriptors_to_csv.restype = C.c_long
+        L.efx_descriptors_to_csv.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_char_p, C.c_size_t]
         L.efx_cvt_gray_async.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
         L.efx_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
         L.efx_host_free.argtypes = [C.c_void_p]
@@ -490,6 +495,29 @@ class HashSIFT(_Describer):
             C.c_float(max_size), resp.data_ptr(), T.data_ptr(), _stream_ptr(stream)))
         return resp[:n], T[:n]
 
+
+
+def icAngles(image, keypoints, patch_size):
+    """ICAngles of samples/hpatches_description.cpp:128-162 on host data: returns a copy of the keypoint records with
+    the angle filled (computed on the device)."""
+    img = _host_image(image)
+    kps = np.ascontiguousarray(keypoints, dtype=KEYPOINT_DTYPE).copy()
+    rc = lib().efx_ic_angles(img.ctypes.data, img.shape[0], img.shape[1], img.strides[0], kps.ctypes.data, len(kps), int(patch_size))
+    if rc != EFX_OK:
+        raise EfxError(rc, lib().efx_last_error(None).decode())
+    return kps
+
+
+def descriptorsToCsv(descriptors):
+    """saveDescriptors of samples/hpatches_description.cpp:76-105: the text of the CSV file."""
+    d = np.ascontiguousarray(descriptors, dtype=np.uint8)
+    n, nbytes = d.shape
+    size = lib().efx_descriptors_to_csv(d.ctypes.data, n, nbytes, d.strides[0], None, 0)
+    if size < 0:
+        raise EfxError(-1, "bad descriptor matrix")
+    buf = C.create_string_buffer(int(size) + 1)
+    lib().efx_descriptors_to_csv(d.ctypes.data, n, nbytes, d.strides[0], buf, int(size))
+    return buf.raw[:size].decode("ascii")
 
 
 def cvtGray(image, out=None, stream=None):

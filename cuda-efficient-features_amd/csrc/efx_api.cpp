@@ -787,6 +787,57 @@ int efx_describer_hashsift_debug_async(efx_describer* d, const uint8_t* d_image,
                            nullptr, 0, d_responses, d_T, (hipStream_t)stream);
 }
 
+// ---- HPatches exporter helpers ----
+int efx_ic_angles_async(const uint8_t* d_image, int rows, int cols, size_t pitch, float* d_kp4, int n, int patch_size, void* stream)
+{
+    if (!d_image || rows <= 0 || cols <= 0 || pitch < (size_t)cols || n < 0 || (n > 0 && !d_kp4) || patch_size < 3 || patch_size > 257)
+        return set_err(g_create_error, EFX_ERR_BAD_ARG, "bad arguments (patch_size must be in [3, 257])");
+    hipError_t e = efx_launch_ic_angles(d_image, pitch, rows, cols, reinterpret_cast<float4*>(d_kp4), n, patch_size, (hipStream_t)stream);
+    if (e != hipSuccess) return set_err(g_create_error, EFX_ERR_HIP, "ic_angles launch failed: %s", hipGetErrorString(e));
+    return EFX_OK;
+}
+
+int efx_ic_angles(const uint8_t* h_image, int rows, int cols, size_t pitch, efx_keypoint* keypoints, int n, int patch_size)
+{
+    if (!h_image || rows <= 0 || cols <= 0 || pitch < (size_t)cols || n < 0 || (n > 0 && !keypoints))
+        return set_err(g_create_error, EFX_ERR_BAD_ARG, "bad arguments");
+    if (n == 0) return EFX_OK;
+    DevBuf img, kp;
+    const size_t ipitch = align_up((size_t)cols, 256);
+    std::vector<float4> k((size_t)n);
+    for (int i = 0; i < n; i++) k[i] = make_float4(keypoints[i].x, keypoints[i].y, keypoints[i].size, keypoints[i].angle);
+    hipError_t e = img.reserve(ipitch * rows);
+    if (e == hipSuccess) e = kp.reserve((size_t)n * sizeof(float4));
+    if (e == hipSuccess) e = hipMemcpy2D(img.p, ipitch, h_image, pitch, cols, rows, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(kp.p, k.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice);
+    int rc = EFX_OK;
+    if (e == hipSuccess) rc = efx_ic_angles_async(static_cast<const uint8_t*>(img.p), rows, cols, ipitch, static_cast<float*>(kp.p), n, patch_size, nullptr);
+    if (e == hipSuccess && rc == EFX_OK) e = hipMemcpy(k.data(), kp.p, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost);
+    img.release(); kp.release();
+    if (rc) return rc;
+    if (e != hipSuccess) return set_err(g_create_error, EFX_ERR_HIP, "efx_ic_angles failed: %s", hipGetErrorString(e));
+    for (int i = 0; i < n; i++) keypoints[i].angle = k[i].w;
+    return EFX_OK;
+}
+
+// saveDescriptors, samples/hpatches_description.cpp:76-105: one line per descriptor, bits MSB first, comma separated
+long efx_descriptors_to_csv(const uint8_t* h_descriptors, int n, int nbytes, size_t desc_pitch, char* out, size_t out_capacity)
+{
+    if (n < 0 || nbytes <= 0 || (n > 0 && !h_descriptors) || desc_pitch < (size_t)nbytes) return -1;
+    const size_t line = (size_t)nbytes * 16;          // 8 x "b," per byte, the last comma replaced by the newline
+    const size_t need = line * (size_t)n;
+    if (!out) return (long)need;
+    if (out_capacity < need) return -1;
+    char* p = out;
+    for (int i = 0; i < n; i++) {
+        const uint8_t* d = h_descriptors + (size_t)i * desc_pitch;
+        for (int j = 0; j < nbytes; j++)
+            for (int k = 7; k >= 0; k--) { *p++ = (char)('0' + ((d[j] >> k) & 1)); *p++ = ','; }
+        p[-1] = '\n';
+    }
+    return (long)need;
+}
+
 // ---- input stage ----
 int efx_cvt_gray_async(const uint8_t* d_src, int rows, int cols, size_t src_pitch, int channels,
                        uint8_t* d_gray, size_t gray_pitch, void* stream)

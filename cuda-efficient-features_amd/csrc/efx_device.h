@@ -227,6 +227,9 @@ hipError_t efx_launch_copy2d(const uint8_t* src, size_t spitch, uint8_t* dst, si
 
 void efx_gaussian_taps_host(float taps[7]);
 
+// ICAngles of samples/hpatches_description.cpp:128-162 on n x {x, y, size, angle} keypoints (input_kernels.hip)
+hipError_t efx_launch_ic_angles(const uint8_t* img, size_t pitch, int rows, int cols, float4* kp4, int n, int patch_size, hipStream_t stream);
+
 // BGR / BGRA -> gray (input_kernels.hip, spec S11)
 hipError_t efx_launch_cvt_gray(const uint8_t* src, size_t spitch, int rows, int cols, int channels, uint8_t* dst, size_t dpitch,
                                hipStream_t stream);

@@ -269,6 +269,18 @@ int efx_describer_compute_color(efx_describer* d, const uint8_t* h_image, int ro
                                 const efx_keypoint* keypoints, int n, uint8_t* h_descriptors, size_t desc_pitch);
 
 /* ------------------------------------------------------------------------------------------------ */
+/* HPatches exporter helpers: samples/hpatches_description.cpp                     */
+
+/* ICAngles (hpatches_description.cpp:128-162): intensity-centroid angle of the circular patch of `patch_size` pixels
+ * around (floor(x), floor(y)) of every keypoint, cv::fastAtan2 of the integer moments, degrees in [0, 360).  d_kp4 is
+ * n x {x, y, size, angle} floats on the device; only `angle` is written.  Pixels outside the image count as 0. */
+int efx_ic_angles_async(const uint8_t* d_image, int rows, int cols, size_t pitch, float* d_kp4, int n, int patch_size, void* stream);
+int efx_ic_angles(const uint8_t* h_image, int rows, int cols, size_t pitch, efx_keypoint* keypoints, int n, int patch_size);
+/* saveDescriptors (hpatches_description.cpp:76-105): n descriptors -> text, one line each, bits MSB first separated by
+ * commas.  Returns the number of characters (n * nbytes * 16); out == NULL only sizes; -1 on bad arguments. */
+long efx_descriptors_to_csv(const uint8_t* h_descriptors, int n, int nbytes, size_t desc_pitch, char* out, size_t out_capacity);
+
+/* ------------------------------------------------------------------------------------------------ */
 /* introspection used by the parity tests (no reference equivalent)                                  */
 
 /* Per-launch timing of the pipeline's kernels with HIP events on the caller's stream: efx_profile_enable

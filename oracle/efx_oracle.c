@@ -919,3 +919,74 @@ int efxo_compute_provided(const uint8_t* img, int rows, int cols, int stride, co
     free(prev);
     return 0;
 }
+
+/* ---- HPatches exporter helpers (samples/hpatches_description.cpp) ---- */
+
+/* calcUMax, hpatches_description.cpp:107-126: end of each row of a circular patch.  umax must hold patch_size/2 + 2 ints. */
+void efxo_calc_umax(int patch_size, int* umax)
+{
+    const int half = patch_size / 2;
+    int v, v0;
+    const int vmax = (int)floor((double)((float)half * sqrtf(2.f) / 2 + 1));
+    const int vmin = (int)ceil((double)((float)half * sqrtf(2.f) / 2));
+    for (v = 0; v < half + 2; v++) umax[v] = 0;
+    for (v = 0; v <= vmax; ++v) umax[v] = cv_round_d(sqrt((double)half * half - (double)v * v));
+    for (v = half, v0 = 0; v >= vmin; --v) {
+        while (umax[v0] == umax[v0 + 1]) ++v0;
+        umax[v] = v0;
+        ++v0;
+    }
+}
+
+/* cv::fastAtan2 (OpenCV >= 4.6, modules/core/src/mathfuncs_core.simd.hpp, third-party: restated from its published
+ * source): 7th-order odd polynomial in min/max, degrees in [0, 360). */
+float efxo_fast_atan2(float y, float x)
+{
+    const float scale = (float)(180.0 / 3.14159265358979323846);
+    const float p1 = 0.9997878412794807f * scale, p3 = -0.3258083974640975f * scale;
+    const float p5 = 0.1555786518463281f * scale, p7 = -0.04432655554792128f * scale;
+    const float eps = (float)2.2204460492503131e-16;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + eps);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + eps);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+/* ICAngles, hpatches_description.cpp:128-162: intensity-centroid angle of a circular patch of `patch_size` around
+ * (floor(x), floor(y)), cv::fastAtan2 of the integer moments.  Pixels outside the image count as 0 (the sample reads
+ * out of bounds there).  kp4: n x {x, y, size, angle}; only the angle is written. */
+void efxo_ic_angles(const uint8_t* img, int rows, int cols, int stride, float* kp4, int n, int patch_size)
+{
+    const int half = patch_size / 2;
+    int* umax = (int*)malloc(sizeof(int) * (size_t)(half + 2));
+    efxo_calc_umax(patch_size, umax);
+    for (int i = 0; i < n; i++) {
+        const int cx = (int)floorf(kp4[4 * i]), cy = (int)floorf(kp4[4 * i + 1]);
+        int m01 = 0, m10 = 0;
+#define PX(xx, yy) (((xx) >= 0 && (xx) < cols && (yy) >= 0 && (yy) < rows) ? (int)img[(size_t)(yy) * stride + (xx)] : 0)
+        for (int u = -half; u <= half; ++u) m10 += u * PX(cx + u, cy);
+        for (int v = 1; v <= half; ++v) {
+            int v_sum = 0;
+            const int d = umax[v];
+            for (int u = -d; u <= d; ++u) {
+                const int val_plus = PX(cx + u, cy + v), val_minus = PX(cx + u, cy - v);
+                v_sum += (val_plus - val_minus);
+                m10 += u * (val_plus + val_minus);
+            }
+            m01 += v * v_sum;
+        }
+#undef PX
+        kp4[4 * i + 3] = efxo_fast_atan2((float)m01, (float)m10);
+    }
+    free(umax);
+}

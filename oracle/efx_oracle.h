@@ -142,6 +142,11 @@ int efxo_detect_and_compute_masked(const uint8_t* img, int rows, int cols, int s
 int efxo_compute_provided(const uint8_t* img, int rows, int cols, int stride, const efxo_params* p, int desc_type,
                           const void* params_a, const void* params_b, const float* kps, int capacity, int n, uint8_t* desc_out);
 
+/* HPatches exporter helpers (samples/hpatches_description.cpp:107-162) */
+void efxo_calc_umax(int patch_size, int* umax);
+float efxo_fast_atan2(float y, float x);
+void efxo_ic_angles(const uint8_t* img, int rows, int cols, int stride, float* kp4, int n, int patch_size);
+
 /* spec S11: BGR / BGRA -> gray (cv::cvtColor 8-bit fixed point) */
 void efxo_bgr2gray(const uint8_t* src, int rows, int cols, int sstride, int channels, uint8_t* dst, int dstride);
 

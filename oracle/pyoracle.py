@@ -124,6 +124,26 @@ def hashsift_compute(img, kps, nbits, crop_scale=1.0):
     return hashsift_project(resp, nbits)[1]
 
 
+def calc_umax(patch_size):
+    u = (C.c_int * (patch_size // 2 + 2))()
+    lib().efxo_calc_umax(int(patch_size), u)
+    return list(u)
+
+
+def fast_atan2(y, x):
+    lib().efxo_fast_atan2.restype = C.c_float
+    lib().efxo_fast_atan2.argtypes = [C.c_float, C.c_float]
+    return np.float32(lib().efxo_fast_atan2(float(y), float(x)))
+
+
+def ic_angles(img, kp4, patch_size):
+    """ICAngles of hpatches_description.cpp:128-162; returns a copy of kp4 with the angle column filled."""
+    img = _u8(img)
+    k = np.ascontiguousarray(kp4, dtype=np.float32).copy()
+    lib().efxo_ic_angles(_p(img), img.shape[0], img.shape[1], img.strides[0], _p(k), len(k), int(patch_size))
+    return k
+
+
 def bgr2gray(img):
     """H x W x 3|4 uint8 -> H x W uint8 (spec S11)."""
     img = np.ascontiguousarray(img, dtype=np.uint8)
