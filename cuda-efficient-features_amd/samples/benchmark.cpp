@@ -29,7 +29,7 @@ static std::vector<uint8_t> synth(int w, int h, uint32_t seed)
 {
     std::vector<uint8_t> img((size_t)w * h, 128);
     auto rnd = [&seed]() { seed = seed * 1664525u + 1013904223u; return seed >> 8; };
-    const int nshapes = (int)(800.0 * w * h / 1e6);
+    const int nshapes = (int)(700.0 * w * h / 1e6);   // every level above its quota, FAST corners below the 10 % cap
     for (int i = 0; i < nshapes; i++) {
         const int sc[5] = { 10, 18, 32, 56, 96 };
         const int s = sc[rnd() % 5];
