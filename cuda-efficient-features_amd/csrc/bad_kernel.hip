@@ -12,23 +12,13 @@
 // global one; the float expressions are evaluated exactly as in bad.cpp (compile with -ffp-contract=off).
 
 #include "efx_device.h"
+#include "blur_window.h"
 
 namespace {
-
-__device__ __forceinline__ int reflect101(int p, int len)
-{
-    if (len == 1) return 0;
-    while (p < 0 || p >= len) {
-        if (p < 0) p = -p;
-        else p = 2 * (len - 1) - p;
-    }
-    return p;
-}
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 struct __attribute__((aligned(16))) Affine { float m00, m01, m02, m10, m11, m12, s, pad; };
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // rectifyBoxes, bad.cpp:115-147: the patch -> image affine map of every keypoint, one lane per keypoint (the double
 // cos/sin of bad.cpp:138-139 is ~400 instructions: far too long to run on one lane of a per-keypoint workgroup)
@@ -99,8 +89,7 @@ __global__ __launch_bounds__(256) void bad_kernel(
 
     int* I = reinterpret_cast<int*>(smem);                       // (S+1) x (S+1)
     const int IP = S + 1;
-    const int G = (S + 7) >> 3, HP = G * 8;
-    const int RP = S + 6;                                        // raw rows / valid raw columns
+    const int RP = S + 6;                                        // raw rows / valid raw columns (blur_window.h)
     const int RPB = ((S + 12 + 3) >> 2) << 2;                    // raw row pitch in bytes
     uint8_t* raw = smem;                                         // aliases I (dead before I is written)
     size_t ibytes = (size_t)IP * IP * 4;
@@ -109,94 +98,14 @@ __global__ __launch_bounds__(256) void bad_kernel(
 
     if (fits) {
         if (BLUR) {
-            // ---- raw window with a 3-px apron -> LDS.  Interior + 4-byte aligned images: aligned dword loads
-            //      (row start rounded down to 4, byte offset `off` kept); otherwise bytes with REFLECT_101.
-            const bool interior = (wx0 - 3 >= 0) && (wx0 + S + 3 <= cols) && (wy0 - 3 >= 0) && (wy0 + S + 3 <= rows);
-            const bool fastld = interior && ((((uintptr_t)img) | (uintptr_t)pitch) & 3u) == 0;
-            const int off = fastld ? ((wx0 - 3) & 3) : 0;
-            if (fastld) {
-                const int ndw = (off + RP + 3) >> 2;
-                const int sh = ndw <= 16 ? 4 : (ndw <= 32 ? 5 : 6);      // lanes per row: 16 / 32 / 64
-                const int j = tid & ((1 << sh) - 1), r0 = tid >> sh, rstep = 256 >> sh;
-                const uint8_t* base = img + (size_t)(wy0 - 3) * pitch + ((wx0 - 3) & ~3);
-                for (int jj = j; jj < ndw; jj += (1 << sh))
-                    for (int r = r0; r < RP; r += rstep)
-                        *reinterpret_cast<uint32_t*>(raw + r * RPB + 4 * jj) =
-                            *reinterpret_cast<const uint32_t*>(base + (size_t)r * pitch + 4 * jj);
-            } else {
-                for (int r = wid; r < RP; r += 4) {
-                    const int gy = reflect101(wy0 - 3 + r, rows);
-                    const uint8_t* src = img + (size_t)gy * pitch;
-                    for (int c = lane; c < RP; c += 64) raw[r * RPB + c] = src[reflect101(wx0 - 3 + c, cols)];
-                }
-            }
-            __syncthreads();
-            const float tp[7] = { taps0, taps1, taps2, taps3, taps2, taps1, taps0 };
-            // ---- row pass (spec S6): u8 -> float, acc = fma(tap_j, v_j, acc) for j = 0..6.  An item is 8
-            //      consecutive outputs of TWO adjacent rows, so every FMA is a v_pk_fma_f32 on a (row r, row r+1)
-            //      register pair and every raw byte is read from LDS once.  RP = S + 6 is even.
-            {
-                const int nitems = (RP >> 1) * G;
-                for (int it = tid; it < nitems; it += 256) {
-                    const int rp = it / G, g = it - rp * G;
-                    const uint32_t* wa = reinterpret_cast<const uint32_t*>(raw + (2 * rp) * RPB + 8 * g);
-                    const uint32_t* wb = wa + (RPB >> 2);
-                    const uint32_t a0 = wa[0], a1 = wa[1], a2 = wa[2], a3 = wa[3], a4 = wa[4];
-                    const uint32_t c0 = wb[0], c1 = wb[1], c2 = wb[2], c3 = wb[3], c4 = wb[4];
-                    const uint32_t ba[4] = { __builtin_amdgcn_alignbyte(a1, a0, off), __builtin_amdgcn_alignbyte(a2, a1, off),
-                                             __builtin_amdgcn_alignbyte(a3, a2, off), __builtin_amdgcn_alignbyte(a4, a3, off) };
-                    const uint32_t bb[4] = { __builtin_amdgcn_alignbyte(c1, c0, off), __builtin_amdgcn_alignbyte(c2, c1, off),
-                                             __builtin_amdgcn_alignbyte(c3, c2, off), __builtin_amdgcn_alignbyte(c4, c3, off) };
-                    f32x2 v[14];
-#pragma unroll
-                    for (int k = 0; k < 14; k++) {
-                        v[k].x = (float)((ba[k >> 2] >> (8 * (k & 3))) & 0xff);
-                        v[k].y = (float)((bb[k >> 2] >> (8 * (k & 3))) & 0xff);
-                    }
-                    f32x2 o[8];
-#pragma unroll
-                    for (int i = 0; i < 8; i++) {
-                        f32x2 acc = v[i] * tp[0];                        // == fma(tp[0], v, 0) exactly
-#pragma unroll
-                        for (int jt = 1; jt < 7; jt++) acc = __builtin_elementwise_fma(v[i + jt], (f32x2)(tp[jt]), acc);
-                        o[i] = acc;
-                    }
-                    float4* d0 = reinterpret_cast<float4*>(hb + (2 * rp) * HP + 8 * g);
-                    float4* d1 = reinterpret_cast<float4*>(hb + (2 * rp + 1) * HP + 8 * g);
-                    d0[0] = make_float4(o[0].x, o[1].x, o[2].x, o[3].x); d0[1] = make_float4(o[4].x, o[5].x, o[6].x, o[7].x);
-                    d1[0] = make_float4(o[0].y, o[1].y, o[2].y, o[3].y); d1[1] = make_float4(o[4].y, o[5].y, o[6].y, o[7].y);
-                }
-            }
-            __syncthreads();
-            // ---- column pass: float -> u8 (round half even, saturate: v_cvt_pk_u8_f32) -> source of the
-            //      integral.  An item is 8 consecutive rows of TWO adjacent columns (S is even): 14 ds_read_b64,
-            //      56 v_pk_fma_f32.
-            {
-                const int ncp = S >> 1;
-                const int nitems = ncp * G;
-                for (int it = tid; it < nitems; it += 256) {
-                    const int rg = it / ncp, cp = it - rg * ncp;
-                    const int c = 2 * cp;
-                    const bool cin0 = (wx0 + c) < cols, cin1 = (wx0 + c + 1) < cols;
-                    f32x2 v[14];
-#pragma unroll
-                    for (int k = 0; k < 14; k++) v[k] = *reinterpret_cast<const f32x2*>(hb + (8 * rg + k) * HP + c);
-#pragma unroll
-                    for (int i = 0; i < 8; i++) {
-                        const int r = 8 * rg + i;
-                        f32x2 acc = v[i] * tp[0];
-#pragma unroll
-                        for (int jt = 1; jt < 7; jt++) acc = __builtin_elementwise_fma(v[i + jt], (f32x2)(tp[jt]), acc);
-                        const int q0 = (int)__builtin_amdgcn_cvt_pk_u8_f32(acc.x, 0, 0u);
-                        const int q1 = (int)__builtin_amdgcn_cvt_pk_u8_f32(acc.y, 0, 0u);
-                        if (r < S) {
-                            const bool rin = (wy0 + r) < rows;
-                            I[(r + 1) * IP + (c + 1)] = (cin0 && rin) ? q0 : 0;
-                            I[(r + 1) * IP + (c + 2)] = (cin1 && rin) ? q1 : 0;
-                        }
-                    }
-                }
-            }
+            // 7x7 sigma-2 Gaussian of the window (spec S6) on packed fp32 FMAs; the quantised pixels go straight into
+            // the integral's source (zero outside the frame)
+            efx_blur_window_lds<256>(img, pitch, rows, cols, wx0, wy0, S, raw, hb, taps0, taps1, taps2, taps3, tid,
+                [&](int r, int c, int q0, int q1) {
+                    const bool rin = (wy0 + r) < rows;
+                    I[(r + 1) * IP + (c + 1)] = (rin && (wx0 + c) < cols) ? q0 : 0;
+                    I[(r + 1) * IP + (c + 2)] = (rin && (wx0 + c + 1) < cols) ? q1 : 0;
+                });
         } else {
             for (int r = wid; r < S; r += 4) {
                 const int gy = wy0 + r;

@@ -21,6 +21,7 @@
 //     binarize pass as in cuda_hash_sift.cu:414-435).
 
 #include "efx_device.h"
+#include "blur_window.h"
 #include <stdlib.h>
 
 #define HS_KPAD 132   // 129 padded to a multiple of 4 floats
@@ -29,19 +30,9 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ int reflect101(int p, int len)
-{
-    if (len == 1) return 0;
-    while (p < 0 || p >= len) {
-        if (p < 0) p = -p;
-        else p = 2 * (len - 1) - p;
-    }
-    return p;
-}
-
 struct AffineF { float m00, m01, m02, m10, m11, m12, pad0, pad1; };
 
-// LDS plan (dynamic, BLUR only): [ hblur (S+6)*S float | raw (S+6)^2 u8 | win S*S u8 ]
+// LDS plan (dynamic, BLUR only): [ raw | hb | win S*S u8 ] (blur_window.h)
 template <bool BLUR>
 #define HS_NT 384    // 6 waves: one lane per histogram bin (6 x 6 x 10 = 360) in the accumulation phase
 __global__ __launch_bounds__(HS_NT) void patch_sift_kernel(
@@ -114,39 +105,20 @@ __global__ __launch_bounds__(HS_NT) void patch_sift_kernel(
     const int ix = (int)floorf(px), iy = (int)floorf(py);
     const int wx0 = min(max(ix - R, 0), max(cols - S, 0));
     const int wy0 = min(max(iy - R, 0), max(rows - S, 0));
-    float* hb = reinterpret_cast<float*>(smem);
-    uint8_t* raw = reinterpret_cast<uint8_t*>(hb + (S + 6) * S);
-    const int RP = S + 6;
-    uint8_t* win = raw + RP * RP;
+    // LDS plan (BLUR): [ raw | hb | win S x S u8 ], raw / hb as blur_window.h lays them out
+    const BlurGeom bg(S);
+    uint8_t* raw = smem;
+    float* hb = reinterpret_cast<float*>(smem + bg.raw_bytes());
+    uint8_t* win = smem + bg.raw_bytes() + bg.hb_bytes();
 
     if (BLUR && fits) {
-        for (int i = tid; i < RP * RP; i += HS_NT) {
-            const int r = i / RP, c = i % RP;
-            const int gy = reflect101(wy0 - 3 + r, rows), gx = reflect101(wx0 - 3 + c, cols);
-            raw[i] = img[(size_t)gy * pitch + gx];
-        }
-        __syncthreads();
-        const float tp[7] = { taps0, taps1, taps2, taps3, taps2, taps1, taps0 };
-        for (int i = tid; i < RP * S; i += HS_NT) {
-            const int r = i / S, c = i % S;
-            const uint8_t* p = raw + r * RP + c;
-            float acc = 0.f;
-#pragma unroll
-            for (int j = 0; j < 7; j++) acc = __builtin_fmaf(tp[j], (float)p[j], acc);
-            hb[i] = acc;
-        }
-        __syncthreads();
-        for (int i = tid; i < S * S; i += HS_NT) {
-            const int r = i / S, c = i % S;
-            float acc = 0.f;
-#pragma unroll
-            for (int j = 0; j < 7; j++) acc = __builtin_fmaf(tp[j], hb[(r + j) * S + c], acc);
-            float v = rintf(acc);
-            v = v < 0.f ? 0.f : (v > 255.f ? 255.f : v);
-            win[i] = (uint8_t)v;
-        }
+        efx_blur_window_lds<HS_NT>(img, pitch, rows, cols, wx0, wy0, S, raw, hb, taps0, taps1, taps2, taps3, tid,
+            [&](int r, int c, int q0, int q1) {
+                *reinterpret_cast<uint16_t*>(win + r * S + c) = (uint16_t)(q0 | (q1 << 8));      // S and c are even
+            });
     }
     __syncthreads();
+    if (dbg == 5) return;
 
     // warpAffineLinear, hash_sift.cpp:68-109
     {
@@ -184,8 +156,14 @@ __global__ __launch_bounds__(HS_NT) void patch_sift_kernel(
     // gradients, magnitude, orientation of the 30x30 interior (hash_sift.cpp:244-260) and the trilinear vote
     // (distribute, hash_sift.cpp:193-198, 262-290): a lane per pixel, 8 fixed-point atomic adds
     {
-        for (int i = tid; i < 900; i += HS_NT) {
-            const int y = i / 30, x = i % 30;           // patch pixel (x+1, y+1)
+        // Lane -> pixel mapping: neighbouring lanes take pixels of DIFFERENT 8x8 cells (16 cells, then the next pixel
+        // of each cell), so the atomics of one wave instruction spread over many histogram bins; smooth (blurred)
+        // patches, where neighbouring pixels vote for the same bins, otherwise serialise on a few LDS addresses.
+        for (int j = tid; j < 1024; j += HS_NT) {
+            const int cell = j & 15, w = j >> 4;
+            const int x = 8 * (cell & 3) + (w & 7), y = 8 * (cell >> 2) + (w >> 3);           // patch pixel (x+1, y+1)
+            if (x >= 30 || y >= 30) continue;
+            const int i = y * 30 + x;
             const uint8_t* pc = s_patch + (y + 1) * 32 + (x + 1);
             const int idx = (int)pc[1] - (int)pc[-1], idy = (int)pc[-32] - (int)pc[32];
             const float dx = (float)idx, dy = (float)idy;
@@ -327,7 +305,8 @@ hipError_t efx_launch_hashsift(const DescribeLaunch& a, const HashSiftDev& h, hi
     const int S = hs_smax_for(max_size, a.scale_factor);
     size_t lds = 0;
     if (a.blur) {
-        lds = (size_t)(S + 6) * S * 4 + (size_t)(S + 6) * (S + 6) + (size_t)S * S;
+        const BlurGeom bg(S);
+        lds = bg.raw_bytes() + bg.hb_bytes() + (size_t)S * S;
         lds = (lds + 15) & ~(size_t)15;
         if (lds > 140 * 1024) return hipErrorInvalidValue;
     }
