@@ -257,7 +257,11 @@ static void hs_normalize(float* d, int n)
 }
 
 /* computePatchSIFT, hash_sift.cpp:200-331 (STEP1_PYRAMID is false: no patch blur) */
-static void hs_patch_sift(const uint8_t* patch, float* desc /*128*/, float kp_scale)
+/* fixed_point != 0: the histogram is summed as the HIP kernel does it (hashsift_kernels.hip): every vote is converted
+ * to 32.32 fixed point and added as an integer (order independent), the bin is converted back to float at the end.
+ * This is a CPU MODEL OF THE DEVICE ARITHMETIC used to (a) check the kernel bit for bit and (b) quantify how far that
+ * arithmetic is from the reference's sequentially rounded float sums (fixed_point == 0). */
+static void hs_patch_sift(const uint8_t* patch, float* desc /*128*/, float kp_scale, int fixed_point)
 {
     const int h = 32, w = 32, dh = h - 2, dw = w - 2;
     const float kp_radius = kp_scale * (float)h * 0.5f;
@@ -267,7 +271,12 @@ static void hs_patch_sift(const uint8_t* patch, float* desc /*128*/, float kp_sc
     const float cy = 0.5f * (float)dh;
 
     float hist[HS_R_BINS + 2][HS_C_BINS + 2][HS_ORI_BINS + 2];
+    uint64_t h64[HS_R_BINS + 2][HS_C_BINS + 2][HS_ORI_BINS + 2];
     memset(hist, 0, sizeof(hist));
+    memset(h64, 0, sizeof(h64));
+#define HS_VOTE(R, Cc, O, V) do { if (fixed_point) { const float v_ = (V); const uint32_t hi_ = (uint32_t)v_; \
+        const uint32_t lo_ = (uint32_t)((v_ - (float)hi_) * 4294967296.f); h64[R][Cc][O] += ((uint64_t)hi_ << 32) | lo_; } \
+        else hist[R][Cc][O] += (V); } while (0)
 
     /* HistBin, hash_sift.cpp:162-184 */
     const float cellh = HS_SCL_FCTR * (kp_scale * (float)h * 0.5f);
@@ -309,16 +318,21 @@ static void hs_patch_sift(const uint8_t* patch, float* desc /*128*/, float kp_sc
             const float v101 = of * v10, v100 = v10 - v101;
             const float v111 = of * v11, v110 = v11 - v111;
 
-            hist[ri + 1][ci + 1][oi + 0] += v000;
-            hist[ri + 1][ci + 1][oi + 1] += v001;
-            hist[ri + 1][ci + 2][oi + 0] += v010;
-            hist[ri + 1][ci + 2][oi + 1] += v011;
-            hist[ri + 2][ci + 1][oi + 0] += v100;
-            hist[ri + 2][ci + 1][oi + 1] += v101;
-            hist[ri + 2][ci + 2][oi + 0] += v110;
-            hist[ri + 2][ci + 2][oi + 1] += v111;
+            HS_VOTE(ri + 1, ci + 1, oi + 0, v000);
+            HS_VOTE(ri + 1, ci + 1, oi + 1, v001);
+            HS_VOTE(ri + 1, ci + 2, oi + 0, v010);
+            HS_VOTE(ri + 1, ci + 2, oi + 1, v011);
+            HS_VOTE(ri + 2, ci + 1, oi + 0, v100);
+            HS_VOTE(ri + 2, ci + 1, oi + 1, v101);
+            HS_VOTE(ri + 2, ci + 2, oi + 0, v110);
+            HS_VOTE(ri + 2, ci + 2, oi + 1, v111);
         }
     }
+#undef HS_VOTE
+    if (fixed_point)
+        for (int r = 0; r < HS_R_BINS + 2; r++)
+            for (int c = 0; c < HS_C_BINS + 2; c++)
+                for (int o = 0; o < HS_ORI_BINS + 2; o++) hist[r][c][o] = (float)((double)h64[r][c][o] * (1.0 / 4294967296.0));
     /* circular orientation fold + copy, hash_sift.cpp:293-308 */
     for (int r = 0; r < HS_R_BINS; r++)
         for (int c = 0; c < HS_C_BINS; c++) {
@@ -343,7 +357,21 @@ void efxo_hashsift_responses(const uint8_t* img, int rows, int cols, int stride,
         float* r = responses + (size_t)i * 129;
         r[0] = 1;
         efxo_hashsift_patch(img, rows, cols, stride, kps + 4 * i, crop_scale, patch);
-        hs_patch_sift(patch, r + 1, kp_scale);
+        hs_patch_sift(patch, r + 1, kp_scale, 0);
+    }
+}
+
+/* the same with the device's fixed-point histogram sums (see hs_patch_sift) */
+void efxo_hashsift_responses_fixedpoint(const uint8_t* img, int rows, int cols, int stride,
+                                        const float* kps, int n, float crop_scale, float* responses)
+{
+    const float kp_scale = 1.f / 6;
+    uint8_t patch[32 * 32];
+    for (int i = 0; i < n; i++) {
+        float* r = responses + (size_t)i * 129;
+        r[0] = 1;
+        efxo_hashsift_patch(img, rows, cols, stride, kps + 4 * i, crop_scale, patch);
+        hs_patch_sift(patch, r + 1, kp_scale, 1);
     }
 }
 

@@ -110,6 +110,15 @@ def hashsift_responses(img, kps, crop_scale=1.0):
     return resp
 
 
+def hashsift_responses_fixedpoint(img, kps, crop_scale=1.0):
+    img = _u8(img)
+    kps = np.ascontiguousarray(kps, dtype=np.float32).reshape(-1, 4)
+    resp = np.zeros((kps.shape[0], 129), dtype=np.float32)
+    lib().efxo_hashsift_responses_fixedpoint(_p(img), img.shape[0], img.shape[1], img.strides[0], _p(kps), kps.shape[0],
+                                  C.c_float(crop_scale), _p(resp))
+    return resp
+
+
 def hashsift_project(resp, nbits):
     resp = np.ascontiguousarray(resp, dtype=np.float32).reshape(-1, 129)
     W = load_hashsift_weights(nbits)

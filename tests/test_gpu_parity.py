@@ -236,6 +236,19 @@ def test_hashsift_compute_tolerance(cef, torch_mod, oracle, nbits):
     assert np.array_equal(bits, T > 0)
 
 
+def test_hashsift_vectors_equal_fixed_point_model_bit_exact(cef, torch_mod, oracle):
+    """The kernel against the CPU model of ITS OWN arithmetic (fixed-point histogram sums): every 129-vector element
+    must match, except where cosf/sinf of the keypoint angle (rounded double results on the device) move a patch pixel."""
+    img = synth.synth_frame(480, 640, seed=4)
+    kps = synth.random_keypoints(480, 640, 4000, seed=23)
+    hs = cef.HashSIFT.create(1.0, cef.HashSIFT.SIZE_256_BITS)
+    resp, _ = hs.debug(_dev(torch_mod, img), _dev(torch_mod, kps), max_size=31.0)
+    torch_mod.cuda.synchronize()
+    want = oracle.hashsift_responses_fixedpoint(img, kps)
+    rows_off = np.nonzero((resp.cpu().numpy() != want).any(axis=1))[0]
+    assert rows_off.size <= 1, f"{rows_off.size} of 4000 vectors differ from the fixed-point model: {rows_off[:8]}"
+
+
 @pytest.mark.parametrize("desc_type", [2, 3])
 def test_detect_and_compute_hashsift(cef, torch_mod, oracle, desc_type):
     img = synth.synth_frame(480, 640, seed=1002)
