@@ -93,18 +93,30 @@ public:
         check(efx_compute(ctx_, image.data, image.rows, image.cols, image.step, keypoints.data(), (int)keypoints.size(),
                           descriptors.data(), (size_t)descriptorSize()));
     }
-    void detectAndCompute(const HostImage& image, std::vector<KeyPoint>& keypoints, std::vector<uint8_t>& descriptors,
-                          bool useProvidedKeypoints = false)
+    // Feature2D::detectAndCompute(image, mask, keypoints, descriptors, useProvidedKeypoints).  The reference ignores the
+    // mask and asserts !useProvidedKeypoints (.cpp:225-229); here both work.  mask.data == nullptr: none.
+    void detectAndCompute(const HostImage& image, const HostImage& mask, std::vector<KeyPoint>& keypoints,
+                          std::vector<uint8_t>& descriptors, bool useProvidedKeypoints = false)
     {
-        if (useProvidedKeypoints) throw Exception(EFX_ERR_BAD_ARG, "useProvidedKeypoints is not supported");   // .cpp:229
+        int n = (int)keypoints.size();
+        if (useProvidedKeypoints) {
+            descriptors.assign(keypoints.size() * (size_t)descriptorSize(), 0);
+            check(efx_detect_and_compute_ex(ctx_, image.data, image.rows, image.cols, image.step, nullptr, 0, keypoints.data(),
+                                            descriptors.data(), (size_t)descriptorSize(), n, &n, 1));
+            return;
+        }
         const int cap = getMaxFeatures();
         keypoints.resize((size_t)(cap > 0 ? cap : 1));
         descriptors.assign(keypoints.size() * (size_t)descriptorSize(), 0);
-        int n = 0;
-        check(efx_detect_and_compute(ctx_, image.data, image.rows, image.cols, image.step, keypoints.data(),
-                                     descriptors.data(), (size_t)descriptorSize(), cap, &n));
+        check(efx_detect_and_compute_ex(ctx_, image.data, image.rows, image.cols, image.step, mask.data, mask.step, keypoints.data(),
+                                        descriptors.data(), (size_t)descriptorSize(), cap, &n, 0));
         keypoints.resize((size_t)n);
         descriptors.resize((size_t)n * descriptorSize());
+    }
+    void detectAndCompute(const HostImage& image, std::vector<KeyPoint>& keypoints, std::vector<uint8_t>& descriptors,
+                          bool useProvidedKeypoints = false)
+    {
+        detectAndCompute(image, HostImage{ nullptr, 0, 0, 0 }, keypoints, descriptors, useProvidedKeypoints);
     }
 
     // ---- asynchronous, device images.  `keypoints` becomes a 5 x nfeatures float matrix (capacity, not exact N:
@@ -116,15 +128,28 @@ public:
         check(efx_detect_async(ctx_, image.data, image.rows, image.cols, image.step, keypoints.data(), keypoints.step, cap,
                                countPtr(), stream));
     }
-    void detectAndComputeAsync(const DeviceImage& image, DeviceMatrix& keypoints, DeviceMatrix& descriptors,
-                               bool useProvidedKeypoints = false, hipStream_t stream = nullptr)
+    // detectAndComputeAsync(image, mask, keypoints, descriptors, useProvidedKeypoints, stream), cuda_efficient_features.h:66-73.
+    // useProvidedKeypoints: the first nProvided columns of `keypoints` are described (spec S13), nothing is detected.
+    void detectAndComputeAsync(const DeviceImage& image, const DeviceImage& mask, DeviceMatrix& keypoints, DeviceMatrix& descriptors,
+                               bool useProvidedKeypoints = false, hipStream_t stream = nullptr, int nProvided = 0)
     {
-        if (useProvidedKeypoints) throw Exception(EFX_ERR_BAD_ARG, "useProvidedKeypoints is not supported");
+        if (useProvidedKeypoints) {
+            descriptors.create(nProvided > 0 ? nProvided : 1, descriptorSize(), 1);
+            check(efx_compute_provided_async(ctx_, image.data, image.rows, image.cols, image.step, keypoints.data(), keypoints.step,
+                                             nProvided, static_cast<uint8_t*>(descriptors.data()), descriptors.step, stream));
+            return;
+        }
         const int cap = getMaxFeatures();
         keypoints.create(ROWS_COUNT, cap > 0 ? cap : 1, 4);
         descriptors.create(cap > 0 ? cap : 1, descriptorSize(), 1);
-        check(efx_detect_and_compute_async(ctx_, image.data, image.rows, image.cols, image.step, keypoints.data(), keypoints.step,
-                                           static_cast<uint8_t*>(descriptors.data()), descriptors.step, cap, countPtr(), stream));
+        check(efx_detect_and_compute_masked_async(ctx_, image.data, image.rows, image.cols, image.step, mask.data, mask.step,
+                                                  keypoints.data(), keypoints.step, static_cast<uint8_t*>(descriptors.data()),
+                                                  descriptors.step, cap, countPtr(), stream));
+    }
+    void detectAndComputeAsync(const DeviceImage& image, DeviceMatrix& keypoints, DeviceMatrix& descriptors,
+                               bool useProvidedKeypoints = false, hipStream_t stream = nullptr, int nProvided = 0)
+    {
+        detectAndComputeAsync(image, DeviceImage{ nullptr, 0, 0, 0 }, keypoints, descriptors, useProvidedKeypoints, stream, nProvided);
     }
     // keypoints: 5 x n matrix in the detector's layout (size forced to 31: cuda_efficient_features.cu:260)
     void computeAsync(const DeviceImage& image, const DeviceMatrix& keypoints, int n, DeviceMatrix& descriptors, hipStream_t stream = nullptr)
@@ -224,6 +249,79 @@ public:
     }
 private:
     explicit HashSIFT(efx_describer* d) : EfficientDescriptorsAsync(d) {}
+};
+
+
+// cv::BFMatcher(NORM_HAMMING) as the samples use it (sample_feature_matching.cpp:99-101, sample_image_sequence.cpp:81)
+struct DMatch { int queryIdx, trainIdx, distance; };
+class BFMatcher {
+public:
+    explicit BFMatcher(bool crossCheck = false) : cross_(crossCheck)
+    {
+        if (efx_matcher_create(&m_) != EFX_OK) throw Exception(EFX_ERR_HIP, efx_matcher_last_error(nullptr));
+    }
+    ~BFMatcher() { efx_matcher_destroy(m_); }
+    BFMatcher(const BFMatcher&) = delete;
+    // device descriptors in, host matches out (one stream synchronisation)
+    void knnMatch(const DeviceMatrix& query, int nq, const DeviceMatrix& train, int nt, int descBytes,
+                  std::vector<std::vector<DMatch>>& matches, hipStream_t stream = nullptr)
+    {
+        idx_.create(1, 2 * (nq > 0 ? nq : 1), 4); dist_.create(1, 2 * (nq > 0 ? nq : 1), 4);      // tight nq x 2 ints
+        check(efx_match_knn2_async(m_, static_cast<const uint8_t*>(query.data()), query.step, nq, static_cast<const uint8_t*>(train.data()),
+                                   train.step, nt, descBytes, static_cast<int*>(idx_.data()), static_cast<int*>(dist_.data()), stream));
+        std::vector<int> hi((size_t)nq * 2), hd((size_t)nq * 2);
+        if (hipStreamSynchronize(stream) != hipSuccess ||
+            hipMemcpy(hi.data(), idx_.data(), hi.size() * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(hd.data(), dist_.data(), hd.size() * 4, hipMemcpyDeviceToHost) != hipSuccess)
+            throw Exception(EFX_ERR_HIP, "download failed");
+        matches.assign((size_t)nq, {});
+        for (int i = 0; i < nq; i++)
+            for (int k = 0; k < 2; k++)
+                if (hi[2 * i + k] >= 0) matches[i].push_back(DMatch{ i, hi[2 * i + k], hd[2 * i + k] });
+    }
+    void match(const DeviceMatrix& query, int nq, const DeviceMatrix& train, int nt, int descBytes, std::vector<DMatch>& matches,
+               hipStream_t stream = nullptr)
+    {
+        matches.clear();
+        if (!cross_) {
+            std::vector<std::vector<DMatch>> knn;
+            knnMatch(query, nq, train, nt, descBytes, knn, stream);
+            for (auto& v : knn) if (!v.empty()) matches.push_back(v[0]);
+            return;
+        }
+        idx_.create(1, nq > 0 ? nq : 1, 4); dist_.create(1, nq > 0 ? nq : 1, 4);
+        check(efx_match_crosscheck_async(m_, static_cast<const uint8_t*>(query.data()), query.step, nq, static_cast<const uint8_t*>(train.data()),
+                                         train.step, nt, descBytes, static_cast<int*>(idx_.data()), static_cast<int*>(dist_.data()), stream));
+        std::vector<int> hi((size_t)nq), hd((size_t)nq);
+        if (hipStreamSynchronize(stream) != hipSuccess ||
+            hipMemcpy(hi.data(), idx_.data(), hi.size() * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(hd.data(), dist_.data(), hd.size() * 4, hipMemcpyDeviceToHost) != hipSuccess)
+            throw Exception(EFX_ERR_HIP, "download failed");
+        for (int i = 0; i < nq; i++) if (hi[i] >= 0) matches.push_back(DMatch{ i, hi[i], hd[i] });
+    }
+private:
+    void check(int rc) const { if (rc != EFX_OK) throw Exception(rc, efx_matcher_last_error(m_)); }
+    efx_matcher* m_ = nullptr;
+    bool cross_;
+    DeviceMatrix idx_, dist_;
+};
+
+// getInputMat's upload as a double-buffered stage (cuda_efficient_features.cpp:71-84): host frame (1, 3 or 4 channels)
+// -> device gray frame ordered on `stream`; upload k+1 overlaps the work enqueued for frame k.
+class Uploader {
+public:
+    Uploader() { if (efx_uploader_create(&u_) != EFX_OK) throw Exception(EFX_ERR_HIP, efx_uploader_last_error(nullptr)); }
+    ~Uploader() { efx_uploader_destroy(u_); }
+    Uploader(const Uploader&) = delete;
+    DeviceImage upload(const uint8_t* data, int rows, int cols, size_t step, int channels, hipStream_t stream = nullptr)
+    {
+        const uint8_t* d = nullptr; size_t pitch = 0;
+        const int rc = efx_upload_gray_async(u_, data, rows, cols, step, channels, &d, &pitch, stream);
+        if (rc != EFX_OK) throw Exception(rc, efx_uploader_last_error(u_));
+        return DeviceImage{ d, rows, cols, pitch };
+    }
+private:
+    efx_uploader* u_ = nullptr;
 };
 
 } // namespace efx

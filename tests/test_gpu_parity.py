@@ -363,3 +363,14 @@ def test_matcher_on_detected_descriptors(cef, torch_mod):
     dy = ka["y"][ok] - kb["y"][mm[ok]]
     good = (np.abs(dx - 60) <= 1) & (np.abs(dy - 40) <= 1)
     assert ok.sum() > 100 and good.mean() > 0.8
+
+
+def test_cpp_facade_program(cef):
+    """The C++ facade (host/efficient_features.hpp) exercised by samples/facade_check.cpp: detectAndCompute, the
+    useProvidedKeypoints round trip, mask, uploader + colour conversion, cross-check and knn matcher."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cuda-efficient-features_amd", "efx_facade_check")
+    assert os.path.exists(exe), "build it with make -C cuda-efficient-features_amd/csrc"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "facade ok" in r.stdout, r.stdout + r.stderr
