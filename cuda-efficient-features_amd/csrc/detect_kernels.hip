@@ -79,6 +79,37 @@ __device__ __forceinline__ bool fast9_lds(const uint8_t* c, int t)
     return ((br | dk) & 0xffffu) != 0;
 }
 
+// The same test for a pixel that already passed the compass quick test of fast_kernel: the compass points say which
+// polarity can succeed, so only ONE 16-bit ring mask is built (dark pixels are mirrored, x -> 255 - x, so both
+// polarities share one instruction stream); the other polarity is tested in a second pass only for the rare pixels
+// whose compass points allow both.
+template <int P>
+__device__ __forceinline__ bool fast9_survivor_lds(const uint8_t* c, int t)
+{
+    const int p = c[0];
+    const int v[16] = { c[3 * P],    c[3 * P + 1],  c[2 * P + 2],  c[P + 3],
+                        c[3],        c[-P + 3],     c[-2 * P + 2], c[-3 * P + 1],
+                        c[-3 * P],   c[-3 * P - 1], c[-2 * P - 2], c[-P - 3],
+                        c[-3],       c[P - 3],      c[2 * P - 2],  c[3 * P - 1] };
+    const bool bp = min(max(v[0], v[8]), max(v[4], v[12])) > p + t;     // two neighbouring compass points brighter
+    const bool dp = max(min(v[0], v[8]), min(v[4], v[12])) < p - t;     // ... darker
+    auto arc9 = [&](int flip) -> bool {
+        const int ph = (p ^ flip) + t;                                   // flip = 0xff mirrors: v < p - t  <=>  255 - v > 255 - p + t
+        unsigned m = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) m |= (unsigned)((v[k] ^ flip) > ph) << k;
+        m |= m << 16;
+        m &= m >> 1; m &= m >> 2; m &= m >> 4; m &= m >> 1;              // runs of >= 9
+        return (m & 0xffffu) != 0;
+    };
+    bool res = arc9(bp ? 0 : 0xff);
+    const bool again = bp && dp && !res;
+    if (__builtin_amdgcn_ballot_w64(again) != 0ull) {
+        if (again) res = arc9(0xff);
+    }
+    return res;
+}
+
 // Harris response, spec S4 (cuda_efficient_features.cu:99-139): exact int32 sums of the 49 Sobel products,
 // then one fixed, uncontracted float formula.  The 9x9 footprint is pulled as 9 rows x 3 aligned dwords and
 // re-aligned with v_alignbyte (27 LDS reads instead of 81 byte reads); the Sobel sums share the pairwise row /
@@ -265,11 +296,28 @@ __global__ __launch_bounds__(NT) void resize_kernel(
 }
 
 // tile + halo -> LDS: 72 rows x 72 bytes as 9 x 8-byte pieces per row (the global address is only 4-byte
-// aligned: x0 - 4), LDS row pitch 80 B; pixels outside the image read as 0
+// aligned: x0 - 4), LDS row pitch 80 B.
+// 4-byte aligned images go through a raw buffer resource: rows above / below the image fall outside the resource's
+// byte range and read as 0 in hardware, so the loop carries no bounds checks.  Columns left / right of the image wrap
+// into the neighbouring row instead; those halo bytes are never consumed, because every pixel that is tested lies at
+// least 15 px inside the frame (createMask, cuda_efficient_features.cpp:176-182) and the tests reach 3 px.
+typedef unsigned int efx_u32x2 __attribute__((ext_vector_type(2)));
+
 template <int NT>
 __device__ __forceinline__ void load_tile_lds(uint32_t* s_tile, const uint8_t* __restrict__ src, int spitch, int rows, int cols,
                                               bool aligned, int x0, int y0, int tid)
 {
+    if (aligned) {
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src), 0, (rows - 1) * spitch + cols, 0x00020000);
+        const int base = (y0 - EFX_HALO) * spitch + x0 - EFX_HALO;
+        for (int i = tid; i < EFX_LT * 9; i += NT) {
+            const int r = i / 9, c8 = i - r * 9;
+            const efx_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, base + r * spitch + c8 * 8, 0, 0);
+            *reinterpret_cast<efx_u32x2*>(reinterpret_cast<uint8_t*>(s_tile) + r * EFX_LP + c8 * 8) = v;
+        }
+        return;
+    }
+    // byte path (caller's level-0 image with an unaligned base or pitch): zero outside the image
     for (int i = tid; i < EFX_LT * 9; i += NT) {
         const int r = i / 9, c8 = i - r * 9;
         const int gy = y0 - EFX_HALO + r;
@@ -277,15 +325,11 @@ __device__ __forceinline__ void load_tile_lds(uint32_t* s_tile, const uint8_t* _
         uint2 v = make_uint2(0u, 0u);
         if (gy >= 0 && gy < rows) {
             const uint8_t* p = src + (size_t)gy * spitch;
-            if (aligned && gx >= 0 && gx + 8 <= cols) {
-                v = *reinterpret_cast<const uint2*>(p + gx);
-            } else {
 #pragma unroll
-                for (int b = 0; b < 4; b++) {
-                    const int xa = gx + b, xb = gx + 4 + b;
-                    if (xa >= 0 && xa < cols) v.x |= (uint32_t)p[xa] << (8 * b);
-                    if (xb >= 0 && xb < cols) v.y |= (uint32_t)p[xb] << (8 * b);
-                }
+            for (int b = 0; b < 4; b++) {
+                const int xa = gx + b, xb = gx + 4 + b;
+                if (xa >= 0 && xa < cols) v.x |= (uint32_t)p[xa] << (8 * b);
+                if (xb >= 0 && xb < cols) v.y |= (uint32_t)p[xb] << (8 * b);
             }
         }
         *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(s_tile) + r * EFX_LP + c8 * 8) = v;
@@ -407,7 +451,7 @@ __global__ __launch_bounds__(256) void fast_kernel(
         for (int idx = lane; idx < ((dbg & 8) ? 0 : nq); idx += 64) {
             const int e = ql[idx];
             const int lx = e & 0xff, ly = e >> 8;
-            bool corner = fast9_lds<EFX_LP>(tb + (ly + EFX_HALO) * EFX_LP + lx + EFX_HALO, threshold);
+            bool corner = fast9_survivor_lds<EFX_LP>(tb + (ly + EFX_HALO) * EFX_LP + lx + EFX_HALO, threshold);
             if (corner && mask) {
                 // spec S12: the level-0 mask is sampled where the keypoint will be reported (scalePoints, .cu:236-248)
                 const int sx = min((int)(short)(L.scale * (float)(x0 + lx) + 0.5f), T->lv[0].cols - 1);
