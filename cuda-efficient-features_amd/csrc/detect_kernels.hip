@@ -413,23 +413,41 @@ __global__ __launch_bounds__(256) void fast_kernel(
                 if ((gx0 + i) >= EFX_HALF_PATCH && (gx0 + i) < cols - EFX_HALF_PATCH) xm |= 0x1111u << i;
                 if ((gy0 + i) >= EFX_HALF_PATCH && (gy0 + i) < rows - EFX_HALF_PATCH) ym |= 0xfu << (4 * i);
             }
+            // Two pixels per instruction on packed 16-bit lanes (v_perm_b32 widens byte pairs, v_pk_max/min_u16,
+            // saturating v_pk_sub_u16 instead of compares).  Two neighbouring compass points brighter than p+t
+            // <=> min(max(N,S), max(E,W)) > p+t, and the mirrored form for darker.
+            //   C[r][h]: columns (2h, 2h+1) of the block in footprint row r;  E/W: the pixels 3 to the right / left
+            const u16x2 thr2 = { (unsigned short)threshold, (unsigned short)threshold };
+            const u16x2 bias2 = { 0x7fff, 0x7fff };
+            u16x2 C[10][2];
+#pragma unroll
+            for (int r = 0; r < 10; r++) {
+                C[r][0] = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(0u, R[r][1], 0x0c010c00u));
+                C[r][1] = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(0u, R[r][1], 0x0c030c02u));
+            }
+            unsigned acc = 0;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
+                const uint32_t d0 = R[j + 3][0], d1 = R[j + 3][1], d2 = R[j + 3][2];
+                const u16x2 E[2] = { __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(d2, d1, 0x0c040c03u)),      // x+3 of columns 0,1
+                                     __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(d2, d1, 0x0c060c05u)) };    // x+3 of columns 2,3
+                const u16x2 W[2] = { __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(d1, d0, 0x0c020c01u)),      // x-3 of columns 0,1
+                                     __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(d1, d0, 0x0c040c03u)) };    // x-3 of columns 2,3
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const int p = (R[j + 3][1] >> (8 * i)) & 0xff;
-                    const int cn = (R[j][1] >> (8 * i)) & 0xff;                       // (x, y-3)   k = 8
-                    const int cs = (R[j + 6][1] >> (8 * i)) & 0xff;                   // (x, y+3)   k = 0
-                    const int ce = i == 0 ? (int)(R[j + 3][1] >> 24) : (int)((R[j + 3][2] >> (8 * (i - 1))) & 0xff);   // (x+3, y) k = 4
-                    const int cw = i == 3 ? (int)(R[j + 3][1] & 0xff) : (int)((R[j + 3][0] >> (8 * (i + 1))) & 0xff);  // (x-3, y) k = 12
-                    // two neighbouring compass points brighter than p+t  <=>  min(max(N,S), max(E,W)) > p+t,
-                    // and the mirrored form for darker: 6 min/max + 2 compares per pixel
-                    const int bright = min(max(cs, cn), max(ce, cw));
-                    const int dark = max(min(cs, cn), min(ce, cw));
-                    const bool pass = (bright > p + threshold) | (dark < p - threshold);
-                    qm |= (pass ? 1u : 0u) << (j * 4 + i);
+                for (int h = 0; h < 2; h++) {
+                    const u16x2 p2 = C[j + 3][h], cn = C[j][h], cs = C[j + 6][h];
+                    const u16x2 bright = __builtin_elementwise_min(__builtin_elementwise_max(cs, cn), __builtin_elementwise_max(E[h], W[h]));
+                    const u16x2 dark = __builtin_elementwise_max(__builtin_elementwise_min(cs, cn), __builtin_elementwise_min(E[h], W[h]));
+                    // bright > p + t  <=>  sat(bright - (p + t)) != 0;   dark < p - t  <=>  sat(sat(p - t) - dark) != 0
+                    const u16x2 pb = __builtin_elementwise_sub_sat(bright, (u16x2)(p2 + thr2));
+                    const u16x2 pd = __builtin_elementwise_sub_sat(__builtin_elementwise_sub_sat(p2, thr2), dark);
+                    // nonzero (<= 0x1ff) -> 1 without compares: bit 15 of x + 0x7fff
+                    const u16x2 pass = (u16x2)(((u16x2)(pb | pd) + bias2) >> 15);
+                    // even columns land in the low half of acc, odd columns in the high half (same bit position)
+                    acc |= __builtin_bit_cast(uint32_t, pass) << (4 * j + 2 * h);
                 }
             }
+            qm = (acc | (acc >> 15)) & 0xffffu;
             qm &= xm & ym;
             if (dbg & 2) qm = 0;
         }
