@@ -738,20 +738,22 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
             const int bx1 = mx / EFX_CELL, by1 = my / EFX_CELL;
             hard = true;
             if (quick_ok) {
-                if (block_radius == 1) {
-                    // all 9 loads are issued before the first compare (no load-compare-branch chains)
+                if (block_radius == 1 && !capped) {
+                    // the common case as straight-line code: 9 loads, then branch-free compares (this kernel is bound
+                    // by instruction issue, scalar exec-mask bookkeeping included)
                     Corner o[9];
 #pragma unroll
                     for (int q = 0; q < 9; q++) {
                         const int bx = min(max(bx1 - 1 + (q % 3), 0), gw - 1), by = min(max(by1 - 1 + (q / 3), 0), gh - 1);
                         o[q] = cmax[by * gwp + bx];
                     }
+                    int kill = 0;
 #pragma unroll
                     for (int q = 0; q < 9; q++) {
                         const int dx = mx - (int)(o[q].xy & 0xffff), dy = my - (int)(o[q].xy >> 16);
-                        if (o[q].xy != me.xy && me.resp <= o[q].resp && dx * dx + dy * dy < image_radius &&
-                            usable(min(max(bx1 - 1 + (q % 3), 0), gw - 1), min(max(by1 - 1 + (q / 3), 0), gh - 1))) hard = false;
+                        kill |= (int)(o[q].xy != me.xy) & (int)(me.resp <= o[q].resp) & (int)(dx * dx + dy * dy < image_radius);
                     }
+                    hard = kill == 0;
                 } else {
                     const int minx = max(bx1 - block_radius, 0), maxx = min(bx1 + block_radius, gw - 1);
                     const int miny = max(by1 - block_radius, 0), maxy = min(by1 + block_radius, gh - 1);
