@@ -374,3 +374,30 @@ def test_cpp_facade_program(cef):
     assert os.path.exists(exe), "build it with make -C cuda-efficient-features_amd/csrc"
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "facade ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_context_reuse_across_sizes_and_parameters(cef, torch_mod, oracle):
+    """One context, several frames: image size and every parameter change between calls (grow-only scratch buffers and
+    the cached pyramid geometry must follow; setDescriptorType swaps the describer, cuda_efficient_features.cpp:373-377)."""
+    det = cef.EfficientFeatures.create(2000, dtype=cef.EfficientFeatures.BAD_256)
+    steps = [((480, 640), {}),
+             ((1080, 1920), dict(nfeatures=6000)),
+             ((300, 333), dict(nlevels=4, nonmax_radius=7)),
+             ((480, 640), dict(fast_threshold=35, first_level=1, scale_factor=1.35)),
+             ((600, 800), dict(desc_type=1))]
+    kw = dict(nfeatures=2000, scale_factor=1.2, nlevels=8, first_level=0, fast_threshold=20, nonmax_radius=15, desc_type=0)
+    for i, (shape, change) in enumerate(steps):
+        kw.update(change)
+        det.setMaxFeatures(kw["nfeatures"]); det.setScaleFactor(kw["scale_factor"]); det.setNLevels(kw["nlevels"])
+        det.setFirstLevel(kw["first_level"]); det.setFastThreshold(kw["fast_threshold"]); det.setNonmaxRadius(kw["nonmax_radius"])
+        det.setDescriptorType(kw["desc_type"])
+        assert det.getNLevels() == kw["nlevels"] and det.getDescriptorType() == kw["desc_type"]
+        assert det.descriptorSize() == (32 if kw["desc_type"] == 0 else 64)
+        img = synth.synth_frame(shape[0], shape[1], seed=70 + i)
+        kps, desc, cnt = det.detectAndComputeAsync(_dev(torch_mod, img))
+        torch_mod.cuda.synchronize()
+        n = int(cnt.item())
+        ref = oracle.detect_and_compute(img, **kw)
+        assert n == ref["n"], f"step {i}"
+        assert np.array_equal(kps[:, :n].cpu().numpy().view(np.uint32), ref["kps"].view(np.uint32)), f"step {i}"
+        assert np.array_equal(desc[:n].cpu().numpy(), ref["desc"]), f"step {i}"
