@@ -401,3 +401,33 @@ def test_context_reuse_across_sizes_and_parameters(cef, torch_mod, oracle):
         assert n == ref["n"], f"step {i}"
         assert np.array_equal(kps[:, :n].cpu().numpy().view(np.uint32), ref["kps"].view(np.uint32)), f"step {i}"
         assert np.array_equal(desc[:n].cpu().numpy(), ref["desc"]), f"step {i}"
+
+
+def test_two_threads_two_contexts(cef, torch_mod, oracle):
+    """A context is not re-entrant, but contexts are independent (no process-global tables, unlike cuda_bad.cu:49-50):
+    two host threads, each with its own context and stream, BAD256 in one and BAD512 in the other."""
+    import threading
+    imgs = [synth.synth_frame(480, 640, seed=90 + i) for i in range(2)]
+    dts = [cef.EfficientFeatures.BAD_256, cef.EfficientFeatures.BAD_512]
+    out = [None, None]
+
+    def work(i):
+        torch_mod.cuda.set_device(0)
+        det = cef.EfficientFeatures.create(3000, dtype=dts[i])
+        st = torch_mod.cuda.Stream()
+        d_img = _dev(torch_mod, imgs[i])
+        res = []
+        for _ in range(6):
+            kps, desc, cnt = det.detectAndComputeAsync(d_img, stream=st)
+            st.synchronize()
+            n = int(cnt.item())
+            res.append((n, kps[:, :n].cpu().numpy().copy(), desc[:n].cpu().numpy().copy()))
+        out[i] = res
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for i in range(2):
+        ref = oracle.detect_and_compute(imgs[i], nfeatures=3000, desc_type=dts[i])
+        for n, k, d in out[i]:
+            assert n == ref["n"] and np.array_equal(k.view(np.uint32), ref["kps"].view(np.uint32)) and np.array_equal(d, ref["desc"])
