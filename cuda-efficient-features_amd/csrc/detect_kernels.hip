@@ -1001,18 +1001,19 @@ __global__ __launch_bounds__(256) void angle_kernel(const LevelTable* __restrict
                                                     float4* __restrict__ kp4, const int* __restrict__ kp_level,
                                                     uint8_t* __restrict__ kps, size_t kps_pitch)
 {
-    const int lane = threadIdx.x & 63;
-    // neighbouring keypoints (canonical order) on the same XCD: their patches share L2 lines
-    const int kid = xcd_chunked(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
+    // two keypoints per wave (31 of each 32 lanes hold one patch column), 8 per workgroup; neighbouring keypoints
+    // (canonical order) stay on the same XCD: their patches share L2 lines
+    const int lane = threadIdx.x & 31;
+    const int kid = xcd_chunked(blockIdx.x, gridDim.x) * 8 + (threadIdx.x >> 5);
     const int count = min(*d_count, capacity);
-    if (kid >= count) return;
-    const float4 kp = kp4[kid];
-    const int l = kp_level[kid];
+    const bool act = kid < count;
+    const float4 kp = act ? kp4[kid] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int l = act ? kp_level[kid] : 0;
     const uint8_t* img = l == 0 ? img0 : pyramid + T->lv[l].img_off;
     const int pitch = l == 0 ? pitch0 : T->lv[l].pitch;
     const int x = (int)kp.x, y = (int)kp.y;
     int m01 = 0, m10 = 0;
-    if (lane < 31) {
+    if (act && lane < 31) {
         const int dx = lane - EFX_HALF_PATCH;
         const int adx = dx < 0 ? -dx : dx;
         const uint8_t* c = img + (size_t)y * pitch + x + dx;
@@ -1032,11 +1033,16 @@ __global__ __launch_bounds__(256) void angle_kernel(const LevelTable* __restrict
         }
     }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { m10 += __shfl_xor(m10, d, 64); m01 += __shfl_xor(m01, d, 64); }
-    if (lane == 0) {
-        const float angle = atan2_deg(m01, m10);
-        kp4[kid].w = angle;
-        if (kps) *reinterpret_cast<float*>(kps + 2 * kps_pitch + 4 * (size_t)kid) = angle;
+    for (int d = 16; d >= 1; d >>= 1) { m10 += __shfl_xor(m10, d, 64); m01 += __shfl_xor(m01, d, 64); }
+    // the double-precision atan2 (spec S7) is ~100 instructions: the 8 keypoints of the workgroup share one pass of it
+    __shared__ int s_m[8][2];
+    if (lane == 0) { s_m[threadIdx.x >> 5][0] = m01; s_m[threadIdx.x >> 5][1] = m10; }
+    __syncthreads();
+    const int k8 = xcd_chunked(blockIdx.x, gridDim.x) * 8 + threadIdx.x;
+    if (threadIdx.x < 8 && k8 < count) {
+        const float angle = atan2_deg(s_m[threadIdx.x][0], s_m[threadIdx.x][1]);
+        kp4[k8].w = angle;
+        if (kps) *reinterpret_cast<float*>(kps + 2 * kps_pitch + 4 * (size_t)k8) = angle;
     }
 }
 
@@ -1139,7 +1145,7 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
         for (int s = 0; s < H.nlevels; s++) if (H.lv[s].active) nmax += H.lv[s].quota;
         if (nmax > a.capacity) nmax = a.capacity;
         if (nmax > 0)
-            hipLaunchKernelGGL(angle_kernel, dim3((nmax + 3) / 4), dim3(256), 0, stream, a.d_table, a.d_count, a.capacity,
+            hipLaunchKernelGGL(angle_kernel, dim3((nmax + 7) / 8), dim3(256), 0, stream, a.d_table, a.d_count, a.capacity,
                                a.img0, a.pitch0, a.pyramid, a.kp4, a.kp_level, (uint8_t*)a.d_keypoints, a.kps_pitch);
     }
     a.prof.end(prof, 3, stream);
