@@ -7,12 +7,6 @@ import zlib
 import numpy as np
 
 
-def _paeth(a, b, c):
-    p = a.astype(np.int16) + b - c
-    pa, pb, pc = np.abs(p - a), np.abs(p - b), np.abs(p - c)
-    return np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, b, c)).astype(np.uint8)
-
-
 def read(path):
     data = open(path, "rb").read()
     if data[:8] != b"\x89PNG\r\n\x1a\n":
