@@ -33,7 +33,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct AffineF { float m00, m01, m02, m10, m11, m12, pad0, pad1; };
 
 // LDS plan (dynamic, BLUR only): [ raw | hb | win S*S u8 ] (blur_window.h)
-template <bool BLUR>
+// SF != 0: every keypoint is known to need exactly an SF x SF window (detector keypoints: size 31, crop scale 1 ->
+// 50), so the blur's index arithmetic (divisions by the group / column-pair counts) folds to constants
+template <bool BLUR, int SF>
 #define HS_NT 384    // 6 waves: one lane per histogram bin (6 x 6 x 10 = 360) in the accumulation phase
 __global__ __launch_bounds__(HS_NT) void patch_sift_kernel(
     const uint8_t* __restrict__ img0, int pitch0, int rows0, int cols0,
@@ -99,9 +101,9 @@ __global__ __launch_bounds__(HS_NT) void patch_sift_kernel(
     // window the patch can touch
     const float sg = fabsf(crop_scale * size / 32.f);
     int R = (int)floorf(sg * 22.63f + 3.f);
-    int S = 2 * R + 2;
-    const bool fits = !BLUR || (S <= smax && S > 0);
-    if (!fits) S = smax;
+    int S = SF ? SF : 2 * R + 2;
+    const bool fits = !BLUR || (SF ? (2 * R + 2 == SF) : (S <= smax && S > 0));
+    if (!fits && !SF) S = smax;
     const int ix = (int)floorf(px), iy = (int)floorf(py);
     const int wx0 = min(max(ix - R, 0), max(cols - S, 0));
     const int wy0 = min(max(iy - R, 0), max(rows - S, 0));
@@ -316,13 +318,18 @@ hipError_t efx_launch_hashsift(const DescribeLaunch& a, const HashSiftDev& h, hi
     const int dbg = dbge ? atoi(dbge) : 0;
     const float* mag = h.W + (size_t)h.nbits * HS_KPAD;    // the 30x30 weight table is stored behind W
     const float* lut = mag + 900;                          // followed by the 511x511 orientation-bin table
-    if (a.blur) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_sift_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(patch_sift_kernel<true>, dim3(a.n), dim3(HS_NT), lds, stream, a.img0, a.pitch0, a.rows0, a.cols0,
+    if (a.blur && S == 50 && a.uniform_size) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_sift_kernel<true, 50>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((patch_sift_kernel<true, 50>), dim3(a.n), dim3(HS_NT), lds, stream, a.img0, a.pitch0, a.rows0, a.cols0,
+                           a.pyramid, a.d_table, a.kp4, a.kp_level, a.d_count, a.n, a.scale_factor, S, mag, lut,
+                           t[0], t[1], t[2], t[3], h.responses, h.dbg_responses, dbg);
+    } else if (a.blur) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_sift_kernel<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((patch_sift_kernel<true, 0>), dim3(a.n), dim3(HS_NT), lds, stream, a.img0, a.pitch0, a.rows0, a.cols0,
                            a.pyramid, a.d_table, a.kp4, a.kp_level, a.d_count, a.n, a.scale_factor, S, mag, lut,
                            t[0], t[1], t[2], t[3], h.responses, h.dbg_responses, dbg);
     } else {
-        hipLaunchKernelGGL(patch_sift_kernel<false>, dim3(a.n), dim3(HS_NT), 0, stream, a.img0, a.pitch0, a.rows0, a.cols0,
+        hipLaunchKernelGGL((patch_sift_kernel<false, 0>), dim3(a.n), dim3(HS_NT), 0, stream, a.img0, a.pitch0, a.rows0, a.cols0,
                            a.pyramid, a.d_table, a.kp4, a.kp_level, a.d_count, a.n, a.scale_factor, S, mag, lut,
                            t[0], t[1], t[2], t[3], h.responses, h.dbg_responses, dbg);
     }
