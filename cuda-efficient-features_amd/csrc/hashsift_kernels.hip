@@ -36,7 +36,7 @@ struct AffineF { float m00, m01, m02, m10, m11, m12, pad0, pad1; };
 // SF != 0: every keypoint is known to need exactly an SF x SF window (detector keypoints: size 31, crop scale 1 ->
 // 50), so the blur's index arithmetic (divisions by the group / column-pair counts) folds to constants
 template <bool BLUR, int SF>
-#define HS_NT 384    // 6 waves: one lane per histogram bin (6 x 6 x 10 = 360) in the accumulation phase
+#define HS_NT 256
 __global__ __launch_bounds__(HS_NT) void patch_sift_kernel(
     const uint8_t* __restrict__ img0, int pitch0, int rows0, int cols0,
     const uint8_t* __restrict__ pyramid, const LevelTable* __restrict__ T,
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(HS_NT) void patch_sift_kernel(
         else { rows = T->lv[0].rows; cols = T->lv[0].cols; }
     }
     const float px = kp.x, py = kp.y, size = kp.z, angle = kp.w;
-    if (tid < 360) s_h64[tid] = 0ull;                      // ordered before the votes by the barriers below
+    for (int i = tid; i < 360; i += HS_NT) s_h64[i] = 0ull;     // ordered before the votes by the barriers below
 
     // rectifyPatch, hash_sift.cpp:111-132
     if (tid == 0) {
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(HS_NT) void patch_sift_kernel(
     }
     __syncthreads();
     if (dbg == 2) return;
-    if (tid < 360) s_hist[tid] = (float)((double)s_h64[tid] * (1.0 / 4294967296.0));
+    for (int i = tid; i < 360; i += HS_NT) s_hist[i] = (float)((double)s_h64[i] * (1.0 / 4294967296.0));
     __syncthreads();
     if (dbg == 3) return;
     // circular fold + copy (hash_sift.cpp:293-308)
