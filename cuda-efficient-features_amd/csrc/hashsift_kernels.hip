@@ -36,7 +36,9 @@ struct AffineF { float m00, m01, m02, m10, m11, m12, pad0, pad1; };
 // SF != 0: every keypoint is known to need exactly an SF x SF window (detector keypoints: size 31, crop scale 1 ->
 // 50), so the blur's index arithmetic (divisions by the group / column-pair counts) folds to constants
 template <bool BLUR, int SF>
+#ifndef HS_NT
 #define HS_NT 256
+#endif
 __global__ __launch_bounds__(HS_NT) void patch_sift_kernel(
     const uint8_t* __restrict__ img0, int pitch0, int rows0, int cols0,
     const uint8_t* __restrict__ pyramid, const LevelTable* __restrict__ T,
