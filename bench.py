@@ -78,9 +78,11 @@ def main():
     desc = [torch.zeros((NFEATURES, 64), dtype=torch.uint8, device="cuda") for _ in range(F)]
     cnt = [torch.zeros(1, dtype=torch.int32, device="cuda") for _ in range(F)]
 
+    # one step = one batched call over the F frames (efx_detect_and_compute_batch_async: frame i on context / stream i % NS)
+    batch = cef.Batch(dets, streams, frames, kps, desc, cnt, NFEATURES)
+
     def step():
-        for i in range(F):
-            dets[i % NS].detectAndComputeAsync(frames[i], kps[i], desc[i], cnt[i], capacity=NFEATURES, stream=streams[i % NS])
+        batch.run()
 
     def barrier():
         torch.cuda.synchronize()

@@ -40,7 +40,7 @@ ABI_SYMBOLS = [
     "efx_describer_compute", "efx_describer_hashsift_debug_async",
     "efx_matcher_create", "efx_matcher_destroy", "efx_matcher_last_error", "efx_match_knn2_async",
     "efx_match_crosscheck_async",
-    "efx_detect_and_compute_masked_async", "efx_compute_provided_async", "efx_detect_and_compute_ex",
+    "efx_detect_and_compute_batch_async", "efx_detect_and_compute_masked_async", "efx_compute_provided_async", "efx_detect_and_compute_ex",
     "efx_ic_angles_async", "efx_ic_angles", "efx_descriptors_to_csv",
     "efx_cvt_gray_async", "efx_host_alloc", "efx_host_free", "efx_uploader_create", "efx_uploader_destroy",
     "efx_uploader_last_error", "efx_upload_gray_async", "efx_describer_compute_color",
@@ -132,6 +132,8 @@ def lib():
         for name in ("efx_match_knn2_async", "efx_match_crosscheck_async"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int,
                                          C.c_void_p, C.c_void_p, C.c_void_p]
+        L.efx_detect_and_compute_batch_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t,
+                                                         C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
         L.efx_detect_and_compute_masked_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t,
                                                           C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
         L.efx_compute_provided_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t,
@@ -518,6 +520,33 @@ def descriptorsToCsv(descriptors):
     buf = C.create_string_buffer(int(size) + 1)
     lib().efx_descriptors_to_csv(d.ctypes.data, n, nbytes, d.strides[0], buf, int(size))
     return buf.raw[:size].decode("ascii")
+
+
+class Batch:
+    """efx_detect_and_compute_batch_async with prepared pointer tables: nframes frames of one size, frame i on
+    detectors[i % n] / streams[i % n].  The tensors are kept referenced here; run() only crosses the ABI once."""
+
+    def __init__(self, detectors, streams, images, keypoints, descriptors, counts, capacity):
+        n, f = len(detectors), len(images)
+        self._keep = (detectors, streams, images, keypoints, descriptors, counts)
+        P = C.c_void_p
+        self._ctx = (P * n)(*[d._h for d in detectors])
+        self._st = (P * n)(*[P(s.cuda_stream) for s in streams])
+        self._img = (P * f)(*[P(t.data_ptr()) for t in images])
+        self._kps = (P * f)(*[P(t.data_ptr()) for t in keypoints])
+        self._desc = (P * f)(*[P(t.data_ptr()) for t in descriptors]) if descriptors is not None else None
+        self._cnt = (P * f)(*[P(t.data_ptr()) for t in counts])
+        im = images[0]
+        self._args = (n, f, im.shape[0], im.shape[1], im.stride(0), keypoints[0].stride(0) * 4,
+                      descriptors[0].stride(0) if descriptors is not None else 0, int(capacity))
+        self._det0 = detectors[0]
+
+    def run(self):
+        n, f, rows, cols, pitch, kp, dp, cap = self._args
+        rc = lib().efx_detect_and_compute_batch_async(self._ctx, self._st, n, self._img, f, rows, cols, pitch, self._kps, kp,
+                                                      self._desc, dp, cap, self._cnt)
+        if rc != EFX_OK:
+            raise EfxError(rc, "batch: " + lib().efx_last_error(self._det0._h).decode())
 
 
 def cvtGray(image, out=None, stream=None):

@@ -584,6 +584,23 @@ int efx_compute_provided_async(efx_context* ctx, const uint8_t* d_image, int row
     return compute_provided(ctx, d_image, rows, cols, pitch, d_keypoints, kps_pitch, n, d_descriptors, desc_pitch, (hipStream_t)stream);
 }
 
+int efx_detect_and_compute_batch_async(efx_context* const* ctxs, void* const* streams, int nctx,
+                                       const uint8_t* const* d_images, int nframes, int rows, int cols, size_t pitch,
+                                       void* const* d_keypoints, size_t kps_pitch,
+                                       uint8_t* const* d_descriptors, size_t desc_pitch, int capacity, int* const* d_counts)
+{
+    if (!ctxs || nctx <= 0 || nframes < 0 || !d_images || !d_keypoints || !d_counts) return EFX_ERR_BAD_ARG;
+    for (int i = 0; i < nframes; i++) {
+        efx_context* c = ctxs[i % nctx];
+        if (!c) return EFX_ERR_BAD_ARG;
+        const int rc = detect_common(c, d_images[i], rows, cols, pitch, d_keypoints[i], kps_pitch,
+                                     d_descriptors ? d_descriptors[i] : nullptr, desc_pitch, capacity, d_counts[i],
+                                     streams ? (hipStream_t)streams[i % nctx] : nullptr);
+        if (rc) return rc;
+    }
+    return EFX_OK;
+}
+
 int efx_compute_async(efx_context* ctx, const uint8_t* d_image, int rows, int cols, size_t pitch,
                       const void* d_keypoints, size_t kps_pitch, int n, uint8_t* d_descriptors, size_t desc_pitch, void* stream)
 {

@@ -214,6 +214,15 @@ int efx_match_crosscheck_async(efx_matcher* m, const uint8_t* d_query, size_t q_
                                const uint8_t* d_train, size_t t_pitch, int nt, int desc_bytes,
                                int* d_match, int* d_dist, void* stream);
 
+/* Batched variant: nframes independent frames of one size in one call.  Frame i runs on context
+ * ctxs[i % nctx] and stream streams[i % nctx] (a context is not re-entrant, so nctx frames are in flight at a time and
+ * a context's frames are ordered on its stream); d_descriptors may be NULL (detect only).  Equivalent to calling
+ * efx_detect_and_compute_async nframes times, without the caller's per-call overhead.  Stops at the first error. */
+int efx_detect_and_compute_batch_async(efx_context* const* ctxs, void* const* streams, int nctx,
+                                       const uint8_t* const* d_images, int nframes, int rows, int cols, size_t pitch,
+                                       void* const* d_keypoints, size_t kps_pitch,
+                                       uint8_t* const* d_descriptors, size_t desc_pitch, int capacity, int* const* d_counts);
+
 /* ------------------------------------------------------------------------------------------------ */
 /* mask and useProvidedKeypoints: arguments the reference accepts but ignores / asserts  */
 

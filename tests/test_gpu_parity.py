@@ -431,3 +431,23 @@ def test_two_threads_two_contexts(cef, torch_mod, oracle):
         ref = oracle.detect_and_compute(imgs[i], nfeatures=3000, desc_type=dts[i])
         for n, k, d in out[i]:
             assert n == ref["n"] and np.array_equal(k.view(np.uint32), ref["kps"].view(np.uint32)) and np.array_equal(d, ref["desc"])
+
+
+def test_batched_entry_point(cef, torch_mod, oracle):
+    """efx_detect_and_compute_batch_async == the per-frame calls (SURVEY 8b "batched variants"): 5 frames over 2 contexts."""
+    imgs = [synth.synth_frame(480, 640, seed=120 + i) for i in range(5)]
+    d_imgs = [_dev(torch_mod, im) for im in imgs]
+    dets = [cef.EfficientFeatures.create(2500, dtype=cef.EfficientFeatures.BAD_256) for _ in range(2)]
+    streams = [torch_mod.cuda.Stream() for _ in range(2)]
+    kps = [torch_mod.zeros((5, 2500), dtype=torch_mod.float32, device="cuda") for _ in imgs]
+    desc = [torch_mod.zeros((2500, 32), dtype=torch_mod.uint8, device="cuda") for _ in imgs]
+    cnt = [torch_mod.zeros(1, dtype=torch_mod.int32, device="cuda") for _ in imgs]
+    b = cef.Batch(dets, streams, d_imgs, kps, desc, cnt, 2500)
+    b.run(); b.run()
+    torch_mod.cuda.synchronize()
+    for i, im in enumerate(imgs):
+        ref = oracle.detect_and_compute(im, nfeatures=2500, desc_type=oracle.BAD_256)
+        n = int(cnt[i].item())
+        assert n == ref["n"]
+        assert np.array_equal(kps[i][:, :n].cpu().numpy().view(np.uint32), ref["kps"].view(np.uint32))
+        assert np.array_equal(desc[i][:n].cpu().numpy(), ref["desc"])
