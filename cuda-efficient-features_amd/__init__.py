@@ -324,7 +324,7 @@ class EfficientFeatures:
         self._check(lib().efx_profile_set_stride(self._h, int(stride)))
 
     def profileRead(self, capacity=65536):
-        """(ms, level) arrays of the recorded pyramid+FAST launches; call after synchronising the stream."""
+        """(ms, code) arrays of the recorded launches (codes: include/efx.h, efx_profile_enable); call after synchronising."""
         ms = (C.c_float * capacity)()
         lv = (C.c_int * capacity)()
         n = C.c_int(0)

@@ -346,11 +346,11 @@ __device__ __forceinline__ int level_of_tile(const LevelTable* T, int gt)
 }
 
 // ================================================================================================
-// Kernel A: FAST-9 + Harris for every 64x64 tile of every pyramid level in ONE launch (no per-level tails).
-//   tile+halo -> LDS | quick test on all pixels (register blocked) | full segment test on the survivors
-//   -> corner bitmap | canonical enumeration (cell-major) | Harris on the corners
-//   | append {xy, response} to the level's corner array + tile header
-// Algorithmic HBM bytes: every level is read once.
+// Kernel A: FAST-9 for every 64x64 tile of every pyramid level in ONE launch (no per-level tails).
+//   tile+halo -> LDS | compass quick test on all pixels (4x4 block per lane, packed 16-bit lanes)
+//   | single-polarity segment test on the survivors -> corner bitmap | canonical enumeration (cell-major)
+//   | append xy to the level's corner array + tile header (responses: harris_kernel)
+// Algorithmic HBM bytes: every level is read once.  Bound by VALU issue.
 // ================================================================================================
 __global__ __launch_bounds__(256) void fast_kernel(
     const LevelTable* __restrict__ T, const uint8_t* __restrict__ img0, int pitch0, int aligned0,

@@ -193,7 +193,7 @@ struct efx_context {
     Summary* h_mirror = nullptr;    // pinned
     bool has_frame = false;
     const uint8_t* last_img0 = nullptr; int last_pitch0 = 0;
-    // per-launch timing of the pyramid+FAST kernel (efx_profile_*)
+    // per-launch timing of the pipeline's kernels (efx_profile_*)
     std::vector<hipEvent_t> prof_start, prof_stop;
     std::vector<int> prof_level;
     int prof_count = 0;

@@ -183,7 +183,6 @@ struct DetectLaunch {
     void* d_keypoints; size_t kps_pitch; int capacity; int* d_count;
     float4* kp4; int* kp_level;
     int* h_mirror;              // pinned host mirror of Counters (may be null)
-    // optional per-launch timing of the pyramid+FAST kernel (bench roofline): event pairs + their level
     ProfRec prof;                                          // optional HIP-event pairs around the launches
 };
 
