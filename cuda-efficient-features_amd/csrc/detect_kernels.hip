@@ -220,7 +220,7 @@ __device__ __forceinline__ uint8_t sat_u8_rne(float v)
 template <int NT>
 __global__ __launch_bounds__(NT) void resize_kernel(
     const uint8_t* __restrict__ src, int spitch, int rows, int cols, int aligned,
-    uint8_t* __restrict__ dst, int dpitch, int drows, int dcols, float fx, float fy, int tiles_x, int tiles_y, int lpitch)
+    uint8_t* __restrict__ dst, int dpitch, int drows, int dcols, float fx, float fy, int tiles_x, int tiles_y, int lpitch, int ytab_off)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -234,21 +234,40 @@ __global__ __launch_bounds__(NT) void resize_kernel(
     const int sy1 = min(min((int)floorf((float)(oy1 - 1) * fy), rows - 1) + 1, rows - 1);
     const int ax0 = sx0 & ~3;                              // LDS column 0 <-> source column ax0
     const int ndw = ((sx1 - ax0) >> 2) + 1, nrow = sy1 - sy0 + 1;
-    {   // 32 lanes per source row (ndw <= 32 for scale factors up to ~1.9), 8 rows per pass; wider rows loop
+    {   // 32 lanes per source row (ndw <= 32 for scale factors up to ~1.9), 8 rows per pass; wider rows loop.
+        // 4-byte aligned sources go through a raw buffer resource (no per-load bounds tests): every dword that holds a
+        // pixel of the footprint lies inside [0, (rows-1)*pitch + roundup4(cols)); bytes beyond `cols` are never used.
         const int j0 = tid & 31, r0 = tid >> 5;
-        for (int j = j0; j < ndw; j += 32) {
-            const int gx = ax0 + 4 * j;
-            for (int r = r0; r < nrow; r += NT / 32) {
-                const uint8_t* p = src + (size_t)(sy0 + r) * spitch;
-                uint32_t v = 0;
-                if (aligned && gx + 4 <= cols) {
-                    v = *reinterpret_cast<const uint32_t*>(p + gx);
-                } else {
+        if (aligned) {
+            const __amdgpu_buffer_rsrc_t rsrc =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src), 0, (rows - 1) * spitch + ((cols + 3) & ~3), 0x00020000);
+            for (int j = j0; j < ndw; j += 32)
+                for (int r = r0; r < nrow; r += NT / 32)
+                    *reinterpret_cast<uint32_t*>(smem + r * lpitch + 4 * j) =
+                        __builtin_amdgcn_raw_buffer_load_b32(rsrc, (sy0 + r) * spitch + ax0 + 4 * j, 0, 0);
+        } else {
+            for (int j = j0; j < ndw; j += 32) {
+                const int gx = ax0 + 4 * j;
+                for (int r = r0; r < nrow; r += NT / 32) {
+                    const uint8_t* p = src + (size_t)(sy0 + r) * spitch;
+                    uint32_t v = 0;
 #pragma unroll
                     for (int b = 0; b < 4; b++) if (gx + b < cols) v |= (uint32_t)p[gx + b] << (8 * b);
+                    *reinterpret_cast<uint32_t*>(smem + r * lpitch + 4 * j) = v;
                 }
-                *reinterpret_cast<uint32_t*>(smem + r * lpitch + 4 * j) = v;
             }
+        }
+        // per output row of the tile: LDS offsets of its two source rows and the y weights (the same for all lanes of
+        // a row, so computed once per workgroup instead of once per lane and row)
+        int4* ytab = reinterpret_cast<int4*>(smem + ytab_off);
+        if (tid < EFX_TILE) {
+            const int oy = min(oy0 + tid, drows - 1);
+            const float sy = (float)oy * fy;
+            int y1 = (int)floorf(sy);
+            if (y1 > rows - 1) y1 = rows - 1;
+            const int y2 = y1 + 1;
+            const int y2r = y2 < rows - 1 ? y2 : rows - 1;
+            ytab[tid] = make_int4((y1 - sy0) * lpitch, (y2r - sy0) * lpitch, __float_as_int((float)y2 - sy), __float_as_int(sy - (float)y1));
         }
     }
     __syncthreads();
@@ -268,15 +287,12 @@ __global__ __launch_bounds__(NT) void resize_kernel(
         lc[k] = x1 - ax0; dxr[k] = x2r - x1;
     }
     const bool full4 = oxq + 4 <= ox1 && ((((uintptr_t)dst) | (uintptr_t)dpitch) & 3u) == 0;
+    const int4* ytab = reinterpret_cast<const int4*>(smem + ytab_off);
     for (int oy = oy0 + rq; oy < oy1; oy += NT / 16) {
-        const float sy = (float)oy * fy;
-        int y1 = (int)floorf(sy);
-        if (y1 > rows - 1) y1 = rows - 1;
-        const int y2 = y1 + 1;
-        const int y2r = y2 < rows - 1 ? y2 : rows - 1;
-        const float wy0 = (float)y2 - sy, wy1 = sy - (float)y1;
-        const uint8_t* ra = smem + (y1 - sy0) * lpitch;
-        const uint8_t* rb = smem + (y2r - sy0) * lpitch;
+        const int4 yt = ytab[oy - oy0];
+        const float wy0 = __int_as_float(yt.z), wy1 = __int_as_float(yt.w);
+        const uint8_t* ra = smem + yt.x;
+        const uint8_t* rb = smem + yt.y;
         uint32_t packed = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -1108,14 +1124,17 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
         if (L.rows <= 0 || L.cols <= 0 || N.rows <= 0 || N.cols <= 0) break;
         const uint8_t* src = s == 0 ? a.img0 : a.pyramid + L.img_off;
         const int spitch = s == 0 ? a.pitch0 : L.pitch;
-        const int aligned = (((uintptr_t)src | (uintptr_t)spitch) & 3u) == 0;
+        // dword staging reads up to roundup4(cols) bytes of a row: always inside our own (padded) pyramid levels, inside a
+        // caller's image only when its width is a multiple of 4 (otherwise the byte path)
+        const int aligned = (((uintptr_t)src | (uintptr_t)spitch) & 3u) == 0 && (s > 0 || (L.cols & 3) == 0);
         const int sw = (int)ceilf((float)(EFX_TILE - 1) * N.fx) + 8, sh = (int)ceilf((float)(EFX_TILE - 1) * N.fy) + 3;
         const int lpitch = (sw + 3) & ~3;
-        const size_t lds = (size_t)lpitch * sh;
+        const int ytab_off = ((lpitch * sh) + 15) & ~15;          // per-row table behind the tile
+        const size_t lds = (size_t)ytab_off + EFX_TILE * 16;
         if (lds > 64 * 1024) return hipErrorInvalidValue;
         const bool prof = a.prof.begin(stream);
         hipLaunchKernelGGL((resize_kernel<256>), dim3(N.tiles_x * N.tiles_y), dim3(256), lds, stream, src, spitch, L.rows, L.cols, aligned,
-                           a.pyramid + N.img_off, N.pitch, N.rows, N.cols, N.fx, N.fy, N.tiles_x, N.tiles_y, lpitch);
+                           a.pyramid + N.img_off, N.pitch, N.rows, N.cols, N.fx, N.fy, N.tiles_x, N.tiles_y, lpitch, ytab_off);
         a.prof.end(prof, 100 + s, stream);
     }
     if (a.pyramid_only) return hipGetLastError();
