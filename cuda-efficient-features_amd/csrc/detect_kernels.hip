@@ -271,10 +271,16 @@ __global__ __launch_bounds__(NT) void resize_kernel(
         }
     }
     __syncthreads();
+    // The +1 neighbour of the last source column is that column itself (spec S5 clamp): tiles that touch it get one
+    // replicated byte column, so the inner loop always reads the pair (x1, x1 + 1) from one base address.
+    if (sx1 == cols - 1) {
+        for (int r = tid; r < nrow; r += NT) smem[r * lpitch + (cols - ax0)] = smem[r * lpitch + (cols - 1 - ax0)];
+        __syncthreads();
+    }
     const int cq = tid & 15, rq = tid >> 4;               // 16 lanes x 4 outputs per row, 16 rows per pass
     const int oxq = ox0 + 4 * cq;
     if (oxq >= ox1) return;
-    float wx0[4], wx1[4]; int lc[4], dxr[4];
+    float wx0[4], wx1[4]; int lc[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int ox = min(oxq + k, dcols - 1);
@@ -282,9 +288,8 @@ __global__ __launch_bounds__(NT) void resize_kernel(
         int x1 = (int)floorf(sx);
         if (x1 > cols - 1) x1 = cols - 1;
         const int x2 = x1 + 1;
-        const int x2r = x2 < cols - 1 ? x2 : cols - 1;
         wx0[k] = (float)x2 - sx; wx1[k] = sx - (float)x1;
-        lc[k] = x1 - ax0; dxr[k] = x2r - x1;
+        lc[k] = x1 - ax0;                                   // the clamped +1 neighbour is the next LDS byte
     }
     const bool full4 = oxq + 4 <= ox1 && ((((uintptr_t)dst) | (uintptr_t)dpitch) & 3u) == 0;
     const int4* ytab = reinterpret_cast<const int4*>(smem + ytab_off);
@@ -299,9 +304,9 @@ __global__ __launch_bounds__(NT) void resize_kernel(
             const uint8_t* pa = ra + lc[k];
             const uint8_t* pb = rb + lc[k];
             float out = (float)pa[0] * (wx0[k] * wy0);                  // == 0.f + ... exactly
-            out = out + (float)pa[dxr[k]] * (wx1[k] * wy0);
+            out = out + (float)pa[1] * (wx1[k] * wy0);
             out = out + (float)pb[0] * (wx0[k] * wy1);
-            out = out + (float)pb[dxr[k]] * (wx1[k] * wy1);
+            out = out + (float)pb[1] * (wx1[k] * wy1);
             packed = __builtin_amdgcn_cvt_pk_u8_f32(out, k, packed);     // rint (half even) + saturate + pack
         }
         uint8_t* d = dst + (size_t)oy * dpitch + oxq;
