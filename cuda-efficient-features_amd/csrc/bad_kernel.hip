@@ -18,12 +18,21 @@ namespace {
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-struct __attribute__((aligned(16))) Affine { float m00, m01, m02, m10, m11, m12, s, pad; };
+// Everything about a keypoint that is uniform over its workgroup, computed once by one lane of bad_affine_kernel and
+// read back as scalars: the affine map (rectifyBoxes), the LDS window origin / size and the border flag.
+struct __attribute__((aligned(16))) Affine {
+    float m00, m01, m02, m10, m11, m12, s;
+    int wx0, wy0, S;            // window [wx0, wx0 + S) x [wy0, wy0 + S); S == 0: the keypoint does not fit (zero descriptor)
+    int border;                 // isKeypointInTheBorder (bad.cpp:86-103)
+    int level;                  // pyramid level of the keypoint (0 in single-image mode)
+};
 
 // rectifyBoxes, bad.cpp:115-147: the patch -> image affine map of every keypoint, one lane per keypoint (the double
 // cos/sin of bad.cpp:138-139 is ~400 instructions: far too long to run on one lane of a per-keypoint workgroup)
-__global__ __launch_bounds__(256) void bad_affine_kernel(const float4* __restrict__ kp4, const int* __restrict__ d_count, int n,
-                                                         float scale_factor, Affine* __restrict__ aff)
+__global__ __launch_bounds__(256) void bad_affine_kernel(const float4* __restrict__ kp4, const int* __restrict__ kp_level,
+                                                         const LevelTable* __restrict__ T, int rows0, int cols0,
+                                                         const int* __restrict__ d_count, int n,
+                                                         float scale_factor, float reach, int smax, int sfixed, Affine* __restrict__ aff)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int count = d_count ? min(*d_count, n) : n;
@@ -43,7 +52,24 @@ __global__ __launch_bounds__(256) void bad_affine_kernel(const float4* __restric
         A.m10 = s * sine; A.m11 = s * cosine;
         A.m12 = (-s * sine - s * cosine) * (float)32 * 0.5f + y;
     }
-    A.s = s; A.pad = 0.f;
+    A.s = s;
+    int rows = rows0, cols = cols0, l = 0;
+    if (kp_level) { l = kp_level[i]; rows = T->lv[l].rows; cols = T->lv[l].cols; }
+    A.level = l;
+    // window geometry: every (clamped) box coordinate of this keypoint lies in [wx0, wx0+S] x [wy0, wy0+S]
+    const float sg = scale_factor * size / 32.f;
+    const int R = (int)floorf(fabsf(sg) * reach + 4.f);
+    const int Srt = 2 * R + 2;
+    const bool fits = sfixed ? (Srt == sfixed) : (Srt <= smax && Srt > 0);
+    const int S = sfixed ? sfixed : (fits ? Srt : smax);
+    const int ix = (int)floorf(x), iy = (int)floorf(y);
+    A.wx0 = min(max(ix - R, 0), max(cols - S, 0));
+    A.wy0 = min(max(iy - R, 0), max(rows - S, 0));
+    A.S = fits ? S : 0;                                // keypoint larger than the caller's max_size: zero descriptor
+    // isKeypointInTheBorder, bad.cpp:86-103
+    const float sb = scale_factor * size / (float)(32 + 32);
+    const float bw = (float)32 * sb * 1.75f, bh = (float)32 * sb * 1.75f;
+    A.border = ((x < bw || x + bw >= (float)cols) || (y < bh || y + bh >= (float)rows)) ? 1 : 0;
     aff[i] = A;
 }
 
@@ -67,25 +93,17 @@ __global__ __launch_bounds__(256) void bad_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
 
-    const float4 kp = kp4[kid];
+    const Affine A = aff[kid];                                   // uniform address: scalar loads
     const uint8_t* img = img0; int pitch = pitch0, rows = rows0, cols = cols0;
     if (kp_level) {
-        const int l = kp_level[kid];
+        const int l = A.level;
         if (l > 0) { const LevelDev& L = T->lv[l]; img = pyramid + L.img_off; pitch = L.pitch; rows = L.rows; cols = L.cols; }
         else { rows = T->lv[0].rows; cols = T->lv[0].cols; }
     }
     const int nbits = P->nbits;
-    const float x = kp.x, y = kp.y, size = kp.z;
-
-    // window geometry: every (clamped) box coordinate of this keypoint lies in [wx0, wx0+S] x [wy0, wy0+S]
-    const float sg = scale_factor * size / 32.f;
-    const int R = (int)floorf(fabsf(sg) * P->reach + 4.f);
-    const int Srt = 2 * R + 2;
-    const bool fits = SF ? (Srt == SF) : (Srt <= smax && Srt > 0);
-    const int S = SF ? SF : (fits ? Srt : smax);  // keypoint larger than the caller's max_size: zero descriptor
-    const int ix = (int)floorf(x), iy = (int)floorf(y);
-    const int wx0 = min(max(ix - R, 0), max(cols - S, 0));
-    const int wy0 = min(max(iy - R, 0), max(rows - S, 0));
+    const bool fits = A.S != 0;
+    const int S = SF ? SF : (fits ? A.S : smax);
+    const int wx0 = A.wx0, wy0 = A.wy0;
 
     int* I = reinterpret_cast<int*>(smem);                       // (S+1) x (S+1)
     const int IP = S + 1;
@@ -133,11 +151,7 @@ __global__ __launch_bounds__(256) void bad_kernel(
     }
     __syncthreads();
 
-    const Affine A = aff[kid];
-    // isKeypointInTheBorder, bad.cpp:86-103
-    const float sb = scale_factor * size / (float)(32 + 32);
-    const float bw = (float)32 * sb * 1.75f, bh = (float)32 * sb * 1.75f;
-    const bool border = (x < bw || x + bw >= (float)cols) || (y < bh || y + bh >= (float)rows);
+    const bool border = A.border != 0;
     const int fw = cols + 1, fh = rows + 1;       // integral image dims of the full frame
 
     for (int b0 = 0; b0 < nbits; b0 += 256) {
@@ -238,7 +252,9 @@ hipError_t efx_launch_bad(const DescribeLaunch& a, const BadParamsDev* d_params,
     float t[7];
     efx_gaussian_taps_host(t);
     Affine* aff = static_cast<Affine*>(a.bad_affine);
-    hipLaunchKernelGGL(bad_affine_kernel, dim3((a.n + 255) / 256), dim3(256), 0, stream, a.kp4, a.d_count, a.n, a.scale_factor, aff);
+    const int sfixed = (S == 52 && a.uniform_size) ? 52 : 0;
+    hipLaunchKernelGGL(bad_affine_kernel, dim3((a.n + 255) / 256), dim3(256), 0, stream, a.kp4, a.kp_level, a.d_table, a.rows0, a.cols0,
+                       a.d_count, a.n, a.scale_factor, reach, S, sfixed, aff);
     if (a.blur) {
         if (S == 52 && a.uniform_size) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bad_kernel<true, 52>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -49,7 +49,7 @@ struct Describer {                  // cuda::BAD / cuda::HashSIFT state
     float scale = 1.f;              // BAD scaleFactor / HashSIFT croppingScale
     float reach = 0.f;              // BAD: max (centre distance + radius) in patch units
     DevBuf params;                  // BadParamsDev, or W (nbits x 132) + 30x30 weight table
-    DevBuf responses;               // HashSIFT scratch, n x 132; BAD scratch, n x 32 bytes (affine maps)
+    DevBuf responses;               // HashSIFT scratch, n x 132; BAD scratch, n x 48 bytes (per-keypoint affine map + window geometry)
     DevBuf kp4;                     // float4 keypoints for the stand-alone / compute paths
     DevBuf img, desc;               // staging for the host entry points
     std::string err;
@@ -144,7 +144,7 @@ int describer_run(Describer& d, std::string& err, DescribeLaunch a, float* dbg_r
     const bool prof = a.prof.begin(stream);
     struct ProfEnd { const ProfRec& p; bool on; hipStream_t st; ~ProfEnd() { p.end(on, 10, st); } } prof_end{a.prof, prof, stream};
     if (d.kind == 0) {
-        HIP_TRY(err, d.responses.reserve((size_t)a.n * 32));
+        HIP_TRY(err, d.responses.reserve((size_t)a.n * 48));
         a.bad_affine = d.responses.p;
         hipError_t e = efx_launch_bad(a, static_cast<const BadParamsDev*>(d.params.p), d.reach, stream);
         if (e == hipErrorInvalidValue) return set_err(err, EFX_ERR_UNSUPPORTED, "keypoint size %.1f needs a window larger than the 160 KB LDS", a.max_size);

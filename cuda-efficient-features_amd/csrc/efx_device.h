@@ -199,7 +199,7 @@ struct DescribeLaunch {
     float max_size;                                        // upper bound of keypoint size (LDS window)
     int uniform_size;                                      // 1: every keypoint has size == max_size (detector output)
     uint8_t* desc; size_t desc_pitch;
-    void* bad_affine;                                      // BAD scratch: n x 32 bytes (per-keypoint affine map)
+    void* bad_affine;                                      // BAD scratch: n x 48 bytes (per-keypoint affine map + window geometry)
     ProfRec prof;
 };
 
