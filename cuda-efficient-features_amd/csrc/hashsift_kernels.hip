@@ -242,52 +242,88 @@ __global__ __launch_bounds__(HS_NT) void patch_sift_kernel(
 
 // ================================================================================================
 // Projection + sign + pack.  T[i][j] = sum_k R[i][k] * W[j][k]  (matmulAndSign, hash_sift.cpp:353-378).
-// One wave computes a 32 (keypoints) x 64 (bits) tile with two v_mfma_f32_32x32x2_f32 accumulators;
-// a workgroup of 4 waves covers 128 keypoints x 64 bits.  A/B are read straight from L2 (R is 528 B per
-// keypoint, W is 270 KB total and stays cache resident).
+// The one real GEMM of the path, on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains).  A wave owns 64 output bits and
+// keeps their weights W[64][132] in registers for its whole life (132 VGPRs), then walks 32-keypoint tiles of R:
+// per tile 33 eight-byte loads per lane, 132 MFMAs, sign test by ballot, packed bits out -- no T matrix in HBM, no
+// separate binarize pass (cuda_hash_sift.cu:414-435), and W is fetched once per wave instead of once per tile.
+// K is split between the two half-waves (lanes 0-31 take k in [0, 66), lanes 32-63 k in [66, 132)), so every lane
+// reads contiguous floats of its R row.
 // ================================================================================================
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+
 __global__ __launch_bounds__(256) void project_sign_kernel(const float* __restrict__ Rm, const float* __restrict__ W,
                                                            const int* __restrict__ d_count, int n, int nbits,
                                                            uint8_t* __restrict__ desc, size_t desc_pitch, float* __restrict__ dbg_T)
 {
     const int count = d_count ? min(*d_count, n) : n;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int m0 = blockIdx.x * 128 + wid * 32;
-    const int n0 = blockIdx.y * 64;
-    if (m0 >= count) return;
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);          // global wave index
+    const int ntn = nbits >> 6;                                   // 64-bit column tiles
+    const int n0 = (gw % ntn) * 64;
+    const int mgroup = gw / ntn, nmgroups = (gridDim.x * 4) / ntn;
     const int li = lane & 31, lk = lane >> 5;
-    const int arow = min(m0 + li, count - 1);
-    const float* pa = Rm + (size_t)arow * HS_KPAD + lk;
-    const float* pb0 = W + (size_t)(n0 + li) * HS_KPAD + lk;
-    const float* pb1 = W + (size_t)(n0 + 32 + li) * HS_KPAD + lk;
-    f32x16 acc0 = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-    f32x16 acc1 = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-#pragma unroll 6
-    for (int k = 0; k < HS_KPAD; k += 2) {
-        const float a = pa[k], b0 = pb0[k], b1 = pb1[k];
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
-    }
-    // C layout 32x32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    constexpr int KH = HS_KPAD / 2;                               // 66 k-steps
+    // this wave's weights: b0[j] = W[n0 + li][KH * lk + j], b1[j] = W[n0 + 32 + li][KH * lk + j]
+    float b0[KH], b1[KH];
+    {
+        const f32x2v* p0 = reinterpret_cast<const f32x2v*>(W + (size_t)(n0 + li) * HS_KPAD + KH * lk);
+        const f32x2v* p1 = reinterpret_cast<const f32x2v*>(W + (size_t)(n0 + 32 + li) * HS_KPAD + KH * lk);
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const int row = (r & 3) + 8 * (r >> 2);
-        const unsigned long long ba = __ballot(acc0[r] > 0.f);
-        const unsigned long long bb = __ballot(acc1[r] > 0.f);
-        if (dbg_T) {
-            const int i = m0 + row + 4 * lk;
-            if (i < count) { dbg_T[(size_t)i * nbits + n0 + li] = acc0[r]; dbg_T[(size_t)i * nbits + n0 + 32 + li] = acc1[r]; }
+        for (int j = 0; j < KH / 2; j++) {
+            const f32x2v u = p0[j], v = p1[j];
+            b0[2 * j] = u.x; b0[2 * j + 1] = u.y; b1[2 * j] = v.x; b1[2 * j + 1] = v.y;
         }
-        if (desc != nullptr && lane < 4) {
-            // lane 0/1: rows `row` (bits n0.., n0+32..), lane 2/3: rows `row+4`
-            const int hi = lane >> 1, second = lane & 1;
-            const unsigned long long m = second ? bb : ba;
-            const unsigned w = hi ? (unsigned)(m >> 32) : (unsigned)m;
-            const int i = m0 + row + 4 * hi;
-            if (i < count) {
-                // bit j of w -> byte j/8, bit 7 - j%8 (MSB first, hash_sift.cpp:367-374)
-                const unsigned v = __builtin_bswap32(__brev(w));
-                *reinterpret_cast<unsigned*>(desc + (size_t)i * desc_pitch + (n0 + 32 * second) / 8) = v;
+    }
+    const int mtiles = (count + 31) >> 5;
+    for (int mt = mgroup; mt < mtiles; mt += nmgroups) {
+        const int m0 = mt * 32;
+        const int arow = min(m0 + li, count - 1);
+        const f32x2v* pa = reinterpret_cast<const f32x2v*>(Rm + (size_t)arow * HS_KPAD + KH * lk);
+        f32x16 acc0 = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+        f32x16 acc1 = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+        // three blocks of 11 eight-byte loads; the next block's loads are in flight while this block's MFMAs run
+        constexpr int NB = 3, BL = KH / 2 / NB;                    // 33 float2 per lane = 3 x 11
+        f32x2v cur[BL], nxt[BL];
+#pragma unroll
+        for (int j = 0; j < BL; j++) cur[j] = pa[j];
+#pragma unroll
+        for (int blk = 0; blk < NB; blk++) {
+            if (blk + 1 < NB) {
+#pragma unroll
+                for (int j = 0; j < BL; j++) nxt[j] = pa[(blk + 1) * BL + j];
+            }
+#pragma unroll
+            for (int j = 0; j < BL; j++) {
+                const int kk = 2 * (blk * BL + j);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[j].x, b0[kk], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[j].x, b1[kk], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[j].y, b0[kk + 1], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[j].y, b1[kk + 1], acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < BL; j++) cur[j] = nxt[j];
+        }
+        // C layout 32x32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = (r & 3) + 8 * (r >> 2);
+            const unsigned long long ba = __ballot(acc0[r] > 0.f);
+            const unsigned long long bb = __ballot(acc1[r] > 0.f);
+            if (dbg_T) {
+                const int i = m0 + row + 4 * lk;
+                if (i < count) { dbg_T[(size_t)i * nbits + n0 + li] = acc0[r]; dbg_T[(size_t)i * nbits + n0 + 32 + li] = acc1[r]; }
+            }
+            if (desc != nullptr && lane < 4) {
+                // lane 0/1: rows `row` (bits n0.., n0+32..), lane 2/3: rows `row+4`
+                const int hi = lane >> 1, second = lane & 1;
+                const unsigned long long m = second ? bb : ba;
+                const unsigned w = hi ? (unsigned)(m >> 32) : (unsigned)m;
+                const int i = m0 + row + 4 * hi;
+                if (i < count) {
+                    // bit j of w -> byte j/8, bit 7 - j%8 (MSB first, hash_sift.cpp:367-374)
+                    const unsigned v = __builtin_bswap32(__brev(w));
+                    *reinterpret_cast<unsigned*>(desc + (size_t)i * desc_pitch + (n0 + 32 * second) / 8) = v;
+                }
             }
         }
     }
@@ -336,7 +372,12 @@ hipError_t efx_launch_hashsift(const DescribeLaunch& a, const HashSiftDev& h, hi
                            t[0], t[1], t[2], t[3], h.responses, h.dbg_responses, dbg);
     }
     if (a.desc || h.dbg_T) {
-        hipLaunchKernelGGL(project_sign_kernel, dim3((a.n + 127) / 128, h.nbits / 64), dim3(256), 0, stream,
+        // persistent waves: 2 per SIMD (the weights occupy 132 VGPRs), each owning one 64-bit column tile
+        const int ntn = h.nbits / 64;
+        int nblk = 512 / ntn * ntn;                            // 2048 waves on 1024 SIMDs, a multiple of the column tiles
+        const int need = (((a.n + 31) / 32) * ntn + 3) / 4;     // never more waves than (row tile, column tile) pairs
+        if (nblk > need) nblk = (need + ntn - 1) / ntn * ntn;
+        hipLaunchKernelGGL(project_sign_kernel, dim3(nblk), dim3(256), 0, stream,
                            h.responses, h.W, a.d_count, a.n, h.nbits, a.desc, a.desc_pitch, h.dbg_T);
     }
     return hipGetLastError();
