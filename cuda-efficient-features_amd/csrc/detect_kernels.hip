@@ -154,6 +154,7 @@ __device__ __forceinline__ float harris_rows(const uint8_t* p0, int P)
     // E[4] = (8, 7); O[j] = columns (2j+1, 2j+2); H[j] = horizontal 1-2-1 sums at columns (2j+1, 2j+2);
     // S = E(row-1) + E(row) vertical pair sums; V = S(r-1) + S(r) vertical 1-2-1 sums.
     u16x2 Hm2[4], Hm1[4], Sm1[5], Em1[5];      // H(row-2), H(row-1), S(row-1), E(row-1)
+    const u16x2 two2 = { 2, 2 };
     int sxx = 0, sxy = 0, syy = 0;
 #pragma unroll
     for (int row = 0; row < 9; row++) {
@@ -172,7 +173,11 @@ __device__ __forceinline__ float harris_rows(const uint8_t* p0, int P)
         O[2] = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(b, a, 0x0c060c05u));
         O[3] = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(t, b, 0x0c040c03u));
 #pragma unroll
-        for (int j = 0; j < 4; j++) H[j] = (E[j] + E[j + 1]) + (O[j] + O[j]);
+        for (int j = 0; j < 4; j++) {
+            // H = 2 * O + (E[j] + E[j+1]) as one v_pk_mad_u16 (the compiler turns the doubling into a separate shift)
+            const u16x2 e = E[j] + E[j + 1];
+            asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(H[j]) : "v"(O[j]), "v"(two2), "v"(e));
+        }
         if (row >= 1) {
 #pragma unroll
             for (int j = 0; j < 5; j++) S[j] = Em1[j] + E[j];
