@@ -362,13 +362,12 @@ __device__ __forceinline__ void load_tile_lds(uint32_t* s_tile, const uint8_t* _
     }
 }
 
-// level of a global tile index
-__device__ __forceinline__ int level_of_tile(const LevelTable* T, int gt)
+// level and tile coordinates of a global tile index: one packed word per tile behind the level table
+// (level | tx << 4 | ty << 14, written by the host with the geometry)
+__device__ __forceinline__ void efx_tile_of(const LevelTable* T, int gt, int& l, int& tx, int& ty)
 {
-    int l = 0;
-    for (int i = 1; i < T->nlevels; i++)
-        if (gt >= T->lv[i].tile_base) l = i;
-    return l;
+    const uint32_t v = reinterpret_cast<const uint32_t*>(T + 1)[gt];
+    l = (int)(v & 15u); tx = (int)((v >> 4) & 1023u); ty = (int)(v >> 14);
 }
 
 // ================================================================================================
@@ -393,7 +392,8 @@ __global__ __launch_bounds__(256) void fast_kernel(
     const int tid = threadIdx.x;
     // heaviest tiles first: the upper pyramid levels have the densest corners, so they must not form the tail
     const int gt = T->total_tiles - 1 - xcd_interleaved(blockIdx.x, T->total_tiles);
-    const int l = level_of_tile(T, gt);
+    int l, tx, ty;
+    efx_tile_of(T, gt, l, tx, ty);
     const LevelDev& L = T->lv[l];
     if (!L.active) return;
     const int tile = gt - L.tile_base;
@@ -401,7 +401,6 @@ __global__ __launch_bounds__(256) void fast_kernel(
     const uint8_t* src = l == 0 ? img0 : pyramid + L.img_off;
     const int spitch = l == 0 ? pitch0 : L.pitch;
     const bool aligned = l == 0 ? aligned0 != 0 : true;
-    const int tx = tile % L.tiles_x, ty = tile / L.tiles_x;
     const int x0 = tx * EFX_TILE, y0 = ty * EFX_TILE;
     const uint8_t* tb = reinterpret_cast<const uint8_t*>(s_tile);
     Corner* cand = cand_all + L.cand_base;
@@ -551,14 +550,14 @@ __global__ __launch_bounds__(64) void harris_kernel(
     __shared__ unsigned long long s_cellmax[EFX_CELLS_PER_TILE];
     const int lane = threadIdx.x;
     const int gt = T->total_tiles - 1 - xcd_interleaved(blockIdx.x, T->total_tiles);      // densest tiles first
-    const int l = level_of_tile(T, gt);
+    int l, tx, ty;
+    efx_tile_of(T, gt, l, tx, ty);
     const LevelDev& L = T->lv[l];
     if (!L.active) return;
     const int tile = gt - L.tile_base;
     const uint8_t* src = l == 0 ? img0 : pyramid + L.img_off;
     const int spitch = l == 0 ? pitch0 : L.pitch;
     const bool aligned = l == 0 ? aligned0 != 0 : true;
-    const int tx = tile % L.tiles_x, ty = tile / L.tiles_x;
     const TileHdr& h = hdr_all[L.tile_base + tile];
     const int total = h.cell_off[EFX_CELLS_PER_TILE];
     Corner* cand = cand_all + L.cand_base + (size_t)(tile & (EFX_NSUB - 1)) * L.cand_sub_cap + h.cand_start;
@@ -636,14 +635,14 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
     __shared__ __attribute__((aligned(64))) uint32_t s_nb[9][16];   // TileHdr of the 3x3 neighbouring tiles
 
     const int gt = T->total_tiles - 1 - xcd_interleaved(blockIdx.x, T->total_tiles);      // densest (upper-level) tiles first
-    const int l = level_of_tile(T, gt);
+    int l, tx, ty;
+    efx_tile_of(T, gt, l, tx, ty);
     const LevelDev& L = T->lv[l];
     if (!L.active) return;
     const int tile = gt - L.tile_base;
     TileHdr* hl = hdr + L.tile_base;
     const Corner* cand = cand_all + L.cand_base;
     const int lane = threadIdx.x;
-    const int tx = tile % L.tiles_x, ty = tile / L.tiles_x;
 
     s_keep[lane] = 0ull;
     for (int i = lane; i < 9 * 16; i += 64) {
@@ -981,7 +980,8 @@ __global__ __launch_bounds__(64) void emit_kernel(const LevelTable* __restrict__
                                                   float4* __restrict__ kp4, int* __restrict__ kp_level)
 {
     const int gt = blockIdx.x;
-    const int l = level_of_tile(T, gt);
+    int l, tx, ty;
+    efx_tile_of(T, gt, l, tx, ty);
     const LevelDev& L = T->lv[l];
     if (!L.active) return;
     const TileHdr& h = hdr[gt];

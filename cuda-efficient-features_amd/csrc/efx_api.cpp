@@ -287,7 +287,8 @@ int build_geometry(efx_context* c, int rows, int cols)
     T.total_tiles = tiles;
     if (rows > 32767 || cols > 32767) return set_err(c->err, EFX_ERR_UNSUPPORTED, "image larger than 32767 (short2 coordinates)");
 
-    HIP_TRY(c->err, c->d_table.reserve(sizeof(LevelTable)));
+    // the level table is followed by one packed word per tile (level | tx << 4 | ty << 14): efx_tile_of()
+    HIP_TRY(c->err, c->d_table.reserve(sizeof(LevelTable) + (size_t)(tiles + 1) * sizeof(uint32_t)));
     HIP_TRY(c->err, c->pyramid.reserve(pyr + 256));
     HIP_TRY(c->err, c->hdr.reserve((size_t)(tiles + 1) * sizeof(TileHdr)));
     HIP_TRY(c->err, c->cand.reserve((ncand + 1) * sizeof(Corner)));
@@ -297,7 +298,17 @@ int build_geometry(efx_context* c, int rows, int cols)
     HIP_TRY(c->err, c->count.reserve(sizeof(int)));
     if (!c->h_mirror) HIP_TRY(c->err, hipHostMalloc(reinterpret_cast<void**>(&c->h_mirror), sizeof(Summary), hipHostMallocDefault));
     // synchronous upload: geometry changes are rare (first frame / size or parameter change)
-    HIP_TRY(c->err, hipMemcpy(c->d_table.p, &T, sizeof(LevelTable), hipMemcpyHostToDevice));
+    {
+        std::vector<unsigned char> blob(sizeof(LevelTable) + (size_t)(tiles + 1) * sizeof(uint32_t), 0);
+        memcpy(blob.data(), &T, sizeof(LevelTable));
+        uint32_t* info = reinterpret_cast<uint32_t*>(blob.data() + sizeof(LevelTable));
+        for (int s = 0; s < p.nlevels; s++) {
+            const LevelDev& L = T.lv[s];
+            for (int ty = 0; ty < L.tiles_y; ty++)
+                for (int tx = 0; tx < L.tiles_x; tx++) info[L.tile_base + ty * L.tiles_x + tx] = (uint32_t)s | ((uint32_t)tx << 4) | ((uint32_t)ty << 14);
+        }
+        HIP_TRY(c->err, hipMemcpy(c->d_table.p, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    }
     c->g_rows = rows; c->g_cols = cols; c->g_p = p;
     return EFX_OK;
 }
