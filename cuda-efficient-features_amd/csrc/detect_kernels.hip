@@ -865,7 +865,9 @@ __global__ __launch_bounds__(1024) void select_kernel(const LevelTable* __restri
     for (int sub = 0; sub < EFX_NSUB; sub++) n += cnt->surv_total[l][sub].v;
     const Corner* surv = surv_all + L.surv_base;
     unsigned long long thresh = 0;
-    if (n > L.quota) {
+    if (L.quota <= 0) {
+        thresh = ~0ull;                      // a level whose quota rounds to 0 keeps nothing (no key reaches this value)
+    } else if (n > L.quota) {
         unsigned long long prefix = 0;       // decided high bits, right-aligned
         int remaining = L.quota;
         int decided = 0;

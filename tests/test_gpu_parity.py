@@ -451,3 +451,46 @@ def test_batched_entry_point(cef, torch_mod, oracle):
         assert n == ref["n"]
         assert np.array_equal(kps[i][:, :n].cpu().numpy().view(np.uint32), ref["kps"].view(np.uint32))
         assert np.array_equal(desc[i][:n].cpu().numpy(), ref["desc"])
+
+
+@pytest.mark.parametrize("cols,pitch", [(641, 644), (642, 642), (639, 640), (640, 1024)])
+def test_widths_and_pitches(cef, torch_mod, oracle, cols, pitch):
+    """Frame widths that are not multiples of 4, with aligned and unaligned row pitches: the dword / buffer-resource
+    loaders of resize_kernel, fast_kernel and harris_kernel and their byte fallbacks must all give the same answer."""
+    img = synth.synth_frame(480, cols, seed=33)
+    big = np.zeros((480, pitch), np.uint8)
+    big[:, :cols] = img
+    d = _dev(torch_mod, big)[:, :cols]
+    det = cef.EfficientFeatures.create(3000, dtype=cef.EfficientFeatures.BAD_256)
+    kps, desc, cnt = det.detectAndComputeAsync(d)
+    torch_mod.cuda.synchronize()
+    n = int(cnt.item())
+    ref = oracle.detect_and_compute(img, nfeatures=3000, desc_type=oracle.BAD_256)
+    assert n == ref["n"]
+    assert np.array_equal(kps[:, :n].cpu().numpy().view(np.uint32), ref["kps"].view(np.uint32))
+    assert np.array_equal(desc[:n].cpu().numpy(), ref["desc"])
+
+
+def test_small_quota_and_zero_capacity(cef, torch_mod, oracle):
+    img = synth.synth_frame(480, 640, seed=34)
+    got, ref = _detect_both(cef, torch_mod, oracle, img, desc_type=0, nfeatures=10)
+    _assert_same_keypoints(got, ref)
+    assert np.array_equal(got["desc"], ref["desc"])
+    det = cef.EfficientFeatures.create(500)
+    kps, cnt = det.detectAsync(_dev(torch_mod, img), capacity=0)
+    torch_mod.cuda.synchronize()
+    assert int(cnt.item()) == 0
+
+
+def test_mask_with_first_level_and_pitch(cef, torch_mod, oracle):
+    img = synth.synth_frame(480, 640, seed=35)
+    m = np.zeros((480, 640), np.uint8); m[100:400, 50:600] = 1
+    mbig = np.zeros((480, 700), np.uint8); mbig[:, :640] = m
+    det = cef.EfficientFeatures.create(3000, 1.2, 8, 2, 20, 15, cef.EfficientFeatures.BAD_256)
+    kps, desc, cnt = det.detectAndComputeAsync(_dev(torch_mod, img), mask=_dev(torch_mod, mbig)[:, :640])
+    torch_mod.cuda.synchronize()
+    n = int(cnt.item())
+    ref = oracle.detect_and_compute(img, nfeatures=3000, first_level=2, desc_type=oracle.BAD_256, mask=m)
+    assert n == ref["n"] and n > 0
+    assert np.array_equal(kps[:, :n].cpu().numpy().view(np.uint32), ref["kps"].view(np.uint32))
+    assert np.array_equal(desc[:n].cpu().numpy(), ref["desc"])
