@@ -494,3 +494,41 @@ def test_mask_with_first_level_and_pitch(cef, torch_mod, oracle):
     assert n == ref["n"] and n > 0
     assert np.array_equal(kps[:, :n].cpu().numpy().view(np.uint32), ref["kps"].view(np.uint32))
     assert np.array_equal(desc[:n].cpu().numpy(), ref["desc"])
+
+
+@pytest.mark.parametrize("shape,kw", [
+    ((480, 640), dict(nfeatures=100000)),                       # quotas above the survivor counts: nothing is cut
+    ((480, 640), dict(nfeatures=3000, nlevels=12)),             # upper levels shrink below the 31-px border
+    ((240, 320), dict(nfeatures=3000, nlevels=16)),
+    ((480, 640), dict(nfeatures=3000, scale_factor=2.0, nlevels=4)),
+    ((480, 640), dict(nfeatures=3000, scale_factor=1.05, nlevels=8)),
+    ((480, 640), dict(nfeatures=3000, fast_threshold=1)),
+    ((480, 640), dict(nfeatures=3000, fast_threshold=200)),
+    ((480, 640), dict(nfeatures=3000, nonmax_radius=70)),       # neighbour cells beyond the 3x3 tiles held in LDS
+    ((480, 640), dict(nfeatures=3000, nonmax_radius=1)),
+    ((31, 31), dict(nfeatures=100)),                            # no pixel inside the border
+    ((33, 200), dict(nfeatures=100)),
+    ((1, 1), dict(nfeatures=100)),
+])
+def test_parameter_extremes(cef, torch_mod, oracle, shape, kw):
+    img = synth.synth_frame(shape[0], shape[1], seed=55, density=1.0) if min(shape) >= 8 else np.full(shape, 9, np.uint8)
+    got, ref = _detect_both(cef, torch_mod, oracle, img, desc_type=0, **kw)
+    _assert_same_keypoints(got, ref)
+    assert np.array_equal(got["desc"], ref["desc"])
+
+
+def test_descriptor_keypoint_extremes(cef, oracle):
+    """Keypoints outside the image, on its corners, with zero / negative / huge sizes and every angle convention
+    (-1 = axis aligned, < 0 = no rotation; bad.cpp:127,138): defined behaviour on both sides, no crash, same bytes."""
+    img = synth.synth_frame(200, 260, seed=77, density=2.0)
+    kps = np.array([[-50, -50, 31, 10], [400, 10, 31, 0], [130, 100, 0, 0], [130, 100, 90, 45], [0, 0, 31, -1],
+                    [259, 199, 31, 359.9], [130, 100, 31, -7], [5.5, 190.25, 17.3, 123.4], [130, 100, 1, 90],
+                    [129.99, 99.99, 64, 180]], np.float32)
+    for nbits, enum in ((256, cef.BAD.SIZE_256_BITS), (512, cef.BAD.SIZE_512_BITS)):
+        assert np.array_equal(cef.BAD.create(1.0, enum).compute(img, kps), oracle.bad_compute(img, kps, nbits))
+    got = cef.HashSIFT.create(1.0, cef.HashSIFT.SIZE_256_BITS).compute(img, kps)
+    want = oracle.hashsift_compute(img, kps, 256)
+    assert np.count_nonzero(got != want) <= 2
+    # a keypoint whose window cannot fit the 160 KB LDS is refused, not silently mis-described
+    with pytest.raises(cef.EfxError):
+        cef.BAD.create(1.0, cef.BAD.SIZE_256_BITS).compute(img, np.array([[100, 100, 5000, 0]], np.float32))
