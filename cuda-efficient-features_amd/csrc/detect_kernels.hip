@@ -631,6 +631,7 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
 {
     __shared__ Corner s_hme[NMS_HCAP];
     __shared__ uint16_t s_hidx[NMS_HCAP];
+    __shared__ uint16_t s_hneed[NMS_HCAP];                 // block_radius 1: the cells (bit q = cell q of the 3x3) that hold a rival
     __shared__ unsigned long long s_keep[64];            // survivor bits of round r (64 rounds = 4096 corners = a full tile)
     __shared__ __attribute__((aligned(64))) uint32_t s_nb[9][16];   // TileHdr of the 3x3 neighbouring tiles
 
@@ -701,6 +702,43 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
             const int cx0 = max(bx1 - block_radius, 0), cx1 = min(bx1 + block_radius, gw - 1);
             const int cy0 = max(by1 - block_radius, 0), cy1 = min(by1 + block_radius, gh - 1);
             bool kill = false;
+            if (block_radius == 1 && !capped) {
+                // common case: phase A already knows which of the 9 cells hold a rival (s_hneed); lane `sub` fetches the
+                // list range of cell `sub`, lane 0 also that of cell 8, straight from the headers in LDS
+                const int needm = act ? (int)s_hneed[hi] : 0;
+                int lb[2] = { 0, 0 }, le[2] = { 0, 0 }; unsigned lbase[2] = { 0u, 0u };
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const int ci = 8 * q + sub;
+                    if (ci < 9 && ((needm >> ci) & 1)) {
+                        const int bx = min(max(bx1 - 1 + (ci % 3), 0), gw - 1), by = min(max(by1 - 1 + (ci / 3), 0), gh - 1);
+                        const TileHdr* nh2 = reinterpret_cast<const TileHdr*>(&s_nb[((by >> 2) - ty + 1) * 3 + ((bx >> 2) - tx + 1)][0]);
+                        const int c = (by & 3) * 4 + (bx & 3);
+                        lb[q] = nh2->cell_off[c];
+                        le[q] = nh2->cell_off[c + 1];
+                        lbase[q] = (unsigned)(((by >> 2) * L.tiles_x + (bx >> 2)) & (EFX_NSUB - 1)) * L.cand_sub_cap + nh2->cand_start;
+                    }
+                }
+                unsigned gneed = ((unsigned)(__ballot(le[0] > lb[0]) >> (grp * 8)) & 0xffu) |
+                                 (((unsigned)(__ballot(le[1] > lb[1]) >> (grp * 8)) & 0x01u) << 8);
+                while (__ballot(gneed != 0u) != 0ull) {
+                    const int i = gneed ? __ffs(gneed) - 1 : 0;
+                    const int src = (lane & 56) + (i & 7);
+                    const int b0 = __shfl(lb[0], src, 64), b1 = __shfl(lb[1], src, 64);
+                    const int e0 = __shfl(le[0], src, 64), e1 = __shfl(le[1], src, 64);
+                    const unsigned a0 = (unsigned)__shfl((int)lbase[0], src, 64), a1 = (unsigned)__shfl((int)lbase[1], src, 64);
+                    const int nb = i < 8 ? b0 : b1, ne = i < 8 ? e0 : e1;
+                    const unsigned nbase = i < 8 ? a0 : a1;
+                    if (gneed) {
+                        for (int j = nb + sub; j < ne; j += 8) {
+                            const Corner o = cand[(size_t)nbase + j];
+                            const int dx = mx - (int)(o.xy & 0xffff), dy = my - (int)(o.xy >> 16);
+                            kill |= (o.xy != m.xy && m.resp <= o.resp && dx * dx + dy * dy < image_radius);
+                        }
+                    }
+                    gneed &= gneed - 1u;
+                }
+            } else
             // cells of the neighbourhood in chunks of 16: lane `sub` fetches the list ranges of cells c0+sub and
             // c0+8+sub, then the 8 lanes walk every list that is left together
             for (int c0 = 0; c0 < ncell; c0 += 16) {
@@ -755,7 +793,8 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
     int nh = 0;
     for (int k0 = 0; k0 < n_valid; k0 += 64) {
         const int k = k0 + lane;
-        bool hard = false;
+        bool hard = false, sure = false;
+        int need = 0x1ff;                                     // neighbour cells the exact scan has to walk (all, unless phase A knows better)
         Corner me; me.xy = 0; me.resp = 0.f;
         if (k < n_valid) {
             me = own[k];
@@ -772,13 +811,19 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
                         const int bx = min(max(bx1 - 1 + (q % 3), 0), gw - 1), by = min(max(by1 - 1 + (q / 3), 0), gh - 1);
                         o[q] = cmax[by * gwp + bx];
                     }
-                    int kill = 0;
+                    int kill = 0, rival = 0;
 #pragma unroll
                     for (int q = 0; q < 9; q++) {
                         const int dx = mx - (int)(o[q].xy & 0xffff), dy = my - (int)(o[q].xy >> 16);
-                        kill |= (int)(o[q].xy != me.xy) & (int)(me.resp <= o[q].resp) & (int)(dx * dx + dy * dy < image_radius);
+                        const int ge = (int)(o[q].xy != me.xy) & (int)(me.resp <= o[q].resp);
+                        rival |= ge << q;                  // cell q holds a corner at least as strong: the exact scan must walk it
+                        kill |= ge & (int)(dx * dx + dy * dy < image_radius);
                     }
                     hard = kill == 0;
+                    need = rival;
+                    // stronger than every neighbouring cell maximum: nothing in the neighbourhood can suppress it, so
+                    // it survives without the exact scan (most true survivors are such local maxima)
+                    sure = rival == 0;
                 } else {
                     const int minx = max(bx1 - block_radius, 0), maxx = min(bx1 + block_radius, gw - 1);
                     const int miny = max(by1 - block_radius, 0), maxy = min(by1 + block_radius, gh - 1);
@@ -791,11 +836,15 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
                 }
             }
         }
+        const unsigned long long sm = __ballot(sure);
+        if (lane == 0 && sm) atomicOr(&s_keep[k0 >> 6], sm);
+        hard = hard && !sure;
         const unsigned long long hm = __ballot(hard);
         if (hard) {
             const int pos = nh + __popcll(hm & ((1ull << lane) - 1ull));
             s_hme[pos] = me;
             s_hidx[pos] = (uint16_t)k;
+            s_hneed[pos] = (uint16_t)need;
         }
         nh += __popcll(hm);
         if (nh > NMS_HCAP - 64 || k0 + 64 >= n_valid) {
