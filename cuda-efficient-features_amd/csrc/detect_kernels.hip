@@ -634,6 +634,7 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
     __shared__ uint16_t s_hneed[NMS_HCAP];                 // block_radius 1: the cells (bit q = cell q of the 3x3) that hold a rival
     __shared__ unsigned long long s_keep[64];            // survivor bits of round r (64 rounds = 4096 corners = a full tile)
     __shared__ __attribute__((aligned(64))) uint32_t s_nb[9][16];   // TileHdr of the 3x3 neighbouring tiles
+    __shared__ Corner s_cm[6][6];                        // cell maxima of the tile's 4x4 cells + one ring (block_radius 1)
 
     const int gt = T->total_tiles - 1 - xcd_interleaved(blockIdx.x, T->total_tiles);      // densest (upper-level) tiles first
     int l, tx, ty;
@@ -653,6 +654,12 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
         if (ntx >= 0 && ntx < L.tiles_x && nty >= 0 && nty < L.tiles_y)
             v = reinterpret_cast<const uint32_t*>(&hl[nty * L.tiles_x + ntx])[w];
         s_nb[t][w] = v;
+    }
+    if (lane < 36) {
+        // clamped exactly as the quick test clamps its cell coordinates
+        const int gw_ = (L.cols + EFX_CELL - 1) / EFX_CELL, gh_ = (L.rows + EFX_CELL - 1) / EFX_CELL;
+        const int cy = min(max(ty * 4 - 1 + lane / 6, 0), gh_ - 1), cx = min(max(tx * 4 - 1 + lane % 6, 0), gw_ - 1);
+        s_cm[lane / 6][lane % 6] = cmax_all[L.cmax_base + (size_t)cy * (L.tiles_x * 4) + cx];
     }
     __syncthreads();
     // header of the tile that holds cell (bx, by): the LDS copy when it is a neighbour (always, up to radius 64)
@@ -806,11 +813,9 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
                     // the common case as straight-line code: 9 loads, then branch-free compares (this kernel is bound
                     // by instruction issue, scalar exec-mask bookkeeping included)
                     Corner o[9];
+                    const int cj = bx1 - tx * 4, ci = by1 - ty * 4;      // this corner's cell inside the tile, 0..3
 #pragma unroll
-                    for (int q = 0; q < 9; q++) {
-                        const int bx = min(max(bx1 - 1 + (q % 3), 0), gw - 1), by = min(max(by1 - 1 + (q / 3), 0), gh - 1);
-                        o[q] = cmax[by * gwp + bx];
-                    }
+                    for (int q = 0; q < 9; q++) o[q] = s_cm[ci + q / 3][cj + q % 3];
                     int kill = 0, rival = 0;
 #pragma unroll
                     for (int q = 0; q < 9; q++) {
