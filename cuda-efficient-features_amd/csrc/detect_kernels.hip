@@ -476,23 +476,23 @@ __global__ __launch_bounds__(256) void fast_kernel(
             qm &= xm & ym;
             if (dbg & 2) qm = 0;
         }
-        uint16_t* ql = s_list + wid * 1024;
+        // survivors of the four waves go to ONE list, so the full test below runs on packed lanes (a tile has ~100
+        // survivors: two wave passes instead of four quarter-full ones)
         const int qcnt = __popc(qm);
-        const int qincl = wave_incl_scan(qcnt);
-        const int nq = __shfl(qincl, 63, 64);
+        int nq;
         {
-            int pos = qincl - qcnt;
+            int pos = block_excl_scan<4>(qcnt, s_scan, &nq);
             while (qm) {
                 const int b = __ffs(qm) - 1;
                 qm &= qm - 1;
-                ql[pos++] = (uint16_t)((bx + (b & 3)) | ((by + (b >> 2)) << 8));
+                s_list[pos++] = (uint16_t)((bx + (b & 3)) | ((by + (b >> 2)) << 8));
             }
         }
         __syncthreads();
         // ---- phase 2: full 16-point segment test on the survivors, one lane per pixel; corners set their bit in
         //      the 64x64 bitmap ----
-        for (int idx = lane; idx < ((dbg & 8) ? 0 : nq); idx += 64) {
-            const int e = ql[idx];
+        for (int idx = tid; idx < ((dbg & 8) ? 0 : nq); idx += 256) {
+            const int e = s_list[idx];
             const int lx = e & 0xff, ly = e >> 8;
             bool corner = fast9_survivor_lds<EFX_LP>(tb + (ly + EFX_HALO) * EFX_LP + lx + EFX_HALO, threshold);
             if (corner && mask) {
