@@ -58,7 +58,9 @@ __global__ __launch_bounds__(256) void bad_affine_kernel(const float4* __restric
     A.level = l;
     // window geometry: every (clamped) box coordinate of this keypoint lies in [wx0, wx0+S] x [wy0, wy0+S]
     const float sg = scale_factor * size / 32.f;
-    const int R = (int)floorf(fabsf(sg) * reach + 4.f);
+    // R >= |sg| * reach + 1 covers every box: a centre rounds to within 0.5 of its exact position, a radius grows by at
+    // most 0.5, the far integral coordinate is one more, and x - floor(x) < 1
+    const int R = (int)floorf(fabsf(sg) * reach + 2.01f);
     const int Srt = 2 * R + 2;
     const bool fits = sfixed ? (Srt == sfixed) : (Srt <= smax && Srt > 0);
     const int S = sfixed ? sfixed : (fits ? Srt : smax);
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(256) void bad_affine_kernel(const float4* __restric
 
 // LDS plan (dynamic): [ I: (S+1)^2 int32, aliased by raw: (S+6) x RPB u8 | hb: (8G+6) x HP float ]
 //   G = ceil(S/8) groups of 8 outputs, HP = 8G, RPB = 4*ceil((S+12)/4) (room for the dword-alignment slack)
-// SF != 0: every keypoint is known to need exactly an SF x SF window (size 31, scale 1 -> 52: the detector's
+// SF != 0: every keypoint is known to need exactly an SF x SF window (size 31, scale 1 -> 48: the detector's
 // keypoints), so all index arithmetic and loop bounds fold to constants.
 template <bool BLUR, int SF>
 __global__ __launch_bounds__(256) void bad_kernel(
@@ -231,7 +233,7 @@ void efx_gaussian_taps_host(float taps[7])
 static int bad_smax_for(float max_size, float scale_factor, float reach)
 {
     const float sg = fabsf(scale_factor * max_size / 32.f);
-    const int R = (int)floorf(sg * reach + 4.f);
+    const int R = (int)floorf(sg * reach + 2.01f);
     return 2 * R + 2;
 }
 
@@ -252,13 +254,13 @@ hipError_t efx_launch_bad(const DescribeLaunch& a, const BadParamsDev* d_params,
     float t[7];
     efx_gaussian_taps_host(t);
     Affine* aff = static_cast<Affine*>(a.bad_affine);
-    const int sfixed = (S == 52 && a.uniform_size) ? 52 : 0;
+    const int sfixed = (S == 48 && a.uniform_size) ? 48 : 0;
     hipLaunchKernelGGL(bad_affine_kernel, dim3((a.n + 255) / 256), dim3(256), 0, stream, a.kp4, a.kp_level, a.d_table, a.rows0, a.cols0,
                        a.d_count, a.n, a.scale_factor, reach, S, sfixed, aff);
     if (a.blur) {
-        if (S == 52 && a.uniform_size) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bad_kernel<true, 52>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL((bad_kernel<true, 52>), dim3(a.n), dim3(256), lds, stream, a.img0, a.pitch0, a.rows0, a.cols0, a.pyramid,
+        if (S == 48 && a.uniform_size) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bad_kernel<true, 48>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((bad_kernel<true, 48>), dim3(a.n), dim3(256), lds, stream, a.img0, a.pitch0, a.rows0, a.cols0, a.pyramid,
                                a.d_table, a.kp4, a.kp_level, a.d_count, a.n, a.scale_factor, S, d_params, aff, t[0], t[1], t[2], t[3],
                                a.desc, a.desc_pitch);
             return hipGetLastError();
@@ -268,9 +270,9 @@ hipError_t efx_launch_bad(const DescribeLaunch& a, const BadParamsDev* d_params,
                            a.d_table, a.kp4, a.kp_level, a.d_count, a.n, a.scale_factor, S, d_params, aff, t[0], t[1], t[2], t[3],
                            a.desc, a.desc_pitch);
     } else {
-        if (S == 52 && a.uniform_size) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bad_kernel<false, 52>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL((bad_kernel<false, 52>), dim3(a.n), dim3(256), lds, stream, a.img0, a.pitch0, a.rows0, a.cols0, a.pyramid,
+        if (S == 48 && a.uniform_size) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bad_kernel<false, 48>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((bad_kernel<false, 48>), dim3(a.n), dim3(256), lds, stream, a.img0, a.pitch0, a.rows0, a.cols0, a.pyramid,
                                a.d_table, a.kp4, a.kp_level, a.d_count, a.n, a.scale_factor, S, d_params, aff, t[0], t[1], t[2], t[3],
                                a.desc, a.desc_pitch);
             return hipGetLastError();

@@ -34,7 +34,7 @@ struct AffineF { float m00, m01, m02, m10, m11, m12, pad0, pad1; };
 
 // LDS plan (dynamic, BLUR only): [ raw | hb | win S*S u8 ] (blur_window.h)
 // SF != 0: every keypoint is known to need exactly an SF x SF window (detector keypoints: size 31, crop scale 1 ->
-// 50), so the blur's index arithmetic (divisions by the group / column-pair counts) folds to constants
+// 48), so the blur's index arithmetic (divisions by the group / column-pair counts) folds to constants
 template <bool BLUR, int SF>
 #ifndef HS_NT
 #define HS_NT 256
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(HS_NT) void patch_sift_kernel(
 
     // window the patch can touch
     const float sg = fabsf(crop_scale * size / 32.f);
-    int R = (int)floorf(sg * 22.63f + 3.f);
+    int R = (int)floorf(sg * 22.63f + 2.01f);            // >= 22.63 sg + 1: floor(u) and floor(u) + 1 of every patch pixel are inside
     int S = SF ? SF : 2 * R + 2;
     const bool fits = !BLUR || (SF ? (2 * R + 2 == SF) : (S <= smax && S > 0));
     if (!fits && !SF) S = smax;
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void project_sign_kernel(const float* __restri
 static int hs_smax_for(float max_size, float crop_scale)
 {
     const float sg = fabsf(crop_scale * max_size / 32.f);
-    const int R = (int)floorf(sg * 22.63f + 3.f);
+    const int R = (int)floorf(sg * 22.63f + 2.01f);
     return 2 * R + 2;
 }
 
@@ -356,9 +356,9 @@ hipError_t efx_launch_hashsift(const DescribeLaunch& a, const HashSiftDev& h, hi
     const int dbg = dbge ? atoi(dbge) : 0;
     const float* mag = h.W + (size_t)h.nbits * HS_KPAD;    // the 30x30 weight table is stored behind W
     const float* lut = mag + 900;                          // followed by the 511x511 orientation-bin table
-    if (a.blur && S == 50 && a.uniform_size) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_sift_kernel<true, 50>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((patch_sift_kernel<true, 50>), dim3(a.n), dim3(HS_NT), lds, stream, a.img0, a.pitch0, a.rows0, a.cols0,
+    if (a.blur && S == 48 && a.uniform_size) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_sift_kernel<true, 48>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((patch_sift_kernel<true, 48>), dim3(a.n), dim3(HS_NT), lds, stream, a.img0, a.pitch0, a.rows0, a.cols0,
                            a.pyramid, a.d_table, a.kp4, a.kp_level, a.d_count, a.n, a.scale_factor, S, mag, lut,
                            t[0], t[1], t[2], t[3], h.responses, h.dbg_responses, dbg);
     } else if (a.blur) {
