@@ -44,7 +44,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames-per-step", type=int, default=8)
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="independent frames in flight per GPU: one context + one HIP stream each (a context is not "
                          "re-entrant, like the reference's EfficientFeaturesImpl; frames are independent)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -126,7 +126,7 @@ def main():
         #                  2 F P + 5 sum P_s + gathers ~ 1.06 GB for the same stage; reported as survey_design_bytes)
         sumP = float(sum(px))
         kinfo = {0: ("fast_kernel", sumP + 4 * n_corners), 1: ("harris_kernel", sumP + 8 * n_corners),
-                 2: ("nms_kernel", 8 * n_corners + 8 * 60000.0), 10: ("bad_kernel<blur,52>", sumP + 80 * n_kp)}
+                 2: ("nms_kernel", 8 * n_corners + 8 * 60000.0), 10: ("bad_kernel<blur,48>", sumP + 80 * n_kp)}
 
         def table(ms_, lvl_):
             t = {}
