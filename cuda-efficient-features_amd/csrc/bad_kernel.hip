@@ -197,10 +197,13 @@ __global__ __launch_bounds__(256) void bad_kernel(
                 // The window lies inside the frame (or, for frames smaller than the window, the pixels beyond the
                 // frame are zero, so the integral is constant there): clamping to the frame and then to the
                 // window equals clamping to the window.
-                const int lax1 = clampi(cx1 - r - wx0, 0, S), lay1 = clampi(cy1 - r - wy0, 0, S);
-                const int lax2 = clampi(cx1 + r + 1 - wx0, 0, S), lay2 = clampi(cy1 + r + 1 - wy0, 0, S);
-                const int lbx1 = clampi(cx2 - r - wx0, 0, S), lby1 = clampi(cy2 - r - wy0, 0, S);
-                const int lbx2 = clampi(cx2 + r + 1 - wx0, 0, S), lby2 = clampi(cy2 + r + 1 - wy0, 0, S);
+                // Detector keypoints (SF != 0: size 31, scale <= 1, not within 27 px of the frame edge on this path): the
+                // window is never clamped by the frame and R >= s * reach + 1 puts every tap inside it, so no clamp.
+                auto wc = [&](int v) -> int { return SF ? v : clampi(v, 0, S); };
+                const int lax1 = wc(cx1 - r - wx0), lay1 = wc(cy1 - r - wy0);
+                const int lax2 = wc(cx1 + r + 1 - wx0), lay2 = wc(cy1 + r + 1 - wy0);
+                const int lbx1 = wc(cx2 - r - wx0), lby1 = wc(cy2 - r - wy0);
+                const int lbx2 = wc(cx2 + r + 1 - wx0), lby2 = wc(cy2 + r + 1 - wy0);
                 const int side = 1 + (r << 1);
                 const int area_resp = I[lay1 * IP + lax1] + I[lay2 * IP + lax2] - I[lay1 * IP + lax2] - I[lay2 * IP + lax1]
                                     - I[lby1 * IP + lbx1] - I[lby2 * IP + lbx2] + I[lby1 * IP + lbx2] + I[lby2 * IP + lbx1];
