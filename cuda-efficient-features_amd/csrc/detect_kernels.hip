@@ -51,35 +51,7 @@ __device__ __forceinline__ int block_excl_scan(int v, int* scratch, int* total)
 // FAST-9 segment test on an LDS tile (cuda_fast.cu:33-222).  c points at the centre pixel, P = LDS pitch.
 // Circle order as cuda_fast.cu:179-207: k=0 at (0,+3) walking towards +x.
 // ------------------------------------------------------------------------------------------------
-template <int P>
-__device__ __forceinline__ bool fast9_lds(const uint8_t* c, int t)
-{
-    const int p = c[0];
-    const int hi = p + t, lo = p - t;
-    const int c0 = c[3 * P], c4 = c[3], c8 = c[-3 * P], c12 = c[-3];
-    // a 9-arc always contains two neighbouring compass points (pure early-out, cf. cuda_fast.cu:193-197)
-    const bool b0 = c0 > hi, b4 = c4 > hi, b8 = c8 > hi, b12 = c12 > hi;
-    const bool d0 = c0 < lo, d4 = c4 < lo, d8 = c8 < lo, d12 = c12 < lo;
-    const bool quick = (b0 && b4) || (b4 && b8) || (b8 && b12) || (b12 && b0) ||
-                       (d0 && d4) || (d4 && d8) || (d8 && d12) || (d12 && d0);
-    if (!quick) return false;
-    const int v[16] = { c0,          c[3 * P + 1],  c[2 * P + 2],  c[P + 3],
-                        c4,          c[-P + 3],     c[-2 * P + 2], c[-3 * P + 1],
-                        c8,          c[-3 * P - 1], c[-2 * P - 2], c[-P - 3],
-                        c12,         c[P - 3],      c[2 * P - 2],  c[3 * P - 1] };
-    unsigned br = 0, dk = 0;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        br |= (unsigned)(v[k] > hi) << k;
-        dk |= (unsigned)(v[k] < lo) << k;
-    }
-    br |= br << 16; dk |= dk << 16;
-    br &= br >> 1; br &= br >> 2; br &= br >> 4; br &= br >> 1;   // runs of >= 9
-    dk &= dk >> 1; dk &= dk >> 2; dk &= dk >> 4; dk &= dk >> 1;
-    return ((br | dk) & 0xffffu) != 0;
-}
-
-// The same test for a pixel that already passed the compass quick test of fast_kernel: the compass points say which
+// The test is only ever run on pixels that passed the compass quick test of fast_kernel: the compass points say which
 // polarity can succeed, so only ONE 16-bit ring mask is built (dark pixels are mirrored, x -> 255 - x, so both
 // polarities share one instruction stream); the other polarity is tested in a second pass only for the rare pixels
 // whose compass points allow both.
@@ -205,13 +177,6 @@ __device__ __forceinline__ float harris_rows(const uint8_t* p0, int P)
         for (int j = 0; j < 5; j++) { Sm1[j] = S[j]; Em1[j] = E[j]; }
     }
     return harris_from_sums(sxx, sxy, syy);
-}
-
-
-__device__ __forceinline__ uint8_t sat_u8_rne(float v)
-{
-    const float r = rintf(v);                       // v_rndne_f32: round half to even (cvRound)
-    return (uint8_t)(r < 0.f ? 0.f : (r > 255.f ? 255.f : r));
 }
 
 // ================================================================================================
