@@ -195,14 +195,26 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             from oracle import pyoracle
             img = frames[0].cpu().numpy()
+            pyoracle.set_threads(1)
             t1 = time.perf_counter()
             ref = pyoracle.detect_and_compute(img, nfeatures=NFEATURES, desc_type=pyoracle.BAD_512)
             t_cpu = time.perf_counter() - t1
+            # the same frame with OpenMP over rows / candidates / keypoints on the host's cores (bounded at 64 threads)
+            nthr = max(1, min(os.cpu_count() or 1, 64))
+            pyoracle.set_threads(nthr)
+            pyoracle.detect_and_compute(img[:512, :512].copy(), nfeatures=100, desc_type=pyoracle.BAD_512)   # start the thread pool
+            t1 = time.perf_counter()
+            ref_mt = pyoracle.detect_and_compute(img, nfeatures=NFEATURES, desc_type=pyoracle.BAD_512)
+            t_mt = time.perf_counter() - t1
+            pyoracle.set_threads(1)
             out["cpu_baseline"] = {"value": round(ref["n"] / t_cpu / 1e6, 5), "unit": "Mkeypoints/s", "cores": 1,
                                    "kind": "port", "ms_per_frame": round(t_cpu * 1e3, 1),
                                    "sample": "one 8K frame (seed 1000) of the same workload, oracle/efx_oracle.c, "
                                              f"single thread as the reference CPU module; {ref['n']} keypoints",
-                                   "host_cores_available": os.cpu_count()}
+                                   "host_cores_available": os.cpu_count(),
+                                   "all_cores": {"value": round(ref_mt["n"] / t_mt / 1e6, 5), "cores": nthr,
+                                                 "ms_per_frame": round(t_mt * 1e3, 1),
+                                                 "same_result": bool(np.array_equal(ref_mt["desc"], ref["desc"]))}}
             # the bench frame doubles as a full-size parity check (bit-exact keypoints + BAD512 bytes)
             n0 = int(cnt[0].item())
             same = (n0 == ref["n"] and np.array_equal(kps[0][:, :n0].cpu().numpy().view(np.uint32), ref["kps"].view(np.uint32))

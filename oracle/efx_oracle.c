@@ -19,6 +19,13 @@
  * ---------------------------------------------------------------------------------------------- */
 static int cv_round_f(float v) { return (int)lrintf(v); }
 static int cv_round_d(double v) { return (int)lrint(v); }
+
+/* Optional OpenMP over rows / candidates / keypoints for the multi-core CPU baseline: every loop that is
+ * parallelised writes disjoint outputs, so the results do not depend on the thread count.  1 = as the reference. */
+static int g_threads = 1;
+void efxo_set_threads(int n) { g_threads = n > 0 ? n : 1; }
+int efxo_get_threads(void) { return g_threads; }
+#define EFXO_PAR _Pragma("omp parallel for schedule(dynamic, 16) num_threads(g_threads)")
 static int cv_floor_f(float v) { return (int)floorf(v); }
 static uint8_t sat_u8_f(float v)
 {
@@ -152,11 +159,13 @@ void efxo_bad_compute(const uint8_t* img, int rows, int cols, int stride,
     if (n <= 0) return;
     const int fw = cols + 1, fh = rows + 1;
     int32_t* I = (int32_t*)malloc(sizeof(int32_t) * (size_t)fw * fh);
-    box_t* bp = (box_t*)malloc(sizeof(box_t) * (size_t)nbits);
     efxo_integral(img, rows, cols, stride, I);
     const int nbytes = nbits / 8;
+    if (nbits > 512) { free(I); return; }
 
+    EFXO_PAR
     for (int k = 0; k < n; k++) {                                   /* bad.cpp:341 */
+        box_t bp[512];
         const float x = kps[4 * k + 0], y = kps[4 * k + 1], size = kps[4 * k + 2], angle = kps[4 * k + 3];
         uint8_t* d = desc + (size_t)k * nbytes;
         uint8_t byte = 0;
@@ -187,7 +196,6 @@ void efxo_bad_compute(const uint8_t* img, int rows, int cols, int stride,
             }
         }
     }
-    free(bp);
     free(I);
 }
 
@@ -352,8 +360,9 @@ void efxo_hashsift_responses(const uint8_t* img, int rows, int cols, int stride,
 {
     /* computePatchSIFTs, hash_sift.cpp:333-351; keypointScale = 1/6 */
     const float kp_scale = 1.f / 6;
-    uint8_t patch[32 * 32];
+    EFXO_PAR
     for (int i = 0; i < n; i++) {
+        uint8_t patch[32 * 32];
         float* r = responses + (size_t)i * 129;
         r[0] = 1;
         efxo_hashsift_patch(img, rows, cols, stride, kps + 4 * i, crop_scale, patch);
@@ -366,8 +375,9 @@ void efxo_hashsift_responses_fixedpoint(const uint8_t* img, int rows, int cols, 
                                         const float* kps, int n, float crop_scale, float* responses)
 {
     const float kp_scale = 1.f / 6;
-    uint8_t patch[32 * 32];
+    EFXO_PAR
     for (int i = 0; i < n; i++) {
+        uint8_t patch[32 * 32];
         float* r = responses + (size_t)i * 129;
         r[0] = 1;
         efxo_hashsift_patch(img, rows, cols, stride, kps + 4 * i, crop_scale, patch);
@@ -380,6 +390,7 @@ void efxo_hashsift_project(const float* responses, int n, const float* W, int nb
     /* matmulAndSign, hash_sift.cpp:353-378.  cv::gemm (third party) accumulates CV_32F products in
      * double (GEMMSingleMul<float,double>) -- restated as a k-ordered double sum rounded to float. */
     const int nbytes = nbits / 8;
+    EFXO_PAR
     for (int i = 0; i < n; i++) {
         const float* r = responses + (size_t)i * 129;
         uint8_t* d = desc + (size_t)i * nbytes;
@@ -451,6 +462,7 @@ void efxo_resize_linear(const uint8_t* src, int srows, int scols, int sstride,
      * +1 neighbour clamped to the last row/col, four float weights, round-to-nearest-even saturate. */
     const float fx = (float)(1.0 / ((double)dcols / (double)scols));
     const float fy = (float)(1.0 / ((double)drows / (double)srows));
+    EFXO_PAR
     for (int dy = 0; dy < drows; dy++) {
         const float sy = (float)dy * fy;
         int y1 = cv_floor_f(sy);
@@ -505,6 +517,7 @@ void efxo_gaussian7(const uint8_t* src, int rows, int cols, int sstride, uint8_t
     float taps[7];
     efxo_gaussian_taps(taps);
     float* tmp = (float*)malloc(sizeof(float) * (size_t)rows * cols);
+    EFXO_PAR
     for (int y = 0; y < rows; y++) {
         const uint8_t* p = src + (size_t)y * sstride;
         for (int x = 0; x < cols; x++) {
@@ -513,6 +526,7 @@ void efxo_gaussian7(const uint8_t* src, int rows, int cols, int sstride, uint8_t
             tmp[(size_t)y * cols + x] = acc;
         }
     }
+    EFXO_PAR
     for (int y = 0; y < rows; y++) {
         for (int x = 0; x < cols; x++) {
             float acc = 0.f;
@@ -564,12 +578,18 @@ int efxo_fast9_detect(const uint8_t* img, int rows, int cols, int stride, int th
      * is 255 inside [border, cols-border) x [border, rows-border) (cuda_efficient_features.cpp:176-182). */
     int n = 0;
     const int b = border > 3 ? border : 3;
+    if (rows <= 2 * b || cols <= 2 * b) return 0;
+    uint8_t* flag = (uint8_t*)calloc((size_t)rows * cols, 1);
+    EFXO_PAR
+    for (int y = b; y < rows - b; y++)
+        for (int x = b; x < cols - b; x++) flag[(size_t)y * cols + x] = (uint8_t)efxo_fast9_at(img, stride, x, y, threshold);
     for (int y = b; y < rows - b; y++)
         for (int x = b; x < cols - b; x++)
-            if (efxo_fast9_at(img, stride, x, y, threshold)) {
+            if (flag[(size_t)y * cols + x]) {
                 if (n < max_out) { xy[2 * n] = (int16_t)x; xy[2 * n + 1] = (int16_t)y; }
                 n++;
             }
+    free(flag);
     return n;
 }
 
@@ -692,6 +712,7 @@ static void radius_nms(const cand_t* c, int n, int w, int h, int radius, uint8_t
     int* cur = (int*)malloc(sizeof(int) * ((size_t)gw * gh + 1));
     memcpy(cur, start, sizeof(int) * ((size_t)gw * gh + 1));
     for (int i = 0; i < n; i++) ids[cur[(c[i].y / EFXO_CELL) * gw + c[i].x / EFXO_CELL]++] = i;
+    EFXO_PAR
     for (int i = 0; i < n; i++) {
         const int bx1 = c[i].x / EFXO_CELL, by1 = c[i].y / EFXO_CELL;
         const int minx = bx1 - block_radius > 0 ? bx1 - block_radius : 0;
@@ -813,6 +834,7 @@ int efxo_detect_and_compute_masked(const uint8_t* img, int rows, int cols, int s
         int n = ncand < cap ? ncand : cap;                          /* cuda_fast.cu:245 */
         if (stats) { stats->n_candidates[s] = ncand; stats->n_after_cap[s] = n; }
 
+        EFXO_PAR
         for (int i = 0; i < n; i++) c[i].resp = efxo_harris(L, w, c[i].x, c[i].y);   /* :262 */
 
         uint8_t* keep = (uint8_t*)malloc((size_t)(n > 0 ? n : 1));
@@ -837,6 +859,7 @@ int efxo_detect_and_compute_masked(const uint8_t* img, int rows, int cols, int s
 
         /* angles (.cu:376-390), descriptors on the blurred level (.cpp:302-307), scalePoints (.cu:236-248) */
         float* kp4 = (float*)malloc(sizeof(float) * 4 * (size_t)(m > 0 ? m : 1));
+        EFXO_PAR
         for (int i = 0; i < m; i++) {
             kp4[4 * i + 0] = (float)c[i].x;
             kp4[4 * i + 1] = (float)c[i].y;

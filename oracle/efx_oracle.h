@@ -142,6 +142,10 @@ int efxo_detect_and_compute_masked(const uint8_t* img, int rows, int cols, int s
 int efxo_compute_provided(const uint8_t* img, int rows, int cols, int stride, const efxo_params* p, int desc_type,
                           const void* params_a, const void* params_b, const float* kps, int capacity, int n, uint8_t* desc_out);
 
+/* threads used by the row / candidate / keypoint loops (OpenMP; 1 = single-threaded like the reference CPU module) */
+void efxo_set_threads(int n);
+int efxo_get_threads(void);
+
 /* CPU model of the HIP kernel's fixed-point histogram sums (test infrastructure for the HashSIFT tolerance) */
 void efxo_hashsift_responses_fixedpoint(const uint8_t* img, int rows, int cols, int stride,
                                         const float* kps, int n, float crop_scale, float* responses);

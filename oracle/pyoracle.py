@@ -133,6 +133,13 @@ def hashsift_compute(img, kps, nbits, crop_scale=1.0):
     return hashsift_project(resp, nbits)[1]
 
 
+def set_threads(n):
+    """OpenMP threads of the oracle's loops (results do not depend on it); returns the previous value."""
+    prev = lib().efxo_get_threads()
+    lib().efxo_set_threads(int(n))
+    return prev
+
+
 def calc_umax(patch_size):
     u = (C.c_int * (patch_size // 2 + 2))()
     lib().efxo_calc_umax(int(patch_size), u)

@@ -197,3 +197,20 @@ def test_empty_and_ragged_inputs(oracle):
     for nbits in (256, 512):
         assert oracle.bad_compute(img, kps, nbits).shape == (5, nbits // 8)
         assert oracle.hashsift_compute(img, kps, nbits).shape == (5, nbits // 8)
+
+
+def test_thread_count_does_not_change_results(oracle):
+    """The OpenMP loops of the oracle (multi-core CPU baseline of bench.py) write disjoint outputs."""
+    img = synth.synth_frame(300, 400, seed=21)
+    try:
+        oracle.set_threads(1)
+        a = oracle.detect_and_compute(img, nfeatures=2000, desc_type=oracle.HASH_SIFT_256)
+        oracle.set_threads(4)
+        b = oracle.detect_and_compute(img, nfeatures=2000, desc_type=oracle.HASH_SIFT_256)
+        c = oracle.detect_and_compute(img, nfeatures=2000, desc_type=oracle.BAD_512)
+        oracle.set_threads(1)
+        d = oracle.detect_and_compute(img, nfeatures=2000, desc_type=oracle.BAD_512)
+    finally:
+        oracle.set_threads(1)
+    assert np.array_equal(a["kps"].view(np.uint32), b["kps"].view(np.uint32)) and np.array_equal(a["desc"], b["desc"])
+    assert np.array_equal(c["kps"].view(np.uint32), d["kps"].view(np.uint32)) and np.array_equal(c["desc"], d["desc"])
