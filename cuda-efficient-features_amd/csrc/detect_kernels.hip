@@ -397,11 +397,15 @@ __global__ __launch_bounds__(256) void fast_kernel(
             }
             const int gx0 = x0 + bx, gy0 = y0 + by;
             // validity of the 16 pixels of the block (border mask, .cpp:176-182) as one 16-bit mask
-            unsigned xm = 0, ym = 0;
+            unsigned xm = 0xffffu, ym = 0xffffu;
+            if (x0 < EFX_HALF_PATCH || x0 + EFX_TILE > cols - EFX_HALF_PATCH || y0 < EFX_HALF_PATCH || y0 + EFX_TILE > rows - EFX_HALF_PATCH) {
+                // only tiles that touch the 15-px border build the masks (workgroup-uniform branch)
+                xm = 0; ym = 0;
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                if ((gx0 + i) >= EFX_HALF_PATCH && (gx0 + i) < cols - EFX_HALF_PATCH) xm |= 0x1111u << i;
-                if ((gy0 + i) >= EFX_HALF_PATCH && (gy0 + i) < rows - EFX_HALF_PATCH) ym |= 0xfu << (4 * i);
+                for (int i = 0; i < 4; i++) {
+                    if ((gx0 + i) >= EFX_HALF_PATCH && (gx0 + i) < cols - EFX_HALF_PATCH) xm |= 0x1111u << i;
+                    if ((gy0 + i) >= EFX_HALF_PATCH && (gy0 + i) < rows - EFX_HALF_PATCH) ym |= 0xfu << (4 * i);
+                }
             }
             // Two pixels per instruction on packed 16-bit lanes (v_perm_b32 widens byte pairs, v_pk_max/min_u16,
             // saturating v_pk_sub_u16 instead of compares).  Two neighbouring compass points brighter than p+t
