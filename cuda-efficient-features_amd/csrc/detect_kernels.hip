@@ -855,12 +855,13 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
 // ================================================================================================
 #define SEL_BITS 12
 #define SEL_BINS (1 << SEL_BITS)
+#define SEL_MAX_TILES 12288          // per-tile counts of one level in LDS (48 KB); larger levels take the tile-parallel path
 
 __global__ __launch_bounds__(1024) void select_kernel(const LevelTable* __restrict__ T, TileHdr* __restrict__ hdr,
                                                       const Corner* __restrict__ surv_all, Counters* __restrict__ cnt,
                                                       int capacity, int* __restrict__ d_count)
 {
-    __shared__ int s_hist[SEL_BINS];
+    __shared__ int s_hist[SEL_MAX_TILES > SEL_BINS ? SEL_MAX_TILES : SEL_BINS];   // radix histogram, then per-tile counts
     __shared__ int s_scan[20];
     __shared__ int s_bin, s_rem;
 
@@ -944,18 +945,45 @@ __global__ __launch_bounds__(1024) void select_kernel(const LevelTable* __restri
     const int ntiles = L.tiles_x * L.tiles_y;
     TileHdr* hl = hdr + L.tile_base;
     int running = 0;
-    for (int t0 = 0; t0 < ntiles; t0 += 1024) {
-        const int t = t0 + tid;
-        int c = 0;
-        if (t < ntiles) {
-            const int sc = (int)hl[t].surv_count;
-            const Corner* q = surv + (size_t)(t & (EFX_NSUB - 1)) * L.surv_sub_cap + hl[t].surv_start;
-            for (int j = 0; j < sc; j++) c += efx_select_key(q[j].xy, q[j].resp) >= thresh ? 1 : 0;
+    if (ntiles <= SEL_MAX_TILES) {
+        // survivor-parallel: a survivor knows its tile from its coordinates, so the level's survivor arrays are read
+        // once, coalesced, and the per-tile counts live in LDS (the histogram's storage is free by now)
+        int* s_cnt = s_hist;
+        for (int t = tid; t < ntiles; t += 1024) s_cnt[t] = 0;
+        __syncthreads();
+        for (int sub = 0; sub < EFX_NSUB; sub++) {
+            const Corner* q = surv + (size_t)sub * L.surv_sub_cap;
+            const int ns = cnt->surv_total[l][sub].v;
+            for (int i = tid; i < ns; i += 1024) {
+                const Corner c = q[i];
+                if (efx_select_key(c.xy, c.resp) >= thresh)
+                    atomicAdd(&s_cnt[(int)((c.xy >> 16) >> 6) * L.tiles_x + (int)((c.xy & 0xffffu) >> 6)], 1);
+            }
         }
+        __syncthreads();
+        // exclusive scan over the tiles: a thread owns a contiguous chunk
+        const int chunk = (ntiles + 1023) / 1024;
+        const int t0 = tid * chunk, t1 = min(t0 + chunk, ntiles);
+        int local = 0;
+        for (int t = t0; t < t1; t++) local += s_cnt[t];
         int tot;
-        const int pre = block_excl_scan<16>(c, s_scan, &tot);
-        if (t < ntiles) hl[t].out_off = (uint32_t)(base + running + pre);
-        running += tot;
+        int pre = block_excl_scan<16>(local, s_scan, &tot);
+        for (int t = t0; t < t1; t++) { hl[t].out_off = (uint32_t)(base + pre); pre += s_cnt[t]; }
+        running = tot;
+    } else {
+        for (int t0 = 0; t0 < ntiles; t0 += 1024) {
+            const int t = t0 + tid;
+            int c = 0;
+            if (t < ntiles) {
+                const int sc = (int)hl[t].surv_count;
+                const Corner* q = surv + (size_t)(t & (EFX_NSUB - 1)) * L.surv_sub_cap + hl[t].surv_start;
+                for (int j = 0; j < sc; j++) c += efx_select_key(q[j].xy, q[j].resp) >= thresh ? 1 : 0;
+            }
+            int tot;
+            const int pre = block_excl_scan<16>(c, s_scan, &tot);
+            if (t < ntiles) hl[t].out_off = (uint32_t)(base + running + pre);
+            running += tot;
+        }
     }
     if (tid == 0) {
         cnt->sum.kept[l] = running;
