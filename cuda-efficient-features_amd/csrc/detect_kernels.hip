@@ -624,11 +624,25 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
             v = reinterpret_cast<const uint32_t*>(&hl[nty * L.tiles_x + ntx])[w];
         s_nb[t][w] = v;
     }
+    // the per-cell maxima include corners beyond the 10 % cap; when the cap is active (pathological frames) a cell
+    // maximum is a valid suppressor only if its whole tile lies below the cap
+    int lvl_total = 0;
+    for (int sub = 0; sub < EFX_NSUB; sub++) lvl_total += cnt->cand_total[l][sub].v;
+    const bool capped = lvl_total > L.cap;              // only then the canonical ranks were computed
+    __syncthreads();                                     // s_nb is read below
     if (lane < 36) {
         // clamped exactly as the quick test clamps its cell coordinates
         const int gw_ = (L.cols + EFX_CELL - 1) / EFX_CELL, gh_ = (L.rows + EFX_CELL - 1) / EFX_CELL;
         const int cy = min(max(ty * 4 - 1 + lane / 6, 0), gh_ - 1), cx = min(max(tx * 4 - 1 + lane % 6, 0), gw_ - 1);
-        s_cm[lane / 6][lane % 6] = cmax_all[L.cmax_base + (size_t)cy * (L.tiles_x * 4) + cx];
+        Corner cm = cmax_all[L.cmax_base + (size_t)cy * (L.tiles_x * 4) + cx];
+        if (capped) {
+            // a cell of a tile that is cut by the cap may hold invalid corners: its maximum must not suppress anything,
+            // but the cell may still hold a valid rival -> "infinitely strong, infinitely far": never kills, always
+            // sends the corner to the exact scan of that cell (whose list is clipped at the cap)
+            const TileHdr* nh = reinterpret_cast<const TileHdr*>(&s_nb[((cy >> 2) - ty + 1) * 3 + ((cx >> 2) - tx + 1)][0]);
+            if ((int)nh->cand_rank + (int)nh->cell_off[EFX_CELLS_PER_TILE] > L.cap) { cm.xy = 0x7fff7fffu; cm.resp = __int_as_float(0x7f800000); }
+        }
+        s_cm[lane / 6][lane % 6] = cm;
     }
     __syncthreads();
     // header of the tile that holds cell (bx, by): the LDS copy when it is a neighbour (always, up to radius 64)
@@ -641,11 +655,6 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
     const TileHdr& h = *reinterpret_cast<const TileHdr*>(&s_nb[4][0]);
     const Corner* own = cand + (size_t)(tile & (EFX_NSUB - 1)) * L.cand_sub_cap + h.cand_start;
 
-    // the per-cell maxima include corners beyond the cap; when the cap is active (pathological frames) a cell
-    // maximum is a valid suppressor only if its whole tile lies below the cap
-    int lvl_total = 0;
-    for (int sub = 0; sub < EFX_NSUB; sub++) lvl_total += cnt->cand_total[l][sub].v;
-    const bool capped = lvl_total > L.cap;              // only then the canonical ranks were computed
     const int n_own = h.cell_off[EFX_CELLS_PER_TILE];
     int n_valid = capped ? L.cap - (int)h.cand_rank : n_own;   // cap in canonical order (spec S2; cuda_fast.cu:245)
     n_valid = n_valid < 0 ? 0 : (n_valid > n_own ? n_own : n_valid);
@@ -678,7 +687,7 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
             const int cx0 = max(bx1 - block_radius, 0), cx1 = min(bx1 + block_radius, gw - 1);
             const int cy0 = max(by1 - block_radius, 0), cy1 = min(by1 + block_radius, gh - 1);
             bool kill = false;
-            if (block_radius == 1 && !capped) {
+            if (block_radius == 1) {
                 // common case: phase A already knows which of the 9 cells hold a rival (s_hneed); lane `sub` fetches the
                 // list range of cell `sub`, lane 0 also that of cell 8, straight from the headers in LDS
                 const int needm = act ? (int)s_hneed[hi] : 0;
@@ -692,13 +701,15 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
                         const int c = (by & 3) * 4 + (bx & 3);
                         lb[q] = nh2->cell_off[c];
                         le[q] = nh2->cell_off[c + 1];
+                        if (capped) le[q] = min(le[q], L.cap - (int)nh2->cand_rank);       // corners beyond the cap do not exist
                         lbase[q] = (unsigned)(((by >> 2) * L.tiles_x + (bx >> 2)) & (EFX_NSUB - 1)) * L.cand_sub_cap + nh2->cand_start;
                     }
                 }
                 unsigned gneed = ((unsigned)(__ballot(le[0] > lb[0]) >> (grp * 8)) & 0xffu) |
                                  (((unsigned)(__ballot(le[1] > lb[1]) >> (grp * 8)) & 0x01u) << 8);
                 while (__ballot(gneed != 0u) != 0ull) {
-                    const int i = gneed ? __ffs(gneed) - 1 : 0;
+                    // the corner's own cell first: its rivals are the closest ones
+                    const int i = (gneed & 16u) ? 4 : (gneed ? __ffs(gneed) - 1 : 0);
                     const int src = (lane & 56) + (i & 7);
                     const int b0 = __shfl(lb[0], src, 64), b1 = __shfl(lb[1], src, 64);
                     const int e0 = __shfl(le[0], src, 64), e1 = __shfl(le[1], src, 64);
@@ -712,7 +723,10 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
                             kill |= (o.xy != m.xy && m.resp <= o.resp && dx * dx + dy * dy < image_radius);
                         }
                     }
-                    gneed &= gneed - 1u;
+                    gneed &= ~(1u << i);
+                    // one suppressor is enough: a group whose corner is dead stops walking (most hard corners of a
+                    // dense tile die in the first list)
+                    if (((unsigned)(__ballot(kill) >> (grp * 8)) & 0xffu) != 0u) gneed = 0u;
                 }
             } else
             // cells of the neighbourhood in chunks of 16: lane `sub` fetches the list ranges of cells c0+sub and
@@ -756,7 +770,9 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
                         }
                     }
                     gneed &= gneed - 1u;
+                    if (((unsigned)(__ballot(kill) >> (grp * 8)) & 0xffu) != 0u) gneed = 0u;       // one suppressor is enough
                 }
+                if (__ballot(act && !kill) == 0ull) break;       // every corner of this batch is dead
             }
             const unsigned gk = (unsigned)(__ballot(kill) >> (grp * 8)) & 0xffu;
             if (act && sub == 0 && gk == 0u) {
@@ -778,7 +794,7 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
             const int bx1 = mx / EFX_CELL, by1 = my / EFX_CELL;
             hard = true;
             if (quick_ok) {
-                if (block_radius == 1 && !capped) {
+                if (block_radius == 1) {
                     // the common case as straight-line code: 9 loads, then branch-free compares (this kernel is bound
                     // by instruction issue, scalar exec-mask bookkeeping included)
                     Corner o[9];
