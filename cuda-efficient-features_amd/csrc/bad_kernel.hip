@@ -75,8 +75,7 @@ __global__ __launch_bounds__(256) void bad_affine_kernel(const float4* __restric
     aff[i] = A;
 }
 
-// LDS plan (dynamic): [ I: (S+1)^2 int32, aliased by raw: (S+6) x RPB u8 | hb: (8G+6) x HP float ]
-//   G = ceil(S/8) groups of 8 outputs, HP = 8G, RPB = 4*ceil((S+12)/4) (room for the dword-alignment slack)
+// LDS plan (dynamic): [ I: (S+1)^2 int32, aliased by raw: (S+6) x RPB u8 | hb: HR x HP float ]   (BlurGeom, blur_window.h)
 // SF != 0: every keypoint is known to need exactly an SF x SF window (size 31, scale 1 -> 48: the detector's
 // keypoints), so all index arithmetic and loop bounds fold to constants.
 template <bool BLUR, int SF>
@@ -109,11 +108,10 @@ __global__ __launch_bounds__(256) void bad_kernel(
 
     int* I = reinterpret_cast<int*>(smem);                       // (S+1) x (S+1)
     const int IP = S + 1;
-    const int RP = S + 6;                                        // raw rows / valid raw columns (blur_window.h)
-    const int RPB = ((S + 12 + 3) >> 2) << 2;                    // raw row pitch in bytes
+    const BlurGeom bg(S);
     uint8_t* raw = smem;                                         // aliases I (dead before I is written)
     size_t ibytes = (size_t)IP * IP * 4;
-    if (BLUR && (size_t)RP * RPB > ibytes) ibytes = (size_t)RP * RPB;
+    if (BLUR && bg.raw_bytes() > ibytes) ibytes = bg.raw_bytes();
     float* hb = reinterpret_cast<float*>(smem + ((ibytes + 15) & ~(size_t)15));
 
     if (fits) {
@@ -247,10 +245,10 @@ hipError_t efx_launch_bad(const DescribeLaunch& a, const BadParamsDev* d_params,
     const int S = bad_smax_for(max_size, a.scale_factor, reach);
     size_t lds = (size_t)(S + 1) * (S + 1) * 4;
     if (a.blur) {
-        const int G = (S + 7) >> 3, HP = G * 8, RP = S + 6, RPB = ((S + 12 + 3) >> 2) << 2;
-        if ((size_t)RP * RPB > lds) lds = (size_t)RP * RPB;
+        const BlurGeom bg(S);
+        if (bg.raw_bytes() > lds) lds = bg.raw_bytes();
         lds = (lds + 15) & ~(size_t)15;
-        lds += (size_t)(8 * G + 6) * HP * 4;
+        lds += bg.hb_bytes();
     }
     lds = (lds + 15) & ~(size_t)15;
     if (lds > 160 * 1024 - 64) return hipErrorInvalidValue;    // keypoint window does not fit in LDS

@@ -2,18 +2,39 @@
 // BORDER_REFLECT_101), cuda_efficient_features.cpp:193,305) applied to one keypoint's S x S window in LDS.
 // Shared by the BAD and HashSIFT describers: neither needs a global blur pass over the pyramid.
 //
-// Geometry for a window of S pixels (S even):  G = ceil(S/8) groups of 8 outputs,  HP = 8G floats per hb row,
-//   RP = S + 6 raw rows / valid raw columns (3-px apron),  RPB = 4 * ceil((S + 12) / 4) raw row pitch in bytes
-//   (room for the dword-alignment slack).   LDS: raw RP x RPB bytes, hb (8G + 6) x HP floats.
-//   efx_blur_lds_bytes(S) = bytes of [raw | hb] with hb 16-byte aligned behind raw.
+// Item shapes (chosen for lane utilisation at S = 48 with 256 threads, tools/microbench/sweep_define.sh):
+//   row pass     2 adjacent rows x RO = 6 consecutive outputs  -> 27 x 8 = 216 items (84 % of the lanes; 8 outputs: 63 %)
+//   column pass  2 adjacent columns x CR = 5 consecutive rows  -> 24 x 10 = 240 items (94 %; 8 rows: 56 %)
+// Geometry for a window of S pixels (S even):  GR = ceil(S/RO) row-pass groups, GC = ceil(S/CR) column-pass groups,
+//   HP = RO*GR floats per hb row,  RP = S + 6 raw rows / valid raw columns (3-px apron),  RPB = raw row pitch in bytes
+//   (room for the dword-alignment slack of the last group),  hb rows = CR*GC + 6 (rows >= RP are never written; what the
+//   column pass computes from them lies below the window and is discarded).
+//   LDS: raw RP x RPB bytes, then hb (16-byte aligned).
 #pragma once
 #include "efx_device.h"
 
+#ifndef EFX_BLUR_RO
+#define EFX_BLUR_RO 6
+#endif
+#ifndef EFX_BLUR_CR
+#define EFX_BLUR_CR 5
+#endif
+
 struct BlurGeom {
-    int G, HP, RP, RPB;
-    __host__ __device__ explicit BlurGeom(int S) : G((S + 7) >> 3), HP(((S + 7) >> 3) * 8), RP(S + 6), RPB(((S + 12 + 3) >> 2) << 2) {}
+    static constexpr int RO = EFX_BLUR_RO, CR = EFX_BLUR_CR;
+    static constexpr int NV = RO + 6;                   // input pixels of one row of a row-pass item
+    static constexpr int ND = (NV + 3 + 3) / 4;         // dwords that hold them at any byte alignment
+    int GR, GC, HP, RP, RPB, HR;
+    __host__ __device__ explicit BlurGeom(int S)
+        : GR((S + RO - 1) / RO), GC((S + CR - 1) / CR), HP(RO * ((S + RO - 1) / RO)), RP(S + 6), RPB(0), HR(CR * ((S + CR - 1) / CR) + 6)
+    {
+        const int need_items = 4 * (((RO * (GR - 1) + 3) >> 2) + ND);     // last group, worst alignment
+        const int need_load = 4 * ((3 + RP + 3) >> 2);                    // the staged row incl. alignment slack
+        RPB = need_items > need_load ? need_items : need_load;
+        if ((RPB & 63) == 0) RPB += 4;                                    // two rows apart must not be 32 banks apart
+    }
     __host__ __device__ size_t raw_bytes() const { return ((size_t)RP * RPB + 15) & ~(size_t)15; }
-    __host__ __device__ size_t hb_bytes() const { return (size_t)(8 * G + 6) * HP * 4; }
+    __host__ __device__ size_t hb_bytes() const { return (size_t)HR * HP * 4; }
 };
 
 #ifdef __HIPCC__
@@ -38,7 +59,9 @@ __device__ __forceinline__ void efx_blur_window_lds(const uint8_t* __restrict__ 
                                                     int tid, Store store)
 {
     const BlurGeom g_(S);
-    const int G = g_.G, HP = g_.HP, RP = g_.RP, RPB = g_.RPB;
+    constexpr int RO = BlurGeom::RO, CR = BlurGeom::CR, NV = BlurGeom::NV, ND = BlurGeom::ND;
+    static_assert(RO % 2 == 0, "hb rows are written as float2");
+    const int GR = g_.GR, GC = g_.GC, HP = g_.HP, RP = g_.RP, RPB = g_.RPB;
     // ---- raw window with a 3-px apron -> LDS.  Interior + 4-byte aligned images: aligned dword loads (row start
     //      rounded down to 4, byte offset `off` kept); otherwise bytes with REFLECT_101.
     const bool interior = (wx0 - 3 >= 0) && (wx0 + S + 3 <= cols) && (wy0 - 3 >= 0) && (wy0 + S + 3 <= rows);
@@ -62,56 +85,63 @@ __device__ __forceinline__ void efx_blur_window_lds(const uint8_t* __restrict__ 
     }
     __syncthreads();
     const float tp[7] = { taps0, taps1, taps2, taps3, taps2, taps1, taps0 };
-    // ---- row pass: u8 -> float, acc = fma(tap_j, v_j, acc) for j = 0..6.  An item is 8 consecutive outputs of TWO
+    // ---- row pass: u8 -> float, acc = fma(tap_j, v_j, acc) for j = 0..6.  An item is RO consecutive outputs of TWO
     //      adjacent rows, so every FMA is a v_pk_fma_f32 on a (row r, row r+1) register pair and every raw byte is
     //      read from LDS once.  RP = S + 6 is even.
     {
-        const int nitems = (RP >> 1) * G;
+        const int nitems = (RP >> 1) * GR;
         for (int it = tid; it < nitems; it += NT) {
-            const int rp = it / G, g = it - rp * G;
-            const uint32_t* wa = reinterpret_cast<const uint32_t*>(raw + (2 * rp) * RPB + 8 * g);
+            const int rp = it / GR, g = it - rp * GR;
+            const int sb = RO * g + off;                            // first input byte of the item within the raw row
+            const uint32_t* wa = reinterpret_cast<const uint32_t*>(raw + (2 * rp) * RPB) + (sb >> 2);
             const uint32_t* wb = wa + (RPB >> 2);
-            const uint32_t a0 = wa[0], a1 = wa[1], a2 = wa[2], a3 = wa[3], a4 = wa[4];
-            const uint32_t c0 = wb[0], c1 = wb[1], c2 = wb[2], c3 = wb[3], c4 = wb[4];
-            const uint32_t ba[4] = { __builtin_amdgcn_alignbyte(a1, a0, off), __builtin_amdgcn_alignbyte(a2, a1, off),
-                                     __builtin_amdgcn_alignbyte(a3, a2, off), __builtin_amdgcn_alignbyte(a4, a3, off) };
-            const uint32_t bb[4] = { __builtin_amdgcn_alignbyte(c1, c0, off), __builtin_amdgcn_alignbyte(c2, c1, off),
-                                     __builtin_amdgcn_alignbyte(c3, c2, off), __builtin_amdgcn_alignbyte(c4, c3, off) };
-            efx_f32x2 v[14];
+            const int sh = sb & 3;
+            uint32_t a[ND], c[ND], ba[ND - 1], bb[ND - 1];
 #pragma unroll
-            for (int k = 0; k < 14; k++) {
+            for (int k = 0; k < ND; k++) { a[k] = wa[k]; c[k] = wb[k]; }
+#pragma unroll
+            for (int k = 0; k < ND - 1; k++) {
+                ba[k] = __builtin_amdgcn_alignbyte(a[k + 1], a[k], sh);
+                bb[k] = __builtin_amdgcn_alignbyte(c[k + 1], c[k], sh);
+            }
+            efx_f32x2 v[NV];
+#pragma unroll
+            for (int k = 0; k < NV; k++) {
                 v[k].x = (float)((ba[k >> 2] >> (8 * (k & 3))) & 0xff);
                 v[k].y = (float)((bb[k >> 2] >> (8 * (k & 3))) & 0xff);
             }
-            efx_f32x2 o[8];
+            efx_f32x2 o[RO];
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
+            for (int i = 0; i < RO; i++) {
                 efx_f32x2 acc = v[i] * tp[0];                        // == fma(tp[0], v, 0) exactly
 #pragma unroll
                 for (int jt = 1; jt < 7; jt++) acc = __builtin_elementwise_fma(v[i + jt], (efx_f32x2)(tp[jt]), acc);
                 o[i] = acc;
             }
-            float4* d0 = reinterpret_cast<float4*>(hb + (2 * rp) * HP + 8 * g);
-            float4* d1 = reinterpret_cast<float4*>(hb + (2 * rp + 1) * HP + 8 * g);
-            d0[0] = make_float4(o[0].x, o[1].x, o[2].x, o[3].x); d0[1] = make_float4(o[4].x, o[5].x, o[6].x, o[7].x);
-            d1[0] = make_float4(o[0].y, o[1].y, o[2].y, o[3].y); d1[1] = make_float4(o[4].y, o[5].y, o[6].y, o[7].y);
+            float2* d0 = reinterpret_cast<float2*>(hb + (2 * rp) * HP + RO * g);
+            float2* d1 = reinterpret_cast<float2*>(hb + (2 * rp + 1) * HP + RO * g);
+#pragma unroll
+            for (int i = 0; i < RO / 2; i++) {
+                d0[i] = make_float2(o[2 * i].x, o[2 * i + 1].x);
+                d1[i] = make_float2(o[2 * i].y, o[2 * i + 1].y);
+            }
         }
     }
     __syncthreads();
-    // ---- column pass: float -> u8 (round half even, saturate: v_cvt_pk_u8_f32).  An item is 8 consecutive rows of
-    //      TWO adjacent columns (S is even): 14 ds_read_b64, 56 v_pk_fma_f32.
+    // ---- column pass: float -> u8 (round half even, saturate: v_cvt_pk_u8_f32).  An item is CR consecutive rows of
+    //      TWO adjacent columns (S is even): CR + 6 ds_read_b64, 7 CR v_pk_fma_f32.
     {
         const int ncp = S >> 1;
-        const int nitems = ncp * G;
+        const int nitems = ncp * GC;
         for (int it = tid; it < nitems; it += NT) {
             const int rg = it / ncp, cp = it - rg * ncp;
             const int c = 2 * cp;
-            efx_f32x2 v[14];
+            efx_f32x2 v[CR + 6];
 #pragma unroll
-            for (int k = 0; k < 14; k++) v[k] = *reinterpret_cast<const efx_f32x2*>(hb + (8 * rg + k) * HP + c);
+            for (int k = 0; k < CR + 6; k++) v[k] = *reinterpret_cast<const efx_f32x2*>(hb + (CR * rg + k) * HP + c);
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const int r = 8 * rg + i;
+            for (int i = 0; i < CR; i++) {
+                const int r = CR * rg + i;
                 efx_f32x2 acc = v[i] * tp[0];
 #pragma unroll
                 for (int jt = 1; jt < 7; jt++) acc = __builtin_elementwise_fma(v[i + jt], (efx_f32x2)(tp[jt]), acc);
