@@ -517,6 +517,7 @@ __global__ __launch_bounds__(64) void harris_kernel(
     const TileHdr* __restrict__ hdr_all, int dbg)
 {
     __shared__ unsigned long long s_cellmax[EFX_CELLS_PER_TILE];
+    __shared__ unsigned s_celltie[EFX_CELLS_PER_TILE];     // largest response key that two corners of the cell share
     const int lane = threadIdx.x;
     const int gt = T->total_tiles - 1 - xcd_interleaved(blockIdx.x, T->total_tiles);      // densest tiles first
     int l, tx, ty;
@@ -530,7 +531,7 @@ __global__ __launch_bounds__(64) void harris_kernel(
     const TileHdr& h = hdr_all[L.tile_base + tile];
     const int total = h.cell_off[EFX_CELLS_PER_TILE];
     Corner* cand = cand_all + L.cand_base + (size_t)(tile & (EFX_NSUB - 1)) * L.cand_sub_cap + h.cand_start;
-    if (lane < EFX_CELLS_PER_TILE) s_cellmax[lane] = 0ull;
+    if (lane < EFX_CELLS_PER_TILE) { s_cellmax[lane] = 0ull; s_celltie[lane] = 0u; }
     __syncthreads();
     for (int k = lane; k < total; k += 64) {
         const uint32_t xy = cand[k].xy;
@@ -538,8 +539,13 @@ __global__ __launch_bounds__(64) void harris_kernel(
         const uint8_t* c = src + (size_t)y * spitch + x;
         const float resp = (dbg & 4) ? 1.f : (aligned ? harris_rows(c - 4 * spitch - 4, spitch) : harris_bytes(c, spitch));
         cand[k].resp = resp;
-        // strongest corner of the 16x16 cell: 64-bit max of (response key, xy)
-        atomicMax(&s_cellmax[((y >> 4) & 3) * 4 + ((x >> 4) & 3)], (efx_select_key(0u, resp) & 0xffffffff00000000ull) | xy);
+        // strongest corner of the 16x16 cell: 64-bit max of (response key, xy).  A corner that finds its own response
+        // already there has an equal twin in the cell; if that response ends up being the cell's maximum, the NMS quick
+        // test must not treat the stored corner as the only one of that strength (equal responses suppress each other).
+        const int cell = ((y >> 4) & 3) * 4 + ((x >> 4) & 3);
+        const unsigned long long key = (efx_select_key(0u, resp) & 0xffffffff00000000ull) | xy;
+        const unsigned long long old = atomicMax(&s_cellmax[cell], key);
+        if ((unsigned)(old >> 32) == (unsigned)(key >> 32)) atomicMax(&s_celltie[cell], (unsigned)(key >> 32));
     }
     __syncthreads();
     if (lane < EFX_CELLS_PER_TILE) {
@@ -549,6 +555,7 @@ __global__ __launch_bounds__(64) void harris_kernel(
             uint32_t u = (uint32_t)(m >> 32);
             u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;          // inverse of the order-preserving map
             best.resp = __uint_as_float(u); best.xy = (uint32_t)m;
+            if (s_celltie[lane] == (uint32_t)(m >> 32)) best.xy |= EFX_CMAX_TIE;      // y < 2^15: bit 31 is free
         }
         cmax_all[L.cmax_base + (size_t)(ty * 4 + (lane >> 2)) * (L.tiles_x * 4) + tx * 4 + (lane & 3)] = best;
     }
@@ -804,9 +811,13 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
                     int kill = 0, rival = 0;
 #pragma unroll
                     for (int q = 0; q < 9; q++) {
-                        const int dx = mx - (int)(o[q].xy & 0xffff), dy = my - (int)(o[q].xy >> 16);
-                        const int ge = (int)(o[q].xy != me.xy) & (int)(me.resp <= o[q].resp);
-                        rival |= ge << q;                  // cell q holds a corner at least as strong: the exact scan must walk it
+                        const uint32_t oxy = o[q].xy & ~EFX_CMAX_TIE;
+                        const int dx = mx - (int)(oxy & 0xffff), dy = my - (int)(oxy >> 16);
+                        const int other = (int)(oxy != me.xy);
+                        const int ge = other & (int)(me.resp <= o[q].resp);
+                        // cell q holds a corner at least as strong: the exact scan must walk it.  That includes the cell whose
+                        // maximum this corner is, when another corner of the cell has the same response (ties suppress)
+                        rival |= (ge | ((other ^ 1) & (int)(o[q].xy >> 31))) << q;
                         kill |= ge & (int)(dx * dx + dy * dy < image_radius);
                     }
                     hard = kill == 0;
@@ -820,8 +831,9 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
                     for (int by = miny; by <= maxy; by++)
                         for (int bx = minx; bx <= maxx; bx++) {
                             const Corner o = cmax[by * gwp + bx];
-                            const int dx = mx - (int)(o.xy & 0xffff), dy = my - (int)(o.xy >> 16);
-                            if (o.xy != me.xy && me.resp <= o.resp && dx * dx + dy * dy < image_radius && usable(bx, by)) hard = false;
+                            const uint32_t oxy = o.xy & ~EFX_CMAX_TIE;
+                            const int dx = mx - (int)(oxy & 0xffff), dy = my - (int)(oxy >> 16);
+                            if (oxy != me.xy && me.resp <= o.resp && dx * dx + dy * dy < image_radius && usable(bx, by)) hard = false;
                         }
                 }
             }

@@ -82,6 +82,9 @@ struct __attribute__((aligned(8))) Corner {
     uint32_t xy;       // x | y << 16, level coordinates
     float resp;        // Harris response (spec S4)
 };
+// In the per-cell maxima table (Corner* cmax) bit 31 of xy (y < 2^15) says that another corner of the cell has the same
+// response as the stored one (equal responses suppress each other: the NMS must then walk the cell's list)
+#define EFX_CMAX_TIE 0x80000000u
 
 // 64-bit selection key: response descending, then raster (y, x) ascending (spec S3).
 __host__ __device__ inline unsigned long long efx_select_key(uint32_t xy, float resp)

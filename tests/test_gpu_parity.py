@@ -532,3 +532,15 @@ def test_descriptor_keypoint_extremes(cef, oracle):
     # a keypoint whose window cannot fit the 160 KB LDS is refused, not silently mis-described
     with pytest.raises(cef.EfxError):
         cef.BAD.create(1.0, cef.BAD.SIZE_256_BITS).compute(img, np.array([[100, 100, 5000, 0]], np.float32))
+
+
+@pytest.mark.parametrize("period,radius", [(9, 15), (12, 8), (17, 16), (6, 3)])
+def test_equal_responses_suppress_each_other(cef, torch_mod, oracle, period, radius):
+    """A checkerboard gives every crossing the same Harris response: corners of equal strength inside the radius kill
+    each other (IsMaxPoint compares with <=, cuda_efficient_features.cu:90), including the strongest corner of a cell
+    and its equal twin in the same cell."""
+    y, x = np.mgrid[0:300, 0:400]
+    img = ((((x // period) + (y // period)) & 1) * 200).astype(np.uint8)
+    got, ref = _detect_both(cef, torch_mod, oracle, img, desc_type=1, nonmax_radius=radius, nlevels=4)
+    _assert_same_keypoints(got, ref)
+    assert np.array_equal(got["desc"], ref["desc"])
