@@ -2,6 +2,8 @@
 oracle through the C-ABI.  Bit-exact keypoints (location, response bits, angle bits, octave, size) and BAD bytes;
 HashSIFT within the byte tolerance of tests/test_golden.py (spec S8).  The cases are small so the oracle stays fast;
 every case prints its parameters on failure, so a failing seed is a ready-made regression test."""
+import os
+
 import numpy as np
 import pytest
 
@@ -47,10 +49,12 @@ def _image(rng, rows, cols, kind):
 def _case(seed):
     rng = np.random.default_rng(seed)
     rows, cols = int(rng.integers(33, 420)), int(rng.integers(33, 520))
+    if rng.random() < 0.15:                         # some frames span many 64x64 tiles
+        rows, cols = int(rng.integers(400, 1000)), int(rng.integers(500, 1400))
     kw = dict(nfeatures=int(rng.choice([1, 7, 100, 1000, 5000, 20000])),
               scale_factor=float(rng.choice([1.1, 1.2, 1.2, 1.2, 1.5, 2.0])),
               nlevels=int(rng.integers(1, 9)),
-              first_level=0,
+              first_level=int(rng.choice([0, 0, 0, 0, 1, 2])),
               fast_threshold=int(rng.choice([1, 5, 10, 20, 20, 40, 90])),
               nonmax_radius=int(rng.choice([0, 1, 3, 8, 15, 15, 15, 16, 17, 24, 33])))
     img = _image(rng, rows, cols, int(rng.integers(0, 5)))
@@ -66,7 +70,12 @@ def _hashsift_tol(nbits, n):
     return 2 * max(1, n // 100)
 
 
-@pytest.mark.parametrize("seed", range(60))
+# EFX_FUZZ_CASES / EFX_FUZZ_FIRST widen the sweep from the command line (the committed default keeps the suite fast)
+_N = int(os.environ.get("EFX_FUZZ_CASES", "60"))
+_FIRST = int(os.environ.get("EFX_FUZZ_FIRST", "0"))
+
+
+@pytest.mark.parametrize("seed", range(_FIRST, _FIRST + _N))
 def test_fuzz_detect_and_compute(cef, torch_mod, oracle, seed):
     torch = torch_mod
     img, mask, desc_type, kw = _case(seed)
@@ -100,3 +109,75 @@ def test_fuzz_detect_and_compute(cef, torch_mod, oracle, seed):
         assert d.shape == ref["desc"].shape, info
         nbad = int(np.count_nonzero(d != ref["desc"]))
         assert nbad <= _hashsift_tol(256 if desc_type == 2 else 512, max(n, 1)), f"{info}: {nbad} descriptor bytes differ"
+
+
+@pytest.mark.parametrize("seed", range(_FIRST, _FIRST + max(_N // 2, 1)))
+def test_fuzz_compute(cef, oracle, seed):
+    """Stand-alone describers on random keypoints: positions inside / on the border / outside the frame, random sizes,
+    every angle convention (-1 axis aligned, < 0 unrotated, degrees), random scale factors."""
+    rng = np.random.default_rng(10_000 + seed)
+    rows, cols = int(rng.integers(20, 300)), int(rng.integers(20, 400))
+    img = _image(rng, rows, cols, int(rng.integers(0, 5)))
+    n = int(rng.integers(1, 300))
+    kps = np.zeros((n, 4), np.float32)
+    kps[:, 0] = rng.uniform(-20, cols + 20, n)
+    kps[:, 1] = rng.uniform(-20, rows + 20, n)
+    kps[:, 2] = rng.choice([31.0, 31.0, 7.0, 12.5, 48.0, 64.0, 90.0], n)
+    kps[:, 3] = rng.uniform(0, 360, n)
+    sel = rng.random(n)
+    kps[sel < 0.1, 3] = -1.0
+    kps[(sel >= 0.1) & (sel < 0.15), 3] = -7.0
+    if rng.random() < 0.5:
+        kps[:, :2] = np.floor(kps[:, :2])               # integer positions, as the detector reports them
+    scale = float(rng.choice([1.0, 1.0, 0.75, 1.5, 2.0]))
+    # a keypoint whose window exceeds the 160 KB LDS is refused (DESIGN.md limits; test_descriptor_keypoint_extremes)
+    kps[:, 2] = np.minimum(kps[:, 2], np.float32(110.0 / scale))
+    info = f"seed {seed}: {img.shape} n {n} scale {scale}"
+    kind = int(rng.integers(0, 4))
+    if kind < 2:
+        nbits, enum = ((256, cef.BAD.SIZE_256_BITS), (512, cef.BAD.SIZE_512_BITS))[kind]
+        got = cef.BAD.create(scale, enum).compute(img, kps)
+        want = oracle.bad_compute(img, kps, nbits, scale_factor=scale)
+        assert np.array_equal(got, want), f"{info} BAD{nbits}: rows {np.nonzero((got != want).any(axis=1))[0][:6].tolist()} differ"
+    else:
+        nbits, enum = ((256, cef.HashSIFT.SIZE_256_BITS), (512, cef.HashSIFT.SIZE_512_BITS))[kind - 2]
+        got = cef.HashSIFT.create(scale, enum).compute(img, kps)
+        want = oracle.hashsift_compute(img, kps, nbits, crop_scale=scale)
+        nbad = int(np.count_nonzero(got != want))
+        assert nbad <= _hashsift_tol(nbits, n), f"{info} HashSIFT{nbits}: {nbad} bytes differ"
+
+
+@pytest.mark.parametrize("seed", range(_FIRST, _FIRST + max(_N // 3, 1)))
+def test_fuzz_provided_keypoints(cef, torch_mod, oracle, seed):
+    """detectAndCompute(useProvidedKeypoints=True) on random raw 5 x N matrices (spec S13): positions anywhere on the frame,
+    octaves inside and outside the pyramid, arbitrary angles."""
+    torch = torch_mod
+    rng = np.random.default_rng(20_000 + seed)
+    rows, cols = int(rng.integers(40, 400)), int(rng.integers(40, 500))
+    img = _image(rng, rows, cols, int(rng.integers(0, 5)))
+    nlevels = int(rng.integers(1, 9))
+    scale = float(rng.choice([1.2, 1.2, 1.5, 2.0]))
+    dt = int(rng.integers(0, 4))
+    n = int(rng.integers(1, 200))
+    kps = np.zeros((5, n), np.float32)
+    x = rng.integers(0, cols, n).astype(np.uint32)
+    y = rng.integers(0, rows, n).astype(np.uint32)
+    kps[0] = (x | (y << 16)).view(np.float32)
+    kps[1] = rng.random(n).astype(np.float32)
+    kps[2] = rng.uniform(0, 360, n).astype(np.float32)
+    octv = rng.integers(0, nlevels, n).astype(np.int32)
+    octv[rng.random(n) < 0.05] = int(rng.choice([-1, nlevels, 31, 1000]))
+    kps[3] = octv.view(np.float32)
+    kps[4] = 31.0
+    det = cef.EfficientFeatures.create(1000, scale, nlevels, 0, 20, 15, dt)
+    got = det.detectAndComputeAsync(torch.from_numpy(img).cuda(), keypoints=torch.from_numpy(kps).cuda(), n=n,
+                                    useProvidedKeypoints=True)
+    torch.cuda.synchronize()
+    got = got.cpu().numpy()
+    want = oracle.compute_provided(img, kps, dt, scale_factor=scale, nlevels=nlevels)
+    info = f"seed {seed}: {img.shape} n {n} levels {nlevels} scale {scale} desc_type {dt}"
+    if dt <= 1:
+        assert np.array_equal(got, want), f"{info}: rows {np.nonzero((got != want).any(axis=1))[0][:6].tolist()} differ"
+    else:
+        nbad = int(np.count_nonzero(got != want))
+        assert nbad <= _hashsift_tol(0, n), f"{info}: {nbad} bytes differ"
