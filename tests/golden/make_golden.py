@@ -32,14 +32,21 @@ DETECTOR_CASES = [
     ("synth_480x640", "synth", 480, 640, 1000, dict(nfeatures=4000)),
     ("synth_480x640_r5_t40", "synth", 480, 640, 32, dict(nfeatures=4000, nonmax_radius=5, fast_threshold=40)),
     ("noise_200x260_cap", "noise", 200, 260, 7, dict(nfeatures=3000)),
+    # bright squares on a grid of period `seed`: thousands of corners with identical Harris responses, which suppress
+    # each other (the <= rule of IsMaxPoint, spec S3): level 0 has 6583 FAST corners and no survivor
+    ("squares_200x260_ties", "squares", 200, 260, 12, dict(nfeatures=2000)),
 ]
 
 
 def frame(kind, rows, cols, seed):
+    if kind == "squares":
+        y, x = np.mgrid[0:rows, 0:cols]
+        return ((((x % seed) < seed // 2) & ((y % seed) < seed // 2)) * 200).astype(np.uint8)
     return synth.synth_frame(rows, cols, seed=seed) if kind == "synth" else synth.noise_frame(rows, cols, seed=seed)
 
 
 def main():
+    only = sys.argv[1] if len(sys.argv) > 1 else None        # regenerate a single detector fixture by name
     img, kps = probe_input()
     out = {}
     for nbits in (256, 512):
@@ -50,9 +57,12 @@ def main():
             if h != REFERENCE_HASHES[(kind, nbits)]:
                 raise SystemExit(f"{kind}{nbits}: hash {h:08x} != reference {REFERENCE_HASHES[(kind, nbits)]:08x}")
     out["image"] = img; out["keypoints"] = kps
-    np.savez_compressed(os.path.join(HERE, "descriptors_probe.npz"), **out)
+    if only is None:
+        np.savez_compressed(os.path.join(HERE, "descriptors_probe.npz"), **out)
 
     for name, kind, rows, cols, seed, kw in DETECTOR_CASES:
+        if only is not None and name != only:
+            continue
         im = frame(kind, rows, cols, seed)
         d = {"image": im}
         for dt, tag in ((O.BAD_256, "bad256"), (O.BAD_512, "bad512"), (O.HASH_SIFT_256, "hashsift256"), (O.HASH_SIFT_512, "hashsift512")):

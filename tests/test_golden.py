@@ -17,7 +17,7 @@ DETECTOR_FILES = sorted(glob.glob(os.path.join(HERE, "detector_*.npz")))
 # must mirror tests/golden/make_golden.py DETECTOR_CASES
 DETECTOR_KW = {"synth_240x320": dict(nfeatures=1500), "synth_480x640": dict(nfeatures=4000),
                "synth_480x640_r5_t40": dict(nfeatures=4000, nonmax_radius=5, fast_threshold=40),
-               "noise_200x260_cap": dict(nfeatures=3000)}
+               "noise_200x260_cap": dict(nfeatures=3000), "squares_200x260_ties": dict(nfeatures=2000)}
 DESC_TAGS = ["bad256", "bad512", "hashsift256", "hashsift512"]
 
 
