@@ -88,9 +88,12 @@ __global__ __launch_bounds__(256) void bad_kernel(
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-    const int kid = xcd_chunked(blockIdx.x, gridDim.x);   // neighbouring keypoints on the same XCD: windows share L2 lines
+    // the grid is sized for the capacity; only the first `count` workgroups have a keypoint.  Neighbouring keypoints go
+    // to the same XCD (their windows share L2 lines): chunked over the COUNT, so that a frame with few keypoints still
+    // uses all eight XCDs
     const int count = d_count ? min(*d_count, n) : n;
-    if (kid >= count) return;
+    if ((int)blockIdx.x >= count) return;
+    const int kid = xcd_chunked(blockIdx.x, count);
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
 

@@ -1111,8 +1111,11 @@ __global__ __launch_bounds__(256) void angle_kernel(const LevelTable* __restrict
     // two keypoints per wave (31 of each 32 lanes hold one patch column), 8 per workgroup; neighbouring keypoints
     // (canonical order) stay on the same XCD: their patches share L2 lines
     const int lane = threadIdx.x & 31;
-    const int kid = xcd_chunked(blockIdx.x, gridDim.x) * 8 + (threadIdx.x >> 5);
     const int count = min(*d_count, capacity);
+    const int ngroups = (count + 7) >> 3;                 // the grid is sized for the capacity
+    if ((int)blockIdx.x >= ngroups) return;
+    const int group = xcd_chunked(blockIdx.x, ngroups);  // chunked over the groups that exist: all XCDs busy at any count
+    const int kid = group * 8 + (threadIdx.x >> 5);
     const bool act = kid < count;
     const float4 kp = act ? kp4[kid] : make_float4(0.f, 0.f, 0.f, 0.f);
     const int l = act ? kp_level[kid] : 0;
@@ -1145,7 +1148,7 @@ __global__ __launch_bounds__(256) void angle_kernel(const LevelTable* __restrict
     __shared__ int s_m[8][2];
     if (lane == 0) { s_m[threadIdx.x >> 5][0] = m01; s_m[threadIdx.x >> 5][1] = m10; }
     __syncthreads();
-    const int k8 = xcd_chunked(blockIdx.x, gridDim.x) * 8 + threadIdx.x;
+    const int k8 = group * 8 + threadIdx.x;
     if (threadIdx.x < 8 && k8 < count) {
         const float angle = atan2_deg(s_m[threadIdx.x][0], s_m[threadIdx.x][1]);
         kp4[k8].w = angle;
