@@ -13,6 +13,7 @@
 // Compile with -ffp-contract=off: the float expressions below must not be fused.
 
 #include "efx_device.h"
+#include <algorithm>
 
 namespace {
 
@@ -283,6 +284,190 @@ __global__ __launch_bounds__(NT) void resize_kernel(
         if (full4) *reinterpret_cast<uint32_t*>(d) = packed;
         else
             for (int k = 0; k < 4; k++) if (oxq + k < ox1) d[k] = (uint8_t)(packed >> (8 * k));
+    }
+}
+
+// ================================================================================================
+// Kernel R2: a whole small pyramid in one launch ("tower"; frames up to EFX_TOWER_MAX_PX pixels, see plan_tower).  The
+// per-level kernel above is launch- and latency-bound once the levels are small (7 dependent launches cost a third of
+// an FHD frame's detectAndCompute).  Here a workgroup owns one
+// TT x TT tile of the TOP level and produces, for every level s0+1 .. top, the pixels that tile descends from: the
+// region of level s0 it needs is staged in LDS once, level s+1 is computed from level s LDS -> LDS (ping-pong) and
+// the pixels the workgroup OWNS are written to the pyramid.  Ownership partitions every level: the owned range of tile
+// t at level s starts at the source column of the first owned column at level s+1 (x1 of the resize), so ranges are
+// contiguous and disjoint; the few columns / rows beyond it that the +1 neighbour of the next level needs are
+// recomputed by both neighbours (same arithmetic, same bits, not written twice).  Per pixel the arithmetic is
+// resize_kernel's, so the levels are bit-identical whichever kernel makes them.
+// ================================================================================================
+struct TowerArgs {
+    int s0, top;                 // source level, last level produced
+    int tt;                      // tile edge at the top level
+    int tiles_x, tiles_y;        // tiles of the top level
+    int bufA, bufB;              // byte offsets / sizes: [bufA | bufB | ytab0 | ytab1]
+    int ytab_off, ytab_rows;
+    int aligned0;                // the source level may be staged with dword loads
+};
+
+// source column (row) of destination column o of a level with `n` source columns: resize_kernel's x1
+__device__ __forceinline__ int tower_src(int o, float f, int n) { const int v = (int)floorf((float)o * f); return v > n - 1 ? n - 1 : v; }
+
+template <int NT>
+__global__ __launch_bounds__(NT) void pyramid_tower_kernel(const LevelTable* __restrict__ T, const uint8_t* __restrict__ img0, int pitch0,
+                                                            uint8_t* __restrict__ pyramid, TowerArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int s_rng[EFX_MAX_LEVELS][8];        // per level: lox, hix, ownlox, ownhix, loy, hiy, ownloy, ownhiy
+    const int tid = threadIdx.x;
+    const int tile = xcd_chunked(blockIdx.x, A.tiles_x * A.tiles_y);
+    const int tx = tile % A.tiles_x, ty = tile / A.tiles_x;
+
+    // ---- ranges, top level down (uniform; two threads: x and y) ----
+    if (tid < 2) {
+        const bool isx = tid == 0;
+        const int t = isx ? tx : ty, nt = isx ? A.tiles_x : A.tiles_y;
+        const LevelDev& Lt = T->lv[A.top];
+        const int ntop = isx ? Lt.cols : Lt.rows;
+        int ownlo = t * A.tt, ownhi = min((t + 1) * A.tt, ntop);      // [ownlo, ownhi)
+        int lo = ownlo, hi = ownhi - 1;                                // computed range, inclusive
+        int* r = &s_rng[A.top][isx ? 0 : 4];
+        r[0] = lo; r[1] = hi; r[2] = ownlo; r[3] = ownhi;
+        for (int s = A.top - 1; s >= A.s0; s--) {
+            const LevelDev& D = T->lv[s + 1];
+            const LevelDev& S = T->lv[s];
+            const float f = isx ? D.fx : D.fy;
+            const int n = isx ? S.cols : S.rows;
+            const int nownlo = t == 0 ? 0 : tower_src(ownlo, f, n);
+            const int nownhi = t == nt - 1 ? n : tower_src(ownhi, f, n);
+            int nlo = tower_src(lo, f, n);
+            if (isx) nlo &= ~3;                                        // columns: dword-aligned region origin
+            int nhi = min(tower_src(hi, f, n) + 1, n - 1);
+            nhi = max(nhi, nownhi - 1);
+            lo = nlo; hi = nhi; ownlo = nownlo; ownhi = nownhi;
+            r = &s_rng[s][isx ? 0 : 4];
+            r[0] = lo; r[1] = hi; r[2] = ownlo; r[3] = ownhi;
+        }
+    }
+    __syncthreads();
+
+    // every LDS access below is smem + integer offset: pointers picked from an array would decay to FLAT accesses
+    auto ytab_off = [&](int which) -> int { return A.ytab_off + which * A.ytab_rows * 16; };
+    auto buf_off = [&](int which) -> int { return which ? A.bufB : A.bufA; };
+
+    // per-row source offsets and y weights of the phase that makes level s+1 (same expressions as resize_kernel)
+    auto fill_ytab = [&](int s, int yt_off, int spitch_l) {
+        int4* yt = reinterpret_cast<int4*>(smem + yt_off);
+        const LevelDev& D = T->lv[s + 1];
+        const LevelDev& S = T->lv[s];
+        const int loy1 = s_rng[s + 1][4], hiy1 = s_rng[s + 1][5], loy0 = s_rng[s][4];
+        for (int i = tid; i <= hiy1 - loy1; i += NT) {
+            const int oy = loy1 + i;
+            const float sy = (float)oy * D.fy;
+            int y1 = (int)floorf(sy);
+            if (y1 > S.rows - 1) y1 = S.rows - 1;
+            const int y2 = y1 + 1;
+            const int y2r = y2 < S.rows - 1 ? y2 : S.rows - 1;
+            yt[i] = make_int4((y1 - loy0) * spitch_l, (y2r - loy0) * spitch_l, __float_as_int((float)y2 - sy), __float_as_int(sy - (float)y1));
+        }
+    };
+    // LDS row pitch of a level's region: its columns plus the replicated +1 neighbour of the last one, in dwords
+    auto pitch_of = [&](int s) -> int { return (s_rng[s][1] - s_rng[s][0] + 2 + 3) & ~3; };
+
+    // ---- the region of level s0 -> LDS ----
+    {
+        const LevelDev& S = T->lv[A.s0];
+        const uint8_t* src = A.s0 == 0 ? img0 : pyramid + S.img_off;
+        const int spitch = A.s0 == 0 ? pitch0 : S.pitch;
+        const int lox = s_rng[A.s0][0], hix = s_rng[A.s0][1], loy = s_rng[A.s0][4], hiy = s_rng[A.s0][5];
+        const int lp = pitch_of(A.s0);
+        const int ndw = ((hix - lox) >> 2) + 1, nrow = hiy - loy + 1;
+        uint8_t* dst = smem + buf_off(0);
+        if (A.aligned0) {
+            const __amdgpu_buffer_rsrc_t rsrc =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src), 0, (S.rows - 1) * spitch + ((S.cols + 3) & ~3), 0x00020000);
+            for (int i = tid; i < ndw * nrow; i += NT) {
+                const int r = i / ndw, j = i - r * ndw;
+                *reinterpret_cast<uint32_t*>(dst + r * lp + 4 * j) = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (loy + r) * spitch + lox + 4 * j, 0, 0);
+            }
+        } else {
+            for (int i = tid; i < ndw * nrow; i += NT) {
+                const int r = i / ndw, j = i - r * ndw;
+                const uint8_t* p = src + (size_t)(loy + r) * spitch;
+                const int gx = lox + 4 * j;
+                uint32_t v = 0;
+#pragma unroll
+                for (int b = 0; b < 4; b++) if (gx + b < S.cols) v |= (uint32_t)p[gx + b] << (8 * b);
+                *reinterpret_cast<uint32_t*>(dst + r * lp + 4 * j) = v;
+            }
+        }
+        fill_ytab(A.s0, ytab_off(0), lp);
+        __syncthreads();
+        // the +1 neighbour of the last source column is that column itself (spec S5 clamp)
+        if (hix == S.cols - 1) {
+            for (int r = tid; r < nrow; r += NT) dst[r * lp + (S.cols - lox)] = dst[r * lp + (S.cols - 1 - lox)];
+            __syncthreads();
+        }
+    }
+
+    // ---- level s+1 from level s, LDS -> LDS (+ the owned pixels -> pyramid) ----
+    for (int s = A.s0, ph = 0; s < A.top; s++, ph++) {
+        const LevelDev& D = T->lv[s + 1];
+        const LevelDev& S = T->lv[s];
+        const int sb = buf_off(ph & 1), db = buf_off((ph & 1) ^ 1);
+        const int lox0 = s_rng[s][0];
+        const int lox1 = s_rng[s + 1][0], hix1 = s_rng[s + 1][1], ownlox = s_rng[s + 1][2], ownhix = s_rng[s + 1][3];
+        const int loy1 = s_rng[s + 1][4], hiy1 = s_rng[s + 1][5], ownloy = s_rng[s + 1][6], ownhiy = s_rng[s + 1][7];
+        const int lp1 = pitch_of(s + 1);
+        const int W = hix1 - lox1 + 2, H = hiy1 - loy1 + 1;         // computed columns incl. the replicated one
+        const int ngrp = (W + 3) >> 2;
+        // column groups of 4 outputs: the smallest power of two that covers them -> rows per pass
+        int sh = 1;
+        while ((1 << sh) < ngrp && (2 << sh) <= NT) sh++;
+        const int cq = tid & ((1 << sh) - 1), rq = tid >> sh, rstep = NT >> sh;
+        const int yt = ytab_off(ph & 1);
+        uint8_t* gdst = pyramid + D.img_off;
+        const bool keep = s + 1 < A.top;                               // the top level feeds nothing
+        for (int g = cq; g < ngrp; g += (1 << sh)) {
+            const int oxq = lox1 + 4 * g;
+            float wx0[4], wx1[4]; int lc[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int ox = min(oxq + k, hix1);                      // beyond the range: the last column again (replication)
+                const float sx = (float)ox * D.fx;
+                int x1 = (int)floorf(sx);
+                if (x1 > S.cols - 1) x1 = S.cols - 1;
+                const int x2 = x1 + 1;
+                wx0[k] = (float)x2 - sx; wx1[k] = sx - (float)x1;
+                lc[k] = x1 - lox0;
+            }
+            const bool colfull = oxq >= ownlox && oxq + 4 <= ownhix;
+            for (int i = rq; i < H; i += rstep) {
+                const int4 t4 = *reinterpret_cast<const int4*>(smem + yt + i * 16);
+                const float wy0 = __int_as_float(t4.z), wy1 = __int_as_float(t4.w);
+                const uint8_t* ra = smem + sb + t4.x;
+                const uint8_t* rb = smem + sb + t4.y;
+                uint32_t packed = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint8_t* pa = ra + lc[k];
+                    const uint8_t* pb = rb + lc[k];
+                    float out = (float)pa[0] * (wx0[k] * wy0);
+                    out = out + (float)pa[1] * (wx1[k] * wy0);
+                    out = out + (float)pb[0] * (wx0[k] * wy1);
+                    out = out + (float)pb[1] * (wx1[k] * wy1);
+                    packed = __builtin_amdgcn_cvt_pk_u8_f32(out, k, packed);
+                }
+                if (keep) *reinterpret_cast<uint32_t*>(smem + db + i * lp1 + 4 * g) = packed;
+                const int oy = loy1 + i;
+                if (oy >= ownloy && oy < ownhiy) {
+                    uint8_t* d = gdst + (size_t)oy * D.pitch + oxq;
+                    if (colfull) *reinterpret_cast<uint32_t*>(d) = packed;
+                    else
+                        for (int k = 0; k < 4; k++) if (oxq + k >= ownlox && oxq + k < ownhix) d[k] = (uint8_t)(packed >> (8 * k));
+                }
+            }
+        }
+        if (keep) fill_ytab(s + 1, ytab_off((ph & 1) ^ 1), lp1);
+        __syncthreads();
     }
 }
 
@@ -1205,17 +1390,84 @@ __global__ void copy2d_kernel(const uint8_t* __restrict__ src, size_t spitch, ui
 // ------------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------------
+// Plan of the tower launch (pyramid_tower_kernel): which level it starts from, its tile size and its LDS layout.  The
+// ranges are the kernel's own recurrence evaluated for every tile column / row, so the sizes are exact maxima.
+#ifndef EFX_TOWER_MAX_PX
+#define EFX_TOWER_MAX_PX 9000000      // larger frames keep one launch per level (each fills the chip by itself)
+#endif
+static inline int tower_src_host(int o, float f, int n) { const int v = (int)floorf((float)o * f); return v > n - 1 ? n - 1 : v; }
+
+static bool plan_tower(const LevelTable& H, int last, const uint8_t* img0, int pitch0, TowerArgs* out, size_t* lds_out)
+{
+    if (last < 2) return false;
+    // Measured (MI355X, one stream, sync per call): the tower beats the launch chain when the WHOLE pyramid is small
+    // (FHD 0.166 -> 0.147 ms, 4K 0.270 -> 0.259 ms per detectAndCompute); fusing only the upper levels of a large frame
+    // (8K levels 4..7) does not pay: those levels are as large as a 4K pyramid and the tower recomputes ~1.7x the pixels.
+    if ((long long)H.lv[0].rows * H.lv[0].cols > EFX_TOWER_MAX_PX) return false;
+    for (int s0 = 0; s0 == 0; s0++) {
+        const LevelDev& Lt = H.lv[last];
+        const int tt = 32;
+        const int ntx = (Lt.cols + tt - 1) / tt, nty = (Lt.rows + tt - 1) / tt;
+        int maxw[EFX_MAX_LEVELS] = { 0 }, maxh[EFX_MAX_LEVELS] = { 0 };
+        for (int dim = 0; dim < 2; dim++) {
+            const int nt = dim == 0 ? ntx : nty;
+            for (int t = 0; t < nt; t++) {
+                const int ntop = dim == 0 ? Lt.cols : Lt.rows;
+                int ownhi = std::min((t + 1) * tt, ntop);
+                int lo = t * tt, hi = ownhi - 1;
+                int* mx = dim == 0 ? maxw : maxh;
+                mx[last] = std::max(mx[last], hi - lo + 1);
+                for (int s = last - 1; s >= s0; s--) {
+                    const float f = dim == 0 ? H.lv[s + 1].fx : H.lv[s + 1].fy;
+                    const int n = dim == 0 ? H.lv[s].cols : H.lv[s].rows;
+                    const int nownhi = t == nt - 1 ? n : tower_src_host(ownhi, f, n);
+                    int nlo = tower_src_host(lo, f, n);
+                    if (dim == 0) nlo &= ~3;
+                    int nhi = std::min(tower_src_host(hi, f, n) + 1, n - 1);
+                    nhi = std::max(nhi, nownhi - 1);
+                    lo = nlo; hi = nhi; ownhi = nownhi;
+                    mx[s] = std::max(mx[s], hi - lo + 1);
+                }
+            }
+        }
+        size_t bufA = 0, bufB = 0;
+        int yrows = 0;
+        for (int s = s0; s <= last; s++) {
+            const size_t bytes = (size_t)((maxw[s] + 1 + 3) & ~3) * maxh[s];
+            if (((s - s0) & 1) == 0) bufA = std::max(bufA, bytes); else bufB = std::max(bufB, bytes);
+            if (s > s0) yrows = std::max(yrows, maxh[s]);
+        }
+        bufA = (bufA + 15) & ~(size_t)15; bufB = (bufB + 15) & ~(size_t)15;
+        const size_t lds = bufA + bufB + 2 * (size_t)yrows * 16;
+        if (lds > 64 * 1024) return false;                    // too deep for this scale factor: one launch per level
+        const uint8_t* src = s0 == 0 ? img0 : nullptr;
+        const int spitch = s0 == 0 ? pitch0 : H.lv[s0].pitch;
+        out->s0 = s0; out->top = last; out->tt = tt; out->tiles_x = ntx; out->tiles_y = nty;
+        out->bufA = 0; out->bufB = (int)bufA; out->ytab_off = (int)(bufA + bufB); out->ytab_rows = yrows;
+        out->aligned0 = s0 > 0 ? 1 : ((((uintptr_t)src | (uintptr_t)spitch) & 3u) == 0 && (H.lv[0].cols & 3) == 0);
+        *lds_out = lds;
+        return true;
+    }
+    return false;
+}
+
 hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
 {
     const LevelTable& H = *a.h_table;
     hipError_t e = hipMemsetAsync(a.counters, 0, sizeof(Counters), stream);
     if (e != hipSuccess) return e;
 
-    // pyramid chain (calcImagePyramid, .cpp:136-157): level s+1 from level s
-    for (int s = 0; s + 1 < H.nlevels; s++) {
+    // pyramid chain (calcImagePyramid, .cpp:136-157): level s+1 from level s.  The large lower levels get one launch each;
+    // the small upper levels (launch- and latency-bound one by one) are produced by ONE tower launch from level s0.
+    int last = 0;                                              // last level with pixels
+    while (last + 1 < H.nlevels && H.lv[last + 1].rows > 0 && H.lv[last + 1].cols > 0 && H.lv[last].rows > 0 && H.lv[last].cols > 0) last++;
+    TowerArgs tw;
+    size_t tw_lds = 0;
+    const bool use_tower = plan_tower(H, last, a.img0, a.pitch0, &tw, &tw_lds);
+    const int chain_end = use_tower ? tw.s0 : last;           // levels 1 .. chain_end by the per-level kernel
+    for (int s = 0; s < chain_end; s++) {
         const LevelDev& L = H.lv[s];
         const LevelDev& N = H.lv[s + 1];
-        if (L.rows <= 0 || L.cols <= 0 || N.rows <= 0 || N.cols <= 0) break;
         const uint8_t* src = s == 0 ? a.img0 : a.pyramid + L.img_off;
         const int spitch = s == 0 ? a.pitch0 : L.pitch;
         // dword staging reads up to roundup4(cols) bytes of a row: always inside our own (padded) pyramid levels, inside a
@@ -1230,6 +1482,12 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
         hipLaunchKernelGGL((resize_kernel<256>), dim3(N.tiles_x * N.tiles_y), dim3(256), lds, stream, src, spitch, L.rows, L.cols, aligned,
                            a.pyramid + N.img_off, N.pitch, N.rows, N.cols, N.fx, N.fy, N.tiles_x, N.tiles_y, lpitch, ytab_off);
         a.prof.end(prof, 100 + s, stream);
+    }
+    if (use_tower) {
+        const bool prof = a.prof.begin(stream);
+        hipLaunchKernelGGL((pyramid_tower_kernel<1024>), dim3(tw.tiles_x * tw.tiles_y), dim3(1024), tw_lds, stream, a.d_table, a.img0,
+                           a.pitch0, a.pyramid, tw);
+        a.prof.end(prof, 100 + tw.s0, stream);
     }
     if (a.pyramid_only) return hipGetLastError();
     {
