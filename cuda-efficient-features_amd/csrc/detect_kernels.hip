@@ -699,11 +699,37 @@ __global__ __launch_bounds__(256) void fast_kernel(
 __global__ __launch_bounds__(64) void harris_kernel(
     const LevelTable* __restrict__ T, const uint8_t* __restrict__ img0, int pitch0, int aligned0,
     const uint8_t* __restrict__ pyramid, Corner* __restrict__ cand_all, Corner* __restrict__ cmax_all,
-    const TileHdr* __restrict__ hdr_all, int dbg)
+    TileHdr* __restrict__ hdr_all, const Counters* __restrict__ cnt, int dbg)
 {
     __shared__ unsigned long long s_cellmax[EFX_CELLS_PER_TILE];
     __shared__ unsigned s_celltie[EFX_CELLS_PER_TILE];     // largest response key that two corners of the cell share
     const int lane = threadIdx.x;
+    if ((int)blockIdx.x >= T->total_tiles) {
+        // One extra workgroup per level: canonical rank of every tile's first corner = exclusive scan of the tile counts
+        // in tile order, needed to apply the 10 % cap deterministically (spec S2).  Only consulted (and only computed)
+        // when the level has more corners than its cap, i.e. on pathological frames; it rides in this launch because a
+        // launch of its own costs ~5 us of every frame.  fast_kernel, the launch before this one, wrote the counts.
+        const int l = (int)blockIdx.x - T->total_tiles;
+        const LevelDev& L = T->lv[l];
+        if (!L.active) return;
+        int lvl_total = 0;
+        for (int sub = 0; sub < EFX_NSUB; sub++) lvl_total += cnt->cand_total[l][sub].v;
+        if (lvl_total <= L.cap) return;
+        const int n = L.tiles_x * L.tiles_y;
+        TileHdr* h = hdr_all + L.tile_base;
+        // a lane owns a contiguous chunk of tiles: its loads are independent of each other (one memory round trip per
+        // pass instead of one per 64 tiles)
+        const int chunk = (n + 63) >> 6;
+        const int t_begin = min(lane * chunk, n), t_end = min(t_begin + chunk, n);
+        int mine = 0;
+        for (int t = t_begin; t < t_end; t++) mine += (int)h[t].cell_off[EFX_CELLS_PER_TILE];
+        int running = wave_incl_scan(mine) - mine;
+        for (int t = t_begin; t < t_end; t++) {
+            h[t].cand_rank = (uint32_t)running;
+            running += (int)h[t].cell_off[EFX_CELLS_PER_TILE];
+        }
+        return;
+    }
     const int gt = T->total_tiles - 1 - xcd_interleaved(blockIdx.x, T->total_tiles);      // densest tiles first
     int l, tx, ty;
     efx_tile_of(T, gt, l, tx, ty);
@@ -743,32 +769,6 @@ __global__ __launch_bounds__(64) void harris_kernel(
             if (s_celltie[lane] == (uint32_t)(m >> 32)) best.xy |= EFX_CMAX_TIE;      // y < 2^15: bit 31 is free
         }
         cmax_all[L.cmax_base + (size_t)(ty * 4 + (lane >> 2)) * (L.tiles_x * 4) + tx * 4 + (lane & 3)] = best;
-    }
-}
-
-// ================================================================================================
-// Kernel B: canonical rank of every tile's first corner = exclusive scan of the tile counts in tile
-// order (needed to apply the 10% cap deterministically, spec S2).  One workgroup per level.
-// ================================================================================================
-__global__ __launch_bounds__(1024) void tile_rank_scan_kernel(const LevelTable* __restrict__ T, TileHdr* __restrict__ hdr, const Counters* __restrict__ cnt)
-{
-    __shared__ int s_scan[20];
-    const LevelDev& L = T->lv[blockIdx.x];
-    if (!L.active) return;
-    // the ranks are only consulted when the level has more corners than its cap (pathological frames)
-    int lvl_total = 0;
-    for (int sub = 0; sub < EFX_NSUB; sub++) lvl_total += cnt->cand_total[blockIdx.x][sub].v;
-    if (lvl_total <= L.cap) return;
-    const int n = L.tiles_x * L.tiles_y;
-    TileHdr* h = hdr + L.tile_base;
-    int running = 0;
-    for (int t0 = 0; t0 < n; t0 += 1024) {
-        const int t = t0 + threadIdx.x;
-        const int v = t < n ? (int)h[t].cell_off[EFX_CELLS_PER_TILE] : 0;
-        int tot;
-        const int pre = block_excl_scan<16>(v, s_scan, &tot);
-        if (t < n) h[t].cand_rank = (uint32_t)(running + pre);
-        running += tot;
     }
 }
 
@@ -1072,7 +1072,7 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
 
 __global__ __launch_bounds__(1024) void select_kernel(const LevelTable* __restrict__ T, TileHdr* __restrict__ hdr,
                                                       const Corner* __restrict__ surv_all, Counters* __restrict__ cnt,
-                                                      int capacity, int* __restrict__ d_count)
+                                                      int capacity, int* __restrict__ d_count, Summary* __restrict__ mirror)
 {
     __shared__ int s_hist[SEL_MAX_TILES > SEL_BINS ? SEL_MAX_TILES : SEL_BINS];   // radix histogram, then per-tile counts
     __shared__ int s_scan[20];
@@ -1094,9 +1094,15 @@ __global__ __launch_bounds__(1024) void select_kernel(const LevelTable* __restri
     if (tid == 0) {
         cnt->level_out_base[l] = base;
         if (l == T->nlevels - 1) cnt->level_out_base[T->nlevels] = all;
-        if (l == 0) { const int n = all < capacity ? all : capacity; cnt->sum.n_out = n; if (d_count) *d_count = n; }
+        if (l == 0) { const int n = all < capacity ? all : capacity; cnt->sum.n_out = n; if (d_count) *d_count = n; if (mirror) { mirror->n_out = n; mirror->dbg = 0; } }
     }
-    if (!L.active) { if (tid == 0) { cnt->sum.kept[l] = 0; cnt->thresh[l] = 0; } return; }
+    if (!L.active) {
+        if (tid == 0) {
+            cnt->sum.kept[l] = 0; cnt->thresh[l] = 0;
+            if (mirror) { mirror->kept[l] = 0; mirror->surv[l] = 0; mirror->cand[l] = 0; }
+        }
+        return;
+    }
 
     int n = 0;
     for (int sub = 0; sub < EFX_NSUB; sub++) n += cnt->surv_total[l][sub].v;
@@ -1204,6 +1210,9 @@ __global__ __launch_bounds__(1024) void select_kernel(const LevelTable* __restri
         int nc = 0;
         for (int sub = 0; sub < EFX_NSUB; sub++) nc += cnt->cand_total[l][sub].v;
         cnt->sum.cand[l] = nc;
+        // the host's copy of the summary lives in pinned, device-visible memory: written here instead of by a copy
+        // command behind the frame (one launch less on the critical path)
+        if (mirror) { mirror->kept[l] = running; mirror->surv[l] = n; mirror->cand[l] = nc; }
     }
 }
 
@@ -1497,18 +1506,17 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
                            a.pyramid, a.threshold, a.mask, a.mask_pitch, a.cand, a.hdr, a.counters, a.dbg & 15);
         a.prof.end(prof, 0, stream);
         prof = a.prof.begin(stream);
-        hipLaunchKernelGGL(harris_kernel, dim3(H.total_tiles), dim3(64), 0, stream, a.d_table, a.img0, a.pitch0, aligned0, a.pyramid,
-                           a.cand, a.cmax, a.hdr, a.dbg & 15);
+        hipLaunchKernelGGL(harris_kernel, dim3(H.total_tiles + H.nlevels), dim3(64), 0, stream, a.d_table, a.img0, a.pitch0, aligned0, a.pyramid,
+                           a.cand, a.cmax, a.hdr, a.counters, a.dbg & 15);
         a.prof.end(prof, 1, stream);
     }
-    hipLaunchKernelGGL(tile_rank_scan_kernel, dim3(H.nlevels), dim3(1024), 0, stream, a.d_table, a.hdr, a.counters);
     bool prof = a.prof.begin(stream);
     hipLaunchKernelGGL(nms_kernel, dim3(H.total_tiles), dim3(64), 0, stream, a.d_table, a.hdr, a.cand, a.cmax, a.surv,
                        a.counters, a.nonmax_radius, a.dbg >> 4);
     a.prof.end(prof, 2, stream);
     prof = a.prof.begin(stream);
     hipLaunchKernelGGL(select_kernel, dim3(H.nlevels), dim3(1024), 0, stream, a.d_table, a.hdr, a.surv, a.counters,
-                       a.capacity, a.d_count);
+                       a.capacity, a.d_count, reinterpret_cast<Summary*>(a.h_mirror_dev));
     hipLaunchKernelGGL(emit_kernel, dim3(H.total_tiles), dim3(64), 0, stream, a.d_table, a.hdr, a.surv, a.counters,
                        a.img0, a.pitch0, a.pyramid, (uint8_t*)a.d_keypoints, a.kps_pitch, a.capacity, a.kp4, a.kp_level);
     if (a.capacity > 0) {
@@ -1522,7 +1530,7 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
     a.prof.end(prof, 3, stream);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    if (a.h_mirror) e = hipMemcpyAsync(a.h_mirror, &a.counters->sum, sizeof(Summary), hipMemcpyDeviceToHost, stream);
+    if (a.h_mirror && !a.h_mirror_dev) e = hipMemcpyAsync(a.h_mirror, &a.counters->sum, sizeof(Summary), hipMemcpyDeviceToHost, stream);
     return e;
 }
 

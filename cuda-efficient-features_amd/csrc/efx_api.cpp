@@ -191,6 +191,7 @@ struct efx_context {
     LevelTable h_table;
     DevBuf d_table, pyramid, hdr, cand, cmax, surv, counters, kp4, kp_level, img, kps, descout, count, maskbuf;
     Summary* h_mirror = nullptr;    // pinned
+    Summary* h_mirror_dev = nullptr; // the same buffer through the device's address (null if it cannot be mapped)
     bool has_frame = false;
     const uint8_t* last_img0 = nullptr; int last_pitch0 = 0;
     // per-launch timing of the pipeline's kernels (efx_profile_*)
@@ -296,7 +297,12 @@ int build_geometry(efx_context* c, int rows, int cols)
     HIP_TRY(c->err, c->cmax.reserve((ncmax + 1) * sizeof(Corner)));
     HIP_TRY(c->err, c->counters.reserve(sizeof(Counters)));
     HIP_TRY(c->err, c->count.reserve(sizeof(int)));
-    if (!c->h_mirror) HIP_TRY(c->err, hipHostMalloc(reinterpret_cast<void**>(&c->h_mirror), sizeof(Summary), hipHostMallocDefault));
+    if (!c->h_mirror) {
+        HIP_TRY(c->err, hipHostMalloc(reinterpret_cast<void**>(&c->h_mirror), sizeof(Summary), hipHostMallocMapped));
+        memset(c->h_mirror, 0, sizeof(Summary));
+        void* dp = nullptr;
+        c->h_mirror_dev = hipHostGetDevicePointer(&dp, c->h_mirror, 0) == hipSuccess ? static_cast<Summary*>(dp) : nullptr;
+    }
     // synchronous upload: geometry changes are rare (first frame / size or parameter change)
     {
         std::vector<unsigned char> blob(sizeof(LevelTable) + (size_t)(tiles + 1) * sizeof(uint32_t), 0);
@@ -352,6 +358,7 @@ int detect_common(efx_context* c, const uint8_t* d_image, int rows, int cols, si
     a.kp4 = static_cast<float4*>(c->kp4.p);
     a.kp_level = static_cast<int*>(c->kp_level.p);
     a.h_mirror = reinterpret_cast<int*>(c->h_mirror);
+    a.h_mirror_dev = reinterpret_cast<int*>(c->h_mirror_dev);
     if (!c->prof_start.empty() && (c->prof_calls++ % c->prof_stride) == 0) {
         a.prof.start = c->prof_start.data(); a.prof.stop = c->prof_stop.data(); a.prof.code = c->prof_level.data();
         a.prof.count = &c->prof_count; a.prof.capacity = (int)c->prof_start.size();
