@@ -180,6 +180,20 @@ __device__ __forceinline__ float harris_rows(const uint8_t* p0, int P)
     return harris_from_sums(sxx, sxy, syy);
 }
 
+// The frame's counters are zeroed by workgroup 0 of the frame's first kernel (a memset command of its own costs ~5 us
+// on the critical path of every frame): only the words that are read need it -- the per-level allocation counters of the
+// levels in use and the small tables behind them.
+__device__ __forceinline__ void efx_zero_counters(Counters* __restrict__ c, int nlevels, int tid, int nthreads)
+{
+    for (int i = tid; i < nlevels * EFX_NSUB; i += nthreads) {
+        c->cand_total[i / EFX_NSUB][i % EFX_NSUB].v = 0;
+        c->surv_total[i / EFX_NSUB][i % EFX_NSUB].v = 0;
+    }
+    int* tail = c->level_out_base;                      // level_out_base, thresh, sum: contiguous plain words
+    const int nwords = (int)((sizeof(Counters) - offsetof(Counters, level_out_base)) / sizeof(int));
+    for (int i = tid; i < nwords; i += nthreads) tail[i] = 0;
+}
+
 // ================================================================================================
 // Kernel R: one 64x64 tile of pyramid level s+1 per workgroup, bilinear from level s (spec S5; the
 // cv::cuda::resize call of calcImagePyramid, cuda_efficient_features.cpp:154).  The source footprint of the
@@ -191,10 +205,12 @@ __device__ __forceinline__ float harris_rows(const uint8_t* p0, int P)
 template <int NT>
 __global__ __launch_bounds__(NT) void resize_kernel(
     const uint8_t* __restrict__ src, int spitch, int rows, int cols, int aligned,
-    uint8_t* __restrict__ dst, int dpitch, int drows, int dcols, float fx, float fy, int tiles_x, int tiles_y, int lpitch, int ytab_off)
+    uint8_t* __restrict__ dst, int dpitch, int drows, int dcols, float fx, float fy, int tiles_x, int tiles_y, int lpitch, int ytab_off,
+    Counters* __restrict__ zero, int zero_levels)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
+    if (zero && blockIdx.x == 0) efx_zero_counters(zero, zero_levels, tid, NT);
     const int tile = xcd_chunked(blockIdx.x, tiles_x * tiles_y);
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int ox0 = tx * EFX_TILE, oy0 = ty * EFX_TILE;
@@ -313,9 +329,10 @@ __device__ __forceinline__ int tower_src(int o, float f, int n) { const int v = 
 
 template <int NT>
 __global__ __launch_bounds__(NT) void pyramid_tower_kernel(const LevelTable* __restrict__ T, const uint8_t* __restrict__ img0, int pitch0,
-                                                            uint8_t* __restrict__ pyramid, TowerArgs A)
+                                                            uint8_t* __restrict__ pyramid, TowerArgs A, Counters* __restrict__ zero)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (zero && blockIdx.x == 0) efx_zero_counters(zero, T->nlevels, threadIdx.x, NT);
     __shared__ int s_rng[EFX_MAX_LEVELS][8];        // per level: lox, hix, ownlox, ownhix, loy, hiy, ownloy, ownhiy
     const int tid = threadIdx.x;
     const int tile = xcd_chunked(blockIdx.x, A.tiles_x * A.tiles_y);
@@ -1463,8 +1480,7 @@ static bool plan_tower(const LevelTable& H, int last, const uint8_t* img0, int p
 hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
 {
     const LevelTable& H = *a.h_table;
-    hipError_t e = hipMemsetAsync(a.counters, 0, sizeof(Counters), stream);
-    if (e != hipSuccess) return e;
+    hipError_t e = hipSuccess;
 
     // pyramid chain (calcImagePyramid, .cpp:136-157): level s+1 from level s.  The large lower levels get one launch each;
     // the small upper levels (launch- and latency-bound one by one) are produced by ONE tower launch from level s0.
@@ -1474,6 +1490,13 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
     size_t tw_lds = 0;
     const bool use_tower = plan_tower(H, last, a.img0, a.pitch0, &tw, &tw_lds);
     const int chain_end = use_tower ? tw.s0 : last;           // levels 1 .. chain_end by the per-level kernel
+    // the counters are zeroed by the first pyramid kernel; a single-level "pyramid" has none: memset command
+    bool zeroed = false;
+    if (chain_end == 0 && !use_tower) {
+        e = hipMemsetAsync(a.counters, 0, sizeof(Counters), stream);
+        if (e != hipSuccess) return e;
+        zeroed = true;
+    }
     for (int s = 0; s < chain_end; s++) {
         const LevelDev& L = H.lv[s];
         const LevelDev& N = H.lv[s + 1];
@@ -1489,13 +1512,16 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
         if (lds > 64 * 1024) return hipErrorInvalidValue;
         const bool prof = a.prof.begin(stream);
         hipLaunchKernelGGL((resize_kernel<256>), dim3(N.tiles_x * N.tiles_y), dim3(256), lds, stream, src, spitch, L.rows, L.cols, aligned,
-                           a.pyramid + N.img_off, N.pitch, N.rows, N.cols, N.fx, N.fy, N.tiles_x, N.tiles_y, lpitch, ytab_off);
+                           a.pyramid + N.img_off, N.pitch, N.rows, N.cols, N.fx, N.fy, N.tiles_x, N.tiles_y, lpitch, ytab_off,
+                           zeroed ? nullptr : a.counters, H.nlevels);
+        zeroed = true;
         a.prof.end(prof, 100 + s, stream);
     }
     if (use_tower) {
         const bool prof = a.prof.begin(stream);
         hipLaunchKernelGGL((pyramid_tower_kernel<1024>), dim3(tw.tiles_x * tw.tiles_y), dim3(1024), tw_lds, stream, a.d_table, a.img0,
-                           a.pitch0, a.pyramid, tw);
+                           a.pitch0, a.pyramid, tw, zeroed ? nullptr : a.counters);
+        zeroed = true;
         a.prof.end(prof, 100 + tw.s0, stream);
     }
     if (a.pyramid_only) return hipGetLastError();
