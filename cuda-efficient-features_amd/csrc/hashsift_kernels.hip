@@ -57,9 +57,10 @@ __global__ __launch_bounds__(HS_NT) void patch_sift_kernel(
     __shared__ int s_ri[32], s_ci[32];
     __shared__ float s_scale;
 
-    const int kid = blockIdx.x;
+    // neighbouring keypoints (canonical order) on the same XCD: their windows share L2 lines; chunked over the count
     const int count = d_count ? min(*d_count, n) : n;
-    if (kid >= count) return;
+    if ((int)blockIdx.x >= count) return;
+    const int kid = xcd_chunked(blockIdx.x, count);
     const int tid = threadIdx.x;
 
     const float4 kp = kp4[kid];

@@ -181,3 +181,22 @@ def test_fuzz_provided_keypoints(cef, torch_mod, oracle, seed):
     else:
         nbad = int(np.count_nonzero(got != want))
         assert nbad <= _hashsift_tol(0, n), f"{info}: {nbad} bytes differ"
+
+
+def test_every_small_frame_size(cef, torch_mod, oracle):
+    """Frames from 1 x 1 upwards (every level geometry degenerates somewhere on the way): no crash, same result as the
+    oracle -- including the single-launch pyramid, whose tiles and halos are mostly clipped at these sizes."""
+    torch = torch_mod
+    rng = np.random.default_rng(77)
+    det = cef.EfficientFeatures.create(500, 1.2, 8, 0, 10, 3, cef.EfficientFeatures.BAD_256)
+    for rows, cols in [(1, 1), (1, 50), (50, 1), (2, 2), (7, 9), (16, 16), (31, 31), (32, 33), (33, 32), (40, 47), (48, 64),
+                       (63, 65), (64, 64), (65, 63), (96, 40), (40, 96), (100, 129), (129, 100)]:
+        img = rng.integers(0, 256, (rows, cols), dtype=np.uint8)
+        img[rows // 3: rows // 3 + 9, cols // 3: cols // 3 + 9] = 255
+        kps, desc, cnt = det.detectAndComputeAsync(torch.from_numpy(img).cuda())
+        torch.cuda.synchronize()
+        n = int(cnt.item())
+        ref = oracle.detect_and_compute(img, desc_type=0, nfeatures=500, fast_threshold=10, nonmax_radius=3)
+        assert n == ref["n"], (rows, cols)
+        assert np.array_equal(kps[:, :n].cpu().numpy().view(np.uint32), ref["kps"].view(np.uint32)), (rows, cols)
+        assert np.array_equal(desc[:n].cpu().numpy(), ref["desc"]), (rows, cols)
