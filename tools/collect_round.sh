@@ -7,6 +7,10 @@ tag=${1:-rXX}
 tools/gpu_check.sh $tag > /dev/null
 python tools/prof_summary.py gpurun_out/prof_$tag/bench_results.db gpurun_out/${tag}_kernel_stats.csv > /dev/null
 python bench.py | tail -1 > gpurun_out/${tag}_bench.json
+# the same default command (three frames in flight) under rocprofv3: the kernel durations stretch with the concurrency,
+# these are the ones bench.py's live `roofline.avg_launch_ms` must agree with
+(cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" && rocprofv3 --kernel-trace --stats -d gpurun_out/prof_${tag}_3s -o bench -- python bench.py --no-cpu-baseline > gpurun_out/bench_${tag}_3s.log 2>&1)
+python tools/prof_summary.py gpurun_out/prof_${tag}_3s/bench_results.db gpurun_out/${tag}_kernel_stats_3streams.csv > /dev/null
 python tools/bench_configs.py --out gpurun_out/${tag%_*}_configs.json > /dev/null
 tools/pmc_run.sh sq SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_LDS > /dev/null
 python tools/pmc_summary.py gpurun_out/pmc_sq/pmc_results.db > gpurun_out/${tag}_pmc_sq.txt
