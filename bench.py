@@ -199,6 +199,7 @@ def main():
         # The reference's own protocol (samples/sample_benchmark.cpp:39-52: 1 warm-up, then N x {detectAndComputeAsync;
         # stream.waitForCompletion()}): one frame at a time on one stream, host wait included.  This is the figure that
         # corresponds cell for cell to BASELINE.md's "8.2 ms"; `value` above keeps several frames in flight.
+        det.profileEnable(0)                             # no event pairs between the kernels of these calls
         det.detectAndComputeAsync(frames[0], kps[0], desc[0], cnt[0], capacity=NFEATURES)
         torch.cuda.synchronize()
         nlat = 20
