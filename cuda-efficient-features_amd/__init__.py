@@ -44,7 +44,7 @@ ABI_SYMBOLS = [
     "efx_ic_angles_async", "efx_ic_angles", "efx_descriptors_to_csv",
     "efx_cvt_gray_async", "efx_host_alloc", "efx_host_free", "efx_uploader_create", "efx_uploader_destroy",
     "efx_uploader_last_error", "efx_upload_gray_async", "efx_describer_compute_color",
-    "efx_profile_enable", "efx_profile_set_stride", "efx_profile_read",
+    "efx_profile_enable", "efx_profile_set_stride", "efx_profile_set_groups", "efx_profile_read",
     "efx_level_geometry", "efx_copy_level_async",
 ]
 
@@ -157,6 +157,7 @@ def lib():
                                                   C.c_int, C.c_void_p, C.c_size_t]
         L.efx_profile_enable.argtypes = [C.c_void_p, C.c_int]
         L.efx_profile_set_stride.argtypes = [C.c_void_p, C.c_int]
+        L.efx_profile_set_groups.argtypes = [C.c_void_p, C.c_uint]
         L.efx_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]
         L.efx_level_geometry.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                          C.POINTER(C.c_float)]
@@ -319,9 +320,11 @@ class EfficientFeatures:
         return [dict(n_candidates=st[i].n_candidates, n_after_nms=st[i].n_after_nms, n_kept=st[i].n_kept)
                 for i in range(nl.value)]
 
-    def profileEnable(self, max_launches, stride=1):
+    def profileEnable(self, max_launches, stride=1, groups=0x3f):
+        """groups: bit 0 fast, 1 harris, 2 nms, 3 select+emit+angle, 4 describe, 5 pyramid (include/efx.h)."""
         self._check(lib().efx_profile_enable(self._h, int(max_launches)))
         self._check(lib().efx_profile_set_stride(self._h, int(stride)))
+        self._check(lib().efx_profile_set_groups(self._h, int(groups)))
 
     def profileRead(self, capacity=65536):
         """(ms, code) arrays of the recorded launches (codes: include/efx.h, efx_profile_enable); call after synchronising."""

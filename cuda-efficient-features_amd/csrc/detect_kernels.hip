@@ -1510,7 +1510,7 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
         const int ytab_off = ((lpitch * sh) + 15) & ~15;          // per-row table behind the tile
         const size_t lds = (size_t)ytab_off + EFX_TILE * 16;
         if (lds > 64 * 1024) return hipErrorInvalidValue;
-        const bool prof = a.prof.begin(stream);
+        const bool prof = a.prof.begin(100 + s, stream);
         hipLaunchKernelGGL((resize_kernel<256>), dim3(N.tiles_x * N.tiles_y), dim3(256), lds, stream, src, spitch, L.rows, L.cols, aligned,
                            a.pyramid + N.img_off, N.pitch, N.rows, N.cols, N.fx, N.fy, N.tiles_x, N.tiles_y, lpitch, ytab_off,
                            zeroed ? nullptr : a.counters, H.nlevels);
@@ -1518,7 +1518,7 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
         a.prof.end(prof, 100 + s, stream);
     }
     if (use_tower) {
-        const bool prof = a.prof.begin(stream);
+        const bool prof = a.prof.begin(100 + tw.s0, stream);
         hipLaunchKernelGGL((pyramid_tower_kernel<1024>), dim3(tw.tiles_x * tw.tiles_y), dim3(1024), tw_lds, stream, a.d_table, a.img0,
                            a.pitch0, a.pyramid, tw, zeroed ? nullptr : a.counters);
         zeroed = true;
@@ -1527,20 +1527,20 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
     if (a.pyramid_only) return hipGetLastError();
     {
         const int aligned0 = (((uintptr_t)a.img0 | (uintptr_t)a.pitch0) & 3u) == 0;
-        bool prof = a.prof.begin(stream);
+        bool prof = a.prof.begin(0, stream);
         hipLaunchKernelGGL(fast_kernel, dim3(H.total_tiles), dim3(256), 0, stream, a.d_table, a.img0, a.pitch0, aligned0,
                            a.pyramid, a.threshold, a.mask, a.mask_pitch, a.cand, a.hdr, a.counters, a.dbg & 15);
         a.prof.end(prof, 0, stream);
-        prof = a.prof.begin(stream);
+        prof = a.prof.begin(1, stream);
         hipLaunchKernelGGL(harris_kernel, dim3(H.total_tiles + H.nlevels), dim3(64), 0, stream, a.d_table, a.img0, a.pitch0, aligned0, a.pyramid,
                            a.cand, a.cmax, a.hdr, a.counters, a.dbg & 15);
         a.prof.end(prof, 1, stream);
     }
-    bool prof = a.prof.begin(stream);
+    bool prof = a.prof.begin(2, stream);
     hipLaunchKernelGGL(nms_kernel, dim3(H.total_tiles), dim3(64), 0, stream, a.d_table, a.hdr, a.cand, a.cmax, a.surv,
                        a.counters, a.nonmax_radius, a.dbg >> 4);
     a.prof.end(prof, 2, stream);
-    prof = a.prof.begin(stream);
+    prof = a.prof.begin(3, stream);
     hipLaunchKernelGGL(select_kernel, dim3(H.nlevels), dim3(1024), 0, stream, a.d_table, a.hdr, a.surv, a.counters,
                        a.capacity, a.d_count, reinterpret_cast<Summary*>(a.h_mirror_dev));
     hipLaunchKernelGGL(emit_kernel, dim3(H.total_tiles), dim3(64), 0, stream, a.d_table, a.hdr, a.surv, a.counters,

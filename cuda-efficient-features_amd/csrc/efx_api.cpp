@@ -141,7 +141,7 @@ int describer_run(Describer& d, std::string& err, DescribeLaunch a, float* dbg_r
 {
     a.scale_factor = d.scale;
     if (a.n <= 0) return EFX_OK;
-    const bool prof = a.prof.begin(stream);
+    const bool prof = a.prof.begin(10, stream);
     struct ProfEnd { const ProfRec& p; bool on; hipStream_t st; ~ProfEnd() { p.end(on, 10, st); } } prof_end{a.prof, prof, stream};
     if (d.kind == 0) {
         HIP_TRY(err, d.responses.reserve((size_t)a.n * 48));
@@ -199,6 +199,7 @@ struct efx_context {
     std::vector<int> prof_level;
     int prof_count = 0;
     int prof_stride = 1, prof_calls = 0;   // record events on every prof_stride-th detect call only
+    unsigned prof_skip = 0;                // launch groups that are not timed (efx_profile_set_groups)
 
     ~efx_context()
     {
@@ -361,7 +362,7 @@ int detect_common(efx_context* c, const uint8_t* d_image, int rows, int cols, si
     a.h_mirror_dev = reinterpret_cast<int*>(c->h_mirror_dev);
     if (!c->prof_start.empty() && (c->prof_calls++ % c->prof_stride) == 0) {
         a.prof.start = c->prof_start.data(); a.prof.stop = c->prof_stop.data(); a.prof.code = c->prof_level.data();
-        a.prof.count = &c->prof_count; a.prof.capacity = (int)c->prof_start.size();
+        a.prof.count = &c->prof_count; a.prof.capacity = (int)c->prof_start.size(); a.prof.skip = c->prof_skip;
     }
     hipError_t e = efx_launch_detect(a, stream);
     if (e != hipSuccess) return set_err(c->err, EFX_ERR_HIP, "detect launch failed: %s", hipGetErrorString(e));
@@ -1023,6 +1024,13 @@ int efx_profile_set_stride(efx_context* ctx, int stride)
 {
     if (!ctx || stride < 1) return EFX_ERR_BAD_ARG;
     ctx->prof_stride = stride; ctx->prof_calls = 0;
+    return EFX_OK;
+}
+
+int efx_profile_set_groups(efx_context* ctx, unsigned groups)
+{
+    if (!ctx) return EFX_ERR_BAD_ARG;
+    ctx->prof_skip = ~groups & 0x3fu;
     return EFX_OK;
 }
 

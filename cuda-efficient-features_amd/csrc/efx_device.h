@@ -150,9 +150,12 @@ __device__ __forceinline__ int xcd_interleaved(int bid, int n)
 // 0 fast_kernel, 1 harris_kernel, 2 nms_kernel, 3 select+emit+angle, 10 describe (BAD / HashSIFT), 100+s resize of level s+1
 struct ProfRec {
     hipEvent_t* start; hipEvent_t* stop; int* code; int* count; int capacity;
-    bool begin(hipStream_t st) const
+    unsigned skip;              // bit g set: launches of group g are not timed (0 fast, 1 harris, 2 nms, 3 select+emit+angle,
+                                // 4 describe, 5 pyramid) -- every event pair costs a few microseconds of stream idle time
+    static int group_of(int c) { return c >= 100 ? 5 : (c == 10 ? 4 : c); }
+    bool begin(int c, hipStream_t st) const
     {
-        if (!count || *count >= capacity) return false;
+        if (!count || *count >= capacity || ((skip >> group_of(c)) & 1u)) return false;
         (void)hipEventRecord(start[*count], st);
         return true;
     }

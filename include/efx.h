@@ -301,6 +301,10 @@ long efx_descriptors_to_csv(const uint8_t* h_descriptors, int n, int nbytes, siz
 int efx_profile_enable(efx_context* ctx, int max_launches);
 /* Record events only on every `stride`-th detect call (an event pair costs a few microseconds of stream idle time). */
 int efx_profile_set_stride(efx_context* ctx, int stride);
+/* Which launch groups are timed (default: all).  Bit 0 fast_kernel, 1 harris_kernel, 2 nms_kernel, 3 select + emit + angle,
+ * 4 the describe stage, 5 the pyramid kernels.  Every timed launch costs a few microseconds of stream idle time, so a
+ * caller that measures inside a throughput run times only what it reports. */
+int efx_profile_set_groups(efx_context* ctx, unsigned groups);
 int efx_profile_read(efx_context* ctx, float* ms, int* level, int capacity, int* n);
 
 /* Geometry of pyramid level `level` for a rows x cols frame with the context's parameters
