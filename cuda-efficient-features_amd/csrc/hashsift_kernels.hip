@@ -15,13 +15,14 @@
 //     129-vector elements by one unit (measured over 40 000 keypoints), 1/60 of the stated tolerance;
 //   * the Gaussian pixel weights expf(...) (30x30) and the orientation bins scaleO*atan2f(dy,dx) (511x511
 //     integer gradients) are tables computed on the host with the same libm calls the CPU code makes;
-//     sqrtf is IEEE; cosf/sinf of the keypoint angle are taken as the rounded double result;
+//     sqrtf is IEEE; cosf/sinf of the keypoint angle are glibc's (glibc_sincosf.h, bit-identical to the host libm);
 //   * projection T = R[N x 129] . W^T is the one real GEMM of the path: v_mfma_f32_32x32x2_f32 (exact fp32
 //     FMA chain), fused with the sign test and MSB-first bit packing (no T matrix in HBM, no separate
 //     binarize pass as in cuda_hash_sift.cu:414-435).
 
 #include "efx_device.h"
 #include "blur_window.h"
+#include "glibc_sincosf.h"
 #include <stdlib.h>
 
 #define HS_KPAD 132   // 129 padded to a multiple of 4 floats
@@ -78,10 +79,15 @@ __global__ __launch_bounds__(HS_NT) void patch_sift_kernel(
         const float PI_1 = (float)3.1415926535897932384626433832795;
         const float s = crop_scale * size / (0.5f * (float)(32 + 32));
         const float theta = PI_1 * angle / 180;
-        // cosf/sinf of the CPU code: evaluated in double and rounded, i.e. the correctly rounded float
-        // result (the device's float versions are a few ulp off, which occasionally flips a patch pixel)
-        const float cost = s * (angle >= 0 ? (float)cos((double)theta) : 1.f);
-        const float sint = s * (angle >= 0 ? (float)sin((double)theta) : 0.f);
+        // cosf / sinf exactly as the CPU code gets them from libm (glibc's sincosf restated in glibc_sincosf.h and checked
+        // against the host libm for every float up to 11); larger angles: the rounded double result
+        float c1 = 1.f, s1 = 0.f;
+        if (angle >= 0) {
+            if (theta < EFX_GLIBC_SINCOSF_MAX) { c1 = efx_glibc_sincosf(theta, 1); s1 = efx_glibc_sincosf(theta, 0); }
+            else { c1 = (float)cos((double)theta); s1 = (float)sin((double)theta); }
+        }
+        const float cost = s * c1;
+        const float sint = s * s1;
         AffineF A;
         A.m00 = +cost; A.m01 = -sint; A.m02 = (-cost + sint) * (float)32 / 2.f + px;
         A.m10 = +sint; A.m11 = +cost; A.m12 = (-sint - cost) * (float)32 / 2.f + py;

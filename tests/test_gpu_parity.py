@@ -201,7 +201,7 @@ HS_T_ABS_TOL = 2e-3      # |T_hip - T_oracle| for identical 129-vectors: fp32 FM
                          # of 129 products; |T| is typically ~15, at most ~400; measured max 2.2e-4
 HS_VEC_FRAC = 1e-4       # fraction of 129-vector elements allowed to differ by one unit: the HIP histogram is summed in
                          # 32.32 fixed point (order independent), the CPU loop in sequentially rounded floats -- measured
-                         # 1.5e-6; cosf/sinf of the keypoint angle are rounded double results, expf / atan2f host tables
+                         # 1.5e-6; cosf/sinf of the keypoint angle are glibc's (csrc/glibc_sincosf.h), expf / atan2f host tables
 HS_VEC_MAX = 4.0         # a one-grey-level flip of a patch pixel moves an element by a few units
 
 
@@ -238,7 +238,7 @@ def test_hashsift_compute_tolerance(cef, torch_mod, oracle, nbits):
 
 def test_hashsift_vectors_equal_fixed_point_model_bit_exact(cef, torch_mod, oracle):
     """The kernel against the CPU model of ITS OWN arithmetic (fixed-point histogram sums): every 129-vector element
-    must match, except where cosf/sinf of the keypoint angle (rounded double results on the device) move a patch pixel."""
+    must match (cosf / sinf of the keypoint angle included: csrc/glibc_sincosf.h restates the host libm's)."""
     img = synth.synth_frame(480, 640, seed=4)
     kps = synth.random_keypoints(480, 640, 4000, seed=23)
     hs = cef.HashSIFT.create(1.0, cef.HashSIFT.SIZE_256_BITS)
@@ -246,7 +246,7 @@ def test_hashsift_vectors_equal_fixed_point_model_bit_exact(cef, torch_mod, orac
     torch_mod.cuda.synchronize()
     want = oracle.hashsift_responses_fixedpoint(img, kps)
     rows_off = np.nonzero((resp.cpu().numpy() != want).any(axis=1))[0]
-    assert rows_off.size <= 1, f"{rows_off.size} of 4000 vectors differ from the fixed-point model: {rows_off[:8]}"
+    assert rows_off.size == 0, f"{rows_off.size} of 4000 vectors differ from the fixed-point model: {rows_off[:8]}"
 
 
 @pytest.mark.parametrize("desc_type", [2, 3])
