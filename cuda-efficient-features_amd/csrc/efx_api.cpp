@@ -38,6 +38,11 @@ struct DevBuf {                     // grow-only device allocation
         if (p) { hipError_t e = hipFree(p); p = nullptr; bytes = 0; if (e != hipSuccess) return e; }
         hipError_t e = hipMalloc(&p, n);
         if (e == hipSuccess) bytes = n;
+        // EFX_POISON=1 (tests): fill every new allocation with a pattern, so that a kernel that reads memory nobody wrote
+        // fails the parity tests deterministically instead of once in 10^5 frames (fresh allocations are zero pages,
+        // recycled ones hold a previous frame's data)
+        static const bool poison = getenv("EFX_POISON") != nullptr;
+        if (e == hipSuccess && poison) { e = hipMemset(p, 0xA5, n); if (e == hipSuccess) e = hipDeviceSynchronize(); }   // before any non-blocking stream touches it
         return e;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
@@ -190,8 +195,7 @@ struct efx_context {
     efx_params g_p;
     LevelTable h_table;
     DevBuf d_table, pyramid, hdr, cand, cmax, surv, counters, kp4, kp_level, img, kps, descout, count, maskbuf;
-    Summary* h_mirror = nullptr;    // pinned
-    Summary* h_mirror_dev = nullptr; // the same buffer through the device's address (null if it cannot be mapped)
+    Summary* h_mirror = nullptr;    // host copy of the last frame's summary, filled on demand by fetch_summary()
     bool has_frame = false;
     const uint8_t* last_img0 = nullptr; int last_pitch0 = 0;
     // per-launch timing of the pipeline's kernels (efx_profile_*)
@@ -205,7 +209,7 @@ struct efx_context {
     {
         d_table.release(); pyramid.release(); hdr.release(); cand.release(); cmax.release(); surv.release(); counters.release();
         kp4.release(); kp_level.release(); img.release(); kps.release(); descout.release(); count.release(); maskbuf.release();
-        if (h_mirror) (void)hipHostFree(h_mirror);
+        delete h_mirror;
         for (hipEvent_t e : prof_start) (void)hipEventDestroy(e);
         for (hipEvent_t e : prof_stop) (void)hipEventDestroy(e);
     }
@@ -299,10 +303,9 @@ int build_geometry(efx_context* c, int rows, int cols)
     HIP_TRY(c->err, c->counters.reserve(sizeof(Counters)));
     HIP_TRY(c->err, c->count.reserve(sizeof(int)));
     if (!c->h_mirror) {
-        HIP_TRY(c->err, hipHostMalloc(reinterpret_cast<void**>(&c->h_mirror), sizeof(Summary), hipHostMallocMapped));
+        c->h_mirror = new (std::nothrow) Summary;
+        if (!c->h_mirror) return set_err(c->err, EFX_ERR_NOMEM, "out of host memory");
         memset(c->h_mirror, 0, sizeof(Summary));
-        void* dp = nullptr;
-        c->h_mirror_dev = hipHostGetDevicePointer(&dp, c->h_mirror, 0) == hipSuccess ? static_cast<Summary*>(dp) : nullptr;
     }
     // synchronous upload: geometry changes are rare (first frame / size or parameter change)
     {
@@ -358,8 +361,8 @@ int detect_common(efx_context* c, const uint8_t* d_image, int rows, int cols, si
     a.d_count = d_count ? d_count : static_cast<int*>(c->count.p);
     a.kp4 = static_cast<float4*>(c->kp4.p);
     a.kp_level = static_cast<int*>(c->kp_level.p);
-    a.h_mirror = reinterpret_cast<int*>(c->h_mirror);
-    a.h_mirror_dev = reinterpret_cast<int*>(c->h_mirror_dev);
+    a.h_mirror = nullptr;            // the summary is fetched on demand (fetch_summary), nothing is copied per frame
+    a.h_mirror_dev = nullptr;
     if (!c->prof_start.empty() && (c->prof_calls++ % c->prof_stride) == 0) {
         a.prof.start = c->prof_start.data(); a.prof.stop = c->prof_stop.data(); a.prof.code = c->prof_level.data();
         a.prof.count = &c->prof_count; a.prof.capacity = (int)c->prof_start.size(); a.prof.skip = c->prof_skip;
@@ -635,9 +638,23 @@ int efx_compute_kp4_async(efx_context* ctx, const uint8_t* d_image, int rows, in
                            d_descriptors, desc_pitch, nullptr, nullptr, (hipStream_t)stream);
 }
 
+// The last frame's summary (N, per-level counts) lives in device memory (select_kernel writes it).  The host fetches it ON
+// DEMAND with a blocking copy after the caller has synchronised the frame's stream.  (Two cheaper transports were tried
+// and dropped: an asynchronous 400-byte copy command behind every frame, and select_kernel writing a pinned, mapped host
+// buffer directly.  Under 16 processes sharing the GPU, one frame in ~20 000-40 000 read zeros through either -- the whole
+// struct with the copy command, one level's row with the direct writes -- while the device data was correct every time.)
+static int fetch_summary(const efx_context* ctx)
+{
+    if (!ctx->h_mirror || !ctx->counters.p) return EFX_ERR_BAD_ARG;
+    const Counters* dc = static_cast<const Counters*>(ctx->counters.p);
+    return hipMemcpy(ctx->h_mirror, &dc->sum, sizeof(Summary), hipMemcpyDeviceToHost) == hipSuccess ? EFX_OK : EFX_ERR_HIP;
+}
+
 int efx_last_count(const efx_context* ctx, int* n)
 {
     if (!ctx || !n || !ctx->h_mirror || !ctx->has_frame) return EFX_ERR_BAD_ARG;
+    const int rc = fetch_summary(ctx);
+    if (rc) return rc;
     *n = ctx->h_mirror->n_out;
     return EFX_OK;
 }
@@ -645,6 +662,8 @@ int efx_last_count(const efx_context* ctx, int* n)
 int efx_last_level_stats(const efx_context* ctx, efx_level_stats* stats, int max_levels, int* nlevels)
 {
     if (!ctx || !stats || !ctx->h_mirror || !ctx->has_frame) return EFX_ERR_BAD_ARG;
+    const int frc = fetch_summary(ctx);
+    if (frc) return frc;
     const int nl = ctx->h_table.nlevels < max_levels ? ctx->h_table.nlevels : max_levels;
     for (int i = 0; i < nl; i++) {
         stats[i].n_candidates = ctx->h_mirror->cand[i];
@@ -700,6 +719,7 @@ static int host_detect_impl(efx_context* ctx, const uint8_t* h_image, int rows, 
                            h_mask ? static_cast<const uint8_t*>(ctx->maskbuf.p) : nullptr, ipitch);
     if (rc) return rc;
     HIP_TRY(ctx->err, hipStreamSynchronize(nullptr));
+    if (fetch_summary(ctx) != EFX_OK) return set_err(ctx->err, EFX_ERR_HIP, "summary copy failed");
     const int cnt = ctx->h_mirror->n_out;
     *n = cnt;
     if (cnt > 0) {

@@ -95,11 +95,13 @@ def test_fuzz_detect_and_compute(cef, torch_mod, oracle, seed):
     n = int(cnt.item())
     ref = oracle.detect_and_compute(img, desc_type=desc_type, mask=mask, **kw)
     st = det.lastLevelStats()
+    full = (f"{info}: gpu cand {[s['n_candidates'] for s in st]} nms {[s['n_after_nms'] for s in st]} kept {[s['n_kept'] for s in st]} n {n}"
+            f" | oracle cand {list(ref['stats']['n_candidates'])} nms {list(ref['stats']['n_after_nms'])} kept {list(ref['stats']['n_kept'])} n {ref['n']}")
     for l, s in enumerate(st):
-        assert s["n_candidates"] == ref["stats"]["n_candidates"][l], f"{info}: level {l} FAST corners"
-        assert s["n_after_nms"] == ref["stats"]["n_after_nms"][l], f"{info}: level {l} NMS survivors"
-        assert s["n_kept"] == ref["stats"]["n_kept"][l], f"{info}: level {l} kept"
-    assert n == ref["n"], info
+        assert s["n_candidates"] == ref["stats"]["n_candidates"][l], f"level {l} FAST corners: {full}"
+        assert s["n_after_nms"] == ref["stats"]["n_after_nms"][l], f"level {l} NMS survivors: {full}"
+        assert s["n_kept"] == ref["stats"]["n_kept"][l], f"level {l} kept: {full}"
+    assert n == ref["n"], full
     g, r = kps[:, :n].cpu().numpy().view(np.uint32), ref["kps"].view(np.uint32)
     assert np.array_equal(g, r), f"{info}: keypoint rows differ at {np.argwhere(g != r)[:4].tolist()}"
     if desc_type in (0, 1):
