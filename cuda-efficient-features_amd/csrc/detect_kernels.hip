@@ -1089,7 +1089,7 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
 
 __global__ __launch_bounds__(1024) void select_kernel(const LevelTable* __restrict__ T, TileHdr* __restrict__ hdr,
                                                       const Corner* __restrict__ surv_all, Counters* __restrict__ cnt,
-                                                      int capacity, int* __restrict__ d_count, Summary* __restrict__ mirror)
+                                                      int capacity, int* __restrict__ d_count)
 {
     __shared__ int s_hist[SEL_MAX_TILES > SEL_BINS ? SEL_MAX_TILES : SEL_BINS];   // radix histogram, then per-tile counts
     __shared__ int s_scan[20];
@@ -1111,15 +1111,9 @@ __global__ __launch_bounds__(1024) void select_kernel(const LevelTable* __restri
     if (tid == 0) {
         cnt->level_out_base[l] = base;
         if (l == T->nlevels - 1) cnt->level_out_base[T->nlevels] = all;
-        if (l == 0) { const int n = all < capacity ? all : capacity; cnt->sum.n_out = n; if (d_count) *d_count = n; if (mirror) { mirror->n_out = n; mirror->dbg = 0; } }
+        if (l == 0) { const int n = all < capacity ? all : capacity; cnt->sum.n_out = n; if (d_count) *d_count = n; }
     }
-    if (!L.active) {
-        if (tid == 0) {
-            cnt->sum.kept[l] = 0; cnt->thresh[l] = 0;
-            if (mirror) { mirror->kept[l] = 0; mirror->surv[l] = 0; mirror->cand[l] = 0; }
-        }
-        return;
-    }
+    if (!L.active) { if (tid == 0) { cnt->sum.kept[l] = 0; cnt->thresh[l] = 0; } return; }
 
     int n = 0;
     for (int sub = 0; sub < EFX_NSUB; sub++) n += cnt->surv_total[l][sub].v;
@@ -1227,9 +1221,6 @@ __global__ __launch_bounds__(1024) void select_kernel(const LevelTable* __restri
         int nc = 0;
         for (int sub = 0; sub < EFX_NSUB; sub++) nc += cnt->cand_total[l][sub].v;
         cnt->sum.cand[l] = nc;
-        // the host's copy of the summary lives in pinned, device-visible memory: written here instead of by a copy
-        // command behind the frame (one launch less on the critical path)
-        if (mirror) { mirror->kept[l] = running; mirror->surv[l] = n; mirror->cand[l] = nc; }
     }
 }
 
@@ -1542,7 +1533,7 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
     a.prof.end(prof, 2, stream);
     prof = a.prof.begin(3, stream);
     hipLaunchKernelGGL(select_kernel, dim3(H.nlevels), dim3(1024), 0, stream, a.d_table, a.hdr, a.surv, a.counters,
-                       a.capacity, a.d_count, reinterpret_cast<Summary*>(a.h_mirror_dev));
+                       a.capacity, a.d_count);
     hipLaunchKernelGGL(emit_kernel, dim3(H.total_tiles), dim3(64), 0, stream, a.d_table, a.hdr, a.surv, a.counters,
                        a.img0, a.pitch0, a.pyramid, (uint8_t*)a.d_keypoints, a.kps_pitch, a.capacity, a.kp4, a.kp_level);
     if (a.capacity > 0) {
@@ -1556,8 +1547,7 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
     a.prof.end(prof, 3, stream);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    if (a.h_mirror && !a.h_mirror_dev) e = hipMemcpyAsync(a.h_mirror, &a.counters->sum, sizeof(Summary), hipMemcpyDeviceToHost, stream);
-    return e;
+    return e;        // the host reads the summary (N, per-level counts) on demand: fetch_summary(), efx_api.cpp
 }
 
 hipError_t efx_launch_convert_keypoints(const void* d_keypoints, size_t kps_pitch, int n, float4* kp4, hipStream_t stream)

@@ -361,8 +361,6 @@ int detect_common(efx_context* c, const uint8_t* d_image, int rows, int cols, si
     a.d_count = d_count ? d_count : static_cast<int*>(c->count.p);
     a.kp4 = static_cast<float4*>(c->kp4.p);
     a.kp_level = static_cast<int*>(c->kp_level.p);
-    a.h_mirror = nullptr;            // the summary is fetched on demand (fetch_summary), nothing is copied per frame
-    a.h_mirror_dev = nullptr;
     if (!c->prof_start.empty() && (c->prof_calls++ % c->prof_stride) == 0) {
         a.prof.start = c->prof_start.data(); a.prof.stop = c->prof_stop.data(); a.prof.code = c->prof_level.data();
         a.prof.count = &c->prof_count; a.prof.capacity = (int)c->prof_start.size(); a.prof.skip = c->prof_skip;

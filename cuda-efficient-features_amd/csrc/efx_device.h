@@ -188,8 +188,6 @@ struct DetectLaunch {
     // outputs
     void* d_keypoints; size_t kps_pitch; int capacity; int* d_count;
     float4* kp4; int* kp_level;
-    int* h_mirror;              // pinned host mirror of the Summary (may be null)
-    int* h_mirror_dev;          // the same buffer as the device sees it (select_kernel writes it); null: copy command instead
     ProfRec prof;                                          // optional HIP-event pairs around the launches
 };
 

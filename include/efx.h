@@ -114,8 +114,8 @@ int efx_default_norm(const efx_context* ctx);      /* 6 == cv::NORM_HAMMING, .cp
 /* detectAsync (cuda_efficient_features.cpp:215-218).  d_image: rows x cols u8, `pitch` bytes per row.
  * d_keypoints: 5 x capacity matrix (layout above).  d_count: device int receiving N (<= capacity).
  * The mask argument of the reference is accepted and ignored there (.cpp:225-250); it has no parameter here.
- * No host synchronisation happens inside; N is also mirrored to pinned host memory, readable with
- * efx_last_count() once the stream has been synchronised. */
+ * No host synchronisation happens inside; once the stream has been synchronised, efx_last_count() and
+ * efx_last_level_stats() fetch N and the per-level counts from the device (one small blocking copy per call). */
 int efx_detect_async(efx_context* ctx, const uint8_t* d_image, int rows, int cols, size_t pitch,
                      void* d_keypoints, size_t kps_pitch, int capacity, int* d_count, void* stream);
 
