@@ -838,12 +838,14 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
     int lvl_total = 0;
     for (int sub = 0; sub < EFX_NSUB; sub++) lvl_total += cnt->cand_total[l][sub].v;
     const bool capped = lvl_total > L.cap;              // only then the canonical ranks were computed
+    // the cell maxima are fetched in the same memory round trip as the headers (both only need the tile's coordinates)
+    // clamped exactly as the quick test clamps its cell coordinates
+    const int gw_ = (L.cols + EFX_CELL - 1) / EFX_CELL, gh_ = (L.rows + EFX_CELL - 1) / EFX_CELL;
+    const int cy = min(max(ty * 4 - 1 + lane / 6, 0), gh_ - 1), cx = min(max(tx * 4 - 1 + lane % 6, 0), gw_ - 1);
+    Corner cm; cm.xy = 0u; cm.resp = 0.f;
+    if (lane < 36) cm = cmax_all[L.cmax_base + (size_t)cy * (L.tiles_x * 4) + cx];
     __syncthreads();                                     // s_nb is read below
     if (lane < 36) {
-        // clamped exactly as the quick test clamps its cell coordinates
-        const int gw_ = (L.cols + EFX_CELL - 1) / EFX_CELL, gh_ = (L.rows + EFX_CELL - 1) / EFX_CELL;
-        const int cy = min(max(ty * 4 - 1 + lane / 6, 0), gh_ - 1), cx = min(max(tx * 4 - 1 + lane % 6, 0), gw_ - 1);
-        Corner cm = cmax_all[L.cmax_base + (size_t)cy * (L.tiles_x * 4) + cx];
         if (capped) {
             // a cell of a tile that is cut by the cap may hold invalid corners: its maximum must not suppress anything,
             // but the cell may still hold a valid rival -> "infinitely strong, infinitely far": never kills, always
