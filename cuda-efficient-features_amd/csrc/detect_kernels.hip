@@ -304,6 +304,142 @@ __global__ __launch_bounds__(NT) void resize_kernel(
 }
 
 // ================================================================================================
+// Kernel R': the same tiles as resize_kernel, STREAMED.  Measured on the 8K level 1: staging the footprint alone costs
+// 22 us, the arithmetic alone 21 us, the two in sequence 33 us -- a workgroup spends most of its life waiting for its
+// own loads.  Here the grid is only as large as the chip holds at once; a workgroup walks through tiles and issues the
+// (range-checked, branch-free) buffer loads of its NEXT tile into registers before it computes the current one from
+// LDS, so the memory latency is hidden behind arithmetic.  The barriers in the loop order LDS traffic only
+// (__syncthreads() would also wait for the loads in flight).  Requirements checked by the host: aligned source,
+// footprint <= 32 dwords x 80 rows (scale factors up to ~1.22; others use resize_kernel).
+// ================================================================================================
+__device__ __forceinline__ void efx_lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+__global__ __launch_bounds__(256) void resize_stream_kernel(
+    const uint8_t* __restrict__ src, int spitch, int rows, int cols,
+    uint8_t* __restrict__ dst, int dpitch, int drows, int dcols, float fx, float fy, int tiles_x, int tiles_y, int lpitch, int ytab_off,
+    Counters* __restrict__ zero, int zero_levels)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NP = 10;                                  // 8 rows per pass, up to 80 footprint rows
+    const int tid = threadIdx.x;
+    if (zero && blockIdx.x == 0) efx_zero_counters(zero, zero_levels, tid, 256);
+    // XCD x owns the x-th contiguous eighth of the tiles, its workgroups stride through it
+    const int ntiles = tiles_x * tiles_y;
+    const int W = gridDim.x / EFX_NXCD, xcd = blockIdx.x % EFX_NXCD, wg = blockIdx.x / EFX_NXCD;
+    const int cq_ = ntiles / EFX_NXCD, cr_ = ntiles % EFX_NXCD;
+    const int c0 = xcd < cr_ ? xcd * (cq_ + 1) : cr_ * (cq_ + 1) + (xcd - cr_) * cq_;
+    const int c1 = c0 + cq_ + (xcd < cr_ ? 1 : 0);
+    int tile = c0 + wg;
+    if (tile >= c1) return;
+
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src), 0, (rows - 1) * spitch + ((cols + 3) & ~3), 0x00020000);
+    const int j0 = tid & 31, r0 = tid >> 5;
+    struct Geo { int ox0, oy0, ox1, oy1, sx1, sy0, ax0, ndw, nrow; };
+    auto geo_of = [&](int t) -> Geo {
+        Geo g;
+        const int tx = t % tiles_x, ty = t / tiles_x;
+        g.ox0 = tx * EFX_TILE; g.oy0 = ty * EFX_TILE;
+        g.ox1 = min(g.ox0 + EFX_TILE, dcols); g.oy1 = min(g.oy0 + EFX_TILE, drows);
+        const int sx0 = min((int)floorf((float)g.ox0 * fx), cols - 1);
+        g.sy0 = min((int)floorf((float)g.oy0 * fy), rows - 1);
+        g.sx1 = min(min((int)floorf((float)(g.ox1 - 1) * fx), cols - 1) + 1, cols - 1);
+        const int sy1 = min(min((int)floorf((float)(g.oy1 - 1) * fy), rows - 1) + 1, rows - 1);
+        g.ax0 = sx0 & ~3;
+        g.ndw = ((g.sx1 - g.ax0) >> 2) + 1; g.nrow = sy1 - g.sy0 + 1;
+        return g;
+    };
+    uint32_t pf[NP];
+    auto issue = [&](const Geo& g) {
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            const int r = r0 + 8 * p;
+            // lanes / rows outside the footprint read beyond the resource: the hardware range check returns 0, no branch
+            const int off = (j0 < g.ndw && r < g.nrow) ? (g.sy0 + r) * spitch + g.ax0 + 4 * j0 : 0x7ffffff0;
+            pf[p] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0);
+        }
+    };
+
+    Geo g = geo_of(tile);
+    issue(g);
+    for (;;) {
+        // ---- the prefetched footprint and the per-row table -> LDS ----
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            const int r = r0 + 8 * p;
+            if (j0 < g.ndw && r < g.nrow) *reinterpret_cast<uint32_t*>(smem + r * lpitch + 4 * j0) = pf[p];
+        }
+        int4* ytab = reinterpret_cast<int4*>(smem + ytab_off);
+        if (tid < EFX_TILE) {
+            const int oy = min(g.oy0 + tid, drows - 1);
+            const float sy = (float)oy * fy;
+            int y1 = (int)floorf(sy);
+            if (y1 > rows - 1) y1 = rows - 1;
+            const int y2 = y1 + 1;
+            const int y2r = y2 < rows - 1 ? y2 : rows - 1;
+            ytab[tid] = make_int4((y1 - g.sy0) * lpitch, (y2r - g.sy0) * lpitch, __float_as_int((float)y2 - sy), __float_as_int(sy - (float)y1));
+        }
+        efx_lds_barrier();
+        if (g.sx1 == cols - 1) {                            // replicated +1 neighbour of the last source column (S5 clamp)
+            for (int r = tid; r < g.nrow; r += 256) smem[r * lpitch + (cols - g.ax0)] = smem[r * lpitch + (cols - 1 - g.ax0)];
+            efx_lds_barrier();
+        }
+        // ---- next tile's loads go out now and land while this tile is computed ----
+        const int tnext = tile + W;
+        const bool more = tnext < c1;
+        Geo gn = g;
+        if (more) { gn = geo_of(tnext); issue(gn); }
+
+        // ---- this tile: the arithmetic of resize_kernel ----
+        const int cq = tid & 15, rq = tid >> 4;
+        const int oxq = g.ox0 + 4 * cq;
+        if (oxq < g.ox1) {
+            float wx0[4], wx1[4]; int lc[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int ox = min(oxq + k, dcols - 1);
+                const float sx = (float)ox * fx;
+                int x1 = (int)floorf(sx);
+                if (x1 > cols - 1) x1 = cols - 1;
+                const int x2 = x1 + 1;
+                wx0[k] = (float)x2 - sx; wx1[k] = sx - (float)x1;
+                lc[k] = x1 - g.ax0;
+            }
+            const bool full4 = oxq + 4 <= g.ox1 && ((((uintptr_t)dst) | (uintptr_t)dpitch) & 3u) == 0;
+            for (int oy = g.oy0 + rq; oy < g.oy1; oy += 16) {
+                const int4 yt = ytab[oy - g.oy0];
+                const float wy0 = __int_as_float(yt.z), wy1 = __int_as_float(yt.w);
+                const uint8_t* ra = smem + yt.x;
+                const uint8_t* rb = smem + yt.y;
+                uint32_t packed = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint8_t* pa = ra + lc[k];
+                    const uint8_t* pb = rb + lc[k];
+                    float out = (float)pa[0] * (wx0[k] * wy0);
+                    out = out + (float)pa[1] * (wx1[k] * wy0);
+                    out = out + (float)pb[0] * (wx0[k] * wy1);
+                    out = out + (float)pb[1] * (wx1[k] * wy1);
+                    packed = __builtin_amdgcn_cvt_pk_u8_f32(out, k, packed);
+                }
+                uint8_t* d = dst + (size_t)oy * dpitch + oxq;
+                if (full4) *reinterpret_cast<uint32_t*>(d) = packed;
+                else
+                    for (int k = 0; k < 4; k++) if (oxq + k < g.ox1) d[k] = (uint8_t)(packed >> (8 * k));
+            }
+        }
+        if (!more) break;
+        efx_lds_barrier();                                  // every read of this tile's LDS is done
+        g = gn; tile = tnext;
+    }
+}
+
+// ================================================================================================
 // Kernel R2: a whole small pyramid in one launch ("tower"; frames up to EFX_TOWER_MAX_PX pixels, see plan_tower).  The
 // per-level kernel above is launch- and latency-bound once the levels are small (7 dependent launches cost a third of
 // an FHD frame's detectAndCompute).  Here a workgroup owns one
@@ -1423,6 +1559,7 @@ static bool plan_tower(const LevelTable& H, int last, const uint8_t* img0, int p
     // (FHD 0.166 -> 0.147 ms, 4K 0.270 -> 0.259 ms per detectAndCompute); fusing only the upper levels of a large frame
     // (8K levels 4..7) does not pay: those levels are as large as a 4K pyramid and the tower recomputes ~1.7x the pixels.
     if ((long long)H.lv[0].rows * H.lv[0].cols > EFX_TOWER_MAX_PX) return false;
+    if (getenv("EFX_NO_TOWER")) return false;                 // tests: exercise the per-level kernels on small frames
     for (int s0 = 0; s0 == 0; s0++) {
         const LevelDev& Lt = H.lv[last];
         const int tt = 32;
@@ -1504,7 +1641,22 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
         const size_t lds = (size_t)ytab_off + EFX_TILE * 16;
         if (lds > 64 * 1024) return hipErrorInvalidValue;
         const bool prof = a.prof.begin(100 + s, stream);
-        hipLaunchKernelGGL((resize_kernel<256>), dim3(N.tiles_x * N.tiles_y), dim3(256), lds, stream, src, spitch, L.rows, L.cols, aligned,
+        const int ntiles = N.tiles_x * N.tiles_y;
+        const bool no_stream = getenv("EFX_NO_RESIZE_STREAM") != nullptr;     // tests: force the one-tile-per-workgroup kernel
+        if (aligned && sw <= 128 && sh <= 80 && !no_stream) {
+            // streamed variant: a grid the chip holds at once (8 workgroups of 256 threads per CU), a multiple of the 8 XCDs
+            static int s_slots = 0;
+            if (s_slots == 0) {
+                int dev = 0, cus = 0;
+                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+                s_slots = cus * 8;
+            }
+            const int per_xcd = std::min(s_slots / EFX_NXCD, (ntiles + EFX_NXCD - 1) / EFX_NXCD);
+            hipLaunchKernelGGL(resize_stream_kernel, dim3(per_xcd * EFX_NXCD), dim3(256), lds, stream, src, spitch, L.rows, L.cols,
+                               a.pyramid + N.img_off, N.pitch, N.rows, N.cols, N.fx, N.fy, N.tiles_x, N.tiles_y, lpitch, ytab_off,
+                               zeroed ? nullptr : a.counters, H.nlevels);
+        } else
+        hipLaunchKernelGGL((resize_kernel<256>), dim3(ntiles), dim3(256), lds, stream, src, spitch, L.rows, L.cols, aligned,
                            a.pyramid + N.img_off, N.pitch, N.rows, N.cols, N.fx, N.fy, N.tiles_x, N.tiles_y, lpitch, ytab_off,
                            zeroed ? nullptr : a.counters, H.nlevels);
         zeroed = true;

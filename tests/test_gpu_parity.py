@@ -544,3 +544,26 @@ def test_equal_responses_suppress_each_other(cef, torch_mod, oracle, period, rad
     got, ref = _detect_both(cef, torch_mod, oracle, img, desc_type=1, nonmax_radius=radius, nlevels=4)
     _assert_same_keypoints(got, ref)
     assert np.array_equal(got["desc"], ref["desc"])
+
+
+@pytest.mark.parametrize("mode", ["tower", "chain_streamed", "chain_plain"])
+@pytest.mark.parametrize("shape,scale", [((480, 640), 1.2), ((501, 703), 1.2), ((333, 1111), 1.1), ((700, 900), 1.5)])
+def test_pyramid_kernel_variants_bit_exact(cef, torch_mod, oracle, monkeypatch, mode, shape, scale):
+    """The three ways a pyramid is produced -- one tower launch (small frames), the streamed per-level kernel and the
+    one-tile-per-workgroup per-level kernel (large frames / other scale factors) -- give the same levels, bit for bit."""
+    if mode != "tower":
+        monkeypatch.setenv("EFX_NO_TOWER", "1")
+    if mode == "chain_plain":
+        monkeypatch.setenv("EFX_NO_RESIZE_STREAM", "1")
+    img = synth.synth_frame(shape[0], shape[1], seed=21)
+    det = cef.EfficientFeatures.create(1000, scale, 8, 0, 20, 15, 0)
+    d_img = _dev(torch_mod, img)
+    det.detectAsync(d_img)
+    torch_mod.cuda.synchronize()
+    for level in range(8):
+        got = det.copyLevel(level, shape[0], shape[1]).cpu().numpy()
+        want = oracle.pyramid_level(img, level, scale_factor=scale)
+        assert got.shape == want.shape
+        assert np.array_equal(got, want), f"{mode} level {level}: {np.count_nonzero(got != want)} pixels differ"
+    ref = oracle.detect_and_compute(img, desc_type=-1, nfeatures=1000, scale_factor=scale)
+    assert det.lastCount() == ref["n"]
