@@ -192,9 +192,9 @@ def main():
                           "frames_per_step_per_gpu": F, "frames_per_step": F * world, "streams_per_gpu": NS,
                           "keypoints_per_frame": round(nkp / F, 1), "parallelism": f"frames sharded over {world} GPU(s)"},
                "roofline": roof}
-        roof["profiles"] = {"avg_launch_ms (live, frames of other streams share the GPU)": "profiles/r01_m_kernel_stats_3streams.csv",
-                            "isolated / kernels_isolated (one stream)": "profiles/r01_m_kernel_stats.csv",
-                            "traffic": "profiles/traffic.json", "instruction counts": "profiles/r01_pmc_sq_m.txt"}
+        roof["profiles"] = {"avg_launch_ms (live, frames of other streams share the GPU)": "profiles/r01_n_kernel_stats_3streams.csv",
+                            "isolated / kernels_isolated (one stream)": "profiles/r01_n_kernel_stats.csv",
+                            "traffic": "profiles/traffic.json", "instruction counts": "profiles/r01_pmc_sq_n.txt"}
 
         # The reference's own protocol (samples/sample_benchmark.cpp:39-52: 1 warm-up, then N x {detectAndComputeAsync;
         # stream.waitForCompletion()}): one frame at a time on one stream, host wait included.  This is the figure that
