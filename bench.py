@@ -39,6 +39,73 @@ def detect_algorithmic_bytes(det, rows, cols, nlevels=8):
     return px, float(sum(px) + sum(px[1:]))
 
 
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) under torch.distributed.run on this
+    node, exactly as the driver does, and pass their exit status on.  Fails loudly when the node has fewer GPUs."""
+    import subprocess
+    if not args.dry_run:
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} requested but {have} GPU(s) visible on this node", file=sys.stderr, flush=True)
+            raise SystemExit(2)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (RCCL across processes on this host driver)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def collective_world(dist, one):
+    """Number of ranks that took part in a real all-reduce (SUM of a one per rank) -- not just the configured world."""
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    return int(round(float(one.item())))
+
+
+def dry_run(args, rank, world):
+    """The N > 1 plumbing without a GPU: rendezvous, sharding, the counter reductions and the JSON line, with stand-in
+    per-frame numbers (frame k 'yields' 40000 keypoints, a step 'takes' 1 ms on rank 0 and a little longer on others)."""
+    import torch
+    import torch.distributed as dist
+    import cef_loader
+    sharding = cef_loader.load_submodule("sharding")
+    F = args.frames_per_step
+    if world > 1 or "WORLD_SIZE" in os.environ:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
+        seen = collective_world(dist, torch.ones(1, dtype=torch.float64))
+        gathered = [None] * world
+        mine = sharding.frames_for_rank(F, rank, world)
+        dist.all_gather_object(gathered, mine)
+        d = dist
+    else:
+        seen, d = 1, None
+        gathered = [sharding.frames_for_rank(F, rank, world)]
+    dt = 1e-3 * args.steps * (1.0 + 0.01 * rank)
+    t_max, kp_step, nfr = sharding.reduce_counters(d, "cpu", dt, NFEATURES * F, F)
+    if rank == 0:
+        frames = sorted(sum(gathered, []))
+        print(json.dumps({"metric": "Mkeypoints/s detectAndCompute (8K, 40k kp, BAD512)", "dry_run": True,
+                          "value": round(kp_step * args.steps / t_max / 1e6, 3), "unit": "Mkeypoints/s",
+                          "n_gpus": world, "rccl_world": seen, "backend": args.backend, "steps": args.steps,
+                          "warmup": args.warmup, "frames_per_step": int(nfr),
+                          "frames_each_once": frames == list(range(F * world)), "scaling": "weak"}), flush=True)
+    if d is not None:
+        d.barrier()
+        d.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -49,30 +116,57 @@ def main():
                     help="independent frames in flight per GPU: one context + one HIP stream each (a context is not "
                          "re-entrant, like the reference's EfficientFeaturesImpl; frames are independent)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for the counters: nccl (= RCCL, the GPU path) or gloo (only with --dry-run)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU work: run the launcher, the rendezvous, the frame sharding and the counter reductions with "
+                         "stand-in per-frame numbers (CPU test of the N > 1 plumbing, tests/test_bench_launcher.py)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.backend == "gloo" and not args.dry_run:
+        raise SystemExit("--backend gloo is only valid with --dry-run (the product path has no CPU fallback)")
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args)          # bench.py --gpus N called directly: spawn the N ranks ourselves
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
+    if args.dry_run:
+        return dry_run(args, rank, world)
 
     import torch
     import cef_loader
     cef = cef_loader.load()
     from tools import synth
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback for the product path)")
+    if torch.cuda.device_count() < world or local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: --gpus {world} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     dist = None
+    rccl_world = 1
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world)   # nccl == RCCL on ROCm
+        rccl_world = collective_world(dist, torch.ones(1, dtype=torch.float64, device="cuda"))
+        if rccl_world != world:
+            raise SystemExit(f"bench.py: RCCL all-reduce saw {rccl_world} ranks, expected {world}")
 
     F = args.frames_per_step
     # per-rank frames: global frame k = rank * F + i uses seed 1000 + k
     sharding = cef_loader.load_submodule("sharding")
-    frames = [torch.from_numpy(synth.synth_frame(ROWS, COLS, seed=1000 + k)).cuda()
-              for k in sharding.frames_for_rank(F, rank, world)]
+    my_frames = sharding.frames_for_rank(F, rank, world)
+    frames = [torch.from_numpy(synth.synth_frame(ROWS, COLS, seed=1000 + k)).cuda() for k in my_frames]
+    all_frames = [my_frames]
+    if dist is not None:
+        all_frames = [None] * world
+        dist.all_gather_object(all_frames, my_frames)       # outside the timed region: which rank took which frame
 
     NS = max(1, min(args.streams, F))
     dets = [cef.EfficientFeatures.create(NFEATURES, 1.2, 8, 0, 20, 15, cef.EfficientFeatures.BAD_512) for _ in range(NS)]
@@ -180,7 +274,7 @@ def main():
                 pass
 
         out = {"metric": "Mkeypoints/s detectAndCompute (8K, 40k kp, BAD512)",
-               "value": round(kp_total / t_max / 1e6, 3), "unit": "Mkeypoints/s", "n_gpus": world,
+               "value": round(kp_total / t_max / 1e6, 3), "unit": "Mkeypoints/s", "n_gpus": world, "rccl_world": rccl_world,
                "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(t_max / args.steps * 1e3, 4),
                "ms_per_frame": round(t_max / args.steps / F * 1e3, 4),
@@ -189,7 +283,8 @@ def main():
                "data": "synthetic",
                "config": {"workload": "detectAndCompute BAD512 on 8K (7680x4320) synthetic frames, nfeatures=40000, "
                                       "8 levels, scale 1.2, FAST threshold 20, NMS radius 15 (BASELINE.json configs[4])",
-                          "frames_per_step_per_gpu": F, "frames_per_step": F * world, "streams_per_gpu": NS,
+                          "frames_per_step_per_gpu": F, "frames_per_step": F * world,
+                          "frames_each_once": sorted(sum(all_frames, [])) == list(range(F * world)), "streams_per_gpu": NS,
                           "keypoints_per_frame": round(nkp / F, 1), "parallelism": f"frames sharded over {world} GPU(s)"},
                "roofline": roof}
         roof["profiles"] = {"avg_launch_ms (live, frames of other streams share the GPU)": "profiles/r01_n_kernel_stats_3streams.csv",
