@@ -43,7 +43,8 @@ ABI_SYMBOLS = [
     "efx_detect_and_compute_batch_async", "efx_detect_and_compute_masked_async", "efx_compute_provided_async", "efx_detect_and_compute_ex",
     "efx_ic_angles_async", "efx_ic_angles", "efx_descriptors_to_csv",
     "efx_cvt_gray_async", "efx_host_alloc", "efx_host_free", "efx_uploader_create", "efx_uploader_destroy",
-    "efx_uploader_last_error", "efx_upload_gray_async", "efx_describer_compute_color",
+    "efx_uploader_last_error", "efx_upload_gray_async", "efx_uploader_release", "efx_uploader_wait_uploaded",
+    "efx_describer_compute_color",
     "efx_profile_enable", "efx_profile_set_stride", "efx_profile_set_groups", "efx_profile_read",
     "efx_level_geometry", "efx_copy_level_async",
 ]
@@ -153,6 +154,8 @@ def lib():
         L.efx_uploader_last_error.argtypes = [C.c_void_p]
         L.efx_upload_gray_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int,
                                             C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_void_p]
+        L.efx_uploader_release.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.efx_uploader_wait_uploaded.argtypes = [C.c_void_p, C.c_void_p]
         L.efx_describer_compute_color.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_void_p,
                                                   C.c_int, C.c_void_p, C.c_size_t]
         L.efx_profile_enable.argtypes = [C.c_void_p, C.c_int]
@@ -288,6 +291,11 @@ class EfficientFeatures:
                 keypoints.data_ptr(), keypoints.stride(0) * 4, descriptors.data_ptr() if descriptors is not None else None,
                 descriptors.stride(0) if descriptors is not None else 0, capacity, count.data_ptr(), _stream_ptr(stream)))
             return keypoints, descriptors, count
+        if descriptors is None:          # want_descriptors=False: the detect-only entry point
+            self._check(lib().efx_detect_async(
+                self._h, image.data_ptr(), image.shape[0], image.shape[1], image.stride(0), keypoints.data_ptr(),
+                keypoints.stride(0) * 4, capacity, count.data_ptr(), _stream_ptr(stream)))
+            return keypoints, None, count
         self._check(lib().efx_detect_and_compute_async(
             self._h, image.data_ptr(), image.shape[0], image.shape[1], image.stride(0), keypoints.data_ptr(),
             keypoints.stride(0) * 4, descriptors.data_ptr(), descriptors.stride(0), capacity, count.data_ptr(),
@@ -621,6 +629,18 @@ class Uploader:
         if rc != EFX_OK:
             raise EfxError(rc, lib().efx_uploader_last_error(self._h).decode())
         return d.value, pitch.value, img.shape[0], img.shape[1]
+
+    def release(self, d_gray, stream=None):
+        """Everything enqueued on `stream` so far is the last reader of frame `d_gray`: recycle its slot only behind it."""
+        rc = lib().efx_uploader_release(self._h, d_gray, _stream_ptr(stream))
+        if rc != EFX_OK:
+            raise EfxError(rc, lib().efx_uploader_last_error(self._h).decode())
+
+    def waitUploaded(self, d_gray):
+        """Block until frame `d_gray` has left the host buffer it was uploaded from."""
+        rc = lib().efx_uploader_wait_uploaded(self._h, d_gray)
+        if rc != EFX_OK:
+            raise EfxError(rc, lib().efx_uploader_last_error(self._h).decode())
 
 
 class BFMatcher:

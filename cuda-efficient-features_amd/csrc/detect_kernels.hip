@@ -666,11 +666,11 @@ __device__ __forceinline__ void load_tile_lds(uint32_t* s_tile, const uint8_t* _
 }
 
 // level and tile coordinates of a global tile index: one packed word per tile behind the level table
-// (level | tx << 4 | ty << 14, written by the host with the geometry)
+// (efx_pack_tile, written by the host with the geometry)
 __device__ __forceinline__ void efx_tile_of(const LevelTable* T, int gt, int& l, int& tx, int& ty)
 {
     const uint32_t v = reinterpret_cast<const uint32_t*>(T + 1)[gt];
-    l = (int)(v & 15u); tx = (int)((v >> 4) & 1023u); ty = (int)(v >> 14);
+    l = (int)(v & ((1u << EFX_TILE_LEVEL_BITS) - 1u)); tx = (int)((v >> EFX_TILE_LEVEL_BITS) & 1023u); ty = (int)(v >> (EFX_TILE_LEVEL_BITS + 10));
 }
 
 // ================================================================================================
@@ -683,8 +683,9 @@ __device__ __forceinline__ void efx_tile_of(const LevelTable* T, int gt, int& l,
 __global__ __launch_bounds__(256) void fast_kernel(
     const LevelTable* __restrict__ T, const uint8_t* __restrict__ img0, int pitch0, int aligned0,
     const uint8_t* __restrict__ pyramid, int threshold, const uint8_t* __restrict__ mask, int mask_pitch,
-    Corner* __restrict__ cand_all, TileHdr* __restrict__ hdr_all, Counters* __restrict__ cnt, int dbg)
+    Corner* __restrict__ cand_all, TileHdr* __restrict__ hdr_all, Counters* __restrict__ cnt, int dbg_arg)
 {
+    const int dbg = EFX_DBG(dbg_arg);
     __shared__ __attribute__((aligned(16))) uint32_t s_tile[EFX_LT * (EFX_LP / 4)];
     __shared__ unsigned long long s_bitmap[EFX_TILE];
     __shared__ uint16_t s_list[EFX_TILE * EFX_TILE];     // phase 1-2: per-wave quick-test survivors; phase 3+: corner list
@@ -852,8 +853,9 @@ __global__ __launch_bounds__(256) void fast_kernel(
 __global__ __launch_bounds__(64) void harris_kernel(
     const LevelTable* __restrict__ T, const uint8_t* __restrict__ img0, int pitch0, int aligned0,
     const uint8_t* __restrict__ pyramid, Corner* __restrict__ cand_all, Corner* __restrict__ cmax_all,
-    TileHdr* __restrict__ hdr_all, const Counters* __restrict__ cnt, int dbg)
+    TileHdr* __restrict__ hdr_all, const Counters* __restrict__ cnt, int dbg_arg)
 {
+    const int dbg = EFX_DBG(dbg_arg);
     __shared__ unsigned long long s_cellmax[EFX_CELLS_PER_TILE];
     __shared__ unsigned s_celltie[EFX_CELLS_PER_TILE];     // largest response key that two corners of the cell share
     const int lane = threadIdx.x;
@@ -941,8 +943,9 @@ __global__ __launch_bounds__(64) void harris_kernel(
 
 __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ T, TileHdr* __restrict__ hdr,
                                                  const Corner* __restrict__ cand_all, const Corner* __restrict__ cmax_all,
-                                                 Corner* __restrict__ surv_all, Counters* __restrict__ cnt, int radius, int dbg)
+                                                 Corner* __restrict__ surv_all, Counters* __restrict__ cnt, int radius, int dbg_arg)
 {
+    const int dbg = EFX_DBG(dbg_arg);
     __shared__ Corner s_hme[NMS_HCAP];
     __shared__ uint16_t s_hidx[NMS_HCAP];
     __shared__ uint16_t s_hneed[NMS_HCAP];                 // block_radius 1: the cells (bit q = cell q of the 3x3) that hold a rival
@@ -1552,14 +1555,14 @@ __global__ void copy2d_kernel(const uint8_t* __restrict__ src, size_t spitch, ui
 #endif
 static inline int tower_src_host(int o, float f, int n) { const int v = (int)floorf((float)o * f); return v > n - 1 ? n - 1 : v; }
 
-static bool plan_tower(const LevelTable& H, int last, const uint8_t* img0, int pitch0, TowerArgs* out, size_t* lds_out)
+static bool plan_tower(const LevelTable& H, int last, const uint8_t* img0, int pitch0, bool no_tower, TowerArgs* out, size_t* lds_out)
 {
     if (last < 2) return false;
     // Measured (MI355X, one stream, sync per call): the tower beats the launch chain when the WHOLE pyramid is small
     // (FHD 0.166 -> 0.147 ms, 4K 0.270 -> 0.259 ms per detectAndCompute); fusing only the upper levels of a large frame
     // (8K levels 4..7) does not pay: those levels are as large as a 4K pyramid and the tower recomputes ~1.7x the pixels.
     if ((long long)H.lv[0].rows * H.lv[0].cols > EFX_TOWER_MAX_PX) return false;
-    if (getenv("EFX_NO_TOWER")) return false;                 // tests: exercise the per-level kernels on small frames
+    if (no_tower) return false;                               // EFX_NO_TOWER (tests): exercise the per-level kernels on small frames
     for (int s0 = 0; s0 == 0; s0++) {
         const LevelDev& Lt = H.lv[last];
         const int tt = 32;
@@ -1618,7 +1621,7 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
     while (last + 1 < H.nlevels && H.lv[last + 1].rows > 0 && H.lv[last + 1].cols > 0 && H.lv[last].rows > 0 && H.lv[last].cols > 0) last++;
     TowerArgs tw;
     size_t tw_lds = 0;
-    const bool use_tower = plan_tower(H, last, a.img0, a.pitch0, &tw, &tw_lds);
+    const bool use_tower = plan_tower(H, last, a.img0, a.pitch0, a.knobs.no_tower != 0, &tw, &tw_lds);
     const int chain_end = use_tower ? tw.s0 : last;           // levels 1 .. chain_end by the per-level kernel
     // the counters are zeroed by the first pyramid kernel; a single-level "pyramid" has none: memset command
     bool zeroed = false;
@@ -1642,7 +1645,7 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
         if (lds > 64 * 1024) return hipErrorInvalidValue;
         const bool prof = a.prof.begin(100 + s, stream);
         const int ntiles = N.tiles_x * N.tiles_y;
-        const bool no_stream = getenv("EFX_NO_RESIZE_STREAM") != nullptr;     // tests: force the one-tile-per-workgroup kernel
+        const bool no_stream = a.knobs.no_resize_stream != 0;     // EFX_NO_RESIZE_STREAM (tests): force the one-tile-per-workgroup kernel
         if (aligned && sw <= 128 && sh <= 80 && !no_stream) {
             // streamed variant: a grid the chip holds at once (8 workgroups of 256 threads per CU), a multiple of the 8 XCDs
             static int s_slots = 0;
@@ -1674,16 +1677,16 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
         const int aligned0 = (((uintptr_t)a.img0 | (uintptr_t)a.pitch0) & 3u) == 0;
         bool prof = a.prof.begin(0, stream);
         hipLaunchKernelGGL(fast_kernel, dim3(H.total_tiles), dim3(256), 0, stream, a.d_table, a.img0, a.pitch0, aligned0,
-                           a.pyramid, a.threshold, a.mask, a.mask_pitch, a.cand, a.hdr, a.counters, a.dbg & 15);
+                           a.pyramid, a.threshold, a.mask, a.mask_pitch, a.cand, a.hdr, a.counters, a.knobs.dbg & 15);
         a.prof.end(prof, 0, stream);
         prof = a.prof.begin(1, stream);
         hipLaunchKernelGGL(harris_kernel, dim3(H.total_tiles + H.nlevels), dim3(64), 0, stream, a.d_table, a.img0, a.pitch0, aligned0, a.pyramid,
-                           a.cand, a.cmax, a.hdr, a.counters, a.dbg & 15);
+                           a.cand, a.cmax, a.hdr, a.counters, a.knobs.dbg & 15);
         a.prof.end(prof, 1, stream);
     }
     bool prof = a.prof.begin(2, stream);
     hipLaunchKernelGGL(nms_kernel, dim3(H.total_tiles), dim3(64), 0, stream, a.d_table, a.hdr, a.cand, a.cmax, a.surv,
-                       a.counters, a.nonmax_radius, a.dbg >> 4);
+                       a.counters, a.nonmax_radius, a.knobs.dbg >> 4);
     a.prof.end(prof, 2, stream);
     prof = a.prof.begin(3, stream);
     hipLaunchKernelGGL(select_kernel, dim3(H.nlevels), dim3(1024), 0, stream, a.d_table, a.hdr, a.surv, a.counters,

@@ -49,6 +49,7 @@ struct DevBuf {                     // grow-only device allocation
 };
 
 struct Describer {                  // cuda::BAD / cuda::HashSIFT state
+    int dbg_hs = 0;                 // EFX_DEBUG_HS, read when the describer is created (EFX_DEBUG_BUILD builds only)
     int kind = 0;                   // 0 BAD, 1 HashSIFT
     int nbits = 256;
     float scale = 1.f;              // BAD scaleFactor / HashSIFT croppingScale
@@ -84,6 +85,7 @@ int nbits_from_enum(int e) { return e == EFX_SIZE_512_BITS ? 512 : (e == EFX_SIZ
 int describer_init(Describer& d, int kind, int nbits, float scale)
 {
     d.kind = kind; d.nbits = nbits; d.scale = scale;
+    d.dbg_hs = efx_read_knobs().dbg_hs;
     if (kind == 0) {
         // BAD_Impl ctor, bad.cpp:300-317 / loadBoxPairParams, cuda_bad.cu:318-334 (per-instance here)
         const unsigned char* blob = nbits == 256 ? efx_blob_bad256 : efx_blob_bad512;
@@ -145,6 +147,7 @@ int describer_init(Describer& d, int kind, int nbits, float scale)
 int describer_run(Describer& d, std::string& err, DescribeLaunch a, float* dbg_resp, float* dbg_T, hipStream_t stream)
 {
     a.scale_factor = d.scale;
+    a.dbg_hs = d.dbg_hs;
     if (a.n <= 0) return EFX_OK;
     const bool prof = a.prof.begin(10, stream);
     struct ProfEnd { const ProfRec& p; bool on; hipStream_t st; ~ProfEnd() { p.end(on, 10, st); } } prof_end{a.prof, prof, stream};
@@ -171,6 +174,28 @@ int describer_run(Describer& d, std::string& err, DescribeLaunch a, float* dbg_r
     return EFX_OK;
 }
 
+} // namespace
+
+EfxKnobs efx_read_knobs()
+{
+    EfxKnobs k = { 0, 0, 0, 0 };
+    k.no_tower = getenv("EFX_NO_TOWER") != nullptr;
+    k.no_resize_stream = getenv("EFX_NO_RESIZE_STREAM") != nullptr;
+    const char* d = getenv("EFX_DEBUG");
+    const char* h = getenv("EFX_DEBUG_HS");
+#ifdef EFX_DEBUG_BUILD
+    k.dbg = d ? atoi(d) : 0;
+    k.dbg_hs = h ? atoi(h) : 0;
+    if (k.dbg || k.dbg_hs) fprintf(stderr, "efx: DEBUG BUILD with stage knobs EFX_DEBUG=%d EFX_DEBUG_HS=%d: results are NOT valid\n", k.dbg, k.dbg_hs);
+#else
+    static bool warned = false;
+    if ((d || h) && !warned) { warned = true; fprintf(stderr, "efx: EFX_DEBUG / EFX_DEBUG_HS ignored (library built without -DEFX_DEBUG_BUILD)\n"); }
+#endif
+    return k;
+}
+
+namespace {
+
 int cv_round_f(float v) { return (int)lrintf(v); }
 int cv_round_d(double v) { return (int)lrint(v); }
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -187,6 +212,7 @@ struct efx_matcher {
 
 struct efx_context {
     efx_params p;
+    EfxKnobs knobs = efx_read_knobs();   // investigation knobs, read once (efx_device.h)
     Describer desc;                 // describer_ (cuda_efficient_features.cpp:402), rebuilt by setDescriptorType
     std::string err;
 
@@ -196,6 +222,7 @@ struct efx_context {
     LevelTable h_table;
     DevBuf d_table, pyramid, hdr, cand, cmax, surv, counters, kp4, kp_level, img, kps, descout, count, maskbuf;
     Summary* h_mirror = nullptr;    // host copy of the last frame's summary, filled on demand by fetch_summary()
+    int n_out_max = 0;              // sum of the active levels' quotas
     bool has_frame = false;
     const uint8_t* last_img0 = nullptr; int last_pitch0 = 0;
     // per-launch timing of the pipeline's kernels (efx_profile_*)
@@ -291,9 +318,12 @@ int build_geometry(efx_context* c, int rows, int cols)
         }
     }
     T.total_tiles = tiles;
+    // upper bound of N: calcNumFeaturesPerLevel rounds every level up, so the quotas can sum to more than nfeatures
+    c->n_out_max = 0;
+    for (int s = 0; s < p.nlevels; s++) if (T.lv[s].active) c->n_out_max += T.lv[s].quota;
     if (rows > 32767 || cols > 32767) return set_err(c->err, EFX_ERR_UNSUPPORTED, "image larger than 32767 (short2 coordinates)");
 
-    // the level table is followed by one packed word per tile (level | tx << 4 | ty << 14): efx_tile_of()
+    // the level table is followed by one packed word per tile (efx_pack_tile / efx_tile_of)
     HIP_TRY(c->err, c->d_table.reserve(sizeof(LevelTable) + (size_t)(tiles + 1) * sizeof(uint32_t)));
     HIP_TRY(c->err, c->pyramid.reserve(pyr + 256));
     HIP_TRY(c->err, c->hdr.reserve((size_t)(tiles + 1) * sizeof(TileHdr)));
@@ -315,7 +345,7 @@ int build_geometry(efx_context* c, int rows, int cols)
         for (int s = 0; s < p.nlevels; s++) {
             const LevelDev& L = T.lv[s];
             for (int ty = 0; ty < L.tiles_y; ty++)
-                for (int tx = 0; tx < L.tiles_x; tx++) info[L.tile_base + ty * L.tiles_x + tx] = (uint32_t)s | ((uint32_t)tx << 4) | ((uint32_t)ty << 14);
+                for (int tx = 0; tx < L.tiles_x; tx++) info[L.tile_base + ty * L.tiles_x + tx] = efx_pack_tile((uint32_t)s, (uint32_t)tx, (uint32_t)ty);
         }
         HIP_TRY(c->err, hipMemcpy(c->d_table.p, blob.data(), blob.size(), hipMemcpyHostToDevice));
     }
@@ -355,7 +385,7 @@ int detect_common(efx_context* c, const uint8_t* d_image, int rows, int cols, si
     a.threshold = c->p.fast_threshold;
     a.nonmax_radius = c->p.nonmax_radius;
     a.first_level = c->p.first_level;
-    { const char* e = getenv("EFX_DEBUG"); a.dbg = e ? atoi(e) : 0; }
+    a.knobs = c->knobs;
     a.mask = d_mask; a.mask_pitch = (int)mask_pitch;
     a.d_keypoints = d_keypoints; a.kps_pitch = kps_pitch; a.capacity = capacity;
     a.d_count = d_count ? d_count : static_cast<int*>(c->count.p);
@@ -376,7 +406,7 @@ int detect_common(efx_context* c, const uint8_t* d_image, int rows, int cols, si
         dl.img0 = d_image; dl.pitch0 = (int)pitch; dl.rows0 = rows; dl.cols0 = cols;
         dl.pyramid = a.pyramid; dl.d_table = a.d_table;
         dl.kp4 = a.kp4; dl.kp_level = a.kp_level; dl.d_count = a.d_count;
-        dl.n = capacity < c->p.nfeatures ? capacity : c->p.nfeatures;
+        dl.n = capacity < c->n_out_max ? capacity : c->n_out_max;     // the bound angle_kernel uses: sum of the active quotas
         dl.blur = 1;
         dl.max_size = (float)EFX_PATCH_SIZE;
         dl.uniform_size = 1;
@@ -410,6 +440,7 @@ int compute_provided(efx_context* c, const uint8_t* d_image, int rows, int cols,
     a.d_table = static_cast<const LevelTable*>(c->d_table.p);
     a.h_table = &c->h_table;
     a.counters = static_cast<Counters*>(c->counters.p);
+    a.knobs = c->knobs;
     a.pyramid_only = 1;
     hipError_t e = efx_launch_detect(a, stream);
     if (e == hipSuccess)
@@ -667,7 +698,6 @@ int efx_last_level_stats(const efx_context* ctx, efx_level_stats* stats, int max
         stats[i].n_candidates = ctx->h_mirror->cand[i];
         stats[i].n_after_nms = ctx->h_mirror->surv[i];
         stats[i].n_kept = ctx->h_mirror->kept[i];
-        if (i == 0 && ctx->h_mirror->dbg) stats[i].n_kept = ctx->h_mirror->dbg;   // EFX_DEBUG=96 probe
     }
     if (nlevels) *nlevels = nl;
     return EFX_OK;
@@ -924,7 +954,15 @@ struct efx_uploader {
     void* staging[NCHUNK] = {};
     bool chunk_busy[NCHUNK] = {};
     bool slot_used[NSLOT] = {};
+    bool slot_released[NSLOT] = {};         // consumed[] was recorded explicitly (efx_uploader_release)
+    hipStream_t slot_stream[NSLOT] = {};    // the consumer stream the slot's frame was handed to
     unsigned long long frame = 0;
+    int slot_of(const uint8_t* d) const
+    {
+        for (int i = 0; i < NSLOT; i++)
+            if (slot_used[i] && d && (d == raw[i].p || d == gray[i].p)) return i;
+        return -1;
+    }
     std::string err;
     ~efx_uploader()
     {
@@ -975,10 +1013,13 @@ int efx_upload_gray_async(efx_uploader* u, const uint8_t* h_image, int rows, int
     hipStream_t stream = (hipStream_t)stream_;
     const int slot = (int)(u->frame % efx_uploader::NSLOT);
     const int prev = (int)((u->frame + efx_uploader::NSLOT - 1) % efx_uploader::NSLOT);
-    // everything enqueued on `stream` so far includes the consumers of the previous frame (slot `prev`)
-    if (u->frame > 0) HIP_TRY(u->err, hipEventRecord(u->consumed[prev], stream));
-    // this slot was last used by frame - NSLOT, whose consumers were covered by the event recorded one call ago
+    // Implicit contract: the consumers of the previous frame (slot `prev`) were enqueued on the stream THAT frame was handed
+    // to, before this call.  A caller that enqueues them later, or elsewhere, says so with efx_uploader_release().
+    if (u->frame > 0 && !u->slot_released[prev]) HIP_TRY(u->err, hipEventRecord(u->consumed[prev], u->slot_stream[prev]));
+    // this slot was last used by frame - NSLOT: its consumed event was recorded one call ago or by efx_uploader_release
     if (u->slot_used[slot]) HIP_TRY(u->err, hipStreamWaitEvent(u->copy, u->consumed[slot], 0));
+    u->slot_released[slot] = false;
+    u->slot_stream[slot] = stream;
     const size_t row_bytes = (size_t)cols * channels;
     const size_t dpitch = align_up(row_bytes, 256);
     HIP_TRY(u->err, u->raw[slot].reserve(dpitch * rows));
@@ -1018,6 +1059,25 @@ int efx_upload_gray_async(efx_uploader* u, const uint8_t* h_image, int rows, int
                                        static_cast<uint8_t*>(u->gray[slot].p), gpitch, stream);
     if (e != hipSuccess) return set_err(u->err, EFX_ERR_HIP, "cvt_gray launch failed: %s", hipGetErrorString(e));
     *d_gray = static_cast<const uint8_t*>(u->gray[slot].p); *gray_pitch = gpitch;
+    return EFX_OK;
+}
+
+int efx_uploader_release(efx_uploader* u, const uint8_t* d_gray, void* stream)
+{
+    if (!u) return EFX_ERR_BAD_ARG;
+    const int slot = u->slot_of(d_gray);
+    if (slot < 0) return set_err(u->err, EFX_ERR_BAD_ARG, "not a frame of this uploader (or already recycled)");
+    HIP_TRY(u->err, hipEventRecord(u->consumed[slot], (hipStream_t)stream));
+    u->slot_released[slot] = true;
+    return EFX_OK;
+}
+
+int efx_uploader_wait_uploaded(efx_uploader* u, const uint8_t* d_gray)
+{
+    if (!u) return EFX_ERR_BAD_ARG;
+    const int slot = u->slot_of(d_gray);
+    if (slot < 0) return set_err(u->err, EFX_ERR_BAD_ARG, "not a frame of this uploader (or already recycled)");
+    HIP_TRY(u->err, hipEventSynchronize(u->uploaded[slot]));
     return EFX_OK;
 }
 

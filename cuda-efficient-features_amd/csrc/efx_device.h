@@ -77,6 +77,15 @@ struct Counters {               // zeroed at the start of every frame
     Summary sum;
 };
 
+// One packed word per tile behind the level table: level | tx << 5 | ty << 15.  The level field must hold EFX_MAX_LEVELS
+// values; tx, ty < 32768 / 64 = 512 (images are at most 32767 px per side).
+#define EFX_TILE_LEVEL_BITS 5
+static_assert((1 << EFX_TILE_LEVEL_BITS) >= EFX_MAX_LEVELS, "tile word: level field too narrow for EFX_MAX_LEVELS");
+__host__ __device__ inline uint32_t efx_pack_tile(uint32_t level, uint32_t tx, uint32_t ty)
+{
+    return level | (tx << EFX_TILE_LEVEL_BITS) | (ty << (EFX_TILE_LEVEL_BITS + 10));
+}
+
 // one FAST corner / survivor
 struct __attribute__((aligned(8))) Corner {
     uint32_t xy;       // x | y << 16, level coordinates
@@ -118,6 +127,18 @@ __device__ __forceinline__ int efx_wave_incl_scan(int v)
     return v;
 }
 #endif
+
+// Investigation knobs.  The stage knobs (EFX_DEBUG, EFX_DEBUG_HS: kernels stop early / skip stages, i.e. WRONG results)
+// exist only in builds made with -DEFX_DEBUG_BUILD (make EXTRA=-DEFX_DEBUG_BUILD); a production build ignores the
+// variables and the kernels carry no trace of them.  The variant knobs (EFX_NO_TOWER, EFX_NO_RESIZE_STREAM: pick another,
+// bit-identical pyramid kernel; used by the parity tests) are read ONCE, when a context is created.
+#ifdef EFX_DEBUG_BUILD
+#define EFX_DBG(v) (v)
+#else
+#define EFX_DBG(v) 0
+#endif
+struct EfxKnobs { int dbg, dbg_hs, no_tower, no_resize_stream; };
+EfxKnobs efx_read_knobs();      // efx_api.cpp
 
 // ---- launchers (host side, defined in the .hip files) ----
 #ifdef __HIPCC__
@@ -182,7 +203,7 @@ struct DetectLaunch {
     int threshold;
     int nonmax_radius;
     int first_level;
-    int dbg;                    // EFX_DEBUG stage knob (investigation only, 0 in production)
+    EfxKnobs knobs;             // read at context creation (dbg: EFX_DEBUG_BUILD builds only)
     const uint8_t* mask; int mask_pitch;   // optional level-0 mask (spec S12), null = none
     int pyramid_only;           // 1: build the pyramid and stop (detectAndCompute with provided keypoints)
     // outputs
@@ -205,6 +226,7 @@ struct DescribeLaunch {
     int uniform_size;                                      // 1: every keypoint has size == max_size (detector output)
     uint8_t* desc; size_t desc_pitch;
     void* bad_affine;                                      // BAD scratch: n x 48 bytes (per-keypoint affine map + window geometry)
+    int dbg_hs;                                            // EFX_DEBUG_HS (EFX_DEBUG_BUILD builds only)
     ProfRec prof;
 };
 

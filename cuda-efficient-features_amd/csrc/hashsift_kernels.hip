@@ -46,8 +46,9 @@ __global__ __launch_bounds__(HS_NT) void patch_sift_kernel(
     const float4* __restrict__ kp4, const int* __restrict__ kp_level, const int* __restrict__ d_count, int n,
     float crop_scale, int smax, const float* __restrict__ mag_scale /*30*30*/, const float* __restrict__ obin_lut /*511*511*/,
     float taps0, float taps1, float taps2, float taps3,
-    float* __restrict__ responses /* n x HS_KPAD */, float* __restrict__ dbg_responses /* n x 129 or null */, int dbg)
+    float* __restrict__ responses /* n x HS_KPAD */, float* __restrict__ dbg_responses /* n x 129 or null */, int dbg_arg)
 {
+    const int dbg = EFX_DBG(dbg_arg);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ AffineF s_aff;
     __shared__ uint8_t s_patch[32 * 32];
@@ -359,8 +360,7 @@ hipError_t efx_launch_hashsift(const DescribeLaunch& a, const HashSiftDev& h, hi
     }
     float t[7];
     efx_gaussian_taps_host(t);
-    const char* dbge = getenv("EFX_DEBUG_HS");
-    const int dbg = dbge ? atoi(dbge) : 0;
+    const int dbg = a.dbg_hs;
     const float* mag = h.W + (size_t)h.nbits * HS_KPAD;    // the 30x30 weight table is stored behind W
     const float* lut = mag + 900;                          // followed by the 511x511 orientation-bin table
     if (a.blur && S == 48 && a.uniform_size) {

@@ -272,6 +272,14 @@ int efx_uploader_destroy(efx_uploader* u);
 const char* efx_uploader_last_error(const efx_uploader* u);
 int efx_upload_gray_async(efx_uploader* u, const uint8_t* h_image, int rows, int cols, size_t pitch, int channels,
                           const uint8_t** d_gray, size_t* gray_pitch, void* stream);
+/* Slot reuse contract.  By default the uploader assumes that everything that reads frame k was enqueued on the `stream`
+ * frame k was uploaded for, BEFORE efx_upload_gray_async is called for frame k+1.  A caller that pipelines differently
+ * (uploads ahead, or consumes on another stream) calls efx_uploader_release(u, d_gray_k, s) after enqueuing the last
+ * reader of frame k on stream s: the slot is then recycled only behind that point.
+ * efx_uploader_wait_uploaded blocks the host until frame d_gray's host-to-device copy has completed, i.e. until the
+ * caller may overwrite the (page-locked) host buffer it came from. */
+int efx_uploader_release(efx_uploader* u, const uint8_t* d_gray, void* stream);
+int efx_uploader_wait_uploaded(efx_uploader* u, const uint8_t* d_gray);
 
 /* EfficientDescriptors::compute with a colour host image (bad.cpp:268-281 accepts 8UC1 / 8UC3 / 8UC4). */
 int efx_describer_compute_color(efx_describer* d, const uint8_t* h_image, int rows, int cols, size_t pitch, int channels,

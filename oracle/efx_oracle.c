@@ -553,6 +553,8 @@ static int has_arc9(unsigned m)
     return (d & 0xffffu) != 0;
 }
 
+int efxo_has_arc9(unsigned mask16) { return has_arc9(mask16 & 0xffffu); }
+
 int efxo_fast9_at(const uint8_t* img, int stride, int x, int y, int threshold)
 {
     /* diffType, cuda_fast.cu:36-40: strict comparisons */
@@ -648,10 +650,14 @@ float efxo_atan2_deg(int m01, int m10)
     return (float)(a * (180.0 / PI));
 }
 
+/* U_MAX of IC_Angle, cuda_efficient_features.cu:143 (pinned against the reference's text by tests/test_reference_table_pins.py) */
+static const int IC_U_MAX[17] = { 15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3, 0 };
+void efxo_ic_umax(int* out17) { for (int i = 0; i < 17; i++) out17[i] = IC_U_MAX[i]; }
+
 float efxo_ic_angle(const uint8_t* img, int stride, int x, int y)
 {
     /* IC_Angle, cuda_efficient_features.cu:141-172 */
-    static const int U_MAX[] = { 15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3, 0 };
+    const int* U_MAX = IC_U_MAX;
     int m01 = 0, m10 = 0;
     const uint8_t* c = img + (size_t)y * stride + x;
     for (int dx = -EFXO_HALF_PATCH; dx <= EFXO_HALF_PATCH; dx++) m10 += dx * c[dx];

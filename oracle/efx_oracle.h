@@ -83,6 +83,10 @@ void efxo_gaussian7(const uint8_t* src, int rows, int cols, int sstride, uint8_t
 
 /* FAST-9/16 segment test at one pixel (cuda_fast.cu:33-222); 1 if corner. Needs a 3-px margin. */
 int efxo_fast9_at(const uint8_t* img, int stride, int x, int y, int threshold);
+/* the 9-arc predicate the FAST test applies to a 16-bit ring mask (== the reference's c_table lookup, cuda_fast.cu:160-166) */
+int efxo_has_arc9(unsigned mask16);
+/* the U_MAX row table efxo_ic_angle walks (cuda_efficient_features.cu:143), 17 ints */
+void efxo_ic_umax(int* out17);
 
 /* All FAST corners inside [border, cols-border) x [border, rows-border) in raster order
  * (cuda_fast.cu:168-222 + mask cuda_efficient_features.cpp:176-182). xy: pairs (x,y).

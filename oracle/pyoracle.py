@@ -140,6 +140,16 @@ def set_threads(n):
     return prev
 
 
+def has_arc9(mask16):
+    return int(lib().efxo_has_arc9(C.c_uint(int(mask16))))
+
+
+def ic_umax():
+    u = (C.c_int * 17)()
+    lib().efxo_ic_umax(u)
+    return list(u)
+
+
 def calc_umax(patch_size):
     u = (C.c_int * (patch_size // 2 + 2))()
     lib().efxo_calc_umax(int(patch_size), u)

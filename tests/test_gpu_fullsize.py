@@ -1,0 +1,144 @@
+"""Full-size parity for the BASELINE.json configurations C2-C5, HIP path through the C ABI against
+the oracle on the same frames bench.py / tools/bench_configs.py time.  The reference's own test is full-image too
+(tests/descriptor_test.cpp:19-75).  The oracle runs multi-threaded here (identical output:
+tests/test_oracle_detector.py::test_thread_count_does_not_change_results); an 8K frame costs ~1 s on the GPU box's host."""
+import os
+
+import numpy as np
+import pytest
+
+from tools import workloads
+
+pytestmark = pytest.mark.gpu
+
+HS_T_ABS_TOL = 2e-3      # same tolerances as tests/test_gpu_parity.py::test_hashsift_compute_tolerance
+HS_VEC_FRAC = 1e-4
+HS_VEC_MAX = 4.0
+
+
+@pytest.fixture(scope="module")
+def cef():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import cef_loader
+    return cef_loader.load()
+
+
+@pytest.fixture(scope="module")
+def threaded_oracle(oracle):
+    prev = oracle.set_threads(max(1, min(os.cpu_count() or 1, 64)))
+    yield oracle
+    oracle.set_threads(prev)
+
+
+def _dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _same_keypoints(kps, n, ref):
+    assert n == ref["n"]
+    g, r = kps[:, :n].cpu().numpy().view(np.uint32), ref["kps"].view(np.uint32)
+    for row, name in enumerate(["location", "response", "angle", "octave", "size"]):
+        assert np.array_equal(g[row], r[row]), f"{name} row differs at {np.flatnonzero(g[row] != r[row])[:5]}"
+
+
+def test_c2_4k_detect_only(cef, threaded_oracle):
+    """C2: single 4K frame, detect-only (pyramid + FAST-9 + Harris + radius NMS + quota + IC angle), reference defaults."""
+    import torch
+    img = workloads.frame_c2()
+    det = cef.EfficientFeatures.create(workloads.N40K, dtype=cef.EfficientFeatures.BAD_256)
+    kps, cnt = det.detectAsync(_dev(img))
+    torch.cuda.synchronize()
+    ref = threaded_oracle.detect_and_compute(img, nfeatures=workloads.N40K, desc_type=-1)
+    _same_keypoints(kps, int(cnt.item()), ref)
+    st = det.lastLevelStats()
+    for l in range(8):
+        assert st[l]["n_candidates"] == ref["stats"]["n_candidates"][l]
+        assert st[l]["n_after_nms"] == ref["stats"]["n_after_nms"][l]
+
+
+@pytest.fixture(scope="module")
+def c34(cef, threaded_oracle):
+    """The C3 / C4 workload: 4K frame + EXACTLY 40 000 detector keypoints (tools/workloads.py explains the NMS radius)."""
+    import torch
+    img = workloads.frame_c34()
+    d_img = _dev(img)
+    det = cef.EfficientFeatures.create(workloads.N40K, 1.2, 8, 0, 20, workloads.C34_NMS_RADIUS, cef.EfficientFeatures.BAD_256)
+    kps, cnt = det.detectAsync(d_img)
+    torch.cuda.synchronize()
+    n = int(cnt.item())
+    ref = threaded_oracle.detect_and_compute(img, nfeatures=workloads.N40K, nonmax_radius=workloads.C34_NMS_RADIUS, desc_type=-1)
+    _same_keypoints(kps, n, ref)
+    assert n == workloads.N40K, "the compute-only configurations are quoted on 40 000 keypoints"
+    k = cef.unpack_keypoints(kps[:, :n].cpu().numpy())
+    kp4 = np.stack([k["x"].astype(np.float32), k["y"].astype(np.float32), np.full(n, 31, np.float32), k["angle"]], axis=1)
+    return dict(img=img, d_img=d_img, kps=kps, n=n, kp4=kp4)
+
+
+@pytest.mark.parametrize("nbits", [256, 512])
+def test_c3_4k_40k_compute_bad(cef, threaded_oracle, c34, nbits):
+    """C3: compute-only BAD256 / BAD512 on the 40 000 keypoints of a 4K frame (compute() semantics: the full-resolution
+    image, size forced to 31, no blur; cuda_efficient_features.cpp:102-115, sample_benchmark.cpp:132-141).  Bit-exact."""
+    import torch
+    det = cef.EfficientFeatures.create(workloads.N40K, dtype=cef.EfficientFeatures.BAD_256 if nbits == 256 else cef.EfficientFeatures.BAD_512)
+    desc = det.computeAsync(c34["d_img"], c34["kps"], n=c34["n"])
+    torch.cuda.synchronize()
+    want = threaded_oracle.bad_compute(c34["img"], c34["kp4"], nbits)
+    got = desc.cpu().numpy()
+    assert got.shape == (workloads.N40K, nbits // 8)
+    assert np.array_equal(got, want), f"{np.count_nonzero((got != want).any(axis=1))} of 40000 descriptors differ"
+
+
+def test_c4_4k_40k_compute_hashsift512(cef, threaded_oracle, c34):
+    """C4: compute-only HashSIFT512 (MFMA projection) on the same 40 000 keypoints; the tolerances of
+    test_hashsift_compute_tolerance, at full size."""
+    import torch
+    det = cef.EfficientFeatures.create(workloads.N40K, dtype=cef.EfficientFeatures.HASH_SIFT_512)
+    desc = det.computeAsync(c34["d_img"], c34["kps"], n=c34["n"]).cpu().numpy()
+    hs = cef.HashSIFT.create(1.0, cef.HashSIFT.SIZE_512_BITS)
+    resp, T = hs.debug(c34["d_img"], _dev(c34["kp4"]), max_size=31.0)
+    torch.cuda.synchronize()
+    resp, T = resp.cpu().numpy(), T.cpu().numpy()
+    want_resp = threaded_oracle.hashsift_responses(c34["img"], c34["kp4"])
+    want_T, want_desc = threaded_oracle.hashsift_project(want_resp, 512)
+    d = np.abs(resp - want_resp)
+    assert d.max() <= HS_VEC_MAX and (d > 0).mean() <= HS_VEC_FRAC
+    same = (d == 0).all(axis=1)
+    assert np.abs(T[same] - want_T[same]).max() <= HS_T_ABS_TOL
+    bits = np.unpackbits(desc, axis=1).astype(bool)
+    wbits = np.unpackbits(want_desc, axis=1).astype(bool)
+    decided = np.abs(want_T) > HS_T_ABS_TOL
+    assert np.array_equal(bits[same][decided[same]], wbits[same][decided[same]])
+    assert np.count_nonzero(desc != want_desc) <= max(1, int(1e-4 * desc.size))     # descriptor_test.cpp:72
+    assert np.array_equal(bits, T > 0)
+
+
+@pytest.mark.parametrize("k", [0, 1, 5])
+def test_c5_8k_detect_and_compute_bad512(cef, threaded_oracle, k):
+    """C5: 8K frames of the headline batch (seeds 1000 + k), detectAndCompute BAD512, 40 000 keypoints: every keypoint
+    row and every descriptor byte equal the oracle's."""
+    import torch
+    img = workloads.frame_c5(k)
+    det = cef.EfficientFeatures.create(workloads.N40K, dtype=cef.EfficientFeatures.BAD_512)
+    kps, desc, cnt = det.detectAndComputeAsync(_dev(img))
+    torch.cuda.synchronize()
+    n = int(cnt.item())
+    ref = threaded_oracle.detect_and_compute(img, nfeatures=workloads.N40K, desc_type=threaded_oracle.BAD_512)
+    _same_keypoints(kps, n, ref)
+    assert n == workloads.N40K
+    assert np.array_equal(desc[:n].cpu().numpy(), ref["desc"])
+
+
+def test_c5_8k_detect_and_compute_hashsift512(cef, threaded_oracle):
+    import torch
+    img = workloads.frame_c5(2)
+    det = cef.EfficientFeatures.create(workloads.N40K, dtype=cef.EfficientFeatures.HASH_SIFT_512)
+    kps, desc, cnt = det.detectAndComputeAsync(_dev(img))
+    torch.cuda.synchronize()
+    n = int(cnt.item())
+    ref = threaded_oracle.detect_and_compute(img, nfeatures=workloads.N40K, desc_type=threaded_oracle.HASH_SIFT_512)
+    _same_keypoints(kps, n, ref)
+    got = desc[:n].cpu().numpy()
+    assert np.count_nonzero(got != ref["desc"]) <= max(1, int(1e-4 * got.size))       # descriptor_test.cpp:72

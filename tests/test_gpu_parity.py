@@ -567,3 +567,50 @@ def test_pyramid_kernel_variants_bit_exact(cef, torch_mod, oracle, monkeypatch, 
         assert np.array_equal(got, want), f"{mode} level {level}: {np.count_nonzero(got != want)} pixels differ"
     ref = oracle.detect_and_compute(img, desc_type=-1, nfeatures=1000, scale_factor=scale)
     assert det.lastCount() == ref["n"]
+
+
+@pytest.mark.parametrize("nlevels,scale", [(17, 1.05), (20, 1.05), (26, 1.04), (32, 1.03)])
+def test_more_than_16_levels(cef, torch_mod, oracle, nlevels, scale):
+    """nlevels up to EFX_MAX_LEVELS = 32 is accepted (validate_params), so the packed per-tile word must carry 5 level
+    bits: with 4, tiles of level >= 16 were decoded as level - 16 (efx_api.cpp tile info word)."""
+    img = synth.synth_frame(480, 640, seed=77)
+    got, ref = _detect_both(cef, torch_mod, oracle, img, desc_type=1, nfeatures=3000, nlevels=nlevels, scale_factor=scale)
+    _assert_same_keypoints(got, ref)
+    assert np.array_equal(got["desc"], ref["desc"])
+    assert sum(ref["stats"]["n_kept"][16:]) > 0          # the upper levels really contribute keypoints
+
+
+@pytest.mark.parametrize("desc_type", [0, 1, 3])
+def test_quota_sum_exceeds_nfeatures(cef, torch_mod, oracle, desc_type):
+    """calcNumFeaturesPerLevel (.cpp:159-174) rounds every level's quota up, so the detector can emit more than nfeatures
+    keypoints (nfeatures 3, 5 levels, scale 1.01: quotas 1,1,1,1,0).  Every emitted keypoint must be described, as in the
+    reference (the describe launch was bounded by nfeatures)."""
+    img = synth.synth_frame(300, 400, seed=5)
+    det = cef.EfficientFeatures.create(3, 1.01, 5, 0, 20, 15, desc_type)
+    d_img = _dev(torch_mod, img)
+    cap = 16
+    nbytes = det.descriptorSize()
+    kps = torch_mod.zeros((5, cap), dtype=torch_mod.float32, device="cuda")
+    desc = torch_mod.full((cap, nbytes), 0xEE, dtype=torch_mod.uint8, device="cuda")
+    _, _, cnt = det.detectAndComputeAsync(d_img, kps, desc, capacity=cap)
+    torch_mod.cuda.synchronize()
+    n = int(cnt.item())
+    ref = oracle.detect_and_compute(img, nfeatures=3, scale_factor=1.01, nlevels=5, desc_type=desc_type, capacity=cap)
+    assert n == ref["n"] == 4
+    assert np.array_equal(kps[:, :n].cpu().numpy().view(np.uint32), ref["kps"].view(np.uint32))
+    if desc_type < 2:
+        assert np.array_equal(desc[:n].cpu().numpy(), ref["desc"])
+    else:
+        assert np.mean(desc[:n].cpu().numpy() != ref["desc"]) <= 0.05 and not np.all(desc[3].cpu().numpy() == 0xEE)
+
+
+def test_detect_and_compute_without_descriptors(cef, torch_mod, oracle):
+    """detectAndComputeAsync(want_descriptors=False) is the detect-only mode of that entry point."""
+    img = synth.synth_frame(240, 320, seed=9)
+    det = cef.EfficientFeatures.create(500, dtype=cef.EfficientFeatures.BAD_256)
+    kps, desc, cnt = det.detectAndComputeAsync(_dev(torch_mod, img), want_descriptors=False)
+    torch_mod.cuda.synchronize()
+    ref = oracle.detect_and_compute(img, nfeatures=500, desc_type=-1)
+    n = int(cnt.item())
+    assert desc is None and n == ref["n"]
+    assert np.array_equal(kps[:, :n].cpu().numpy().view(np.uint32), ref["kps"].view(np.uint32))
