@@ -25,12 +25,16 @@ struct __attribute__((aligned(16))) Affine {
     int wx0, wy0, S;            // window [wx0, wx0 + S) x [wy0, wy0 + S); S == 0: the keypoint does not fit (zero descriptor)
     int border;                 // isKeypointInTheBorder (bad.cpp:86-103)
     int level;                  // pyramid level of the keypoint (0 in single-image mode)
+    // the level's image, so that the describing workgroup needs ONE dependent load (this record) before its window loads
+    const uint8_t* img; int pitch, rows, cols, pad;
 };
+static_assert(sizeof(Affine) == 80, "Affine is 80 bytes (DescribeLaunch::bad_affine scratch)");
 
 // rectifyBoxes, bad.cpp:115-147: the patch -> image affine map of every keypoint, one lane per keypoint (the double
 // cos/sin of bad.cpp:138-139 is ~400 instructions: far too long to run on one lane of a per-keypoint workgroup)
 __global__ __launch_bounds__(256) void bad_affine_kernel(const float4* __restrict__ kp4, const int* __restrict__ kp_level,
-                                                         const LevelTable* __restrict__ T, int rows0, int cols0,
+                                                         const LevelTable* __restrict__ T, const uint8_t* __restrict__ img0, int pitch0,
+                                                         const uint8_t* __restrict__ pyramid, int rows0, int cols0,
                                                          const int* __restrict__ d_count, int n,
                                                          float scale_factor, float reach, int smax, int sfixed, Affine* __restrict__ aff)
 {
@@ -54,8 +58,12 @@ __global__ __launch_bounds__(256) void bad_affine_kernel(const float4* __restric
     }
     A.s = s;
     int rows = rows0, cols = cols0, l = 0;
-    if (kp_level) { l = kp_level[i]; rows = T->lv[l].rows; cols = T->lv[l].cols; }
-    A.level = l;
+    A.img = img0; A.pitch = pitch0; A.pad = 0;
+    if (kp_level) {
+        l = kp_level[i]; rows = T->lv[l].rows; cols = T->lv[l].cols;
+        if (l > 0) { A.img = pyramid + T->lv[l].img_off; A.pitch = T->lv[l].pitch; }
+    }
+    A.level = l; A.rows = rows; A.cols = cols;
     // window geometry: every (clamped) box coordinate of this keypoint lies in [wx0, wx0+S] x [wy0, wy0+S]
     const float sg = scale_factor * size / 32.f;
     // R >= |sg| * reach + 1 covers every box: a centre rounds to within 0.5 of its exact position, a radius grows by at
@@ -154,7 +162,7 @@ __global__ __launch_bounds__(256) void bad_kernel(
     }
     __syncthreads();
 
-    const bool border = A.border != 0;
+    const bool border = (A.border & 1) != 0;
     const int fw = cols + 1, fh = rows + 1;       // integral image dims of the full frame
 
     for (int b0 = 0; b0 < nbits; b0 += 256) {
@@ -220,6 +228,159 @@ __global__ __launch_bounds__(256) void bad_kernel(
     }
 }
 
+// ================================================================================================
+// The detector's keypoints (detectAndCompute: size 31, scale 1 -> 48 x 48 window, blurred level): the same arithmetic
+// as bad_kernel<true, 48>, with everything that does not depend on the keypoint taken out of the workgroup and the LDS
+// traffic trimmed (the kernel is bound by the LDS pipe in its integral and box phases, by VALU issue in the blur:
+// profiles/r02_bad_phases.txt):
+//   * the box pairs come from BadParamsDev::ubox (scaled radius, integral strides and thr * side^2 precomputed on the
+//     host with bad.cpp's float expressions), the two boxes of a pair go through the affine map as ONE packed-fp32
+//     sequence (v_pk_mul_f32 / v_pk_add_f32: the same IEEE operations, two per instruction);
+//   * the level's image pointer / pitch / size ride in the Affine record (one dependent load before the window loads);
+//   * the blur's column pass writes a u8 plane (2 pixels per ds_write_b16 instead of two ds_write_b32); the integral's
+//     row pass reads a row as three conflict-free ds_read_b128 and unpacks with SDWA adds; I aliases the dead hb;
+//   * a wave packs its 64 bits with two scalar bit reversals and one 8-byte store.
+// Measured and dropped: blur item lists limited to the disc the boxes can reach (71 % of the pixels, but the 3-row apron
+// leaves 195 of 216 row-pass items: no wave is saved and the compacted order costs bank conflicts).
+// ================================================================================================
+__global__ __launch_bounds__(256) void bad_det_kernel(
+    const int* __restrict__ d_count, int n, const BadParamsDev* __restrict__ P, const Affine* __restrict__ aff,
+    float taps0, float taps1, float taps2, float taps3, uint8_t* __restrict__ desc, size_t desc_pitch)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int S = 48, IP = S + 1;
+    constexpr int PIX_OFF = 3248, HB_OFF = PIX_OFF + S * S;      // raw [0, 3248) | pix [3248, 5552) | hb / I [5552, ...)
+    static_assert(HB_OFF % 16 == 0 && PIX_OFF % 16 == 0, "LDS regions are 16-byte aligned");
+
+    const int tid = threadIdx.x;
+    const int count = d_count ? min(*d_count, n) : n;
+    if ((int)blockIdx.x >= count) return;
+    const int kid = xcd_chunked(blockIdx.x, count);
+    const int lane = tid & 63;
+
+    const uint4 q0 = P->ubox[tid], q1 = P->ubox[256 + tid];     // requested first: they do not depend on the keypoint
+    const Affine A = aff[kid];                                   // uniform address: scalar loads
+    const uint8_t* img = A.img; const int pitch = A.pitch, rows = A.rows, cols = A.cols;
+    const int nbits = P->nbits;
+    const bool fits = A.S != 0;
+    const int wx0 = A.wx0, wy0 = A.wy0;
+
+    uint8_t* raw = smem;
+    uint8_t* pix = smem + PIX_OFF;
+    float* hb = reinterpret_cast<float*>(smem + HB_OFF);
+    int* I = reinterpret_cast<int*>(smem + HB_OFF);              // (S+1) x (S+1), aliases hb (dead after the column pass)
+
+    if (fits) {
+        const bool inside = wx0 + S <= cols && wy0 + S <= rows;  // frames smaller than the window: zero beyond the frame
+        efx_blur_window_lds<256>(img, pitch, rows, cols, wx0, wy0, S, raw, hb, taps0, taps1, taps2, taps3, tid,
+            [&](int r, int c, int p0, int p1) {
+                if (!inside) {
+                    const bool rin = (wy0 + r) < rows;
+                    p0 = (rin && (wx0 + c) < cols) ? p0 : 0;
+                    p1 = (rin && (wx0 + c + 1) < cols) ? p1 : 0;
+                }
+                *reinterpret_cast<uint16_t*>(pix + r * S + c) = (uint16_t)(p0 | (p1 << 8));
+            });
+        __syncthreads();
+        // window-local integral: row prefix from the u8 plane (wave 0; the zero border is written by wave 1), then column prefix
+        if (tid < S) {
+            const uint4* row = reinterpret_cast<const uint4*>(pix + tid * S);
+            const uint4 w0 = row[0], w1 = row[1], w2 = row[2];
+            const uint32_t w[12] = { w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w };
+            int* p = I + (tid + 1) * IP + 1;
+            int run = 0;
+#pragma unroll
+            for (int c = 0; c < S; c++) { run += (int)((w[c >> 2] >> (8 * (c & 3))) & 0xffu); p[c] = run; }
+        } else if (tid >= 64 && tid < 64 + IP) {
+            I[tid - 64] = 0; I[(tid - 64) * IP] = 0;
+        }
+        __syncthreads();
+        if (tid < S) {
+            int* p = I + IP + 1 + tid;
+            int run = 0;
+#pragma unroll
+            for (int r = 0; r < S; r++) { run += p[r * IP]; p[r * IP] = run; }
+        }
+    }
+    __syncthreads();
+
+    const bool border = (A.border & 1) != 0;
+    const int fw = cols + 1, fh = rows + 1;       // integral image dims of the full frame
+    const bool wide_store = ((((uintptr_t)desc) | desc_pitch) & 7u) == 0;
+    const int wbase = -(wy0 * IP + wx0) * 4;
+
+    for (int b0 = 0; b0 < nbits; b0 += 256) {
+        const int b = b0 + tid;
+        bool bit = false;
+        if (fits) {
+            if (border) {
+                const uint2 bq = P->box[b];
+                const float x1f = (float)(bq.x & 31u), x2f = (float)((bq.x >> 5) & 31u);
+                const float y1f = (float)((bq.x >> 10) & 31u), y2f = (float)((bq.x >> 15) & 31u);
+                const int cx1 = (int)((A.m00 * x1f + A.m01 * y1f + A.m02) + 0.5f);
+                const int cy1 = (int)((A.m10 * x1f + A.m11 * y1f + A.m12) + 0.5f);
+                const int cx2 = (int)((A.m00 * x2f + A.m01 * y2f + A.m02) + 0.5f);
+                const int cy2 = (int)((A.m10 * x2f + A.m11 * y2f + A.m12) + 0.5f);
+                const int r = (int)((A.s * (float)(bq.x >> 20)) + 0.5f);
+                const float thr = __uint_as_float(bq.y);
+                // computeBadResponse, bad.cpp:166-251: boxes clamped to the frame, float means
+                int ax1 = cx1 - r; if (ax1 < 0) ax1 = 0; else if (ax1 >= fw - 1) ax1 = fw - 2;
+                int ay1 = cy1 - r; if (ay1 < 0) ay1 = 0; else if (ay1 >= fh - 1) ay1 = fh - 2;
+                int ax2 = cx1 + r + 1; if (ax2 <= 0) ax2 = 1; else if (ax2 >= fw) ax2 = fw - 1;
+                int ay2 = cy1 + r + 1; if (ay2 <= 0) ay2 = 1; else if (ay2 >= fh) ay2 = fh - 1;
+                int lx1 = clampi(ax1 - wx0, 0, S), ly1 = clampi(ay1 - wy0, 0, S);
+                int lx2 = clampi(ax2 - wx0, 0, S), ly2 = clampi(ay2 - wy0, 0, S);
+                const float sum1 = (float)(I[ly1 * IP + lx1] + I[ly2 * IP + lx2] - I[ly1 * IP + lx2] - I[ly2 * IP + lx1]);
+                const int area1 = (ay2 - ay1) * (ax2 - ax1);
+                const float avg1 = sum1 / (float)area1;
+
+                int bx1 = cx2 - r; if (bx1 < 0) bx1 = 0; else if (bx1 >= fw - 1) bx1 = fw - 2;
+                int by1 = cy2 - r; if (by1 < 0) by1 = 0; else if (by1 >= fh - 1) by1 = fh - 2;
+                int bx2 = cx2 + r + 1; if (bx2 <= 0) bx2 = 1; else if (bx2 >= fw) bx2 = fw - 1;
+                int by2 = cy2 + r + 1; if (by2 <= 0) by2 = 1; else if (by2 >= fh) by2 = fh - 1;
+                lx1 = clampi(bx1 - wx0, 0, S); ly1 = clampi(by1 - wy0, 0, S);
+                lx2 = clampi(bx2 - wx0, 0, S); ly2 = clampi(by2 - wy0, 0, S);
+                const float sum2 = (float)(I[ly1 * IP + lx1] + I[ly2 * IP + lx2] - I[ly1 * IP + lx2] - I[ly2 * IP + lx1]);
+                const int area2 = (by2 - by1) * (bx2 - bx1);
+                const float avg2 = sum2 / (float)area2;
+                bit = (avg1 - avg2) <= thr;
+            } else {
+                // integer fast path, bad.cpp:365-393.  Not within 27 px of the frame edge: the window is not clamped by
+                // the frame and R >= s * reach + 1 puts every tap inside it (no clamps, spec S9 is vacuous here).
+                const uint4 q = b0 == 0 ? q0 : q1;
+                const efx_f32x2 xs = { (float)(q.x & 0xffu), (float)((q.x >> 16) & 0xffu) };          // x1, x2
+                const efx_f32x2 ys = { (float)((q.x >> 8) & 0xffu), (float)(q.x >> 24) };             // y1, y2
+                // transform, bad.cpp:151-155: ((m00 x + m01 y) + m02) + 0.5f, truncated -- both boxes per instruction
+                const efx_f32x2 half2 = { 0.5f, 0.5f };
+                const efx_f32x2 cxf = (((efx_f32x2)(A.m00) * xs + (efx_f32x2)(A.m01) * ys) + (efx_f32x2)(A.m02)) + half2;
+                const efx_f32x2 cyf = (((efx_f32x2)(A.m10) * xs + (efx_f32x2)(A.m11) * ys) + (efx_f32x2)(A.m12)) + half2;
+                const int cx1 = (int)cxf.x, cx2 = (int)cxf.y, cy1 = (int)cyf.x, cy2 = (int)cyf.y;
+                // byte address of integral entry (cy - r' - wy0, cx - r' - wx0): (cy * IP + cx) * 4 + [(-r') (IP + 1) 4 + wbase]
+                const int pbase = (int)q.y * (IP + 1) + wbase;
+                const int side4 = (int)(q.z & 0xffffu), sideIP4 = (int)(q.z >> 16);
+                const int a_tl = (cy1 * IP + cx1) * 4 + pbase, b_tl = (cy2 * IP + cx2) * 4 + pbase;
+                const unsigned char* Ib = smem + HB_OFF;
+                auto at = [&](int off) -> int { return *reinterpret_cast<const int*>(Ib + off); };
+                const int area_resp = at(a_tl) + at(a_tl + side4 + sideIP4) - at(a_tl + side4) - at(a_tl + sideIP4)
+                                    - at(b_tl) - at(b_tl + side4 + sideIP4) + at(b_tl + side4) + at(b_tl + sideIP4);
+                bit = (float)area_resp <= __uint_as_float(q.w);
+            }
+        }
+        // 64 consecutive box pairs -> 8 bytes, bit i -> byte i / 8, MSB first (bad.cpp:349,368)
+        const unsigned long long m = __ballot(bit);
+        uint8_t* out = desc + (size_t)kid * desc_pitch + (b0 >> 3) + ((tid >> 6) << 3);
+        if (wide_store) {
+            if (lane == 0) {
+                const uint32_t lo = __builtin_bswap32(__brev((uint32_t)m)), hi = __builtin_bswap32(__brev((uint32_t)(m >> 32)));
+                *reinterpret_cast<uint2*>(out) = make_uint2(lo, hi);
+            }
+        } else if ((lane & 7) == 0) {
+            const unsigned v = (unsigned)(m >> lane) & 0xffu;
+            out[lane >> 3] = (uint8_t)(__brev(v) >> 24);
+        }
+    }
+}
+
 } // namespace
 
 void efx_gaussian_taps_host(float taps[7])
@@ -259,9 +420,16 @@ hipError_t efx_launch_bad(const DescribeLaunch& a, const BadParamsDev* d_params,
     efx_gaussian_taps_host(t);
     Affine* aff = static_cast<Affine*>(a.bad_affine);
     const int sfixed = (S == 48 && a.uniform_size) ? 48 : 0;
-    hipLaunchKernelGGL(bad_affine_kernel, dim3((a.n + 255) / 256), dim3(256), 0, stream, a.kp4, a.kp_level, a.d_table, a.rows0, a.cols0,
+    hipLaunchKernelGGL(bad_affine_kernel, dim3((a.n + 255) / 256), dim3(256), 0, stream, a.kp4, a.kp_level, a.d_table, a.img0, a.pitch0, a.pyramid, a.rows0, a.cols0,
                        a.d_count, a.n, a.scale_factor, reach, S, sfixed, aff);
     if (a.blur) {
+        if (S == 48 && a.uniform_size && max_size == (float)EFX_PATCH_SIZE && a.kp_level && a.bad_det_tables) {
+            // detector keypoints: the per-pair table of BadParamsDev was built for exactly this s; LDS: raw | pix | hb / I
+            const size_t lds_det = 3248 + 48 * 48 + BlurGeom(48).hb_bytes();
+            hipLaunchKernelGGL(bad_det_kernel, dim3(a.n), dim3(256), lds_det, stream, a.d_count, a.n, d_params, aff, t[0], t[1], t[2], t[3],
+                               a.desc, a.desc_pitch);
+            return hipGetLastError();
+        }
         if (S == 48 && a.uniform_size) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bad_kernel<true, 48>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL((bad_kernel<true, 48>), dim3(a.n), dim3(256), lds, stream, a.img0, a.pitch0, a.rows0, a.cols0, a.pyramid,

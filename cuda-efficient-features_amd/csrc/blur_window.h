@@ -37,6 +37,7 @@ struct BlurGeom {
     __host__ __device__ size_t hb_bytes() const { return (size_t)HR * HP * 4; }
 };
 
+#include <stdint.h>
 #ifdef __HIPCC__
 typedef float efx_f32x2 __attribute__((ext_vector_type(2)));
 
@@ -145,9 +146,9 @@ __device__ __forceinline__ void efx_blur_window_lds(const uint8_t* __restrict__ 
                 efx_f32x2 acc = v[i] * tp[0];
 #pragma unroll
                 for (int jt = 1; jt < 7; jt++) acc = __builtin_elementwise_fma(v[i + jt], (efx_f32x2)(tp[jt]), acc);
-                const int q0 = (int)__builtin_amdgcn_cvt_pk_u8_f32(acc.x, 0, 0u);
-                const int q1 = (int)__builtin_amdgcn_cvt_pk_u8_f32(acc.y, 0, 0u);
-                if (r < S) store(r, c, q0, q1);
+                // both pixels through one pack chain: a store that re-packs them gets (pk & 0xffff) for free
+                const uint32_t pk = __builtin_amdgcn_cvt_pk_u8_f32(acc.y, 1, __builtin_amdgcn_cvt_pk_u8_f32(acc.x, 0, 0u));
+                if (r < S) store(r, c, (int)(pk & 0xffu), (int)((pk >> 8) & 0xffu));
             }
         }
     }

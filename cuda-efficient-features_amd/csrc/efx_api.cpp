@@ -55,7 +55,7 @@ struct Describer {                  // cuda::BAD / cuda::HashSIFT state
     float scale = 1.f;              // BAD scaleFactor / HashSIFT croppingScale
     float reach = 0.f;              // BAD: max (centre distance + radius) in patch units
     DevBuf params;                  // BadParamsDev, or W (nbits x 132) + 30x30 weight table
-    DevBuf responses;               // HashSIFT scratch, n x 132; BAD scratch, n x 48 bytes (per-keypoint affine map + window geometry)
+    DevBuf responses;               // HashSIFT scratch, n x 132; BAD scratch, n x 80 bytes (per-keypoint affine map + window geometry)
     DevBuf kp4;                     // float4 keypoints for the stand-alone / compute paths
     DevBuf img, desc;               // staging for the host entry points
     std::string err;
@@ -106,6 +106,21 @@ int describer_init(Describer& d, int kind, int nbits, float scale)
         }
         h->reach = reach;
         d.reach = reach;
+        // the keypoint-independent part of every box pair for the detector's keypoints (size 31): bad.cpp:151-155,393
+        {
+            const float sz = (float)EFX_PATCH_SIZE;
+            const float su = scale * sz / (0.5f * (float)(32 + 32));            // == Affine.s of bad_affine_kernel
+            h->ubox_s = su;
+            for (int i = 0; i < nbits; i++) {
+                const int x1 = boxes[5 * i + 0], x2 = boxes[5 * i + 1], y1 = boxes[5 * i + 2], y2 = boxes[5 * i + 3], r = boxes[5 * i + 4];
+                const int rs = (int)((su * (float)r) + 0.5f);
+                const int side = 1 + (rs << 1);
+                const float ts = thr[i] * (float)(side * side);
+                uint32_t tsb; memcpy(&tsb, &ts, 4);
+                h->ubox[i] = make_uint4((uint32_t)(x1 | (y1 << 8) | (x2 << 16) | (y2 << 24)), (uint32_t)(-4 * rs),
+                                        (uint32_t)(4 * side) | ((uint32_t)(4 * 49 * side) << 16), tsb);
+            }
+        }
         hipError_t e = d.params.reserve(sizeof(BadParamsDev));
         if (e == hipSuccess) e = hipMemcpy(d.params.p, h, sizeof(BadParamsDev), hipMemcpyHostToDevice);
         delete h;
@@ -152,8 +167,9 @@ int describer_run(Describer& d, std::string& err, DescribeLaunch a, float* dbg_r
     const bool prof = a.prof.begin(10, stream);
     struct ProfEnd { const ProfRec& p; bool on; hipStream_t st; ~ProfEnd() { p.end(on, 10, st); } } prof_end{a.prof, prof, stream};
     if (d.kind == 0) {
-        HIP_TRY(err, d.responses.reserve((size_t)a.n * 48));
+        HIP_TRY(err, d.responses.reserve((size_t)a.n * 80));
         a.bad_affine = d.responses.p;
+        a.bad_det_tables = 1;            // describer_init builds ubox for d.scale and size 31
         hipError_t e = efx_launch_bad(a, static_cast<const BadParamsDev*>(d.params.p), d.reach, stream);
         if (e == hipErrorInvalidValue) return set_err(err, EFX_ERR_UNSUPPORTED, "keypoint size %.1f needs a window larger than the 160 KB LDS", a.max_size);
         if (e != hipSuccess) return set_err(err, EFX_ERR_HIP, "BAD launch failed: %s", hipGetErrorString(e));

@@ -111,6 +111,14 @@ struct BadParamsDev {           // per-context copy of the learned tables (no pr
     int nbits;
     float reach;                // max over boxes of (centre distance from (16,16) + radius), patch units
     uint2 box[512];             // {x1 | x2<<5 | y1<<10 | y2<<15 | radius<<20, threshold bits}: 8 B per box pair
+    // Detector keypoints (size 31, describer scale s.t. the window is 48 x 48): everything about a box pair that does not
+    // depend on the keypoint, worked out once on the host with the float expressions of bad.cpp:151-155,393
+    //   .x = x1 | y1 << 8 | x2 << 16 | y2 << 24          (v_cvt_f32_ubyteN)
+    //   .y = -4 r'            r' = (int)(s r + 0.5f), the scaled radius
+    //   .z = 4 side | (4 * 49 side) << 16               side = 2 r' + 1; byte strides in the 49-int integral rows
+    //   .w = bits of thr * (float)(side * side)
+    uint4 ubox[512];
+    float ubox_s;               // the s the table was built for (scale_factor * 31 / 32)
 };
 
 #if defined(__HIPCC__)
@@ -225,7 +233,8 @@ struct DescribeLaunch {
     float max_size;                                        // upper bound of keypoint size (LDS window)
     int uniform_size;                                      // 1: every keypoint has size == max_size (detector output)
     uint8_t* desc; size_t desc_pitch;
-    void* bad_affine;                                      // BAD scratch: n x 48 bytes (per-keypoint affine map + window geometry)
+    void* bad_affine;                                      // BAD scratch: n x 80 bytes (per-keypoint affine map + window geometry)
+    int bad_det_tables;                                    // BadParamsDev::ubox was built for this describer scale and size 31
     int dbg_hs;                                            // EFX_DEBUG_HS (EFX_DEBUG_BUILD builds only)
     ProfRec prof;
 };
