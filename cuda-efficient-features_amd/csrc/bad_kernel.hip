@@ -13,25 +13,13 @@
 
 #include "efx_device.h"
 #include "blur_window.h"
+#include "bad_affine.h"
 
 namespace {
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-// Everything about a keypoint that is uniform over its workgroup, computed once by one lane of bad_affine_kernel and
-// read back as scalars: the affine map (rectifyBoxes), the LDS window origin / size and the border flag.
-struct __attribute__((aligned(16))) Affine {
-    float m00, m01, m02, m10, m11, m12, s;
-    int wx0, wy0, S;            // window [wx0, wx0 + S) x [wy0, wy0 + S); S == 0: the keypoint does not fit (zero descriptor)
-    int border;                 // isKeypointInTheBorder (bad.cpp:86-103)
-    int level;                  // pyramid level of the keypoint (0 in single-image mode)
-    // the level's image, so that the describing workgroup needs ONE dependent load (this record) before its window loads
-    const uint8_t* img; int pitch, rows, cols, pad;
-};
-static_assert(sizeof(Affine) == 80, "Affine is 80 bytes (DescribeLaunch::bad_affine scratch)");
-
-// rectifyBoxes, bad.cpp:115-147: the patch -> image affine map of every keypoint, one lane per keypoint (the double
-// cos/sin of bad.cpp:138-139 is ~400 instructions: far too long to run on one lane of a per-keypoint workgroup)
+// rectifyBoxes etc. for keypoint lists that do not come from the detector (bad_affine.h)
 __global__ __launch_bounds__(256) void bad_affine_kernel(const float4* __restrict__ kp4, const int* __restrict__ kp_level,
                                                          const LevelTable* __restrict__ T, const uint8_t* __restrict__ img0, int pitch0,
                                                          const uint8_t* __restrict__ pyramid, int rows0, int cols0,
@@ -41,46 +29,13 @@ __global__ __launch_bounds__(256) void bad_affine_kernel(const float4* __restric
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int count = d_count ? min(*d_count, n) : n;
     if (i >= count) return;
-    const float4 kp = kp4[i];
-    const float x = kp.x, y = kp.y, size = kp.z, angle = kp.w;
-    Affine A;
-    const float s = scale_factor * size / (0.5f * (float)(32 + 32));
-    if (angle == -1) {
-        A.m00 = s; A.m01 = 0.0f; A.m02 = -0.5f * s * (float)32 + x;
-        A.m10 = 0.0f; A.m11 = s; A.m12 = -s * 0.5f * (float)32 + y;
-    } else {
-        const float cosine = (angle >= 0) ? (float)cos((double)angle * 0.017453292519943295) : 1.f;
-        const float sine = (angle >= 0) ? (float)sin((double)angle * 0.017453292519943295) : 0.f;
-        A.m00 = s * cosine; A.m01 = -s * sine;
-        A.m02 = (-s * cosine + s * sine) * (float)32 * 0.5f + x;
-        A.m10 = s * sine; A.m11 = s * cosine;
-        A.m12 = (-s * sine - s * cosine) * (float)32 * 0.5f + y;
-    }
-    A.s = s;
     int rows = rows0, cols = cols0, l = 0;
-    A.img = img0; A.pitch = pitch0; A.pad = 0;
+    const uint8_t* img = img0; int pitch = pitch0;
     if (kp_level) {
         l = kp_level[i]; rows = T->lv[l].rows; cols = T->lv[l].cols;
-        if (l > 0) { A.img = pyramid + T->lv[l].img_off; A.pitch = T->lv[l].pitch; }
+        if (l > 0) { img = pyramid + T->lv[l].img_off; pitch = T->lv[l].pitch; }
     }
-    A.level = l; A.rows = rows; A.cols = cols;
-    // window geometry: every (clamped) box coordinate of this keypoint lies in [wx0, wx0+S] x [wy0, wy0+S]
-    const float sg = scale_factor * size / 32.f;
-    // R >= |sg| * reach + 1 covers every box: a centre rounds to within 0.5 of its exact position, a radius grows by at
-    // most 0.5, the far integral coordinate is one more, and x - floor(x) < 1
-    const int R = (int)floorf(fabsf(sg) * reach + 2.01f);
-    const int Srt = 2 * R + 2;
-    const bool fits = sfixed ? (Srt == sfixed) : (Srt <= smax && Srt > 0);
-    const int S = sfixed ? sfixed : (fits ? Srt : smax);
-    const int ix = (int)floorf(x), iy = (int)floorf(y);
-    A.wx0 = min(max(ix - R, 0), max(cols - S, 0));
-    A.wy0 = min(max(iy - R, 0), max(rows - S, 0));
-    A.S = fits ? S : 0;                                // keypoint larger than the caller's max_size: zero descriptor
-    // isKeypointInTheBorder, bad.cpp:86-103
-    const float sb = scale_factor * size / (float)(32 + 32);
-    const float bw = (float)32 * sb * 1.75f, bh = (float)32 * sb * 1.75f;
-    A.border = ((x < bw || x + bw >= (float)cols) || (y < bh || y + bh >= (float)rows)) ? 1 : 0;
-    aff[i] = A;
+    aff[i] = efx_bad_affine(kp4[i], img, pitch, rows, cols, l, scale_factor, reach, smax, sfixed);
 }
 
 // LDS plan (dynamic): [ I: (S+1)^2 int32, aliased by raw: (S+6) x RPB u8 | hb: HR x HP float ]   (BlurGeom, blur_window.h)
@@ -395,18 +350,11 @@ void efx_gaussian_taps_host(float taps[7])
     for (int i = 0; i < 7; i++) taps[i] = (float)(e[i] / sum);
 }
 
-static int bad_smax_for(float max_size, float scale_factor, float reach)
-{
-    const float sg = fabsf(scale_factor * max_size / 32.f);
-    const int R = (int)floorf(sg * reach + 2.01f);
-    return 2 * R + 2;
-}
-
 hipError_t efx_launch_bad(const DescribeLaunch& a, const BadParamsDev* d_params, float reach, hipStream_t stream)
 {
     if (a.n <= 0) return hipSuccess;
     const float max_size = a.max_size > 0.f ? a.max_size : (float)EFX_PATCH_SIZE;
-    const int S = bad_smax_for(max_size, a.scale_factor, reach);
+    const int S = efx_bad_smax_for(max_size, a.scale_factor, reach);
     size_t lds = (size_t)(S + 1) * (S + 1) * 4;
     if (a.blur) {
         const BlurGeom bg(S);
@@ -420,8 +368,9 @@ hipError_t efx_launch_bad(const DescribeLaunch& a, const BadParamsDev* d_params,
     efx_gaussian_taps_host(t);
     Affine* aff = static_cast<Affine*>(a.bad_affine);
     const int sfixed = (S == 48 && a.uniform_size) ? 48 : 0;
-    hipLaunchKernelGGL(bad_affine_kernel, dim3((a.n + 255) / 256), dim3(256), 0, stream, a.kp4, a.kp_level, a.d_table, a.img0, a.pitch0, a.pyramid, a.rows0, a.cols0,
-                       a.d_count, a.n, a.scale_factor, reach, S, sfixed, aff);
+    if (!a.affine_ready)         // detectAndCompute: angle_kernel has left the records (DetectLaunch::bad_affine)
+        hipLaunchKernelGGL(bad_affine_kernel, dim3((a.n + 255) / 256), dim3(256), 0, stream, a.kp4, a.kp_level, a.d_table, a.img0, a.pitch0, a.pyramid, a.rows0, a.cols0,
+                           a.d_count, a.n, a.scale_factor, reach, S, sfixed, aff);
     if (a.blur) {
         if (S == 48 && a.uniform_size && max_size == (float)EFX_PATCH_SIZE && a.kp_level && a.bad_det_tables) {
             // detector keypoints: the per-pair table of BadParamsDev was built for exactly this s; LDS: raw | pix | hb / I

@@ -13,6 +13,7 @@
 // Compile with -ffp-contract=off: the float expressions below must not be fused.
 
 #include "efx_device.h"
+#include "bad_affine.h"
 #include <algorithm>
 
 namespace {
@@ -1256,8 +1257,10 @@ __global__ __launch_bounds__(1024) void select_kernel(const LevelTable* __restri
     }
     if (!L.active) { if (tid == 0) { cnt->sum.kept[l] = 0; cnt->thresh[l] = 0; } return; }
 
-    int n = 0;
-    for (int sub = 0; sub < EFX_NSUB; sub++) n += cnt->surv_total[l][sub].v;
+    int nsub[EFX_NSUB];
+    int n = 0, nmaxsub = 0;
+#pragma unroll
+    for (int sub = 0; sub < EFX_NSUB; sub++) { nsub[sub] = cnt->surv_total[l][sub].v; n += nsub[sub]; nmaxsub = max(nmaxsub, nsub[sub]); }
     const Corner* surv = surv_all + L.surv_base;
     unsigned long long thresh = 0;
     if (L.quota <= 0) {
@@ -1271,14 +1274,20 @@ __global__ __launch_bounds__(1024) void select_kernel(const LevelTable* __restri
             const int shift = 64 - decided - width;
             for (int i = tid; i < SEL_BINS; i += 1024) s_hist[i] = 0;
             __syncthreads();
-            for (int sub = 0; sub < EFX_NSUB; sub++) {
-                const Corner* q = surv + (size_t)sub * L.surv_sub_cap;
-                const int ns = cnt->surv_total[l][sub].v;
-                for (int i = tid; i < ns; i += 1024) {
-                    const Corner c = q[i];
-                    const unsigned long long k = efx_select_key(c.xy, c.resp);
+            // entry i of all 8 sub-arrays per step: 8 independent loads in flight, one memory round trip per step instead
+            // of one per sub-array and step (the level's arrays are re-read by every pass; they sit in L2)
+            for (int i = tid; i < nmaxsub; i += 1024) {
+                Corner c[EFX_NSUB];
+#pragma unroll
+                for (int sub = 0; sub < EFX_NSUB; sub++) {
+                    c[sub].xy = 0u; c[sub].resp = 0.f;
+                    if (i < nsub[sub]) c[sub] = surv[(size_t)sub * L.surv_sub_cap + i];
+                }
+#pragma unroll
+                for (int sub = 0; sub < EFX_NSUB; sub++) {
+                    const unsigned long long k = efx_select_key(c[sub].xy, c[sub].resp);
                     const bool match = decided == 0 ? true : ((k >> (64 - decided)) == prefix);
-                    if (match) atomicAdd(&s_hist[(int)((k >> shift) & ((1u << width) - 1))], 1);
+                    if (i < nsub[sub] && match) atomicAdd(&s_hist[(int)((k >> shift) & ((1u << width) - 1))], 1);
                 }
             }
             __syncthreads();
@@ -1322,14 +1331,17 @@ __global__ __launch_bounds__(1024) void select_kernel(const LevelTable* __restri
         int* s_cnt = s_hist;
         for (int t = tid; t < ntiles; t += 1024) s_cnt[t] = 0;
         __syncthreads();
-        for (int sub = 0; sub < EFX_NSUB; sub++) {
-            const Corner* q = surv + (size_t)sub * L.surv_sub_cap;
-            const int ns = cnt->surv_total[l][sub].v;
-            for (int i = tid; i < ns; i += 1024) {
-                const Corner c = q[i];
-                if (efx_select_key(c.xy, c.resp) >= thresh)
-                    atomicAdd(&s_cnt[(int)((c.xy >> 16) >> 6) * L.tiles_x + (int)((c.xy & 0xffffu) >> 6)], 1);
+        for (int i = tid; i < nmaxsub; i += 1024) {
+            Corner c[EFX_NSUB];
+#pragma unroll
+            for (int sub = 0; sub < EFX_NSUB; sub++) {
+                c[sub].xy = 0u; c[sub].resp = 0.f;
+                if (i < nsub[sub]) c[sub] = surv[(size_t)sub * L.surv_sub_cap + i];
             }
+#pragma unroll
+            for (int sub = 0; sub < EFX_NSUB; sub++)
+                if (i < nsub[sub] && efx_select_key(c[sub].xy, c[sub].resp) >= thresh)
+                    atomicAdd(&s_cnt[(int)((c[sub].xy >> 16) >> 6) * L.tiles_x + (int)((c[sub].xy & 0xffffu) >> 6)], 1);
         }
         __syncthreads();
         // exclusive scan over the tiles: a thread owns a contiguous chunk
@@ -1449,7 +1461,8 @@ __global__ __launch_bounds__(64) void emit_kernel(const LevelTable* __restrict__
 __global__ __launch_bounds__(256) void angle_kernel(const LevelTable* __restrict__ T, const int* __restrict__ d_count, int capacity,
                                                     const uint8_t* __restrict__ img0, int pitch0, const uint8_t* __restrict__ pyramid,
                                                     float4* __restrict__ kp4, const int* __restrict__ kp_level,
-                                                    uint8_t* __restrict__ kps, size_t kps_pitch)
+                                                    uint8_t* __restrict__ kps, size_t kps_pitch,
+                                                    Affine* __restrict__ aff, float bad_scale, float bad_reach, int bad_smax, int bad_sfixed)
 {
     // two keypoints per wave (31 of each 32 lanes hold one patch column), 8 per workgroup; neighbouring keypoints
     // (canonical order) stay on the same XCD: their patches share L2 lines
@@ -1496,6 +1509,14 @@ __global__ __launch_bounds__(256) void angle_kernel(const LevelTable* __restrict
         const float angle = atan2_deg(s_m[threadIdx.x][0], s_m[threadIdx.x][1]);
         kp4[k8].w = angle;
         if (kps) *reinterpret_cast<float*>(kps + 2 * kps_pitch + 4 * (size_t)k8) = angle;
+        if (aff) {
+            // the BAD describer's record of this keypoint, while its angle is in a register (saves bad_affine_kernel's launch)
+            float4 kq = kp4[k8]; kq.w = angle;
+            const int lv = kp_level[k8];
+            const LevelDev& L = T->lv[lv];
+            aff[k8] = efx_bad_affine(kq, lv == 0 ? img0 : pyramid + L.img_off, lv == 0 ? pitch0 : L.pitch, L.rows, L.cols, lv,
+                                     bad_scale, bad_reach, bad_smax, bad_sfixed);
+        }
     }
 }
 
@@ -1699,7 +1720,8 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
         if (nmax > a.capacity) nmax = a.capacity;
         if (nmax > 0)
             hipLaunchKernelGGL(angle_kernel, dim3((nmax + 7) / 8), dim3(256), 0, stream, a.d_table, a.d_count, a.capacity,
-                               a.img0, a.pitch0, a.pyramid, a.kp4, a.kp_level, (uint8_t*)a.d_keypoints, a.kps_pitch);
+                               a.img0, a.pitch0, a.pyramid, a.kp4, a.kp_level, (uint8_t*)a.d_keypoints, a.kps_pitch,
+                               static_cast<Affine*>(a.bad_affine), a.bad_scale, a.bad_reach, a.bad_smax, a.bad_sfixed);
     }
     a.prof.end(prof, 3, stream);
     e = hipGetLastError();

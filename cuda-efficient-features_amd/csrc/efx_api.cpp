@@ -6,6 +6,7 @@
 
 #include "../../include/efx.h"
 #include "efx_device.h"
+#include "bad_affine.h"
 
 #include <math.h>
 #include <stdarg.h>
@@ -167,7 +168,7 @@ int describer_run(Describer& d, std::string& err, DescribeLaunch a, float* dbg_r
     const bool prof = a.prof.begin(10, stream);
     struct ProfEnd { const ProfRec& p; bool on; hipStream_t st; ~ProfEnd() { p.end(on, 10, st); } } prof_end{a.prof, prof, stream};
     if (d.kind == 0) {
-        HIP_TRY(err, d.responses.reserve((size_t)a.n * 80));
+        HIP_TRY(err, d.responses.reserve((size_t)a.n * sizeof(Affine)));
         a.bad_affine = d.responses.p;
         a.bad_det_tables = 1;            // describer_init builds ubox for d.scale and size 31
         hipError_t e = efx_launch_bad(a, static_cast<const BadParamsDev*>(d.params.p), d.reach, stream);
@@ -411,6 +412,16 @@ int detect_common(efx_context* c, const uint8_t* d_image, int rows, int cols, si
         a.prof.start = c->prof_start.data(); a.prof.stop = c->prof_stop.data(); a.prof.code = c->prof_level.data();
         a.prof.count = &c->prof_count; a.prof.capacity = (int)c->prof_start.size(); a.prof.skip = c->prof_skip;
     }
+    // BAD behind detectAndCompute: angle_kernel writes the describer's per-keypoint records (no bad_affine_kernel launch)
+    const int n_desc = capacity < c->n_out_max ? capacity : c->n_out_max;     // the bound angle_kernel uses: sum of the active quotas
+    bool affine_ready = false;
+    if (d_desc && capacity > 0 && c->desc.kind == 0 && n_desc > 0) {
+        HIP_TRY(c->err, c->desc.responses.reserve((size_t)n_desc * sizeof(Affine)));
+        const int S = efx_bad_smax_for((float)EFX_PATCH_SIZE, c->desc.scale, c->desc.reach);
+        a.bad_affine = c->desc.responses.p; a.bad_scale = c->desc.scale; a.bad_reach = c->desc.reach;
+        a.bad_smax = S; a.bad_sfixed = S == 48 ? 48 : 0;
+        affine_ready = true;
+    }
     hipError_t e = efx_launch_detect(a, stream);
     if (e != hipSuccess) return set_err(c->err, EFX_ERR_HIP, "detect launch failed: %s", hipGetErrorString(e));
     c->has_frame = true; c->last_img0 = d_image; c->last_pitch0 = (int)pitch;
@@ -422,7 +433,8 @@ int detect_common(efx_context* c, const uint8_t* d_image, int rows, int cols, si
         dl.img0 = d_image; dl.pitch0 = (int)pitch; dl.rows0 = rows; dl.cols0 = cols;
         dl.pyramid = a.pyramid; dl.d_table = a.d_table;
         dl.kp4 = a.kp4; dl.kp_level = a.kp_level; dl.d_count = a.d_count;
-        dl.n = capacity < c->n_out_max ? capacity : c->n_out_max;     // the bound angle_kernel uses: sum of the active quotas
+        dl.n = n_desc;
+        dl.affine_ready = affine_ready ? 1 : 0;
         dl.blur = 1;
         dl.max_size = (float)EFX_PATCH_SIZE;
         dl.uniform_size = 1;

@@ -217,6 +217,8 @@ struct DetectLaunch {
     // outputs
     void* d_keypoints; size_t kps_pitch; int capacity; int* d_count;
     float4* kp4; int* kp_level;
+    // BAD describer behind this detect call: angle_kernel also writes the per-keypoint Affine records (bad_affine.h)
+    void* bad_affine; float bad_scale, bad_reach; int bad_smax, bad_sfixed;
     ProfRec prof;                                          // optional HIP-event pairs around the launches
 };
 
@@ -235,6 +237,7 @@ struct DescribeLaunch {
     uint8_t* desc; size_t desc_pitch;
     void* bad_affine;                                      // BAD scratch: n x 80 bytes (per-keypoint affine map + window geometry)
     int bad_det_tables;                                    // BadParamsDev::ubox was built for this describer scale and size 31
+    int affine_ready;                                      // bad_affine already holds this call's records (written by angle_kernel)
     int dbg_hs;                                            // EFX_DEBUG_HS (EFX_DEBUG_BUILD builds only)
     ProfRec prof;
 };
