@@ -25,6 +25,7 @@ extern const unsigned char efx_blob_bad256[], efx_blob_bad512[], efx_blob_hashsi
 }
 
 #define HS_KPAD 132
+#define HS_KB 144             // K of the bf16 projection: 129 padded to 9 MFMA steps of 16
 
 namespace {
 
@@ -51,12 +52,13 @@ struct DevBuf {                     // grow-only device allocation
 
 struct Describer {                  // cuda::BAD / cuda::HashSIFT state
     int dbg_hs = 0;                 // EFX_DEBUG_HS, read when the describer is created (EFX_DEBUG_BUILD builds only)
+    size_t hs_wb_off = 0;           // HashSIFT: byte offset of the bf16 weight terms inside `params`
     int kind = 0;                   // 0 BAD, 1 HashSIFT
     int nbits = 256;
     float scale = 1.f;              // BAD scaleFactor / HashSIFT croppingScale
     float reach = 0.f;              // BAD: max (centre distance + radius) in patch units
     DevBuf params;                  // BadParamsDev, or W (nbits x 132) + 30x30 weight table
-    DevBuf responses;               // HashSIFT scratch, n x 132; BAD scratch, n x 80 bytes (per-keypoint affine map + window geometry)
+    DevBuf responses;               // HashSIFT scratch, n x 144 bf16; BAD scratch, n x 80 bytes (per-keypoint affine map + window geometry)
     DevBuf kp4;                     // float4 keypoints for the stand-alone / compute paths
     DevBuf img, desc;               // staging for the host entry points
     std::string err;
@@ -152,6 +154,31 @@ int describer_init(Describer& d, int kind, int nbits, float scale)
                 for (int dx = -255; dx <= 255; dx++)
                     lut[(dy + 255) * 511 + (dx + 255)] = scaleO * atan2f((float)dy, (float)dx);
         }
+        // The projection runs on the bf16 matrix cores with W split EXACTLY into three bf16 terms, W = W1 + W2 + W3
+        // (8 + 8 + 8 mantissa bits; each term is the round-to-nearest-even bf16 of what is left): the 129-vector is integer
+        // valued (0..255, and the leading 1) and therefore exact in bf16, every product is exact in the fp32 accumulator.
+        // Layout behind the float tables: [term][bit][HS_KB] bf16, K padded with zeros.
+        const size_t wb_off = (w.size() + 3) & ~(size_t)3;         // 16-byte aligned: the kernel loads 8 bf16 at a time
+        w.resize(wb_off + (size_t)3 * nbits * HS_KB / 2, 0.f);
+        {
+            uint16_t* wb = reinterpret_cast<uint16_t*>(w.data() + wb_off);
+            auto bf16_rne = [](float f) -> uint16_t {
+                uint32_t u; memcpy(&u, &f, 4);
+                u += 0x7fffu + ((u >> 16) & 1u);                   // finite inputs only
+                return (uint16_t)(u >> 16);
+            };
+            auto bf16_f = [](uint16_t b) -> float { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; };
+            for (int j = 0; j < nbits; j++)
+                for (int k = 0; k < 129; k++) {
+                    float rest = w[(size_t)j * HS_KPAD + k];
+                    for (int t = 0; t < 3; t++) {
+                        const uint16_t b = bf16_rne(rest);
+                        wb[((size_t)t * nbits + j) * HS_KB + k] = b;
+                        rest = rest - bf16_f(b);                   // exact: the difference fits the float mantissa
+                    }
+                }
+        }
+        d.hs_wb_off = wb_off * sizeof(float);
         hipError_t e = d.params.reserve(w.size() * sizeof(float));
         if (e == hipSuccess) e = hipMemcpy(d.params.p, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice);
         if (e != hipSuccess) return set_err(d.err, EFX_ERR_HIP, "HashSIFT weight upload failed: %s", hipGetErrorString(e));
@@ -177,11 +204,12 @@ int describer_run(Describer& d, std::string& err, DescribeLaunch a, float* dbg_r
     } else {
         if (a.desc && ((((uintptr_t)a.desc) | a.desc_pitch) & 3u))
             return set_err(err, EFX_ERR_BAD_ARG, "HashSIFT descriptors need a 4-byte aligned base and pitch");
-        HIP_TRY(err, d.responses.reserve((size_t)a.n * HS_KPAD * sizeof(float)));
+        HIP_TRY(err, d.responses.reserve((size_t)a.n * HS_KB * sizeof(uint16_t)));
         HashSiftDev h;
         h.nbits = d.nbits;
         h.W = static_cast<const float*>(d.params.p);
-        h.responses = static_cast<float*>(d.responses.p);
+        h.Wb = reinterpret_cast<const uint16_t*>(static_cast<const unsigned char*>(d.params.p) + d.hs_wb_off);
+        h.responses = static_cast<uint16_t*>(d.responses.p);
         h.dbg_responses = dbg_resp;
         h.dbg_T = dbg_T;
         hipError_t e = efx_launch_hashsift(a, h, stream);

@@ -25,7 +25,8 @@
 #include "glibc_sincosf.h"
 #include <stdlib.h>
 
-#define HS_KPAD 132   // 129 padded to a multiple of 4 floats
+#define HS_KPAD 132   // 129 padded to a multiple of 4 floats (row pitch of the fp32 weights)
+#define HS_KB 144     // K of the bf16 projection: 129 padded to 9 MFMA steps of 16
 
 namespace {
 
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(HS_NT) void patch_sift_kernel(
     const float4* __restrict__ kp4, const int* __restrict__ kp_level, const int* __restrict__ d_count, int n,
     float crop_scale, int smax, const float* __restrict__ mag_scale /*30*30*/, const float* __restrict__ obin_lut /*511*511*/,
     float taps0, float taps1, float taps2, float taps3,
-    float* __restrict__ responses /* n x HS_KPAD */, float* __restrict__ dbg_responses /* n x 129 or null */, int dbg_arg)
+    uint16_t* __restrict__ responses /* n x HS_KB bf16 */, float* __restrict__ dbg_responses /* n x 129 or null */, int dbg_arg)
 {
     const int dbg = EFX_DBG(dbg_arg);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -238,100 +239,108 @@ __global__ __launch_bounds__(HS_NT) void patch_sift_kernel(
         __syncthreads();
     }
     if (dbg == 4) return;
-    float* out = responses + (size_t)kid * HS_KPAD;
+    // the 129-vector {1, 128 x uchar} as bf16 (exact: integers <= 255 need 8 mantissa bits), K padded to HS_KB with zeros
+    uint16_t* out = responses + (size_t)kid * HS_KB;
     if (tid < 128) {
         float v = rintf(512.f * s_desc[tid]);                           // saturate_cast<uchar>: cvRound + clamp
         v = v < 0.f ? 0.f : (v > 255.f ? 255.f : v);
-        out[1 + tid] = v;
+        out[1 + tid] = (uint16_t)(__float_as_uint(v) >> 16);
         if (dbg_responses) dbg_responses[(size_t)kid * 129 + 1 + tid] = v;
     }
-    if (tid == 128) { out[0] = 1.f; out[129] = 0.f; out[130] = 0.f; out[131] = 0.f; if (dbg_responses) dbg_responses[(size_t)kid * 129] = 1.f; }
+    if (tid >= 128 && tid < 128 + HS_KB - 128) {
+        const int k = tid == 128 ? 0 : tid;                             // element 0 and the padding 129 .. 143
+        out[k] = tid == 128 ? (uint16_t)0x3f80 : (uint16_t)0;
+        if (tid == 128 && dbg_responses) dbg_responses[(size_t)kid * 129] = 1.f;
+    }
 }
 
 // ================================================================================================
 // Projection + sign + pack.  T[i][j] = sum_k R[i][k] * W[j][k]  (matmulAndSign, hash_sift.cpp:353-378).
-// The one real GEMM of the path, on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains).  A wave owns 64 output bits and
-// keeps their weights W[64][132] in registers for its whole life (132 VGPRs), then walks 32-keypoint tiles of R:
-// per tile 33 eight-byte loads per lane, 132 MFMAs, sign test by ballot, packed bits out -- no T matrix in HBM, no
-// separate binarize pass (cuda_hash_sift.cu:414-435), and W is fetched once per wave instead of once per tile.
-// K is split between the two half-waves (lanes 0-31 take k in [0, 66), lanes 32-63 k in [66, 132)), so every lane
-// reads contiguous floats of its R row.
+// The one real GEMM of the path, on the bf16 matrix cores: v_mfma_f32_32x32x16_bf16 (16x the rate of the fp32 MFMA the
+// first version used).  R is integer valued (0..255 and the leading 1): exact in bf16.  W is split on the host into three
+// bf16 terms whose sum is W exactly, so every product R * W_t is exact in the fp32 accumulator and T differs from the
+// fp32 FMA chain only by the order / rounding of the accumulation (well inside the stated 2e-3 tolerance on T).
+// A wave owns 32 output bits and keeps their 3 x 9 B-operands (W terms x K steps) in registers for its whole life, then
+// walks 32-keypoint tiles of R: 9 sixteen-byte loads per lane, 27 MFMAs, sign test by ballot, packed bits out -- no T
+// matrix in HBM, no separate binarize pass (cuda_hash_sift.cu:414-435).
+// Operand layout: lane l holds row / column (l & 31) and the 8 consecutive k of half (l >> 5) of the K step, for A and B
+// alike, so whatever order the hardware contracts the 16 k of a step in, A and B elements meet at equal k.
 // ================================================================================================
-typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-__global__ __launch_bounds__(256) void project_sign_kernel(const float* __restrict__ Rm, const float* __restrict__ W,
+__global__ __launch_bounds__(256) void project_sign_kernel(const uint16_t* __restrict__ Rm, const uint16_t* __restrict__ Wb,
                                                            const int* __restrict__ d_count, int n, int nbits,
                                                            uint8_t* __restrict__ desc, size_t desc_pitch, float* __restrict__ dbg_T)
 {
+    __shared__ __attribute__((aligned(16))) uint32_t s_bits[2][32][4];     // [buffer][row of the tile][wave]: 128 bits per row
     const int count = d_count ? min(*d_count, n) : n;
-    const int lane = threadIdx.x & 63;
-    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);          // global wave index
-    const int ntn = nbits >> 6;                                   // 64-bit column tiles
-    const int n0 = (gw % ntn) * 64;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    // the waves that share a row group (one per column tile) run on ONE XCD: they read the same rows of R through one L2
+    const int gw = xcd_chunked(blockIdx.x, gridDim.x) * 4 + wid;   // logical global wave index
+    const int ntn = nbits >> 5;                                   // 32-bit column tiles (a multiple of 4: a workgroup's four
+    const int n0 = (gw % ntn) * 32;                               // waves own 128 adjacent bits of the same row group)
     const int mgroup = gw / ntn, nmgroups = (gridDim.x * 4) / ntn;
     const int li = lane & 31, lk = lane >> 5;
-    constexpr int KH = HS_KPAD / 2;                               // 66 k-steps
-    // this wave's weights: b0[j] = W[n0 + li][KH * lk + j], b1[j] = W[n0 + 32 + li][KH * lk + j]
-    float b0[KH], b1[KH];
-    {
-        const f32x2v* p0 = reinterpret_cast<const f32x2v*>(W + (size_t)(n0 + li) * HS_KPAD + KH * lk);
-        const f32x2v* p1 = reinterpret_cast<const f32x2v*>(W + (size_t)(n0 + 32 + li) * HS_KPAD + KH * lk);
+    constexpr int KS = HS_KB / 16;                                // 9 K steps
+    // this wave's weights: b[t][ks] = W_t[n0 + li][16 ks + 8 lk .. + 8]
+    bf16x8 b[3][KS];
 #pragma unroll
-        for (int j = 0; j < KH / 2; j++) {
-            const f32x2v u = p0[j], v = p1[j];
-            b0[2 * j] = u.x; b0[2 * j + 1] = u.y; b1[2 * j] = v.x; b1[2 * j + 1] = v.y;
-        }
+    for (int t = 0; t < 3; t++) {
+        const uint4* p = reinterpret_cast<const uint4*>(Wb + ((size_t)t * nbits + n0 + li) * HS_KB + 8 * lk);
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) b[t][ks] = __builtin_bit_cast(bf16x8, p[2 * ks]);
     }
     const int mtiles = (count + 31) >> 5;
-    for (int mt = mgroup; mt < mtiles; mt += nmgroups) {
+    // the next row tile of R is in flight while this one is multiplied; two waves per SIMD cover the rest of the latency
+    auto load_tile = [&](int mt, uint4 (&dst)[KS]) {
+        const int arow = max(min(mt * 32 + li, count - 1), 0);
+        const uint4* pa = reinterpret_cast<const uint4*>(Rm + (size_t)arow * HS_KB + 8 * lk);
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) dst[ks] = pa[2 * ks];
+    };
+    uint4 nxt[KS];
+    load_tile(mgroup, nxt);
+    // 16-byte stores of a row's 128 bits need a 16-byte aligned destination
+    const bool wide = desc != nullptr && (((reinterpret_cast<uintptr_t>(desc) | desc_pitch) & 15u) == 0);
+    int buf = 0;
+    for (int mt = mgroup; mt < mtiles; mt += nmgroups, buf ^= 1) {
         const int m0 = mt * 32;
-        const int arow = min(m0 + li, count - 1);
-        const f32x2v* pa = reinterpret_cast<const f32x2v*>(Rm + (size_t)arow * HS_KPAD + KH * lk);
-        f32x16 acc0 = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-        f32x16 acc1 = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-        // three blocks of 11 eight-byte loads; the next block's loads are in flight while this block's MFMAs run
-        constexpr int NB = 3, BL = KH / 2 / NB;                    // 33 float2 per lane = 3 x 11
-        f32x2v cur[BL], nxt[BL];
+        bf16x8 a[KS];
 #pragma unroll
-        for (int j = 0; j < BL; j++) cur[j] = pa[j];
+        for (int ks = 0; ks < KS; ks++) a[ks] = __builtin_bit_cast(bf16x8, nxt[ks]);
+        if (mt + nmgroups < mtiles) load_tile(mt + nmgroups, nxt);
+        f32x16 acc = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+        // smallest terms first: the fp32 accumulator rounds them in before the large ones arrive
 #pragma unroll
-        for (int blk = 0; blk < NB; blk++) {
-            if (blk + 1 < NB) {
+        for (int t = 2; t >= 0; t--)
 #pragma unroll
-                for (int j = 0; j < BL; j++) nxt[j] = pa[(blk + 1) * BL + j];
-            }
-#pragma unroll
-            for (int j = 0; j < BL; j++) {
-                const int kk = 2 * (blk * BL + j);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[j].x, b0[kk], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[j].x, b1[kk], acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[j].y, b0[kk + 1], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[j].y, b1[kk + 1], acc1, 0, 0, 0);
-            }
-#pragma unroll
-            for (int j = 0; j < BL; j++) cur[j] = nxt[j];
-        }
-        // C layout 32x32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+            for (int ks = 0; ks < KS; ks++) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], b[t][ks], acc, 0, 0, 0);
+        // C layout 32x32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).  The sign bits of a row are a
+        // ballot half; lane `row` collects its row's 32 bits (bit j -> byte j/8, bit 7 - j%8: MSB first, hash_sift.cpp:367-374)
+        uint32_t mine = 0u;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int row = (r & 3) + 8 * (r >> 2);
-            const unsigned long long ba = __ballot(acc0[r] > 0.f);
-            const unsigned long long bb = __ballot(acc1[r] > 0.f);
+            const unsigned long long ba = __ballot(acc[r] > 0.f);
             if (dbg_T) {
                 const int i = m0 + row + 4 * lk;
-                if (i < count) { dbg_T[(size_t)i * nbits + n0 + li] = acc0[r]; dbg_T[(size_t)i * nbits + n0 + 32 + li] = acc1[r]; }
+                if (i < count) dbg_T[(size_t)i * nbits + n0 + li] = acc[r];
             }
-            if (desc != nullptr && lane < 4) {
-                // lane 0/1: rows `row` (bits n0.., n0+32..), lane 2/3: rows `row+4`
-                const int hi = lane >> 1, second = lane & 1;
-                const unsigned long long m = second ? bb : ba;
-                const unsigned w = hi ? (unsigned)(m >> 32) : (unsigned)m;
-                const int i = m0 + row + 4 * hi;
-                if (i < count) {
-                    // bit j of w -> byte j/8, bit 7 - j%8 (MSB first, hash_sift.cpp:367-374)
-                    const unsigned v = __builtin_bswap32(__brev(w));
-                    *reinterpret_cast<unsigned*>(desc + (size_t)i * desc_pitch + (n0 + 32 * second) / 8) = v;
+            const uint32_t w_lo = __builtin_bswap32(__brev((unsigned)ba)), w_hi = __builtin_bswap32(__brev((unsigned)(ba >> 32)));
+            mine = lane == row ? w_lo : mine;
+            mine = lane == row + 4 ? w_hi : mine;
+        }
+        if (desc != nullptr) {
+            if (wide) {
+                // the workgroup's four waves hold 128 adjacent bits of the same 32 rows: one 16-byte store per row
+                if (lane < 32) s_bits[buf][lane][wid] = mine;
+                __syncthreads();
+                if (threadIdx.x < 32 && m0 + (int)threadIdx.x < count) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(&s_bits[buf][threadIdx.x][0]);
+                    *reinterpret_cast<uint4*>(desc + (size_t)(m0 + threadIdx.x) * desc_pitch + (n0 & ~127) / 8) = v;
                 }
+            } else if (lane < 32 && m0 + lane < count) {
+                *reinterpret_cast<unsigned*>(desc + (size_t)(m0 + lane) * desc_pitch + n0 / 8) = mine;
             }
         }
     }
@@ -379,13 +388,13 @@ hipError_t efx_launch_hashsift(const DescribeLaunch& a, const HashSiftDev& h, hi
                            t[0], t[1], t[2], t[3], h.responses, h.dbg_responses, dbg);
     }
     if (a.desc || h.dbg_T) {
-        // persistent waves: 2 per SIMD (the weights occupy 132 VGPRs), each owning one 64-bit column tile
-        const int ntn = h.nbits / 64;
+        // persistent waves: 2 per SIMD (the weights occupy 108 VGPRs), each owning one 32-bit column tile
+        const int ntn = h.nbits / 32;
         int nblk = 512 / ntn * ntn;                            // 2048 waves on 1024 SIMDs, a multiple of the column tiles
         const int need = (((a.n + 31) / 32) * ntn + 3) / 4;     // never more waves than (row tile, column tile) pairs
         if (nblk > need) nblk = (need + ntn - 1) / ntn * ntn;
         hipLaunchKernelGGL(project_sign_kernel, dim3(nblk), dim3(256), 0, stream,
-                           h.responses, h.W, a.d_count, a.n, h.nbits, a.desc, a.desc_pitch, h.dbg_T);
+                           h.responses, h.Wb, a.d_count, a.n, h.nbits, a.desc, a.desc_pitch, h.dbg_T);
     }
     return hipGetLastError();
 }
