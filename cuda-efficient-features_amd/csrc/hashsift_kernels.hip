@@ -53,7 +53,11 @@ __global__ __launch_bounds__(HS_NT) void patch_sift_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ AffineF s_aff;
     __shared__ uint8_t s_patch[32 * 32];
-    __shared__ unsigned long long s_h64[6 * 6 * 10];
+    // Histogram in 16.16 fixed point (order-independent integer sums).  A pixel votes for TWO adjacent orientation bins of
+    // each of four cells: the pair goes out as ONE 64-bit LDS atomic on two packed 32-bit counters (a counter stays below
+    // 2^31, so nothing carries from the low into the high one).  Per cell 5 words hold the pairs (0,1) (2,3) .. (8,9), 4 more
+    // the pairs (1,2) (3,4) (5,6) (7,8); a bin is the sum of its two homes.  Half the atomics of one counter per bin.
+    __shared__ unsigned long long s_h64[6 * 6 * 9];
     __shared__ float s_hist[6 * 6 * 10];
     __shared__ float s_desc[128];
     __shared__ float s_rf[32], s_cf[32];
@@ -74,7 +78,7 @@ __global__ __launch_bounds__(HS_NT) void patch_sift_kernel(
         else { rows = T->lv[0].rows; cols = T->lv[0].cols; }
     }
     const float px = kp.x, py = kp.y, size = kp.z, angle = kp.w;
-    for (int i = tid; i < 360; i += HS_NT) s_h64[i] = 0ull;     // ordered before the votes by the barriers below
+    for (int i = tid; i < 6 * 6 * 9; i += HS_NT) s_h64[i] = 0ull;      // ordered before the votes by the barriers below
 
     // rectifyPatch, hash_sift.cpp:111-132
     if (tid == 0) {
@@ -118,7 +122,10 @@ __global__ __launch_bounds__(HS_NT) void patch_sift_kernel(
     const int ix = (int)floorf(px), iy = (int)floorf(py);
     const int wx0 = min(max(ix - R, 0), max(cols - S, 0));
     const int wy0 = min(max(iy - R, 0), max(rows - S, 0));
-    // LDS plan (BLUR): [ raw | hb | win S x S u8 ], raw / hb as blur_window.h lays them out
+    // LDS plan (BLUR): [ raw | hb | win S x S u8 ], raw / hb as blur_window.h lays them out.  Without the blur the warp
+    // below gathers its 4 bytes per patch pixel from memory: staging the raw window in LDS first was measured SLOWER
+    // (staging 28 us + warp 108 us against 88 us per 40 000 keypoints) -- the kernel's bottleneck is the LDS pipe (the
+    // histogram atomics), the gathers go through the texture path, which is otherwise idle.
     const BlurGeom bg(S);
     uint8_t* raw = smem;
     float* hb = reinterpret_cast<float*>(smem + bg.raw_bytes());
@@ -197,18 +204,24 @@ __global__ __launch_bounds__(HS_NT) void patch_sift_kernel(
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const float b1 = of * a4[q], b0 = a4[q] - b1;
-                unsigned long long* h = s_h64 + ((ri + 1 + (q >> 1)) * 6 + (ci + 1 + (q & 1))) * 10 + oi;
-                // 32.32 fixed point: integer part + exact fraction * 2^32 (all contributions are >= 0)
-                const uint32_t h0 = (uint32_t)b0, h1 = (uint32_t)b1;
-                const uint32_t l0 = (uint32_t)((b0 - (float)h0) * 4294967296.f), l1 = (uint32_t)((b1 - (float)h1) * 4294967296.f);
-                atomicAdd(h, ((unsigned long long)h0 << 32) | l0);
-                atomicAdd(h + 1, ((unsigned long long)h1 << 32) | l1);
+                // 16.16 fixed point, rounded to nearest (contributions are >= 0; a bin collects at most 64 pixel-weights
+                // x 361 of magnitude: < 2^15).  A bin holds hundreds of gray levels, so 2^-17 per vote is ~1e-7 relative.
+                const unsigned long long pair = (unsigned long long)(uint32_t)(b0 * 65536.f + 0.5f) |
+                                                ((unsigned long long)(uint32_t)(b1 * 65536.f + 0.5f) << 32);
+                atomicAdd(s_h64 + ((ri + 1 + (q >> 1)) * 6 + (ci + 1 + (q & 1))) * 9 + ((oi & 1) ? 5 : 0) + (oi >> 1), pair);
             }
         }
     }
     __syncthreads();
     if (dbg == 2) return;
-    for (int i = tid; i < 360; i += HS_NT) s_hist[i] = (float)((double)s_h64[i] * (1.0 / 4294967296.0));
+    for (int i = tid; i < 360; i += HS_NT) {
+        const int cell = i / 10, k = i - cell * 10;
+        const unsigned long long* hc = s_h64 + cell * 9;
+        uint32_t v;
+        if (k & 1) v = (uint32_t)(hc[k >> 1] >> 32) + (k < 9 ? (uint32_t)hc[5 + (k >> 1)] : 0u);      // pairs (k-1, k) and (k, k+1)
+        else v = (uint32_t)hc[k >> 1] + (k >= 2 ? (uint32_t)(hc[5 + (k >> 1) - 1] >> 32) : 0u);        // pairs (k, k+1) and (k-1, k)
+        s_hist[i] = (float)((double)v * (1.0 / 65536.0));
+    }
     __syncthreads();
     if (dbg == 3) return;
     // circular fold + copy (hash_sift.cpp:293-308)
@@ -220,15 +233,21 @@ __global__ __launch_bounds__(HS_NT) void patch_sift_kernel(
         for (int k = 0; k < 8; k++) s_desc[(r * 4 + c) * 8 + k] = ph[k];
     }
     __syncthreads();
-    // L2 normalise, clip at 0.2, renormalise, x512 -> uchar (hash_sift.cpp:311-330); the 128-term sums are
-    // serial in the CPU code, so one lane adds them in the same order
+    // L2 normalise, clip at 0.2, renormalise, x512 -> uchar (hash_sift.cpp:311-330).  The CPU code adds the 128 squares
+    // serially; here a fixed tree does (element i with i + 64, then the butterfly 32, 16, .. 1 inside one wave): 10
+    // instructions instead of a 256-instruction chain on one lane.  The order is part of the device arithmetic the oracle
+    // models (efxo_hashsift_responses_fixedpoint); against the serial sum the norm moves by ~1e-7 relative.
     for (int pass = 0; pass < 2; pass++) {
-        if (tid == 0) {
-            float sum = 0;
-            for (int i = 0; i < 128; i++) sum += s_desc[i] * s_desc[i];
-            float norm = sqrtf(sum);
-            if (norm < 1.1920929e-07f) norm = 1.1920929e-07f;          // FLT_EPSILON
-            s_scale = 1.f / norm;
+        if (tid < 64) {
+            const float d0 = s_desc[tid], d1 = s_desc[tid + 64];
+            float t = d0 * d0 + d1 * d1;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) t = t + __shfl_xor(t, off, 64);
+            if (tid == 0) {
+                float norm = sqrtf(t);
+                if (norm < 1.1920929e-07f) norm = 1.1920929e-07f;          // FLT_EPSILON
+                s_scale = 1.f / norm;
+            }
         }
         __syncthreads();
         if (tid < 128) {

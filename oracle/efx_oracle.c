@@ -266,9 +266,27 @@ static void hs_normalize(float* d, int n)
 
 /* computePatchSIFT, hash_sift.cpp:200-331 (STEP1_PYRAMID is false: no patch blur) */
 /* fixed_point != 0: the histogram is summed as the HIP kernel does it (hashsift_kernels.hip): every vote is converted
- * to 32.32 fixed point and added as an integer (order independent), the bin is converted back to float at the end.
+ * to 16.16 fixed point (rounded to nearest) and added as an integer (order independent), the bin is converted back to
+ * float at the end; the two 128-term sums of squares of the normalisation are added in the device's tree order.
  * This is a CPU MODEL OF THE DEVICE ARITHMETIC used to (a) check the kernel bit for bit and (b) quantify how far that
  * arithmetic is from the reference's sequentially rounded float sums (fixed_point == 0). */
+/* the device's order of the 128-term sum of squares: element i with i + 64, then the butterfly 32, 16, .. 1 (float add
+ * is commutative, so every lane of the butterfly holds the same value); otherwise hs_normalize */
+static void hs_normalize_tree128(float* d)
+{
+    float t[64];
+    for (int i = 0; i < 64; i++) t[i] = d[i] * d[i] + d[i + 64] * d[i + 64];
+    for (int off = 32; off >= 1; off >>= 1) {
+        float u[64];
+        for (int i = 0; i < 64; i++) u[i] = t[i] + t[i ^ off];
+        memcpy(t, u, sizeof(t));
+    }
+    float norm = sqrtf(t[0]);
+    if (norm < 1.1920929e-07f) norm = 1.1920929e-07f;
+    const float scale = 1.f / norm;
+    for (int i = 0; i < 128; i++) d[i] = d[i] * scale;
+}
+
 static void hs_patch_sift(const uint8_t* patch, float* desc /*128*/, float kp_scale, int fixed_point)
 {
     const int h = 32, w = 32, dh = h - 2, dw = w - 2;
@@ -282,8 +300,9 @@ static void hs_patch_sift(const uint8_t* patch, float* desc /*128*/, float kp_sc
     uint64_t h64[HS_R_BINS + 2][HS_C_BINS + 2][HS_ORI_BINS + 2];
     memset(hist, 0, sizeof(hist));
     memset(h64, 0, sizeof(h64));
-#define HS_VOTE(R, Cc, O, V) do { if (fixed_point) { const float v_ = (V); const uint32_t hi_ = (uint32_t)v_; \
-        const uint32_t lo_ = (uint32_t)((v_ - (float)hi_) * 4294967296.f); h64[R][Cc][O] += ((uint64_t)hi_ << 32) | lo_; } \
+    /* fixed_point: the device's histogram arithmetic -- 16.16 fixed point, every vote rounded to nearest, integer sums
+     * (order independent), cuda-efficient-features_amd/csrc/hashsift_kernels.hip */
+#define HS_VOTE(R, Cc, O, V) do { if (fixed_point) h64[R][Cc][O] += (uint64_t)(uint32_t)((V) * 65536.f + 0.5f); \
         else hist[R][Cc][O] += (V); } while (0)
 
     /* HistBin, hash_sift.cpp:162-184 */
@@ -340,7 +359,7 @@ static void hs_patch_sift(const uint8_t* patch, float* desc /*128*/, float kp_sc
     if (fixed_point)
         for (int r = 0; r < HS_R_BINS + 2; r++)
             for (int c = 0; c < HS_C_BINS + 2; c++)
-                for (int o = 0; o < HS_ORI_BINS + 2; o++) hist[r][c][o] = (float)((double)h64[r][c][o] * (1.0 / 4294967296.0));
+                for (int o = 0; o < HS_ORI_BINS + 2; o++) hist[r][c][o] = (float)((double)(uint32_t)h64[r][c][o] * (1.0 / 65536.0));
     /* circular orientation fold + copy, hash_sift.cpp:293-308 */
     for (int r = 0; r < HS_R_BINS; r++)
         for (int c = 0; c < HS_C_BINS; c++) {
@@ -349,9 +368,9 @@ static void hs_patch_sift(const uint8_t* patch, float* desc /*128*/, float kp_sc
             ph[1] += ph[HS_ORI_BINS + 1];
             for (int k = 0; k < HS_ORI_BINS; k++) desc[(r * HS_R_BINS + c) * HS_ORI_BINS + k] = ph[k];
         }
-    hs_normalize(desc, 128);                                     /* step 7 */
+    if (fixed_point) hs_normalize_tree128(desc); else hs_normalize(desc, 128);          /* step 7 */
     for (int i = 0; i < 128; i++) desc[i] = desc[i] < HS_MAG_TH ? desc[i] : HS_MAG_TH;   /* step 8 */
-    hs_normalize(desc, 128);
+    if (fixed_point) hs_normalize_tree128(desc); else hs_normalize(desc, 128);
     for (int k = 0; k < 128; k++) desc[k] = (float)sat_u8_f(HS_INT_FACTOR * desc[k]);   /* step 9 */
 }
 
