@@ -194,13 +194,22 @@ def main():
     # HIP event pairs around the kernels of one frame per step on context 0 (each pair costs a few microseconds of
     # stream idle time, so not on every frame)
     det.profileEnable(args.steps * 12 + 12, stride=max(1, F // NS))
+    # one event per step and stream (no host wait): per-step spread, reported next to the mean
+    marks = [[torch.cuda.Event(enable_timing=True) for _ in range(NS)] for _ in range(args.steps + 1)]
     barrier()
+    for s_, ev in zip(streams, marks[0]):
+        ev.record(s_)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for k in range(args.steps):
         step()
+        for s_, ev in zip(streams, marks[k + 1]):
+            ev.record(s_)
     barrier()
     dt = time.perf_counter() - t0
     ms, lvl = det.profileRead()
+    # a step is over when its last stream is: time of step k = latest end of step k - latest end of step k-1
+    ends = np.array([[marks[0][0].elapsed_time(marks[k][s_]) for s_ in range(NS)] for k in range(args.steps + 1)]).max(axis=1)
+    step_ms = np.diff(ends)
 
     nkp = int(sum(int(c.item()) for c in cnt))      # keypoints per step on this rank
     # RCCL over xGMI only for the counters: MAX of the time, SUM of the keypoints
@@ -211,17 +220,20 @@ def main():
         px, bytes_frame = detect_algorithmic_bytes(det, ROWS, COLS)
         stats = dets[0].lastLevelStats()
         n_corners = float(sum(s["n_candidates"] for s in stats))      # FAST corners of the last frame of context 0
+        n_surv = float(sum(s["n_after_nms"] for s in stats))
         n_kp = nkp / F
         # Algorithmic HBM bytes per launch: what any implementation of the stage must move.
         #   fast_kernel    every pyramid level read once (sum_s P_s = 3.096 B per input pixel) + 4 B per corner out
         #   harris_kernel  9x9 footprints lie inside the levels (read once more) + 4 B in / 4 B out per corner
         #   nms_kernel     8 B per corner in, 8 B per survivor out (per-cell maxima are cache traffic)
-        #   bad_kernel     the (blur-extended) windows lie inside the levels: sum_s P_s + 16 B in + 64 B out per keypoint
+        #   bad_det_kernel the (blur-extended) windows lie inside the levels: sum_s P_s + 80 B record in + 64 B out per keypoint
         #                  (the reference design -- per-level blur + global integral images, SURVEY 8d -- moves
         #                  2 F P + 5 sum P_s + gathers ~ 1.06 GB for the same stage; reported as survey_design_bytes)
+        #   resize chain   level s read + level s+1 written, s = 0..6: (2 F - 2) P + P_0 - P_7 ... = sum_s P_s + sum_{s>=1} P_s - P_7
         sumP = float(sum(px))
+        chain_bytes = float(sum(px[:-1]) + sum(px[1:]))
         kinfo = {0: ("fast_kernel", sumP + 4 * n_corners), 1: ("harris_kernel", sumP + 8 * n_corners),
-                 2: ("nms_kernel", 8 * n_corners + 8 * 60000.0), 10: ("bad_kernel<blur,48>", sumP + 80 * n_kp)}
+                 2: ("nms_kernel", 8 * n_corners + 8 * n_surv), 10: ("bad_det_kernel", sumP + 144 * n_kp)}
 
         def table(ms_, lvl_):
             t = {}
@@ -233,50 +245,84 @@ def main():
                                "achieved": round(nbytes / (avg * 1e-3) / 1e9, 1), "frac": round(nbytes / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
             return t
 
+        def chain_ms_per_frame(ms_, lvl_):
+            nl = max(1, int((lvl_ == 0).sum()))
+            return float(ms_[lvl_ >= 100].sum()) / nl
+
         live = table(ms, lvl)
-        chain_ms = ms[lvl >= 100]
-        nl = max(1, int((lvl == 0).sum()))
-        chain_per_frame_ms = float(chain_ms.sum()) / nl
-        dom = max(live, key=lambda k: live[k]["avg_launch_ms"]) if live else None
-        roof = {"bound": "hbm", "kernel": dom, "achieved": live[dom]["achieved"] if dom else None, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": live[dom]["frac"] if dom else None, "traffic": None,
-                "algorithmic_bytes_per_launch": live[dom]["algorithmic_bytes"] if dom else None,
-                "avg_launch_ms": live[dom]["avg_launch_ms"] if dom else None,
-                "launches_timed": live[dom]["launches_timed"] if dom else 0, "concurrent_streams": NS,
-                "note": "dominant kernel = longest average launch among the timed kernels; every kernel of this pipeline "
-                        "is VALU-issue bound on MI355X (DESIGN.md section 5), so the HBM fraction is small by construction",
-                "kernels_live": live,
-                "resize_chain_ms_per_frame": round(chain_per_frame_ms, 5),
+        live_chain = chain_ms_per_frame(ms, lvl)
+        # the same kernels with nothing else running (frames on ONE stream, after the timed region): a kernel property,
+        # unlike the live durations, which stretch with the number of frames sharing the GPU -- this is what `frac` quotes
+        det.profileEnable(512, stride=1)
+        for i in range(min(8, F)):
+            det.detectAndComputeAsync(frames[i], kps[i], desc[i], cnt[i], capacity=NFEATURES)
+        torch.cuda.synchronize()
+        ms2, lvl2 = det.profileRead()
+        iso = table(ms2, lvl2)
+        iso_chain = chain_ms_per_frame(ms2, lvl2)
+        dom = max(iso, key=lambda k: iso[k]["avg_launch_ms"]) if iso else None
+
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r02_counters.json"))) if os.path.exists(os.path.join(ROOT, "profiles", "r02_counters.json")) else {}
+        roof = {"bound": "hbm", "kernel": dom, "achieved": iso[dom]["achieved"] if dom else None, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": iso[dom]["frac"] if dom else None,
+                "traffic": (prof.get("traffic_bytes_per_launch", {}) or {}).get(dom),
+                "algorithmic_bytes_per_launch": iso[dom]["algorithmic_bytes"] if dom else None,
+                "avg_launch_ms": iso[dom]["avg_launch_ms"] if dom else None,
+                "launches_timed": iso[dom]["launches_timed"] if dom else 0,
+                "how": "dominant kernel = longest average launch; duration from HIP event pairs recorded by the library on the "
+                       "launch stream around that kernel, frames on one stream (after the timed region), so that the figure is a "
+                       "property of the kernel; `live` = the same pairs inside the timed region, three frames in flight",
+                "kernels_isolated": iso,
+                "live": {"concurrent_streams": NS, "kernels": live, "resize_chain_ms_per_frame": round(live_chain, 5)},
                 "whole_frame": {"survey_8d_bytes_per_frame": 0.9e9, "ms_per_frame": round(t_max / args.steps / F * 1e3, 4),
                                 "achieved": round(0.9e9 / (t_max / args.steps / F) / 1e9, 1),
                                 "frac": round(0.9e9 / (t_max / args.steps / F) / 1e9 / HBM_PEAK_GBS, 4)}}
         if dom and dom.startswith("bad"):
             roof["survey_design_bytes"] = 2 * sumP + 5 * sumP + 338e6 + 80 * n_kp
-        if NS > 1:
-            # the live events above see each kernel sharing the GPU with the other stream's kernels; for reference,
-            # the same kernels with nothing else running (4 frames on one stream, after the timed region)
-            det.profileEnable(256, stride=1)
-            for i in range(min(4, F)):
-                det.detectAndComputeAsync(frames[i], kps[i], desc[i], cnt[i], capacity=NFEATURES)
-            torch.cuda.synchronize()
-            ms2, lvl2 = det.profileRead()
-            iso = table(ms2, lvl2)
-            roof["kernels_isolated"] = iso
-            if dom in iso:
-                roof["isolated"] = {k: iso[dom][k] for k in ("avg_launch_ms", "achieved", "frac")}
-        tr_path = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tr_path):
-            try:
-                pk = json.load(open(tr_path)).get("per_kernel", {})
-                hit = [v for k, v in pk.items() if k.split("<")[0] == (dom or "").split("<")[0]]
-                roof["traffic"] = hit[0]["bytes_per_launch"] if hit else None
-            except Exception:
-                pass
+        # the pass the north star names: pyramid (resize chain) + FAST, bytes = levels read by FAST + levels read / written by
+        # the chain + corners out, over the isolated durations
+        if "fast_kernel" in iso:
+            pf_ms = iso_chain + iso["fast_kernel"]["avg_launch_ms"]
+            pf_bytes = chain_bytes + iso["fast_kernel"]["algorithmic_bytes"]
+            roof["pyramid_fast"] = {"algorithmic_bytes": pf_bytes, "resize_chain_ms": round(iso_chain, 5),
+                                    "fast_kernel_ms": iso["fast_kernel"]["avg_launch_ms"], "ms": round(pf_ms, 5),
+                                    "achieved": round(pf_bytes / (pf_ms * 1e-3) / 1e9, 1),
+                                    "frac": round(pf_bytes / (pf_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                    "survey_8d_bytes": float(sum(px) + sum(px[1:])),
+                                    "frac_vs_survey_8d_bytes": round((sum(px) + sum(px[1:])) / (pf_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        # the bound that binds: VALU instruction issue (integral / box phases of the BAD kernel: the LDS pipe).  VALU
+        # wave-instructions per launch come from the committed SQ counter pass, the issue peak from the committed
+        # micro-benchmark (profiles/valu_rate.txt): 1024 SIMDs x clock / cycles per wave-instruction
+        if prof.get("valu_wave_instr_per_launch") and prof.get("issue_peak_wave_instr_per_s"):
+            peak = float(prof["issue_peak_wave_instr_per_s"])
+            vt = {}
+            for name, row in iso.items():
+                v = prof["valu_wave_instr_per_launch"].get(name)
+                if v:
+                    rate = v / (row["avg_launch_ms"] * 1e-3)
+                    vt[name] = {"valu_wave_instr": v, "avg_launch_ms": row["avg_launch_ms"], "achieved": round(rate / 1e9, 1), "frac": round(rate / peak, 4)}
+            vchain = prof["valu_wave_instr_per_launch"].get("resize_chain")
+            if vchain and iso_chain > 0:
+                rate = vchain / (iso_chain * 1e-3)
+                vt["resize_chain"] = {"valu_wave_instr": vchain, "avg_launch_ms": round(iso_chain, 5), "achieved": round(rate / 1e9, 1), "frac": round(rate / peak, 4)}
+            tot = prof.get("valu_wave_instr_per_frame")
+            roof["valu"] = {"bound": "valu", "unit": "G wave-instructions/s", "peak": round(peak / 1e9, 1),
+                            "peak_from": "profiles/valu_rate.txt: %s cycles per wave-instruction, 1024 SIMDs, %s GHz" % (prof.get("cycles_per_wave_instr"), prof.get("clock_ghz")),
+                            "kernels_isolated": vt}
+            if tot:
+                rate = tot / (t_max / args.steps / F)
+                roof["valu"]["whole_frame"] = {"valu_wave_instr_per_frame": tot, "ms_per_frame": round(t_max / args.steps / F * 1e3, 4),
+                                               "achieved": round(rate / 1e9, 1), "frac": round(rate / peak, 4)}
+            if prof.get("lds_cycles_per_launch", {}).get(dom):
+                lc = prof["lds_cycles_per_launch"][dom]
+                roof["lds"] = {"kernel": dom, "lds_array_cycles_per_launch": lc, "cus": 256,
+                               "busy_frac": round(lc / 256 / (prof.get("clock_ghz", 2.4) * 1e9) / (iso[dom]["avg_launch_ms"] * 1e-3), 4)}
 
         out = {"metric": "Mkeypoints/s detectAndCompute (8K, 40k kp, BAD512)",
                "value": round(kp_total / t_max / 1e6, 3), "unit": "Mkeypoints/s", "n_gpus": world, "rccl_world": rccl_world,
                "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(t_max / args.steps * 1e3, 4),
+               "ms_per_step_min_median_max": [round(float(step_ms.min()), 4), round(float(np.median(step_ms)), 4), round(float(step_ms.max()), 4)],
                "ms_per_frame": round(t_max / args.steps / F * 1e3, 4),
                "higher_is_better": True, "scaling": "weak",
                "vs_baseline": round(kp_total / t_max / 1e6 / BASELINE_MKPS, 2), "dtype": "u8",
@@ -287,9 +333,9 @@ def main():
                           "frames_each_once": sorted(sum(all_frames, [])) == list(range(F * world)), "streams_per_gpu": NS,
                           "keypoints_per_frame": round(nkp / F, 1), "parallelism": f"frames sharded over {world} GPU(s)"},
                "roofline": roof}
-        roof["profiles"] = {"avg_launch_ms (live, frames of other streams share the GPU)": "profiles/r01_n_kernel_stats_3streams.csv",
-                            "isolated / kernels_isolated (one stream)": "profiles/r01_n_kernel_stats.csv",
-                            "traffic": "profiles/traffic.json", "instruction counts": "profiles/r01_pmc_sq_n.txt"}
+        roof["profiles"] = {"frac / kernels_isolated (one stream)": "profiles/r02_kernel_stats.csv",
+                            "live (the default command, three frames in flight)": "profiles/r02_kernel_stats_3streams.csv",
+                            "traffic, valu, lds": "profiles/r02_counters.json <- profiles/r02_pmc_sq.txt, r02_pmc_lds.txt, r02_traffic.json, valu_rate.txt"}
 
         # The reference's own protocol (samples/sample_benchmark.cpp:39-52: 1 warm-up, then N x {detectAndComputeAsync;
         # stream.waitForCompletion()}): one frame at a time on one stream, host wait included.  This is the figure that

@@ -3,6 +3,8 @@
   C2  4K detect-only                                   (README.md:52-54 protocol)
   C3  4K, 40k keypoints, compute-only BAD256 / BAD512  (README.md:60-62; sample_benchmark.cpp:132-141)
   C4  4K, 40k keypoints, compute-only HashSIFT256/512
+      (tools/workloads.py: the C3 / C4 keypoints are the detector's on a denser 4K frame with NMS radius 5 -- EXACTLY
+      40 000 over all eight levels; the default radius saturates a 4K pyramid at ~22 000)
   plus detect / detectAndCompute on FHD, 4K and 8K for all four descriptor types.
 Protocol of samples/sample_benchmark.cpp:39-52: 1 warm-up + N timed iterations of the async call followed by a
 stream synchronise, input resident on the device.  Prints one JSON object; --out writes it to a file."""
@@ -16,7 +18,7 @@ import numpy as np
 import torch
 
 import cef_loader
-from tools import synth
+from tools import synth, workloads
 
 cef = cef_loader.load()
 EF = cef.EfficientFeatures
@@ -76,6 +78,22 @@ def main():
                 flop = 2.0 * 129 * (nbytes * 8) * n
                 row["projection_GFLOP"] = round(flop / 1e9, 3)
             res["rows"].append(row)
+    # C3 / C4 as BASELINE.json states them: compute-only on EXACTLY 40 000 keypoints of a 4K frame
+    img = torch.from_numpy(workloads.frame_c34()).cuda()
+    rows, cols = workloads.K4
+    kps = torch.zeros((5, 40000), dtype=torch.float32, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    det = EF.create(workloads.N40K, 1.2, 8, 0, 20, workloads.C34_NMS_RADIUS, EF.BAD_256)
+    det.detectAsync(img, kps, cnt); torch.cuda.synchronize()
+    n = int(cnt.item())
+    for name, dt, nbytes, cfg in (("BAD256", EF.BAD_256, 32, "C3"), ("BAD512", EF.BAD_512, 64, "C3"),
+                                  ("HashSIFT256", EF.HASH_SIFT_256, 32, "C4"), ("HashSIFT512", EF.HASH_SIFT_512, 64, "C4")):
+        d = EF.create(40000, dtype=dt)
+        desc = torch.zeros((40000, nbytes), dtype=torch.uint8, device="cuda")
+        ms_c = perf(lambda: d.computeAsync(img, kps, n=n, descriptors=desc), args.iters)
+        res["rows"].append({"config": cfg, "size": "4k", "descriptor": name, "keypoints": n, "compute_ms": round(ms_c, 4),
+                            "Mdescriptors_per_s": round(n / ms_c / 1e3, 2),
+                            "keypoints_from": "detector, NMS radius %d, frame density %.1f (tools/workloads.py)" % (workloads.C34_NMS_RADIUS, workloads.C34_DENSITY)})
     s = json.dumps(res, indent=1)
     print(s)
     if args.out:
