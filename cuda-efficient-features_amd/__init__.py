@@ -22,11 +22,13 @@ LIB_PATH = os.path.join(_HERE, "libefx_hip.so")
 
 EFX_OK = 0
 STATUS_NAMES = {0: "EFX_OK", -1: "EFX_ERR_BAD_ARG", -2: "EFX_ERR_UNSUPPORTED", -3: "EFX_ERR_HIP",
-                -4: "EFX_ERR_NO_DEVICE", -5: "EFX_ERR_NOMEM"}
+                -4: "EFX_ERR_NO_DEVICE", -5: "EFX_ERR_NOMEM", -6: "EFX_ERR_OVERFLOW"}
 
 # every symbol include/efx.h declares (checked by tests/test_abi.py)
+EFX_ERR_OVERFLOW = -6
+
 ABI_SYMBOLS = [
-    "efx_default_params", "efx_create", "efx_destroy", "efx_last_error", "efx_version",
+    "efx_default_params", "efx_create", "efx_destroy", "efx_device_bytes", "efx_last_error", "efx_version",
     "efx_set_max_features", "efx_get_max_features", "efx_set_scale_factor", "efx_get_scale_factor",
     "efx_set_nlevels", "efx_get_nlevels", "efx_set_first_level", "efx_get_first_level",
     "efx_set_fast_threshold", "efx_get_fast_threshold", "efx_set_nonmax_radius", "efx_get_nonmax_radius",
@@ -108,6 +110,8 @@ def lib():
         L.efx_compute_kp4_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_int,
                                             C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]
         L.efx_last_count.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        L.efx_device_bytes.restype = C.c_size_t
+        L.efx_device_bytes.argtypes = [C.c_void_p]
         L.efx_last_level_stats.argtypes = [C.c_void_p, C.POINTER(LevelStats), C.c_int, C.POINTER(C.c_int)]
         L.efx_detect.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         L.efx_compute.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
@@ -315,6 +319,10 @@ class EfficientFeatures:
                                             keypoints.data_ptr(), keypoints.stride(0) * 4, n, descriptors.data_ptr(),
                                             descriptors.stride(0), _stream_ptr(stream)))
         return descriptors[:n]
+
+    def deviceBytes(self):
+        """Device memory the context holds (pyramid, tile headers, corner / survivor arenas, keypoint lists)."""
+        return int(lib().efx_device_bytes(self._h))
 
     def lastCount(self):
         n = C.c_int(0)

@@ -830,14 +830,20 @@ __global__ __launch_bounds__(256) void fast_kernel(
             bits &= bits - 1;
             s_list[pos++] = (uint16_t)((cx * 16 + b) | (brow << 8));
         }
-        if (tid == 0) s_start = total > 0 ? atomicAdd(&cnt->cand_total[l][tile & (EFX_NSUB - 1)].v, total) : 0;
+        if (tid == 0) {
+            s_start = total > 0 ? atomicAdd(&cnt->cand_total[l][tile & (EFX_NSUB - 1)].v, total) : 0;
+            // the arenas are sized for a corner density, not for the worst case (efx_api.cpp, build_geometry): a frame that
+            // does not fit is void -- every later kernel of the frame returns at once, N = 0, the host enlarges the arenas
+            if ((unsigned)(s_start + total) > L.cand_sub_cap) cnt->sum.overflow = 1;
+        }
         __syncthreads();
 
         // ---- phase 4: append the corner coordinates to the level's corner array (responses: harris_kernel) ----
         const int start = s_start;
         for (int k = tid; k < total; k += 256) {
             const int lx = s_list[k] & 0xff, ly = s_list[k] >> 8;
-            cand[(size_t)(tile & (EFX_NSUB - 1)) * L.cand_sub_cap + start + k].xy = (uint32_t)(x0 + lx) | ((uint32_t)(y0 + ly) << 16);
+            if ((unsigned)(start + k) < L.cand_sub_cap)
+                cand[(size_t)(tile & (EFX_NSUB - 1)) * L.cand_sub_cap + start + k].xy = (uint32_t)(x0 + lx) | ((uint32_t)(y0 + ly) << 16);
         }
         TileHdr* h = hdr + tile;
         if (tid <= EFX_CELLS_PER_TILE) h->cell_off[tid] = (uint16_t)s_celloff[tid];
@@ -860,6 +866,7 @@ __global__ __launch_bounds__(64) void harris_kernel(
     __shared__ unsigned long long s_cellmax[EFX_CELLS_PER_TILE];
     __shared__ unsigned s_celltie[EFX_CELLS_PER_TILE];     // largest response key that two corners of the cell share
     const int lane = threadIdx.x;
+    if (cnt->sum.overflow) return;                          // void frame (arena overflow in fast_kernel)
     if ((int)blockIdx.x >= T->total_tiles) {
         // One extra workgroup per level: canonical rank of every tile's first corner = exclusive scan of the tile counts
         // in tile order, needed to apply the 10 % cap deterministically (spec S2).  Only consulted (and only computed)
@@ -963,6 +970,7 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
     TileHdr* hl = hdr + L.tile_base;
     const Corner* cand = cand_all + L.cand_base;
     const int lane = threadIdx.x;
+    if (cnt->sum.overflow) return;                          // void frame (arena overflow in fast_kernel)
 
     s_keep[lane] = 0ull;
     for (int i = lane; i < 9 * 16; i += 64) {
@@ -1205,7 +1213,10 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
     const unsigned long long my_round_mask = s_keep[lane];
     const int nsurv = __shfl(wave_incl_scan(__popcll(my_round_mask)), 63, 64);
     int start = 0;
-    if (lane == 0 && nsurv > 0) start = atomicAdd(&cnt->surv_total[l][tile & (EFX_NSUB - 1)].v, nsurv);
+    if (lane == 0 && nsurv > 0) {
+        start = atomicAdd(&cnt->surv_total[l][tile & (EFX_NSUB - 1)].v, nsurv);
+        if ((unsigned)(start + nsurv) > L.surv_sub_cap) cnt->sum.overflow = 1;      // void frame, see fast_kernel
+    }
     start = __shfl(start, 0, 64);
     // second pass: write the survivors in canonical order
     Corner* surv = surv_all + L.surv_base + (size_t)(tile & (EFX_NSUB - 1)) * L.surv_sub_cap;
@@ -1213,7 +1224,8 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
     for (int k0 = 0; k0 < n_valid; k0 += 64, round++) {
         const unsigned long long m = (unsigned long long)(unsigned)__shfl((int)(my_round_mask & 0xffffffffu), round, 64) |
                                      ((unsigned long long)(unsigned)__shfl((int)(my_round_mask >> 32), round, 64) << 32);
-        if ((m >> lane) & 1ull) surv[(size_t)start + base + __popcll(m & ((1ull << lane) - 1ull))] = own[k0 + lane];
+        const int slot = start + base + __popcll(m & ((1ull << lane) - 1ull));
+        if (((m >> lane) & 1ull) && (unsigned)slot < L.surv_sub_cap) surv[(size_t)slot] = own[k0 + lane];
         base += __popcll(m);
     }
     if (lane == 0) { hl[tile].surv_start = (uint32_t)start; hl[tile].surv_count = (uint32_t)nsurv; }
@@ -1256,6 +1268,14 @@ __global__ __launch_bounds__(1024) void select_kernel(const LevelTable* __restri
         if (l == 0) { const int n = all < capacity ? all : capacity; cnt->sum.n_out = n; if (d_count) *d_count = n; }
     }
     if (!L.active) { if (tid == 0) { cnt->sum.kept[l] = 0; cnt->thresh[l] = 0; } return; }
+    if (cnt->sum.overflow) {
+        // void frame (arena overflow): N = 0, nothing is selected, emitted or described
+        if (tid == 0) {
+            cnt->sum.kept[l] = 0; cnt->thresh[l] = ~0ull;
+            if (l == 0) { cnt->sum.n_out = 0; if (d_count) *d_count = 0; }
+        }
+        return;
+    }
 
     int nsub[EFX_NSUB];
     int n = 0, nmaxsub = 0;
@@ -1422,7 +1442,7 @@ __global__ __launch_bounds__(64) void emit_kernel(const LevelTable* __restrict__
     if (!L.active) return;
     const TileHdr& h = hdr[gt];
     const int sc = (int)h.surv_count;
-    if (sc == 0) return;
+    if (sc == 0 || cnt->sum.overflow) return;
     const unsigned long long thresh = cnt->thresh[l];
     const Corner* q = surv_all + L.surv_base + (size_t)((gt - L.tile_base) & (EFX_NSUB - 1)) * L.surv_sub_cap + h.surv_start;
     const int lane = threadIdx.x;

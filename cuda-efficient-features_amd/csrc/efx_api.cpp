@@ -25,6 +25,7 @@ extern const unsigned char efx_blob_bad256[], efx_blob_bad512[], efx_blob_hashsi
 }
 
 #define HS_KPAD 132
+#define EFX_ARENA_DENSITY_MIN_PX (2u << 20)   // levels above 2 Mpx get density-sized corner / survivor arenas (build_geometry)
 #define HS_KB 144             // K of the bf16 projection: 129 padded to 9 MFMA steps of 16
 
 namespace {
@@ -268,6 +269,8 @@ struct efx_context {
     DevBuf d_table, pyramid, hdr, cand, cmax, surv, counters, kp4, kp_level, img, kps, descout, count, maskbuf;
     Summary* h_mirror = nullptr;    // host copy of the last frame's summary, filled on demand by fetch_summary()
     int n_out_max = 0;              // sum of the active levels' quotas
+    bool arena_full = false;        // corner / survivor arenas sized for the worst case (set after a frame overflowed them)
+    bool g_arena_full = false;      // ... as the cached geometry was built
     bool has_frame = false;
     const uint8_t* last_img0 = nullptr; int last_pitch0 = 0;
     // per-launch timing of the pipeline's kernels (efx_profile_*)
@@ -305,7 +308,7 @@ int validate_params(const efx_params& p, std::string& err)
 int build_geometry(efx_context* c, int rows, int cols)
 {
     const efx_params& p = c->p;
-    if (c->g_rows == rows && c->g_cols == cols && memcmp(&c->g_p, &p, sizeof(p)) == 0) return EFX_OK;
+    if (c->g_rows == rows && c->g_cols == cols && c->g_arena_full == c->arena_full && memcmp(&c->g_p, &p, sizeof(p)) == 0) return EFX_OK;
     LevelTable& T = c->h_table;
     memset(&T, 0, sizeof(T));
     T.nlevels = p.nlevels;
@@ -352,10 +355,21 @@ int build_geometry(efx_context* c, int rows, int cols)
         L.cmax_base = ncmax;
         ncmax += (size_t)L.tiles_x * 4 * L.tiles_y * 4;
         if (L.active) {
-            // sub-array k holds the tiles with (tile & 7) == k; a 64x64 tile has at most 4096 corners
+            // sub-array k holds the tiles with (tile & 7) == k; a 64x64 tile has at most 4096 corners.
+            // Worst-case arenas (every pixel a corner) cost 8 + 6.4 bytes per pyramid pixel: 1.5 GB for an 8K frame.  Large
+            // levels are therefore sized for a corner DENSITY -- 1/8 of the pixels for FAST corners (the reference keeps at
+            // most 1/10, .cpp:252; the benchmark frames have 1/37), 1/32 for NMS survivors (all the corners when the NMS
+            // radius is below 4 px) -- with a quarter of slack for the imbalance between the sub-arrays.  A frame that does
+            // not fit raises Summary::overflow on the device and is void (N = 0); the host then switches the context to
+            // worst-case arenas (arena_full) and reports EFX_ERR_OVERFLOW / reruns (efx_last_count, host_detect_impl).
             const size_t tiles_per_sub = ((size_t)L.tiles_x * L.tiles_y + EFX_NSUB - 1) / EFX_NSUB;
-            const size_t csub = tiles_per_sub * EFX_TILE * EFX_TILE;
-            const size_t ssub = csub < (size_t)L.cap ? csub : (size_t)L.cap;
+            const size_t cfull = tiles_per_sub * EFX_TILE * EFX_TILE;
+            const size_t sfull = cfull < (size_t)L.cap ? cfull : (size_t)L.cap;
+            size_t csub = cfull, ssub = sfull;
+            if (!c->arena_full && (size_t)L.rows * L.cols > EFX_ARENA_DENSITY_MIN_PX) {
+                csub = std::min(cfull, cfull / 8 + cfull / 32);
+                ssub = std::min(sfull, p.nonmax_radius < 4 ? csub : cfull / 32 + cfull / 128);
+            }
             L.cand_sub_cap = (unsigned)csub;
             L.surv_sub_cap = (unsigned)ssub;
             ncand += csub * EFX_NSUB;
@@ -394,7 +408,7 @@ int build_geometry(efx_context* c, int rows, int cols)
         }
         HIP_TRY(c->err, hipMemcpy(c->d_table.p, blob.data(), blob.size(), hipMemcpyHostToDevice));
     }
-    c->g_rows = rows; c->g_cols = cols; c->g_p = p;
+    c->g_rows = rows; c->g_cols = cols; c->g_p = p; c->g_arena_full = c->arena_full;
     return EFX_OK;
 }
 
@@ -735,13 +749,34 @@ static int fetch_summary(const efx_context* ctx)
     return hipMemcpy(ctx->h_mirror, &dc->sum, sizeof(Summary), hipMemcpyDeviceToHost) == hipSuccess ? EFX_OK : EFX_ERR_HIP;
 }
 
+// A frame that overflowed the density-sized arenas is void: switch the context to worst-case arenas and say so.
+static int check_overflow(const efx_context* ctx)
+{
+    if (!ctx->h_mirror->overflow) return EFX_OK;
+    efx_context* c = const_cast<efx_context*>(ctx);
+    c->arena_full = true;
+    return set_err(c->err, EFX_ERR_OVERFLOW, "the frame had more FAST corners / NMS survivors than the scratch arenas hold (they are sized "
+                   "for a corner density of 1/8); the arenas are enlarged to the worst case from the next call on: repeat the call");
+}
+
 int efx_last_count(const efx_context* ctx, int* n)
 {
     if (!ctx || !n || !ctx->h_mirror || !ctx->has_frame) return EFX_ERR_BAD_ARG;
     const int rc = fetch_summary(ctx);
     if (rc) return rc;
     *n = ctx->h_mirror->n_out;
-    return EFX_OK;
+    return check_overflow(ctx);
+}
+
+size_t efx_device_bytes(const efx_context* ctx)
+{
+    if (!ctx) return 0;
+    const DevBuf* b[] = { &ctx->d_table, &ctx->pyramid, &ctx->hdr, &ctx->cand, &ctx->cmax, &ctx->surv, &ctx->counters, &ctx->kp4,
+                          &ctx->kp_level, &ctx->img, &ctx->kps, &ctx->descout, &ctx->count, &ctx->maskbuf, &ctx->desc.params,
+                          &ctx->desc.responses, &ctx->desc.kp4, &ctx->desc.img, &ctx->desc.desc };
+    size_t t = 0;
+    for (const DevBuf* d : b) t += d->bytes;
+    return t;
 }
 
 int efx_last_level_stats(const efx_context* ctx, efx_level_stats* stats, int max_levels, int* nlevels)
@@ -756,7 +791,7 @@ int efx_last_level_stats(const efx_context* ctx, efx_level_stats* stats, int max
         stats[i].n_kept = ctx->h_mirror->kept[i];
     }
     if (nlevels) *nlevels = nl;
-    return EFX_OK;
+    return check_overflow(ctx);
 }
 
 int efx_convert(const void* h_keypoints, size_t kps_pitch, int n, efx_keypoint* out)
@@ -798,12 +833,17 @@ static int host_detect_impl(efx_context* ctx, const uint8_t* h_image, int rows, 
         HIP_TRY(ctx->err, ctx->maskbuf.reserve(ipitch * rows));
         HIP_TRY(ctx->err, hipMemcpy2D(ctx->maskbuf.p, ipitch, h_mask, mask_pitch, cols, rows, hipMemcpyHostToDevice));
     }
-    int rc = detect_common(ctx, static_cast<const uint8_t*>(ctx->img.p), rows, cols, ipitch, ctx->kps.p, kpitch,
-                           want_desc ? static_cast<uint8_t*>(ctx->descout.p) : nullptr, nbytes, capacity, nullptr, nullptr,
-                           h_mask ? static_cast<const uint8_t*>(ctx->maskbuf.p) : nullptr, ipitch);
-    if (rc) return rc;
-    HIP_TRY(ctx->err, hipStreamSynchronize(nullptr));
-    if (fetch_summary(ctx) != EFX_OK) return set_err(ctx->err, EFX_ERR_HIP, "summary copy failed");
+    for (int attempt = 0; attempt < 2; attempt++) {
+        int rc = detect_common(ctx, static_cast<const uint8_t*>(ctx->img.p), rows, cols, ipitch, ctx->kps.p, kpitch,
+                               want_desc ? static_cast<uint8_t*>(ctx->descout.p) : nullptr, nbytes, capacity, nullptr, nullptr,
+                               h_mask ? static_cast<const uint8_t*>(ctx->maskbuf.p) : nullptr, ipitch);
+        if (rc) return rc;
+        HIP_TRY(ctx->err, hipStreamSynchronize(nullptr));
+        if (fetch_summary(ctx) != EFX_OK) return set_err(ctx->err, EFX_ERR_HIP, "summary copy failed");
+        // the synchronous entry points hide an arena overflow: enlarge (check_overflow) and run the frame again
+        if (check_overflow(ctx) == EFX_OK || attempt == 1) break;
+    }
+    if (ctx->h_mirror->overflow) return EFX_ERR_OVERFLOW;
     const int cnt = ctx->h_mirror->n_out;
     *n = cnt;
     if (cnt > 0) {

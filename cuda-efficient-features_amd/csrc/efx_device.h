@@ -68,6 +68,7 @@ struct Summary {                // what the host mirror receives (written by sel
     int kept[EFX_MAX_LEVELS];           // after quota
     int n_out;                          // N written to the caller
     int dbg;
+    int overflow;                       // a corner / survivor sub-array was too small for this frame: the frame is void (N = 0)
 };
 struct Counters {               // zeroed at the start of every frame
     PaddedCounter cand_total[EFX_MAX_LEVELS][EFX_NSUB];

@@ -37,7 +37,9 @@ typedef enum efx_status {
     EFX_ERR_UNSUPPORTED = -2,
     EFX_ERR_HIP = -3,           /* a HIP runtime call failed (the reference only printf's: cuda_macro.h:23-28) */
     EFX_ERR_NO_DEVICE = -4,
-    EFX_ERR_NOMEM = -5
+    EFX_ERR_NOMEM = -5,
+    EFX_ERR_OVERFLOW = -6       /* the frame had more FAST corners / NMS survivors than the context's scratch arenas hold
+                                 * (see efx_last_count); the arenas have been enlarged, repeat the call */
 } efx_status;
 
 /* cuda_efficient_features.h:39-45 */
@@ -91,7 +93,9 @@ typedef struct efx_level_stats {
 
 void efx_default_params(efx_params* p);                         /* the defaults of create(), .h:47-48 */
 int efx_create(const efx_params* p, efx_context** out);         /* EfficientFeatures::create, .cpp:406-411 */
-int efx_destroy(efx_context* ctx);                              /* ~EfficientFeatures, .cpp:413-415 */
+int efx_destroy(efx_context* ctx);
+/* Device memory the context holds (pyramid, tile headers, corner / survivor arenas, keypoint lists), in bytes. */
+size_t efx_device_bytes(const efx_context* ctx);                              /* ~EfficientFeatures, .cpp:413-415 */
 const char* efx_last_error(const efx_context* ctx);             /* ctx may be NULL: last create() error */
 int efx_version(void);
 

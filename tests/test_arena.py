@@ -1,0 +1,67 @@
+"""Right-sized scratch arenas: large pyramid levels get corner / survivor arenas sized for a corner
+density (1/8 of the pixels; the reference keeps at most 1/10, cuda_efficient_features.cpp:252) instead of "every pixel is a
+corner".  A frame that does not fit is void on the device (N = 0, flag raised); the host enlarges the arenas: the async
+API reports EFX_ERR_OVERFLOW at the next query and the repeated call is exact, the synchronous API reruns by itself."""
+import numpy as np
+import pytest
+
+from tools import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cef():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import cef_loader
+    return cef_loader.load()
+
+
+def test_8k_context_is_below_300_mb(cef):
+    import torch
+    img = torch.from_numpy(synth.synth_frame(4320, 7680, seed=1000)).cuda()
+    det = cef.EfficientFeatures.create(40000, dtype=cef.EfficientFeatures.BAD_512)
+    kps, desc, cnt = det.detectAndComputeAsync(img)
+    torch.cuda.synchronize()
+    assert det.lastCount() == 40000
+    assert det.deviceBytes() <= 300e6, det.deviceBytes()
+
+
+def test_overflowing_frame_is_void_then_exact(cef, oracle):
+    """Uniform noise has ~25 % FAST corners at threshold 20: above the 1/8 the arenas of a > 2 Mpx level are sized for."""
+    import torch
+    img = synth.noise_frame(1300, 1900, seed=11)                  # level 0: 2.47 Mpx
+    d_img = torch.from_numpy(img).cuda()
+    det = cef.EfficientFeatures.create(3000, dtype=cef.EfficientFeatures.BAD_256)
+    kps, desc, cnt = det.detectAndComputeAsync(d_img)
+    torch.cuda.synchronize()
+    assert int(cnt.item()) == 0                                    # void frame: nothing written
+    with pytest.raises(cef.EfxError) as e:
+        det.lastCount()
+    assert e.value.status == cef.EFX_ERR_OVERFLOW
+    small = det.deviceBytes()
+    kps, desc, cnt = det.detectAndComputeAsync(d_img)              # the arenas are worst-case now
+    torch.cuda.synchronize()
+    n = det.lastCount()
+    assert det.deviceBytes() > small
+    prev = oracle.set_threads(32)
+    ref = oracle.detect_and_compute(img, nfeatures=3000, desc_type=oracle.BAD_256)
+    oracle.set_threads(prev)
+    assert n == ref["n"] == int(cnt.item())
+    assert ref["stats"]["n_candidates"][0] > ref["stats"]["n_after_cap"][0]      # the 10 % cap is active as well
+    assert np.array_equal(kps[:, :n].cpu().numpy().view(np.uint32), ref["kps"].view(np.uint32))
+    assert np.array_equal(desc[:n].cpu().numpy(), ref["desc"])
+
+
+def test_synchronous_api_reruns_by_itself(cef, oracle):
+    img = synth.noise_frame(1300, 1900, seed=12)
+    det = cef.EfficientFeatures.create(2000, dtype=cef.EfficientFeatures.BAD_256)
+    kps = det.detect(img)
+    prev = oracle.set_threads(32)
+    ref = oracle.detect_and_compute(img, nfeatures=2000, desc_type=-1)
+    oracle.set_threads(prev)
+    k = oracle.unpack_keypoints(ref["kps"])
+    assert len(kps) == ref["n"] > 0
+    assert np.array_equal(kps["x"], k["x"].astype(np.float32)) and np.array_equal(kps["y"], k["y"].astype(np.float32))
