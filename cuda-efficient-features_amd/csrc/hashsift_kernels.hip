@@ -235,8 +235,8 @@ __global__ __launch_bounds__(HS_NT) void patch_sift_kernel(
     __syncthreads();
     // L2 normalise, clip at 0.2, renormalise, x512 -> uchar (hash_sift.cpp:311-330).  The CPU code adds the 128 squares
     // serially; here a fixed tree does (element i with i + 64, then the butterfly 32, 16, .. 1 inside one wave): 10
-    // instructions instead of a 256-instruction chain on one lane.  The order is part of the device arithmetic the oracle
-    // models (efxo_hashsift_responses_fixedpoint); against the serial sum the norm moves by ~1e-7 relative.
+    // instructions instead of a 256-instruction chain on one lane.  The order is part of the device arithmetic the tests'
+    // CPU model reproduces bit for bit; against the serial sum the norm moves by ~1e-7 relative.
     for (int pass = 0; pass < 2; pass++) {
         if (tid < 64) {
             const float d0 = s_desc[tid], d1 = s_desc[tid + 64];
