@@ -15,6 +15,18 @@
 #include "efx_device.h"
 #include "bad_affine.h"
 #include <algorithm>
+#include <stdio.h>
+#include <stdlib.h>
+// INVESTIGATION (EFX_DEBUG_BUILD builds only): EFX_TRACE=1 names every launch on stderr, waits for it
+// and calls a digest hook (efx_api.cpp) -- how the "16 processes share the GPU" discrepancy was traced to stores of one XCD
+// missing from memory after fast_kernel's first run on freshly allocated buffers
+#ifdef EFX_DEBUG_BUILD
+static const bool g_trace = getenv("EFX_TRACE") != nullptr;
+void (*efx_trace_hook)(const DetectLaunch&, const char*) = nullptr;
+#define EFX_TRACE_POINT(name) do { if (g_trace) { hipError_t te_ = hipStreamSynchronize(stream); fprintf(stderr, "efx-trace done: %s (%s)\n", name, hipGetErrorString(te_)); fflush(stderr); if (efx_trace_hook) efx_trace_hook(a, name); } } while (0)
+#else
+#define EFX_TRACE_POINT(name) do { } while (0)
+#endif
 
 namespace {
 
@@ -1705,6 +1717,7 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
                            zeroed ? nullptr : a.counters, H.nlevels);
         zeroed = true;
         a.prof.end(prof, 100 + s, stream);
+        EFX_TRACE_POINT("resize");
     }
     if (use_tower) {
         const bool prof = a.prof.begin(100 + tw.s0, stream);
@@ -1712,28 +1725,42 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
                            a.pitch0, a.pyramid, tw, zeroed ? nullptr : a.counters);
         zeroed = true;
         a.prof.end(prof, 100 + tw.s0, stream);
+        EFX_TRACE_POINT("tower");
     }
     if (a.pyramid_only) return hipGetLastError();
+#ifdef EFX_DEBUG_BUILD
+    if (g_trace) {          // poison the corner arenas, so that entries fast_kernel never stores show up in the digest
+        size_t ncand = 0;
+        for (int l = 0; l < H.nlevels; l++) if (H.lv[l].active) ncand = std::max<size_t>(ncand, H.lv[l].cand_base + (size_t)H.lv[l].cand_sub_cap * EFX_NSUB);
+        (void)hipMemsetAsync(a.cand, 0xFF, ncand * sizeof(Corner), stream);
+        if (getenv("EFX_TRACE_SYNC_POISON")) (void)hipStreamSynchronize(stream);
+    }
+#endif
     {
         const int aligned0 = (((uintptr_t)a.img0 | (uintptr_t)a.pitch0) & 3u) == 0;
         bool prof = a.prof.begin(0, stream);
         hipLaunchKernelGGL(fast_kernel, dim3(H.total_tiles), dim3(256), 0, stream, a.d_table, a.img0, a.pitch0, aligned0,
                            a.pyramid, a.threshold, a.mask, a.mask_pitch, a.cand, a.hdr, a.counters, a.knobs.dbg & 15);
         a.prof.end(prof, 0, stream);
+        EFX_TRACE_POINT("fast");
         prof = a.prof.begin(1, stream);
         hipLaunchKernelGGL(harris_kernel, dim3(H.total_tiles + H.nlevels), dim3(64), 0, stream, a.d_table, a.img0, a.pitch0, aligned0, a.pyramid,
                            a.cand, a.cmax, a.hdr, a.counters, a.knobs.dbg & 15);
         a.prof.end(prof, 1, stream);
+        EFX_TRACE_POINT("harris");
     }
     bool prof = a.prof.begin(2, stream);
     hipLaunchKernelGGL(nms_kernel, dim3(H.total_tiles), dim3(64), 0, stream, a.d_table, a.hdr, a.cand, a.cmax, a.surv,
                        a.counters, a.nonmax_radius, a.knobs.dbg >> 4);
     a.prof.end(prof, 2, stream);
+    EFX_TRACE_POINT("nms");
     prof = a.prof.begin(3, stream);
     hipLaunchKernelGGL(select_kernel, dim3(H.nlevels), dim3(1024), 0, stream, a.d_table, a.hdr, a.surv, a.counters,
                        a.capacity, a.d_count);
+    EFX_TRACE_POINT("select");
     hipLaunchKernelGGL(emit_kernel, dim3(H.total_tiles), dim3(64), 0, stream, a.d_table, a.hdr, a.surv, a.counters,
                        a.img0, a.pitch0, a.pyramid, (uint8_t*)a.d_keypoints, a.kps_pitch, a.capacity, a.kp4, a.kp_level);
+    EFX_TRACE_POINT("emit");
     if (a.capacity > 0) {
         int nmax = 0;
         for (int s = 0; s < H.nlevels; s++) if (H.lv[s].active) nmax += H.lv[s].quota;
@@ -1744,10 +1771,30 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
                                static_cast<Affine*>(a.bad_affine), a.bad_scale, a.bad_reach, a.bad_smax, a.bad_sfixed);
     }
     a.prof.end(prof, 3, stream);
+    EFX_TRACE_POINT("angle");
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     return e;        // the host reads the summary (N, per-level counts) on demand: fetch_summary(), efx_api.cpp
 }
+
+#ifdef EFX_DEBUG_BUILD
+// INVESTIGATION (16-process discrepancy): run harris_kernel (stages & 1) and / or nms_kernel (stages & 2)
+// again on the buffers of the last frame; the survivor counters are reset first.  Not part of the product path.
+hipError_t efx_debug_rerun_stages(const DetectLaunch& a, int stages, hipStream_t stream)
+{
+    const LevelTable& H = *a.h_table;
+    const int aligned0 = (((uintptr_t)a.img0 | (uintptr_t)a.pitch0) & 3u) == 0;
+    hipError_t e = hipMemsetAsync(&a.counters->surv_total[0][0], 0, sizeof(a.counters->surv_total), stream);
+    if (e != hipSuccess) return e;
+    if (stages & 1)
+        hipLaunchKernelGGL(harris_kernel, dim3(H.total_tiles + H.nlevels), dim3(64), 0, stream, a.d_table, a.img0, a.pitch0, aligned0, a.pyramid,
+                           a.cand, a.cmax, a.hdr, a.counters, 0);
+    if (stages & 2)
+        hipLaunchKernelGGL(nms_kernel, dim3(H.total_tiles), dim3(64), 0, stream, a.d_table, a.hdr, a.cand, a.cmax, a.surv,
+                           a.counters, a.nonmax_radius, 0);
+    return hipGetLastError();
+}
+#endif
 
 hipError_t efx_launch_convert_keypoints(const void* d_keypoints, size_t kps_pitch, int n, float4* kp4, hipStream_t stream)
 {

@@ -19,6 +19,12 @@
 #include <string>
 #include <vector>
 
+#ifdef EFX_DEBUG_BUILD
+// INVESTIGATION (EFX_TRACE=1): see trace_digest below
+extern void (*efx_trace_hook)(const DetectLaunch&, const char*);
+static void trace_digest(const DetectLaunch& a, const char* name);
+#endif
+
 // learned parameter blobs, embedded by params_embed.S
 extern "C" {
 extern const unsigned char efx_blob_bad256[], efx_blob_bad512[], efx_blob_hashsift256[], efx_blob_hashsift512[];
@@ -271,6 +277,7 @@ struct efx_context {
     int n_out_max = 0;              // sum of the active levels' quotas
     bool arena_full = false;        // corner / survivor arenas sized for the worst case (set after a frame overflowed them)
     bool g_arena_full = false;      // ... as the cached geometry was built
+    DetectLaunch last_launch;       // investigation (efx_debug_rerun): the last frame's launch arguments
     bool has_frame = false;
     const uint8_t* last_img0 = nullptr; int last_pitch0 = 0;
     // per-launch timing of the pipeline's kernels (efx_profile_*)
@@ -464,9 +471,15 @@ int detect_common(efx_context* c, const uint8_t* d_image, int rows, int cols, si
         a.bad_smax = S; a.bad_sfixed = S == 48 ? 48 : 0;
         affine_ready = true;
     }
+#ifdef EFX_DEBUG_BUILD
+    efx_trace_hook = trace_digest;
+#endif
     hipError_t e = efx_launch_detect(a, stream);
     if (e != hipSuccess) return set_err(c->err, EFX_ERR_HIP, "detect launch failed: %s", hipGetErrorString(e));
     c->has_frame = true; c->last_img0 = d_image; c->last_pitch0 = (int)pitch;
+#ifdef EFX_DEBUG_BUILD
+    c->last_launch = a; c->last_launch.prof = ProfRec{};
+#endif
 
     if (d_desc && capacity > 0) {
         // blur + describe per level (.cpp:302-307), here one launch over the keypoints of all levels
@@ -767,6 +780,95 @@ int efx_last_count(const efx_context* ctx, int* n)
     *n = ctx->h_mirror->n_out;
     return check_overflow(ctx);
 }
+
+#ifdef EFX_DEBUG_BUILD
+// INVESTIGATION: EFX_TRACE=1 -- digest of the corner coordinates (through the tile headers) after every launch
+static void trace_digest(const DetectLaunch& a, const char* name)
+{
+    if (strcmp(name, "fast") && strcmp(name, "harris") && strcmp(name, "nms") && strcmp(name, "angle")) return;
+    const LevelTable& T = *a.h_table;
+    size_t ncand = 0;
+    for (int l = 0; l < T.nlevels; l++) if (T.lv[l].active) ncand = std::max<size_t>(ncand, T.lv[l].cand_base + (size_t)T.lv[l].cand_sub_cap * EFX_NSUB);
+    std::vector<TileHdr> hdr((size_t)T.total_tiles);
+    std::vector<Corner> cand(ncand);
+    static Counters cn;
+    if (hipMemcpy(hdr.data(), a.hdr, hdr.size() * sizeof(TileHdr), hipMemcpyDeviceToHost) != hipSuccess) return;
+    if (hipMemcpy(cand.data(), a.cand, cand.size() * sizeof(Corner), hipMemcpyDeviceToHost) != hipSuccess) return;
+    if (hipMemcpy(&cn, a.counters, sizeof(Counters), hipMemcpyDeviceToHost) != hipSuccess) return;
+    unsigned long long hx = 0; long long nsum = 0; int bad_range = 0, unwritten = 0, off_tile = 0;
+    for (int l = 0; l < T.nlevels; l++) {
+        const LevelDev& L = T.lv[l];
+        if (!L.active) continue;
+        for (int t = 0; t < L.tiles_x * L.tiles_y; t++) {
+            const TileHdr& th = hdr[L.tile_base + t];
+            const int n = th.cell_off[EFX_CELLS_PER_TILE];
+            nsum += n;
+            if ((size_t)th.cand_start + n > L.cand_sub_cap) { bad_range++; continue; }
+            const Corner* q = cand.data() + L.cand_base + (size_t)(t & (EFX_NSUB - 1)) * L.cand_sub_cap + th.cand_start;
+            int uw = 0, ot = 0;
+            for (int k = 0; k < n; k++) {
+                if (q[k].xy == 0xffffffffu) uw++;
+                else if ((int)((q[k].xy & 0xffff) >> 6) != t % L.tiles_x || (int)((q[k].xy >> 16) >> 6) != t / L.tiles_x) ot++;
+            }
+            unwritten += uw; off_tile += ot;
+            if ((uw || ot) && !strcmp(name, "fast"))
+                fprintf(stderr, "efx-trace   level %d tile %d (sub %d): start %u count %d unwritten %d wrong-tile %d | sub total %d\n", l, t, t & 7,
+                        th.cand_start, n, uw, ot, cn.cand_total[l][t & 7].v);
+            for (int k = 0; k < n; k++) { unsigned long long h = 1469598103934665603ull; for (int b = 0; b < 4; b++) { h ^= (q[k].xy >> (8 * b)) & 0xff; h *= 1099511628211ull; } hx += h; }
+        }
+    }
+    int tot0 = 0; for (int sub = 0; sub < EFX_NSUB; sub++) tot0 += cn.cand_total[0][sub].v;
+    fprintf(stderr, "efx-trace digest after %s: xy %llu corners %lld counter_total_l0 %d bad_ranges %d unwritten %d in_wrong_tile %d\n", name, hx & 0x7fffffffull, nsum, tot0, bad_range, unwritten, off_tile);
+    fflush(stderr);
+}
+
+// INVESTIGATION ONLY (not declared in include/efx.h): repeat harris (stages & 1) / nms (stages & 2) on the last frame's
+// buffers and return the per-level survivor totals of the repeated run (tools/microbench/fuzz_stress.py)
+int efx_debug_rerun(efx_context* ctx, int stages, int* surv_totals, int nlevels_max)
+{
+    if (!ctx || !ctx->has_frame || !surv_totals) return EFX_ERR_BAD_ARG;
+    HIP_TRY(ctx->err, hipDeviceSynchronize());
+    hipError_t e = efx_debug_rerun_stages(ctx->last_launch, stages, nullptr);
+    if (e != hipSuccess) return set_err(ctx->err, EFX_ERR_HIP, "rerun failed: %s", hipGetErrorString(e));
+    HIP_TRY(ctx->err, hipDeviceSynchronize());
+    static Counters h;
+    HIP_TRY(ctx->err, hipMemcpy(&h, ctx->counters.p, sizeof(Counters), hipMemcpyDeviceToHost));
+    for (int l = 0; l < nlevels_max && l < ctx->h_table.nlevels; l++) {
+        int t = 0;
+        for (int sub = 0; sub < EFX_NSUB; sub++) t += h.surv_total[l][sub].v;
+        surv_totals[l] = t;
+    }
+    // order-independent digests of what nms_kernel reads: the corners {xy, resp} of every tile (through the headers), the
+    // per-cell maxima, the headers' candidate fields; and of the pyramid
+    if (nlevels_max >= 8) {
+        auto fnv = [](const void* p, size_t n, unsigned long long hsh) { const unsigned char* b = static_cast<const unsigned char*>(p); for (size_t i = 0; i < n; i++) { hsh ^= b[i]; hsh *= 1099511628211ull; } return hsh; };
+        std::vector<unsigned char> hdr(ctx->hdr.bytes), cand(ctx->cand.bytes), cmax(ctx->cmax.bytes), pyr(ctx->pyramid.bytes);
+        HIP_TRY(ctx->err, hipMemcpy(hdr.data(), ctx->hdr.p, hdr.size(), hipMemcpyDeviceToHost));
+        HIP_TRY(ctx->err, hipMemcpy(cand.data(), ctx->cand.p, cand.size(), hipMemcpyDeviceToHost));
+        HIP_TRY(ctx->err, hipMemcpy(cmax.data(), ctx->cmax.p, cmax.size(), hipMemcpyDeviceToHost));
+        HIP_TRY(ctx->err, hipMemcpy(pyr.data(), ctx->pyramid.p, pyr.size(), hipMemcpyDeviceToHost));
+        unsigned long long hc = 0, hx = 0, hh = 0;
+        const LevelTable& T = ctx->h_table;
+        const TileHdr* H = reinterpret_cast<const TileHdr*>(hdr.data());
+        const Corner* C = reinterpret_cast<const Corner*>(cand.data());
+        for (int l = 0; l < T.nlevels; l++) {
+            const LevelDev& L = T.lv[l];
+            if (!L.active) continue;
+            for (int t = 0; t < L.tiles_x * L.tiles_y; t++) {
+                const TileHdr& th = H[L.tile_base + t];
+                const int n = th.cell_off[EFX_CELLS_PER_TILE];
+                const Corner* q = C + L.cand_base + (size_t)(t & (EFX_NSUB - 1)) * L.cand_sub_cap + th.cand_start;
+                for (int k = 0; k < n; k++) { hx += fnv(&q[k].xy, 4, 1469598103934665603ull); hc += fnv(&q[k], 8, 1469598103934665603ull); }
+                hh += fnv(th.cell_off, sizeof(th.cell_off), 1469598103934665603ull + t);
+            }
+        }
+        surv_totals[4] = (int)(hx & 0x7fffffff); surv_totals[5] = (int)(hc & 0x7fffffff);
+        surv_totals[6] = (int)(fnv(cmax.data(), (size_t)T.lv[T.nlevels - 1].cmax_base * 8, 1469598103934665603ull) & 0x7fffffff);
+        surv_totals[7] = (int)((fnv(pyr.data(), pyr.size(), 1469598103934665603ull) ^ hh) & 0x7fffffff);
+    }
+    return EFX_OK;
+}
+#endif
 
 size_t efx_device_bytes(const efx_context* ctx)
 {

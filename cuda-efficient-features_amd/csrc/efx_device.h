@@ -224,6 +224,7 @@ struct DetectLaunch {
 };
 
 hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream);
+hipError_t efx_debug_rerun_stages(const DetectLaunch& a, int stages, hipStream_t stream);      // investigation only
 
 struct DescribeLaunch {
     const uint8_t* img0; int pitch0; int rows0, cols0;     // image for level index 0 / single-image mode
