@@ -176,11 +176,17 @@ def main():
     desc = [torch.zeros((NFEATURES, 64), dtype=torch.uint8, device="cuda") for _ in range(F)]
     cnt = [torch.zeros(1, dtype=torch.int32, device="cuda") for _ in range(F)]
 
-    # one step = one batched call over the F frames (efx_detect_and_compute_batch_async: frame i on context / stream i % NS)
-    batch = cef.Batch(dets, streams, frames, kps, desc, cnt, NFEATURES)
+    # one step = one batched call over the F frames (efx_detect_and_compute_batch_async: frame i on context / stream i % NS).
+    # F = 8 frames do not divide over 3 streams: the frame order rotates from step to step, so that every stream gets the
+    # same number of frames over NS steps (otherwise one stream finishes a third early and the tail runs on two)
+    def rot(lst, r):
+        return lst[r:] + lst[:r]
+    batches = [cef.Batch(dets, streams, rot(frames, r), rot(kps, r), rot(desc, r), rot(cnt, r), NFEATURES) for r in range(NS)]
+    step_no = [0]
 
     def step():
-        batch.run()
+        batches[step_no[0] % NS].run()
+        step_no[0] += 1
 
     def barrier():
         torch.cuda.synchronize()
