@@ -389,6 +389,7 @@ def main():
         print(json.dumps(out), flush=True)
 
     if dist is not None:
+        dist.barrier()                  # rank 0 is still measuring its isolated kernels / latency: leave together
         dist.destroy_process_group()
 
 
