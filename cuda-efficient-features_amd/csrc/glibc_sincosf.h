@@ -12,6 +12,10 @@
 // up to there the reduction's n * (pi/2) is exact (n <= 7, the constant has three trailing zero bits), so the result is
 // the same whether libm was built with fused multiply-add (x86-64 ifunc variants) or not; beyond, the two builds differ.
 // Compile without FP contraction (the Makefile passes -ffp-contract=off).
+//
+// Upstream: Arm Optimized Routines math/sincosf.h, sincosf_data.c -- Copyright (c) 2018, Arm Limited, SPDX MIT -- as
+// adopted by the GNU C Library (sysdeps/ieee754/flt-32/s_sincosf.h, Copyright (C) 2018-2022 Free Software Foundation,
+// Inc., LGPL-2.1-or-later).  Full notices: THIRD_PARTY_NOTICES.md next to this file.
 #define EFX_GLIBC_SINCOSF_MAX 11.0f
 #pragma once
 #include <stdint.h>
