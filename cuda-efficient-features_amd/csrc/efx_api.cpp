@@ -138,28 +138,38 @@ int describer_init(Describer& d, int kind, int nbits, float scale)
     } else {
         // HashSIFTImpl ctor, hash_sift.cpp:384-397: Mat(nbits,129,CV_64F).convertTo(CV_32F)
         const double* w64 = reinterpret_cast<const double*>(nbits == 256 ? efx_blob_hashsift256 : efx_blob_hashsift512);
-        std::vector<float> w((size_t)nbits * HS_KPAD + 900 + 511 * 511, 0.f);
+        std::vector<float> w((size_t)nbits * HS_KPAD + 1024 + 2 * 511 * 511, 0.f);
         for (int j = 0; j < nbits; j++)
             for (int k = 0; k < 129; k++) w[(size_t)j * HS_KPAD + k] = (float)w64[(size_t)j * 129 + k];
-        // Gaussian pixel weights of computePatchSIFT (hash_sift.cpp:220-224,247): host expf, same call as the CPU code
+        // Gaussian pixel weights of computePatchSIFT (hash_sift.cpp:220-224,247): host expf, same call as the CPU code.  Stored
+        // x 2^16 (exact): the kernel's histogram is 16.16 fixed point and a power of two commutes with all its products
         const float kp_scale = 1.f / 6;
         const float kp_radius = kp_scale * (float)32 * 0.5f;
         const float kernel_sigma = 0.5f * (float)4 * 3.f * kp_radius;
         const float dist_scale = -1.f / ((float)2 * kernel_sigma * kernel_sigma);
         const float cx = 0.5f * (float)30, cy = 0.5f * (float)30;
-        for (int y = 0; y < 30; y++)
-            for (int x = 0; x < 30; x++) {
+        // Laid out in the vote loop's order (patch_sift_kernel): thread t owns the pixels (x, y0 + 2 k), k = 0 .. 3, of its cell
+        for (int t = 0; t < 256; t++)
+            for (int k = 0; k < 4; k++) {
+                const int cell = t & 15, wq = t >> 4;
+                const int x = 8 * (cell & 3) + (wq & 7), y = 8 * (cell >> 2) + (wq >> 3) + 2 * k;
+                if (x >= 30 || y >= 30) continue;
                 const float ddx = (float)x - cx, ddy = (float)y - cy;
-                w[(size_t)nbits * HS_KPAD + y * 30 + x] = expf(dist_scale * (ddx * ddx + ddy * ddy));
+                w[(size_t)nbits * HS_KPAD + k * 256 + t] = 65536.f * expf(dist_scale * (ddx * ddx + ddy * ddy));
             }
-        // orientation bins scaleO * atan2f(dy, dx) for every integer gradient (hash_sift.cpp:171,254,258)
+        // orientation bin scaleO * atan2f(dy, dx) and magnitude sqrtf(dx^2 + dy^2) of every integer gradient
+        // (hash_sift.cpp:171,254-258), interleaved: one 8-byte gather per pixel
         {
             const float PI_2 = (float)6.283185307179586476925286766559;
             const float scaleO = (float)8 / PI_2;
-            float* lut = w.data() + (size_t)nbits * HS_KPAD + 900;
+            float* lut = w.data() + (size_t)nbits * HS_KPAD + 1024;
             for (int dy = -255; dy <= 255; dy++)
-                for (int dx = -255; dx <= 255; dx++)
-                    lut[(dy + 255) * 511 + (dx + 255)] = scaleO * atan2f((float)dy, (float)dx);
+                for (int dx = -255; dx <= 255; dx++) {
+                    const float fdx = (float)dx, fdy = (float)dy;
+                    float* e = lut + 2 * ((size_t)(dy + 255) * 511 + (dx + 255));
+                    e[0] = scaleO * atan2f(fdy, fdx);
+                    e[1] = sqrtf(fdx * fdx + fdy * fdy);
+                }
         }
         // The projection runs on the bf16 matrix cores with W split EXACTLY into three bf16 terms, W = W1 + W2 + W3
         // (8 + 8 + 8 mantissa bits; each term is the round-to-nearest-even bf16 of what is left): the 129-vector is integer
@@ -211,12 +221,13 @@ int describer_run(Describer& d, std::string& err, DescribeLaunch a, float* dbg_r
     } else {
         if (a.desc && ((((uintptr_t)a.desc) | a.desc_pitch) & 3u))
             return set_err(err, EFX_ERR_BAD_ARG, "HashSIFT descriptors need a 4-byte aligned base and pitch");
-        HIP_TRY(err, d.responses.reserve((size_t)a.n * HS_KB * sizeof(uint16_t)));
+        HIP_TRY(err, d.responses.reserve((size_t)a.n * (HS_KB * sizeof(uint16_t) + EFX_HS_REC_BYTES)));      // 129-vectors, then the per-keypoint records
         HashSiftDev h;
         h.nbits = d.nbits;
         h.W = static_cast<const float*>(d.params.p);
         h.Wb = reinterpret_cast<const uint16_t*>(static_cast<const unsigned char*>(d.params.p) + d.hs_wb_off);
         h.responses = static_cast<uint16_t*>(d.responses.p);
+        h.records = static_cast<unsigned char*>(d.responses.p) + (size_t)a.n * HS_KB * sizeof(uint16_t);     // 288 n: 32-byte aligned
         h.dbg_responses = dbg_resp;
         h.dbg_T = dbg_T;
         hipError_t e = efx_launch_hashsift(a, h, stream);

@@ -246,11 +246,13 @@ struct DescribeLaunch {
 
 hipError_t efx_launch_bad(const DescribeLaunch& a, const BadParamsDev* d_params, float reach, hipStream_t stream);
 
+#define EFX_HS_REC_BYTES 64
 struct HashSiftDev {
     int nbits;
     const float* W;             // nbits x 132 (129 padded to 132), fp32, device; the 30x30 / 511x511 tables follow
     const uint16_t* Wb;         // 3 x nbits x 144 bf16: W split into three bf16 terms (project_sign_kernel)
     uint16_t* responses;        // scratch n x 144 bf16: the 129-vectors (integer valued, exact), K padded with zeros
+    void* records;              // scratch n x EFX_HS_REC_BYTES: per-keypoint affine map + window (hs_record_kernel)
     float* dbg_responses;       // optional n x 129
     float* dbg_T;               // optional n x nbits
 };

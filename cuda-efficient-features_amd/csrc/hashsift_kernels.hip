@@ -31,38 +31,106 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int efx_u32x2 __attribute__((ext_vector_type(2)));
 
-struct AffineF { float m00, m01, m02, m10, m11, m12, pad0, pad1; };
+// Per-keypoint record of the PatchSIFT kernel: the rectifying affine map (rectifyPatch, hash_sift.cpp:111-132), the
+// keypoint's pyramid level and the window of it the 32 x 32 patch can touch.  One LANE per keypoint computes it
+// (hs_record_kernel): the cosf / sinf restatement is ~600 instructions of double arithmetic, which inside the descriptor
+// kernel ran on one lane of a workgroup while 255 waited (24 M wave-instructions per 40 000 keypoints).
+struct HsRec {
+    float m00, m01, m02, m10, m11, m12;
+    int wx0, wy0;
+    const uint8_t* img;
+    int pitch, rows, cols;
+    int S;                       // window edge; 0: the window does not fit the LDS plan (blurred: descriptor of zeros, as before; raw: gathers from memory)
+    int pad[2];
+};
+static_assert(sizeof(HsRec) == 64, "one record per 64-byte line");
 
-// LDS plan (dynamic, BLUR only): [ raw | hb | win S*S u8 ] (blur_window.h)
-// SF != 0: every keypoint is known to need exactly an SF x SF window (detector keypoints: size 31, crop scale 1 ->
-// 48), so the blur's index arithmetic (divisions by the group / column-pair counts) folds to constants
-template <bool BLUR, int SF>
-#ifndef HS_NT
-#define HS_NT 256
-#endif
-__global__ __launch_bounds__(HS_NT) void patch_sift_kernel(
+__global__ __launch_bounds__(256) void hs_record_kernel(
     const uint8_t* __restrict__ img0, int pitch0, int rows0, int cols0,
     const uint8_t* __restrict__ pyramid, const LevelTable* __restrict__ T,
     const float4* __restrict__ kp4, const int* __restrict__ kp_level, const int* __restrict__ d_count, int n,
-    float crop_scale, int smax, const float* __restrict__ mag_scale /*30*30*/, const float* __restrict__ obin_lut /*511*511*/,
+    float crop_scale, int smax, int sfixed, int dword_rows, HsRec* __restrict__ rec)
+{
+    const int count = d_count ? min(*d_count, n) : n;
+    const int kid = blockIdx.x * 256 + threadIdx.x;
+    if (kid >= count) return;
+    const float4 kp = kp4[kid];
+    HsRec A;
+    A.img = img0; A.pitch = pitch0; A.rows = rows0; A.cols = cols0;
+    if (kp_level) {
+        const int l = kp_level[kid];
+        if (l > 0) { const LevelDev& L = T->lv[l]; A.img = pyramid + L.img_off; A.pitch = L.pitch; A.rows = L.rows; A.cols = L.cols; }
+        else { A.rows = T->lv[0].rows; A.cols = T->lv[0].cols; }
+    }
+    const float px = kp.x, py = kp.y, size = kp.z, angle = kp.w;
+    // rectifyPatch, hash_sift.cpp:111-132
+    const float PI_1 = (float)3.1415926535897932384626433832795;
+    const float s = crop_scale * size / (0.5f * (float)(32 + 32));
+    const float theta = PI_1 * angle / 180;
+    // cosf / sinf exactly as the CPU code gets them from libm (glibc's sincosf restated in glibc_sincosf.h and checked
+    // against the host libm for every float up to 11); larger angles: the rounded double result
+    float c1 = 1.f, s1 = 0.f;
+    if (angle >= 0) {
+        if (theta < EFX_GLIBC_SINCOSF_MAX) { c1 = efx_glibc_sincosf(theta, 1); s1 = efx_glibc_sincosf(theta, 0); }
+        else { c1 = (float)cos((double)theta); s1 = (float)sin((double)theta); }
+    }
+    const float cost = s * c1;
+    const float sint = s * s1;
+    A.m00 = +cost; A.m01 = -sint; A.m02 = (-cost + sint) * (float)32 / 2.f + px;
+    A.m10 = +sint; A.m11 = +cost; A.m12 = (-sint - cost) * (float)32 / 2.f + py;
+    // window the patch can touch
+    const float sg = fabsf(crop_scale * size / 32.f);
+    const int R = (int)floorf(sg * 22.63f + 2.01f);     // >= 22.63 sg + 1: floor(u) and floor(u) + 1 of every patch pixel are inside
+    int S = sfixed ? sfixed : 2 * R + 2;
+    bool fits = sfixed ? (2 * R + 2 == sfixed) : (S <= smax && S > 0);
+    if (dword_rows && ((((uintptr_t)A.img) | (uintptr_t)A.pitch) & 3u)) fits = false;      // the raw window is staged as aligned dwords
+    if (!fits && !sfixed) S = smax;
+    const int ix = (int)floorf(px), iy = (int)floorf(py);
+    A.wx0 = min(max(ix - R, 0), max(A.cols - S, 0));
+    A.wy0 = min(max(iy - R, 0), max(A.rows - S, 0));
+    A.S = fits ? S : 0;
+    A.pad[0] = 0; A.pad[1] = 0;
+    rec[kid] = A;
+}
+
+// floor(x + 0.5) of a non-negative float below 2^31 in one instruction (the sum is formed exactly, not in float)
+__device__ __forceinline__ uint32_t hs_round_half_up(float x)
+{
+    int r;
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return (uint32_t)r;
+}
+
+// LDS plan (dynamic): BLUR [ raw | hb | win S*S u8 ] (blur_window.h); otherwise the raw window, rows of WP bytes.
+// SF != 0: every keypoint is known to need exactly an SF x SF window (detector keypoints: size 31, crop scale 1 ->
+// 48), so the blur's index arithmetic (divisions by the group / column-pair counts) folds to constants.
+// What the kernel's time is made of (tools/microbench/hs_stage.py, 40 000 keypoints): workgroup turnaround 12 us, the
+// warp's arithmetic 26 us, its pixel fetches 61 us when they are gathers from memory -- the vector cache looks up one
+// 128-byte line per clock, and the 64 pixels of a wave lie in 12+ image rows whatever the lane mapping -- which is why
+// the window is staged in LDS by row-coalesced loads first (50 line look-ups per keypoint instead of 450); votes 50 us.
+// Everything that does not depend on the pixel is hoisted: a thread's four patch pixels share their column (warp: x,
+// m00 x, m10 x; votes: x, cf, column offset), the 16.16 scale rides in the weight table (stored in the threads' own order:
+// one coalesced load), the magnitude sqrtf(dx^2 + dy^2) in the orientation table, rounding to fixed point is one instruction.
+template <bool BLUR, int SF>
+__global__ __launch_bounds__(256) void patch_sift_kernel(
+    const HsRec* __restrict__ rec, const int* __restrict__ d_count, int n, int smax,
+    const float* __restrict__ vote_weight16 /*4 x 256: weight x 65536 of pixel k of thread t*/,
+    const float2* __restrict__ grad_lut /*511*511 {orientation bin, magnitude}*/,
     float taps0, float taps1, float taps2, float taps3,
     uint16_t* __restrict__ responses /* n x HS_KB bf16 */, float* __restrict__ dbg_responses /* n x 129 or null */, int dbg_arg)
 {
     const int dbg = EFX_DBG(dbg_arg);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ AffineF s_aff;
     __shared__ uint8_t s_patch[32 * 32];
     // Histogram in 16.16 fixed point (order-independent integer sums).  A pixel votes for TWO adjacent orientation bins of
     // each of four cells: the pair goes out as ONE 64-bit LDS atomic on two packed 32-bit counters (a counter stays below
-    // 2^31, so nothing carries from the low into the high one).  Per cell 5 words hold the pairs (0,1) (2,3) .. (8,9), 4 more
-    // the pairs (1,2) (3,4) (5,6) (7,8); a bin is the sum of its two homes.  Half the atomics of one counter per bin.
+    // 2^31, so nothing carries from the low into the high one).  Slot p of a cell holds the pair (p, p + 1), p = 0 .. 8; a
+    // bin is the sum of its two homes.  Half the atomics of one counter per bin.
     __shared__ unsigned long long s_h64[6 * 6 * 9];
-    __shared__ float s_hist[6 * 6 * 10];
-    __shared__ float s_desc[128];
-    __shared__ float s_rf[32], s_cf[32];
-    __shared__ int s_ri[32], s_ci[32];
-    __shared__ float s_scale;
+    __shared__ float s_rf[32];
+    __shared__ int s_roff[32];                                           // byte offset of the cell row / column in s_h64
 
     // neighbouring keypoints (canonical order) on the same XCD: their windows share L2 lines; chunked over the count
     const int count = d_count ? min(*d_count, n) : n;
@@ -70,37 +138,10 @@ __global__ __launch_bounds__(HS_NT) void patch_sift_kernel(
     const int kid = xcd_chunked(blockIdx.x, count);
     const int tid = threadIdx.x;
 
-    const float4 kp = kp4[kid];
-    const uint8_t* img = img0; int pitch = pitch0, rows = rows0, cols = cols0;
-    if (kp_level) {
-        const int l = kp_level[kid];
-        if (l > 0) { const LevelDev& L = T->lv[l]; img = pyramid + L.img_off; pitch = L.pitch; rows = L.rows; cols = L.cols; }
-        else { rows = T->lv[0].rows; cols = T->lv[0].cols; }
-    }
-    const float px = kp.x, py = kp.y, size = kp.z, angle = kp.w;
-    for (int i = tid; i < 6 * 6 * 9; i += HS_NT) s_h64[i] = 0ull;      // ordered before the votes by the barriers below
-
-    // rectifyPatch, hash_sift.cpp:111-132
-    if (tid == 0) {
-        const float PI_1 = (float)3.1415926535897932384626433832795;
-        const float s = crop_scale * size / (0.5f * (float)(32 + 32));
-        const float theta = PI_1 * angle / 180;
-        // cosf / sinf exactly as the CPU code gets them from libm (glibc's sincosf restated in glibc_sincosf.h and checked
-        // against the host libm for every float up to 11); larger angles: the rounded double result
-        float c1 = 1.f, s1 = 0.f;
-        if (angle >= 0) {
-            if (theta < EFX_GLIBC_SINCOSF_MAX) { c1 = efx_glibc_sincosf(theta, 1); s1 = efx_glibc_sincosf(theta, 0); }
-            else { c1 = (float)cos((double)theta); s1 = (float)sin((double)theta); }
-        }
-        const float cost = s * c1;
-        const float sint = s * s1;
-        AffineF A;
-        A.m00 = +cost; A.m01 = -sint; A.m02 = (-cost + sint) * (float)32 / 2.f + px;
-        A.m10 = +sint; A.m11 = +cost; A.m12 = (-sint - cost) * (float)32 / 2.f + py;
-        A.pad0 = 0; A.pad1 = 0;
-        s_aff = A;
-    }
-    // HistBin rows/cols (hash_sift.cpp:162-184), kpScale = 1/6
+    const HsRec A = rec[kid];                                            // uniform address: scalar loads
+    const uint8_t* img = A.img; const int pitch = A.pitch, rows = A.rows, cols = A.cols;
+    for (int i = tid; i < 6 * 6 * 9; i += 256) s_h64[i] = 0ull;          // ordered before the votes by the barriers below
+    // HistBin rows/cols (hash_sift.cpp:162-184), kpScale = 1/6; cellw == cellh: one table serves rows and columns
     if (tid >= 64 && tid < 64 + 32) {
         const int i = tid - 64;
         const float kp_scale = 1.f / 6;
@@ -108,58 +149,69 @@ __global__ __launch_bounds__(HS_NT) void patch_sift_kernel(
         const float scaleR = 1.f / cellh;
         const float bin = scaleR * ((float)i - 0.5f * (float)32) + ((float)(4 / 2) - 0.5f);
         const int bi = (int)floorf(bin);
-        s_ri[i] = bi; s_rf[i] = bin - (float)bi;
-        s_ci[i] = bi; s_cf[i] = bin - (float)bi;       // cellw == cellh, same formula for columns
+        s_roff[i] = (bi + 1) * 9 * 8; s_rf[i] = bin - (float)bi;
     }
-
-
-    // window the patch can touch
-    const float sg = fabsf(crop_scale * size / 32.f);
-    int R = (int)floorf(sg * 22.63f + 2.01f);            // >= 22.63 sg + 1: floor(u) and floor(u) + 1 of every patch pixel are inside
-    int S = SF ? SF : 2 * R + 2;
-    const bool fits = !BLUR || (SF ? (2 * R + 2 == SF) : (S <= smax && S > 0));
-    if (!fits && !SF) S = smax;
-    const int ix = (int)floorf(px), iy = (int)floorf(py);
-    const int wx0 = min(max(ix - R, 0), max(cols - S, 0));
-    const int wy0 = min(max(iy - R, 0), max(rows - S, 0));
-    // LDS plan (BLUR): [ raw | hb | win S x S u8 ], raw / hb as blur_window.h lays them out.  Without the blur the warp
-    // below gathers its 4 bytes per patch pixel from memory: staging the raw window in LDS first was measured SLOWER
-    // (staging 28 us + warp 108 us against 88 us per 40 000 keypoints) -- the kernel's bottleneck is the LDS pipe (the
-    // histogram atomics), the gathers go through the texture path, which is otherwise idle.
+    const bool staged = A.S != 0;                                        // the window is in LDS
+    const bool fits = !BLUR || staged;
+    const int S = SF ? SF : (A.S ? A.S : smax);
+    const int wx0 = A.wx0, wy0 = A.wy0;
     const BlurGeom bg(S);
     uint8_t* raw = smem;
     float* hb = reinterpret_cast<float*>(smem + bg.raw_bytes());
-    uint8_t* win = smem + bg.raw_bytes() + bg.hb_bytes();
+    const int WP = 4 * ((3 + S + 3) >> 2);                               // window row pitch: a multiple of 4 (the warp reads dword pairs)
+    const int wofs = BLUR ? (int)(bg.raw_bytes() + bg.hb_bytes()) : (wx0 & 3);      // byte offset of window pixel (0, 0) in smem
+    uint8_t* win = smem + wofs;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(img), 0, rows * pitch, 0x00020000);
 
     if (BLUR && fits) {
-        efx_blur_window_lds<HS_NT>(img, pitch, rows, cols, wx0, wy0, S, raw, hb, taps0, taps1, taps2, taps3, tid,
+        efx_blur_window_lds<256>(img, pitch, rows, cols, wx0, wy0, S, raw, hb, taps0, taps1, taps2, taps3, tid,
             [&](int r, int c, int q0, int q1) {
-                *reinterpret_cast<uint16_t*>(win + r * S + c) = (uint16_t)(q0 | (q1 << 8));      // S and c are even
+                *reinterpret_cast<uint16_t*>(win + r * WP + c) = (uint16_t)(q0 | (q1 << 8));      // c is even
             });
+    }
+    if (!BLUR && staged) {
+        // raw window rows as aligned dwords (16 lanes per row); a frame smaller than the window: rows beyond it read as 0
+        // (range check of the buffer resource), columns beyond it hold the next row's bytes -- neither is ever used
+        const int ndw = WP >> 2, base = wy0 * pitch + (wx0 & ~3);
+        for (int r = tid >> 4; r < S; r += 16)
+            for (int jj = tid & 15; jj < ndw; jj += 16)
+                *reinterpret_cast<uint32_t*>(smem + r * WP + 4 * jj) = __builtin_amdgcn_raw_buffer_load_b32(rsrc, base + r * pitch + 4 * jj, 0, 0);
     }
     __syncthreads();
     if (dbg == 5) return;
 
-    // warpAffineLinear, hash_sift.cpp:68-109
+    // warpAffineLinear, hash_sift.cpp:68-109.  Thread (wave w, lane i) takes column x = 8 w + (i & 7) of rows
+    // (i >> 3) + 8 k: a wave covers an 8 x 8 block of the patch per step.  Both pixels of an image row come from ONE
+    // 2-byte load at any byte alignment (global: through a buffer resource, 32-bit offsets; blurred window: LDS).
     {
-        const AffineF A = s_aff;
-        for (int i = tid; i < 1024; i += HS_NT) {
-            const int y = i >> 5, x = i & 31;
-            const float u = A.m00 * (float)x + A.m01 * (float)y + A.m02;
-            const float v = A.m10 * (float)x + A.m11 * (float)y + A.m12;
+        const int x = 8 * (tid >> 6) + (tid & 7), y0 = (tid >> 3) & 7;
+        const float ax = A.m00 * (float)x, bx = A.m10 * (float)x;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float fy = (float)(y0 + 8 * k);
+            const float u = ax + A.m01 * fy + A.m02;
+            const float v = bx + A.m11 * fy + A.m12;
+            const float fu = floorf(u), fv = floorf(v);
+            const int ui = (int)fu, vi = (int)fv;
             uint8_t val = 0;
-            const int ui = (int)floorf(u), vi = (int)floorf(v);
-            if (fits && ui >= 0 && ui + 1 < cols && vi >= 0 && vi + 1 < rows) {
-                float p00, p01, p10, p11;
-                if (BLUR) {
-                    const int lx = min(max(ui - wx0, 0), S - 2), ly = min(max(vi - wy0, 0), S - 2);
-                    const uint8_t* p = win + ly * S + lx;
-                    p00 = (float)p[0]; p01 = (float)p[1]; p10 = (float)p[S]; p11 = (float)p[S + 1];
+            if (fits && (unsigned)ui < (unsigned)(cols - 1) && (unsigned)vi < (unsigned)(rows - 1)) {      // ui >= 0, ui + 1 < cols, ...
+                uint32_t top, bot;
+                if (staged) {
+                    // Inside the frame means inside the window: R covers floor(u), floor(u) + 1 of every patch pixel, and the
+                    // window is only ever shifted to stay in the frame.  The pixel pair may straddle a dword: both dwords in
+                    // one ds_read2_b32, the pair shifted down (an unaligned ds_read_u16 works, at ~50 clocks per wave).
+                    const int pb = wofs + (vi - wy0) * WP + (ui - wx0);
+                    const uint32_t* pw = reinterpret_cast<const uint32_t*>(smem + (pb & ~3));
+                    top = __builtin_amdgcn_alignbyte(pw[1], pw[0], pb & 3);
+                    bot = __builtin_amdgcn_alignbyte(pw[(WP >> 2) + 1], pw[WP >> 2], pb & 3);
                 } else {
-                    const uint8_t* p = img + (size_t)vi * pitch + ui;
-                    p00 = (float)p[0]; p01 = (float)p[1]; p10 = (float)p[pitch]; p11 = (float)p[pitch + 1];
+                    const int off = vi * pitch + ui;
+                    top = __builtin_amdgcn_raw_buffer_load_b16(rsrc, off, 0, 0);
+                    bot = __builtin_amdgcn_raw_buffer_load_b16(rsrc, off, pitch, 0);
                 }
-                const float du = u - (float)ui, dv = v - (float)vi;
+                const float p00 = (float)(top & 0xffu), p01 = (float)((top >> 8) & 0xffu);
+                const float p10 = (float)(bot & 0xffu), p11 = (float)((bot >> 8) & 0xffu);
+                const float du = u - fu, dv = v - fv;
                 const float t0 = (1 - du) * p00 + du * p01;
                 const float t1 = (1 - du) * p10 + du * p11;
                 const float t2 = (1 - dv) * t0 + dv * t1;
@@ -167,109 +219,105 @@ __global__ __launch_bounds__(HS_NT) void patch_sift_kernel(
                 if (iv > 255) iv = 255;
                 val = (uint8_t)iv;
             }
-            s_patch[i] = val;
+            s_patch[(y0 + 8 * k) * 32 + x] = val;
         }
     }
     __syncthreads();
 
     if (dbg == 1) return;
     // gradients, magnitude, orientation of the 30x30 interior (hash_sift.cpp:244-260) and the trilinear vote
-    // (distribute, hash_sift.cpp:193-198, 262-290): a lane per pixel, 8 fixed-point atomic adds
+    // (distribute, hash_sift.cpp:193-198, 262-290): a lane per pixel, 4 fixed-point atomic adds (two orientation bins each).
+    // Lane -> pixel mapping: neighbouring lanes take pixels of DIFFERENT 8x8 cells (16 cells, then the next pixel of each
+    // cell), so the atomics of one wave instruction spread over many histogram bins; smooth (blurred) patches, where
+    // neighbouring pixels vote for the same bins, otherwise serialise on a few LDS addresses.  A thread's four pixels are
+    // (x, y0 + 2 k).
     {
-        // Lane -> pixel mapping: neighbouring lanes take pixels of DIFFERENT 8x8 cells (16 cells, then the next pixel
-        // of each cell), so the atomics of one wave instruction spread over many histogram bins; smooth (blurred)
-        // patches, where neighbouring pixels vote for the same bins, otherwise serialise on a few LDS addresses.
-        for (int j = tid; j < 1024; j += HS_NT) {
-            const int cell = j & 15, w = j >> 4;
-            const int x = 8 * (cell & 3) + (w & 7), y = 8 * (cell >> 2) + (w >> 3);           // patch pixel (x+1, y+1)
-            if (x >= 30 || y >= 30) continue;
-            const int i = y * 30 + x;
-            const uint8_t* pc = s_patch + (y + 1) * 32 + (x + 1);
-            const int idx = (int)pc[1] - (int)pc[-1], idy = (int)pc[-32] - (int)pc[32];
-            const float dx = (float)idx, dy = (float)idy;
-            const float mag = mag_scale[i] * sqrtf(dx * dx + dy * dy);
-            // scaleO * atan2f(dy, dx): dx, dy are integers in [-255, 255], so the host tabulates the CPU
-            // code's own libm result for all 511 x 511 gradients (hash_sift.cpp:254,258)
-            const float obin = obin_lut[(idy + 255) * 511 + (idx + 255)];
-            int oi = (int)floorf(obin);
-            const float of = obin - (float)oi;
-            if (oi < 0) oi += 8;
-            if (oi >= 8) oi -= 8;
-            const float rf = s_rf[y + 1], cf = s_cf[x + 1];
-            const int ri = s_ri[y + 1], ci = s_ci[x + 1];
-            const float v1 = rf * mag, v0 = mag - v1;
-            const float v01 = cf * v0, v00 = v0 - v01;
-            const float v11 = cf * v1, v10 = v1 - v11;
-            const float a4[4] = { v00, v01, v10, v11 };
+        const int cell = tid & 15, w = tid >> 4;
+        const int x = 8 * (cell & 3) + (w & 7), y0 = 8 * (cell >> 2) + (w >> 3);        // patch pixel (x + 1, y + 1)
+        if (x < 30) {
+            const float cf = s_rf[x + 1];
+            const int coff = s_roff[x + 1];
+            const __amdgpu_buffer_rsrc_t lut_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(grad_lut), 0, 511 * 511 * 8, 0x00020000);
+            unsigned long long sink = 0;                                                // EFX_DEBUG_HS=6 only
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const float b1 = of * a4[q], b0 = a4[q] - b1;
-                // 16.16 fixed point, rounded to nearest (contributions are >= 0; a bin collects at most 64 pixel-weights
-                // x 361 of magnitude: < 2^15).  A bin holds hundreds of gray levels, so 2^-17 per vote is ~1e-7 relative.
-                const unsigned long long pair = (unsigned long long)(uint32_t)(b0 * 65536.f + 0.5f) |
-                                                ((unsigned long long)(uint32_t)(b1 * 65536.f + 0.5f) << 32);
-                atomicAdd(s_h64 + ((ri + 1 + (q >> 1)) * 6 + (ci + 1 + (q & 1))) * 9 + ((oi & 1) ? 5 : 0) + (oi >> 1), pair);
+            for (int k = 0; k < 4; k++) {
+                const int y = y0 + 2 * k;
+                if (y >= 30) continue;
+                const uint8_t* pc = s_patch + (y + 1) * 32 + (x + 1);
+                const int idx = (int)pc[1] - (int)pc[-1], idy = (int)pc[-32] - (int)pc[32];
+                // scaleO * atan2f(dy, dx) and sqrtf(dx^2 + dy^2): dx, dy are integers in [-255, 255], so the host tabulates
+                // the CPU code's own libm results for all 511 x 511 gradients (hash_sift.cpp:254-258)
+                const efx_u32x2 gw = __builtin_amdgcn_raw_buffer_load_b64(lut_rsrc, (idy * 511 + idx + 255 * 512) * 8, 0, 0);
+                const float2 g = dbg == 7 ? make_float2(3.f + 0.01f * (float)(idx + idy), (float)(idx * idx + idy * idy))
+                                          : make_float2(__uint_as_float(gw.x), __uint_as_float(gw.y));
+                const float mag = (dbg == 8 ? 32768.f : vote_weight16[k * 256 + tid]) * g.y;   // x 65536: exact, commutes with every product below
+                const float fo = floorf(g.x);
+                const float of = g.x - fo;
+                const int oi = (int)fo & 7;                                             // bins -4 .. 4 -> 4 .. 7, 0 .. 4
+                const float rf = s_rf[y + 1];
+                const float v1 = rf * mag, v0 = mag - v1;
+                const float v01 = cf * v0, v00 = v0 - v01;
+                const float v11 = cf * v1, v10 = v1 - v11;
+                const float a4[4] = { v00, v01, v10, v11 };
+                unsigned char* home = reinterpret_cast<unsigned char*>(s_h64) + 6 * s_roff[y + 1] + coff + 8 * oi;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const float b1 = of * a4[q], b0 = a4[q] - b1;
+                    // 16.16 fixed point, rounded half up (contributions are >= 0; a bin collects at most 64 pixel-weights x 361
+                    // of magnitude: < 2^15).  A bin holds hundreds of gray levels, so 2^-17 per vote is ~1e-7 relative.
+                    const unsigned long long pair = (unsigned long long)hs_round_half_up(b0) | ((unsigned long long)hs_round_half_up(b1) << 32);
+                    if (dbg == 6) sink += pair;
+                    else atomicAdd(reinterpret_cast<unsigned long long*>(home + ((q >> 1) * 6 + (q & 1)) * 72), pair);
+                }
             }
+            if (dbg == 6) s_h64[tid] = sink;
         }
     }
     __syncthreads();
-    if (dbg == 2) return;
-    for (int i = tid; i < 360; i += HS_NT) {
-        const int cell = i / 10, k = i - cell * 10;
-        const unsigned long long* hc = s_h64 + cell * 9;
-        uint32_t v;
-        if (k & 1) v = (uint32_t)(hc[k >> 1] >> 32) + (k < 9 ? (uint32_t)hc[5 + (k >> 1)] : 0u);      // pairs (k-1, k) and (k, k+1)
-        else v = (uint32_t)hc[k >> 1] + (k >= 2 ? (uint32_t)(hc[5 + (k >> 1) - 1] >> 32) : 0u);        // pairs (k, k+1) and (k-1, k)
-        s_hist[i] = (float)((double)v * (1.0 / 65536.0));
-    }
-    __syncthreads();
-    if (dbg == 3) return;
-    // circular fold + copy (hash_sift.cpp:293-308)
-    if (tid < 16) {
-        const int r = tid >> 2, c = tid & 3;
-        float* ph = s_hist + ((r + 1) * 6 + (c + 1)) * 10;
-        ph[0] += ph[8];
-        ph[1] += ph[9];
-        for (int k = 0; k < 8; k++) s_desc[(r * 4 + c) * 8 + k] = ph[k];
-    }
-    __syncthreads();
+    if (dbg == 2 || tid >= 64) return;
+    // ---- the rest is one wave's work, lane t owns elements t and t + 64 of the 128-vector: no LDS round trips, no barriers
+    // fixed point -> float, circular fold of the 10 orientation bins into 8 (hash_sift.cpp:293-308: ph[0] += ph[8], ph[1] += ph[9])
+    auto bin_of = [&](const unsigned long long* hc, int k) -> float {
+        const uint32_t v = (k < 9 ? (uint32_t)hc[k] : 0u) + (k >= 1 ? (uint32_t)(hc[k - 1] >> 32) : 0u);      // pairs (k, k+1) and (k-1, k)
+        return (float)v * (1.f / 65536.f);               // one rounding (u32 -> f32), the power of two is exact
+    };
+    auto element = [&](int e) -> float {
+        const int r = e >> 5, c = (e >> 3) & 3, k = e & 7;
+        const unsigned long long* hc = s_h64 + ((r + 1) * 6 + (c + 1)) * 9;
+        float v = bin_of(hc, k);
+        if (k < 2) v += bin_of(hc, k + 8);
+        return v;
+    };
+    float d0 = element(tid), d1 = element(tid + 64);
+    if (dbg == 3) { s_patch[tid] = (uint8_t)(d0 + d1); return; }
     // L2 normalise, clip at 0.2, renormalise, x512 -> uchar (hash_sift.cpp:311-330).  The CPU code adds the 128 squares
-    // serially; here a fixed tree does (element i with i + 64, then the butterfly 32, 16, .. 1 inside one wave): 10
-    // instructions instead of a 256-instruction chain on one lane.  The order is part of the device arithmetic the tests'
-    // CPU model reproduces bit for bit; against the serial sum the norm moves by ~1e-7 relative.
-    for (int pass = 0; pass < 2; pass++) {
-        if (tid < 64) {
-            const float d0 = s_desc[tid], d1 = s_desc[tid + 64];
-            float t = d0 * d0 + d1 * d1;
+    // serially; here a fixed tree does (element i with i + 64, then the butterfly 32, 16, .. 1: every lane ends with the
+    // same sum).  The order is part of the device arithmetic the tests' CPU model reproduces bit for bit; against the
+    // serial sum the norm moves by ~1e-7 relative.
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) t = t + __shfl_xor(t, off, 64);
-            if (tid == 0) {
-                float norm = sqrtf(t);
-                if (norm < 1.1920929e-07f) norm = 1.1920929e-07f;          // FLT_EPSILON
-                s_scale = 1.f / norm;
-            }
-        }
-        __syncthreads();
-        if (tid < 128) {
-            float v = s_desc[tid] * s_scale;
-            if (pass == 0) v = v < 0.2f ? v : 0.2f;
-            s_desc[tid] = v;
-        }
-        __syncthreads();
+    for (int pass = 0; pass < 2; pass++) {
+        float t = d0 * d0 + d1 * d1;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) t = t + __shfl_xor(t, off, 64);
+        float norm = sqrtf(t);
+        if (norm < 1.1920929e-07f) norm = 1.1920929e-07f;          // FLT_EPSILON
+        const float scale = 1.f / norm;
+        d0 *= scale; d1 *= scale;
+        if (pass == 0) { d0 = d0 < 0.2f ? d0 : 0.2f; d1 = d1 < 0.2f ? d1 : 0.2f; }
     }
-    if (dbg == 4) return;
+    if (dbg == 4) { s_patch[tid] = (uint8_t)(d0 + d1); return; }
     // the 129-vector {1, 128 x uchar} as bf16 (exact: integers <= 255 need 8 mantissa bits), K padded to HS_KB with zeros
     uint16_t* out = responses + (size_t)kid * HS_KB;
-    if (tid < 128) {
-        float v = rintf(512.f * s_desc[tid]);                           // saturate_cast<uchar>: cvRound + clamp
-        v = v < 0.f ? 0.f : (v > 255.f ? 255.f : v);
-        out[1 + tid] = (uint16_t)(__float_as_uint(v) >> 16);
-        if (dbg_responses) dbg_responses[(size_t)kid * 129 + 1 + tid] = v;
-    }
-    if (tid >= 128 && tid < 128 + HS_KB - 128) {
-        const int k = tid == 128 ? 0 : tid;                             // element 0 and the padding 129 .. 143
-        out[k] = tid == 128 ? (uint16_t)0x3f80 : (uint16_t)0;
-        if (tid == 128 && dbg_responses) dbg_responses[(size_t)kid * 129] = 1.f;
+    float q0 = rintf(512.f * d0), q1 = rintf(512.f * d1);             // saturate_cast<uchar>: cvRound + clamp
+    q0 = q0 < 0.f ? 0.f : (q0 > 255.f ? 255.f : q0);
+    q1 = q1 < 0.f ? 0.f : (q1 > 255.f ? 255.f : q1);
+    out[1 + tid] = (uint16_t)(__float_as_uint(q0) >> 16);
+    out[65 + tid] = (uint16_t)(__float_as_uint(q1) >> 16);
+    if (tid < HS_KB - 128) out[tid == 0 ? 0 : 128 + tid] = tid == 0 ? (uint16_t)0x3f80 : (uint16_t)0;     // element 0, padding 129 .. 143
+    if (dbg_responses) {
+        dbg_responses[(size_t)kid * 129 + 1 + tid] = q0;
+        dbg_responses[(size_t)kid * 129 + 65 + tid] = q1;
+        if (tid == 0) dbg_responses[(size_t)kid * 129] = 1.f;
     }
 }
 
@@ -378,32 +426,38 @@ hipError_t efx_launch_hashsift(const DescribeLaunch& a, const HashSiftDev& h, hi
 {
     if (a.n <= 0) return hipSuccess;
     const float max_size = a.max_size > 0.f ? a.max_size : (float)EFX_PATCH_SIZE;
-    const int S = hs_smax_for(max_size, a.scale_factor);
+    int S = hs_smax_for(max_size, a.scale_factor);
     size_t lds = 0;
     if (a.blur) {
         const BlurGeom bg(S);
-        lds = bg.raw_bytes() + bg.hb_bytes() + (size_t)S * S;
+        lds = bg.raw_bytes() + bg.hb_bytes() + (size_t)S * (4 * ((3 + S + 3) >> 2)) + 4;         // + 4: the warp reads dword pairs
         lds = (lds + 15) & ~(size_t)15;
         if (lds > 140 * 1024) return hipErrorInvalidValue;
+    } else {
+        if (S > 120) S = 120;                                  // larger keypoints gather from memory (8 workgroups per CU fit up to here)
+        lds = (size_t)S * (4 * ((3 + S + 3) >> 2)) + 16;
     }
     float t[7];
     efx_gaussian_taps_host(t);
     const int dbg = a.dbg_hs;
-    const float* mag = h.W + (size_t)h.nbits * HS_KPAD;    // the 30x30 weight table is stored behind W
-    const float* lut = mag + 900;                          // followed by the 511x511 orientation-bin table
-    if (a.blur && S == 48 && a.uniform_size) {
+    const float* mag = h.W + (size_t)h.nbits * HS_KPAD;    // the pixel weights (x 2^16, in the vote loop's thread order) are stored behind W
+    const float2* lut = reinterpret_cast<const float2*>(mag + 1024);      // followed by the 511x511 {orientation bin, magnitude} table
+    static_assert(sizeof(HsRec) == EFX_HS_REC_BYTES, "scratch sizing in efx_api.cpp");
+    HsRec* rec = static_cast<HsRec*>(h.records);
+    const bool fixed48 = a.blur && S == 48 && a.uniform_size;
+    hipLaunchKernelGGL(hs_record_kernel, dim3((a.n + 255) / 256), dim3(256), 0, stream, a.img0, a.pitch0, a.rows0, a.cols0,
+                       a.pyramid, a.d_table, a.kp4, a.kp_level, a.d_count, a.n, a.scale_factor, S, fixed48 ? 48 : 0, a.blur ? 0 : 1, rec);
+    if (fixed48) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_sift_kernel<true, 48>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((patch_sift_kernel<true, 48>), dim3(a.n), dim3(HS_NT), lds, stream, a.img0, a.pitch0, a.rows0, a.cols0,
-                           a.pyramid, a.d_table, a.kp4, a.kp_level, a.d_count, a.n, a.scale_factor, S, mag, lut,
+        hipLaunchKernelGGL((patch_sift_kernel<true, 48>), dim3(a.n), dim3(256), lds, stream, rec, a.d_count, a.n, S, mag, lut,
                            t[0], t[1], t[2], t[3], h.responses, h.dbg_responses, dbg);
     } else if (a.blur) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_sift_kernel<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((patch_sift_kernel<true, 0>), dim3(a.n), dim3(HS_NT), lds, stream, a.img0, a.pitch0, a.rows0, a.cols0,
-                           a.pyramid, a.d_table, a.kp4, a.kp_level, a.d_count, a.n, a.scale_factor, S, mag, lut,
+        hipLaunchKernelGGL((patch_sift_kernel<true, 0>), dim3(a.n), dim3(256), lds, stream, rec, a.d_count, a.n, S, mag, lut,
                            t[0], t[1], t[2], t[3], h.responses, h.dbg_responses, dbg);
     } else {
-        hipLaunchKernelGGL((patch_sift_kernel<false, 0>), dim3(a.n), dim3(HS_NT), 0, stream, a.img0, a.pitch0, a.rows0, a.cols0,
-                           a.pyramid, a.d_table, a.kp4, a.kp_level, a.d_count, a.n, a.scale_factor, S, mag, lut,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_sift_kernel<false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((patch_sift_kernel<false, 0>), dim3(a.n), dim3(256), lds, stream, rec, a.d_count, a.n, S, mag, lut,
                            t[0], t[1], t[2], t[3], h.responses, h.dbg_responses, dbg);
     }
     if (a.desc || h.dbg_T) {

@@ -12,17 +12,23 @@
 
 #include "../host/efficient_features.hpp"
 
-template <class F>
-static double perf(int niterations, F f)
+// Protocol of the reference's harness: the first call warms up and is not counted, the mean of the next `n` is reported.
+struct Timing { double mean_ms, min_ms, max_ms; };
+
+template <class Call>
+static Timing time_calls(int n, Call call)
 {
-    double sum = 0;
-    for (int iter = 0; iter <= niterations; iter++) {
-        const auto t0 = std::chrono::steady_clock::now();
-        f();
-        const auto t1 = std::chrono::steady_clock::now();
-        if (iter > 0) sum += std::chrono::duration<double, std::milli>(t1 - t0).count();
+    using clock = std::chrono::steady_clock;
+    call();                                                         // warm-up: allocations, first-launch costs
+    std::vector<double> ms((size_t)n);
+    for (double& m : ms) {
+        const clock::time_point begin = clock::now();
+        call();
+        m = std::chrono::duration<double, std::milli>(clock::now() - begin).count();
     }
-    return sum / niterations;
+    Timing t{ 0, ms.empty() ? 0 : ms[0], 0 };
+    for (double m : ms) { t.mean_ms += m / n; t.min_ms = m < t.min_ms ? m : t.min_ms; t.max_ms = m > t.max_ms ? m : t.max_ms; }
+    return t;
 }
 
 static std::vector<uint8_t> synth(int w, int h, uint32_t seed)
@@ -67,18 +73,23 @@ int main(int argc, char** argv)
         const efx::DeviceImage img{ static_cast<const uint8_t*>(d_gray.data()), h, w, d_gray.step };
         hipStream_t stream;
         if (hipStreamCreate(&stream) != hipSuccess) return 1;
-        double ms = 0;
-        if (benchType == 0)
-            ms = perf(niter, [&] { feature->detectAndComputeAsync(img, d_keypoints, d_descriptors, false, stream); (void)hipStreamSynchronize(stream); });
-        else if (benchType == 1)
-            ms = perf(niter, [&] { feature->detectAsync(img, d_keypoints, stream); (void)hipStreamSynchronize(stream); });
-        else {
+        const auto wait = [&] { (void)hipStreamSynchronize(stream); };
+        int n_computed = 0;
+        if (benchType == 2) {                                       // compute-only works on one detection's keypoints
             feature->detectAsync(img, d_keypoints, stream);
-            (void)hipStreamSynchronize(stream);
-            const int n = feature->lastCount();
-            ms = perf(niter, [&] { feature->computeAsync(img, d_keypoints, n, d_descriptors, stream); (void)hipStreamSynchronize(stream); });
+            wait();
+            n_computed = feature->lastCount();
         }
-        printf("%5d keypoints found.\nprocessing time: %.3f[milli sec]\n", feature->lastCount(), ms);
+        const Timing t = time_calls(niter, [&] {
+            switch (benchType) {
+            case 0: feature->detectAndComputeAsync(img, d_keypoints, d_descriptors, false, stream); break;
+            case 1: feature->detectAsync(img, d_keypoints, stream); break;
+            default: feature->computeAsync(img, d_keypoints, n_computed, d_descriptors, stream); break;
+            }
+            wait();
+        });
+        printf("%5d keypoints found.\nprocessing time: %.3f[milli sec]   (min %.3f, max %.3f over %d calls)\n",
+               feature->lastCount(), t.mean_ms, t.min_ms, t.max_ms, niter);
         efx_level_stats st[32]; int nl = 0;
         if (efx_last_level_stats(feature->handle(), st, 32, &nl) == EFX_OK)
             for (int l = 0; l < nl; l++) printf("level %d: %d FAST corners, %d after NMS, %d kept\n", l, st[l].n_candidates, st[l].n_after_nms, st[l].n_kept);

@@ -300,9 +300,9 @@ static void hs_patch_sift(const uint8_t* patch, float* desc /*128*/, float kp_sc
     uint64_t h64[HS_R_BINS + 2][HS_C_BINS + 2][HS_ORI_BINS + 2];
     memset(hist, 0, sizeof(hist));
     memset(h64, 0, sizeof(h64));
-    /* fixed_point: the device's histogram arithmetic -- 16.16 fixed point, every vote rounded to nearest, integer sums
-     * (order independent), cuda-efficient-features_amd/csrc/hashsift_kernels.hip */
-#define HS_VOTE(R, Cc, O, V) do { if (fixed_point) h64[R][Cc][O] += (uint64_t)(uint32_t)((V) * 65536.f + 0.5f); \
+    /* fixed_point: the device's histogram arithmetic -- 16.16 fixed point, every vote rounded half up (floor(v * 2^16 + 1/2),
+     * the sum formed exactly), integer sums (order independent), cuda-efficient-features_amd/csrc/hashsift_kernels.hip */
+#define HS_VOTE(R, Cc, O, V) do { if (fixed_point) h64[R][Cc][O] += (uint64_t)(uint32_t)floor((double)((V) * 65536.f) + 0.5); \
         else hist[R][Cc][O] += (V); } while (0)
 
     /* HistBin, hash_sift.cpp:162-184 */
