@@ -186,6 +186,7 @@ __global__ __launch_bounds__(256) void patch_sift_kernel(
     {
         const int x = 8 * (tid >> 6) + (tid & 7), y0 = (tid >> 3) & 7;
         const float ax = A.m00 * (float)x, bx = A.m10 * (float)x;
+        const int wbase = wofs - wy0 * WP - wx0;                          // smem byte of image pixel (0, 0), were the window that large
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const float fy = (float)(y0 + 8 * k);
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(256) void patch_sift_kernel(
                     // Inside the frame means inside the window: R covers floor(u), floor(u) + 1 of every patch pixel, and the
                     // window is only ever shifted to stay in the frame.  The pixel pair may straddle a dword: both dwords in
                     // one ds_read2_b32, the pair shifted down (an unaligned ds_read_u16 works, at ~50 clocks per wave).
-                    const int pb = wofs + (vi - wy0) * WP + (ui - wx0);
+                    const int pb = vi * WP + ui + wbase;
                     const uint32_t* pw = reinterpret_cast<const uint32_t*>(smem + (pb & ~3));
                     top = __builtin_amdgcn_alignbyte(pw[1], pw[0], pb & 3);
                     bot = __builtin_amdgcn_alignbyte(pw[(WP >> 2) + 1], pw[WP >> 2], pb & 3);
@@ -335,6 +336,9 @@ __global__ __launch_bounds__(256) void patch_sift_kernel(
 // ================================================================================================
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+// lane `lane` (a constant) of `old` := the wave-uniform `sval`
+#define efx_writelane(sval, old, lane) ([&]() { uint32_t o_ = (old); asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(o_) : "s"(sval), "n"(lane)); return o_; }())
+
 __global__ __launch_bounds__(256) void project_sign_kernel(const uint16_t* __restrict__ Rm, const uint16_t* __restrict__ Wb,
                                                            const int* __restrict__ d_count, int n, int nbits,
                                                            uint8_t* __restrict__ desc, size_t desc_pitch, float* __restrict__ dbg_T)
@@ -349,11 +353,12 @@ __global__ __launch_bounds__(256) void project_sign_kernel(const uint16_t* __res
     const int mgroup = gw / ntn, nmgroups = (gridDim.x * 4) / ntn;
     const int li = lane & 31, lk = lane >> 5;
     constexpr int KS = HS_KB / 16;                                // 9 K steps
-    // this wave's weights: b[t][ks] = W_t[n0 + li][16 ks + 8 lk .. + 8]
+    // this wave's weights: b[t][ks] = W_t[n0 + (li ^ 7)][16 ks + 8 lk .. + 8].  Lane li takes output bit n0 + (li ^ 7): a descriptor
+    // byte holds its 8 bits MSB first (hash_sift.cpp:367-374), so the 32 signs of a row, in lane order, ARE its 4 bytes
     bf16x8 b[3][KS];
 #pragma unroll
     for (int t = 0; t < 3; t++) {
-        const uint4* p = reinterpret_cast<const uint4*>(Wb + ((size_t)t * nbits + n0 + li) * HS_KB + 8 * lk);
+        const uint4* p = reinterpret_cast<const uint4*>(Wb + ((size_t)t * nbits + n0 + (li ^ 7)) * HS_KB + 8 * lk);
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) b[t][ks] = __builtin_bit_cast(bf16x8, p[2 * ks]);
     }
@@ -377,13 +382,14 @@ __global__ __launch_bounds__(256) void project_sign_kernel(const uint16_t* __res
         for (int ks = 0; ks < KS; ks++) a[ks] = __builtin_bit_cast(bf16x8, nxt[ks]);
         if (mt + nmgroups < mtiles) load_tile(mt + nmgroups, nxt);
         f32x16 acc = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-        // smallest terms first: the fp32 accumulator rounds them in before the large ones arrive
+        // smallest terms first: the fp32 accumulator rounds them in before the large ones arrive.  (Three independent
+        // accumulators, one per term, were measured slower: 44 against 29 us.)
 #pragma unroll
         for (int t = 2; t >= 0; t--)
 #pragma unroll
             for (int ks = 0; ks < KS; ks++) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], b[t][ks], acc, 0, 0, 0);
         // C layout 32x32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).  The sign bits of a row are a
-        // ballot half; lane `row` collects its row's 32 bits (bit j -> byte j/8, bit 7 - j%8: MSB first, hash_sift.cpp:367-374)
+        // ballot half; lane `row` collects its row's 32 bits (v_writelane_b32: no compares, no selects)
         uint32_t mine = 0u;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
@@ -391,11 +397,10 @@ __global__ __launch_bounds__(256) void project_sign_kernel(const uint16_t* __res
             const unsigned long long ba = __ballot(acc[r] > 0.f);
             if (dbg_T) {
                 const int i = m0 + row + 4 * lk;
-                if (i < count) dbg_T[(size_t)i * nbits + n0 + li] = acc[r];
+                if (i < count) dbg_T[(size_t)i * nbits + n0 + (li ^ 7)] = acc[r];
             }
-            const uint32_t w_lo = __builtin_bswap32(__brev((unsigned)ba)), w_hi = __builtin_bswap32(__brev((unsigned)(ba >> 32)));
-            mine = lane == row ? w_lo : mine;
-            mine = lane == row + 4 ? w_hi : mine;
+            mine = efx_writelane(__builtin_amdgcn_readfirstlane((uint32_t)ba), mine, row);
+            mine = efx_writelane(__builtin_amdgcn_readfirstlane((uint32_t)(ba >> 32)), mine, row + 4);
         }
         if (desc != nullptr) {
             if (wide) {
