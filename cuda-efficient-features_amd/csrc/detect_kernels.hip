@@ -696,7 +696,7 @@ __device__ __forceinline__ void efx_tile_of(const LevelTable* T, int gt, int& l,
 __global__ __launch_bounds__(256) void fast_kernel(
     const LevelTable* __restrict__ T, const uint8_t* __restrict__ img0, int pitch0, int aligned0,
     const uint8_t* __restrict__ pyramid, int threshold, const uint8_t* __restrict__ mask, int mask_pitch,
-    Corner* __restrict__ cand_all, TileHdr* __restrict__ hdr_all, Counters* __restrict__ cnt, int dbg_arg)
+    uint32_t* __restrict__ cand_xy_all, TileHdr* __restrict__ hdr_all, Counters* __restrict__ cnt, int dbg_arg)
 {
     const int dbg = EFX_DBG(dbg_arg);
     __shared__ __attribute__((aligned(16))) uint32_t s_tile[EFX_LT * (EFX_LP / 4)];
@@ -720,7 +720,7 @@ __global__ __launch_bounds__(256) void fast_kernel(
     const bool aligned = l == 0 ? aligned0 != 0 : true;
     const int x0 = tx * EFX_TILE, y0 = ty * EFX_TILE;
     const uint8_t* tb = reinterpret_cast<const uint8_t*>(s_tile);
-    Corner* cand = cand_all + L.cand_base;
+    uint32_t* cand_xy = cand_xy_all + L.cand_base;
     TileHdr* hdr = hdr_all + L.tile_base;
 
     // ---- phase 0: tile + halo -> LDS.  72 rows x 72 bytes as 9 x 8-byte pieces per row (the global address is
@@ -855,7 +855,7 @@ __global__ __launch_bounds__(256) void fast_kernel(
         for (int k = tid; k < total; k += 256) {
             const int lx = s_list[k] & 0xff, ly = s_list[k] >> 8;
             if ((unsigned)(start + k) < L.cand_sub_cap)
-                cand[(size_t)(tile & (EFX_NSUB - 1)) * L.cand_sub_cap + start + k].xy = (uint32_t)(x0 + lx) | ((uint32_t)(y0 + ly) << 16);
+                cand_xy[(size_t)(tile & (EFX_NSUB - 1)) * L.cand_sub_cap + start + k] = (uint32_t)(x0 + lx) | ((uint32_t)(y0 + ly) << 16);
         }
         TileHdr* h = hdr + tile;
         if (tid <= EFX_CELLS_PER_TILE) h->cell_off[tid] = (uint16_t)s_celloff[tid];
@@ -871,7 +871,7 @@ __global__ __launch_bounds__(256) void fast_kernel(
 // ================================================================================================
 __global__ __launch_bounds__(64) void harris_kernel(
     const LevelTable* __restrict__ T, const uint8_t* __restrict__ img0, int pitch0, int aligned0,
-    const uint8_t* __restrict__ pyramid, Corner* __restrict__ cand_all, Corner* __restrict__ cmax_all,
+    const uint8_t* __restrict__ pyramid, const uint32_t* __restrict__ cand_xy_all, Corner* __restrict__ cand_all, Corner* __restrict__ cmax_all,
     TileHdr* __restrict__ hdr_all, const Counters* __restrict__ cnt, int dbg_arg)
 {
     const int dbg = EFX_DBG(dbg_arg);
@@ -916,15 +916,18 @@ __global__ __launch_bounds__(64) void harris_kernel(
     const bool aligned = l == 0 ? aligned0 != 0 : true;
     const TileHdr& h = hdr_all[L.tile_base + tile];
     const int total = h.cell_off[EFX_CELLS_PER_TILE];
-    Corner* cand = cand_all + L.cand_base + (size_t)(tile & (EFX_NSUB - 1)) * L.cand_sub_cap + h.cand_start;
+    const size_t first = L.cand_base + (size_t)(tile & (EFX_NSUB - 1)) * L.cand_sub_cap + h.cand_start;
+    Corner* cand = cand_all + first;
+    const uint32_t* cand_xy = cand_xy_all + first;
     if (lane < EFX_CELLS_PER_TILE) { s_cellmax[lane] = 0ull; s_celltie[lane] = 0u; }
     __syncthreads();
     for (int k = lane; k < total; k += 64) {
-        const uint32_t xy = cand[k].xy;
+        const uint32_t xy = cand_xy[k];
         const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
         const uint8_t* c = src + (size_t)y * spitch + x;
         const float resp = (dbg & 4) ? 1.f : (aligned ? harris_rows(c - 4 * spitch - 4, spitch) : harris_bytes(c, spitch));
-        cand[k].resp = resp;
+        Corner rec; rec.xy = xy; rec.resp = resp;
+        cand[k] = rec;                                      // whole records: full-line stores (fast_kernel's coordinate array likewise)
         // strongest corner of the 16x16 cell: 64-bit max of (response key, xy).  A corner that finds its own response
         // already there has an equal twin in the cell; if that response ends up being the cell's maximum, the NMS quick
         // test must not treat the stored corner as the only one of that strength (equal responses suppress each other).
@@ -1733,6 +1736,7 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
         size_t ncand = 0;
         for (int l = 0; l < H.nlevels; l++) if (H.lv[l].active) ncand = std::max<size_t>(ncand, H.lv[l].cand_base + (size_t)H.lv[l].cand_sub_cap * EFX_NSUB);
         (void)hipMemsetAsync(a.cand, 0xFF, ncand * sizeof(Corner), stream);
+        (void)hipMemsetAsync(a.cand_xy, 0xFF, ncand * sizeof(uint32_t), stream);
         if (getenv("EFX_TRACE_SYNC_POISON")) (void)hipStreamSynchronize(stream);
     }
 #endif
@@ -1740,12 +1744,12 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
         const int aligned0 = (((uintptr_t)a.img0 | (uintptr_t)a.pitch0) & 3u) == 0;
         bool prof = a.prof.begin(0, stream);
         hipLaunchKernelGGL(fast_kernel, dim3(H.total_tiles), dim3(256), 0, stream, a.d_table, a.img0, a.pitch0, aligned0,
-                           a.pyramid, a.threshold, a.mask, a.mask_pitch, a.cand, a.hdr, a.counters, a.knobs.dbg & 15);
+                           a.pyramid, a.threshold, a.mask, a.mask_pitch, a.cand_xy, a.hdr, a.counters, a.knobs.dbg & 15);
         a.prof.end(prof, 0, stream);
         EFX_TRACE_POINT("fast");
         prof = a.prof.begin(1, stream);
         hipLaunchKernelGGL(harris_kernel, dim3(H.total_tiles + H.nlevels), dim3(64), 0, stream, a.d_table, a.img0, a.pitch0, aligned0, a.pyramid,
-                           a.cand, a.cmax, a.hdr, a.counters, a.knobs.dbg & 15);
+                           a.cand_xy, a.cand, a.cmax, a.hdr, a.counters, a.knobs.dbg & 15);
         a.prof.end(prof, 1, stream);
         EFX_TRACE_POINT("harris");
     }
@@ -1788,7 +1792,7 @@ hipError_t efx_debug_rerun_stages(const DetectLaunch& a, int stages, hipStream_t
     if (e != hipSuccess) return e;
     if (stages & 1)
         hipLaunchKernelGGL(harris_kernel, dim3(H.total_tiles + H.nlevels), dim3(64), 0, stream, a.d_table, a.img0, a.pitch0, aligned0, a.pyramid,
-                           a.cand, a.cmax, a.hdr, a.counters, 0);
+                           a.cand_xy, a.cand, a.cmax, a.hdr, a.counters, 0);
     if (stages & 2)
         hipLaunchKernelGGL(nms_kernel, dim3(H.total_tiles), dim3(64), 0, stream, a.d_table, a.hdr, a.cand, a.cmax, a.surv,
                            a.counters, a.nonmax_radius, 0);

@@ -284,6 +284,7 @@ struct efx_context {
     efx_params g_p;
     LevelTable h_table;
     DevBuf d_table, pyramid, hdr, cand, cmax, surv, counters, kp4, kp_level, img, kps, descout, count, maskbuf;
+    size_t cand_slots = 0;          // records in `cand`; the coordinate-only array of the same length follows them
     Summary* h_mirror = nullptr;    // host copy of the last frame's summary, filled on demand by fetch_summary()
     int n_out_max = 0;              // sum of the active levels' quotas
     bool arena_full = false;        // corner / survivor arenas sized for the worst case (set after a frame overflowed them)
@@ -377,7 +378,8 @@ int build_geometry(efx_context* c, int rows, int cols)
             // Worst-case arenas (every pixel a corner) cost 8 + 6.4 bytes per pyramid pixel: 1.5 GB for an 8K frame.  Large
             // levels are therefore sized for a corner DENSITY -- 1/8 of the pixels for FAST corners (the reference keeps at
             // most 1/10, .cpp:252; the benchmark frames have 1/37), 1/32 for NMS survivors (all the corners when the NMS
-            // radius is below 4 px) -- with a quarter of slack for the imbalance between the sub-arrays.  A frame that does
+            // radius is below 4 px) -- with an eighth / a quarter of slack for the imbalance between the sub-arrays (12 bytes per
+            // FAST corner slot: the record and the coordinate word fast_kernel writes).  A frame that does
             // not fit raises Summary::overflow on the device and is void (N = 0); the host then switches the context to
             // worst-case arenas (arena_full) and reports EFX_ERR_OVERFLOW / reruns (efx_last_count, host_detect_impl).
             const size_t tiles_per_sub = ((size_t)L.tiles_x * L.tiles_y + EFX_NSUB - 1) / EFX_NSUB;
@@ -385,7 +387,7 @@ int build_geometry(efx_context* c, int rows, int cols)
             const size_t sfull = cfull < (size_t)L.cap ? cfull : (size_t)L.cap;
             size_t csub = cfull, ssub = sfull;
             if (!c->arena_full && (size_t)L.rows * L.cols > EFX_ARENA_DENSITY_MIN_PX) {
-                csub = std::min(cfull, cfull / 8 + cfull / 32);
+                csub = std::min(cfull, cfull / 8 + cfull / 64);
                 ssub = std::min(sfull, p.nonmax_radius < 4 ? csub : cfull / 32 + cfull / 128);
             }
             L.cand_sub_cap = (unsigned)csub;
@@ -404,7 +406,9 @@ int build_geometry(efx_context* c, int rows, int cols)
     HIP_TRY(c->err, c->d_table.reserve(sizeof(LevelTable) + (size_t)(tiles + 1) * sizeof(uint32_t)));
     HIP_TRY(c->err, c->pyramid.reserve(pyr + 256));
     HIP_TRY(c->err, c->hdr.reserve((size_t)(tiles + 1) * sizeof(TileHdr)));
-    HIP_TRY(c->err, c->cand.reserve((ncand + 1) * sizeof(Corner)));
+    // corner records, followed by the coordinate-only array fast_kernel fills (harris_kernel writes whole records from it)
+    HIP_TRY(c->err, c->cand.reserve((ncand + 1) * (sizeof(Corner) + sizeof(uint32_t))));
+    c->cand_slots = ncand + 1;
     HIP_TRY(c->err, c->surv.reserve((nsurv + 1) * sizeof(Corner)));
     HIP_TRY(c->err, c->cmax.reserve((ncmax + 1) * sizeof(Corner)));
     HIP_TRY(c->err, c->counters.reserve(sizeof(Counters)));
@@ -456,6 +460,7 @@ int detect_common(efx_context* c, const uint8_t* d_image, int rows, int cols, si
     a.h_table = &c->h_table;
     a.hdr = static_cast<TileHdr*>(c->hdr.p);
     a.cand = static_cast<Corner*>(c->cand.p);
+    a.cand_xy = reinterpret_cast<uint32_t*>(a.cand + c->cand_slots);
     a.surv = static_cast<Corner*>(c->surv.p);
     a.cmax = static_cast<Corner*>(c->cmax.p);
     a.counters = static_cast<Counters*>(c->counters.p);
@@ -805,6 +810,11 @@ static void trace_digest(const DetectLaunch& a, const char* name)
     static Counters cn;
     if (hipMemcpy(hdr.data(), a.hdr, hdr.size() * sizeof(TileHdr), hipMemcpyDeviceToHost) != hipSuccess) return;
     if (hipMemcpy(cand.data(), a.cand, cand.size() * sizeof(Corner), hipMemcpyDeviceToHost) != hipSuccess) return;
+    if (!strcmp(name, "fast")) {         // harris_kernel has not assembled the records yet: the coordinates are in cand_xy
+        std::vector<uint32_t> xy(ncand);
+        if (hipMemcpy(xy.data(), a.cand_xy, xy.size() * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) return;
+        for (size_t i = 0; i < ncand; i++) cand[i].xy = xy[i];
+    }
     if (hipMemcpy(&cn, a.counters, sizeof(Counters), hipMemcpyDeviceToHost) != hipSuccess) return;
     unsigned long long hx = 0; long long nsum = 0; int bad_range = 0, unwritten = 0, off_tile = 0;
     for (int l = 0; l < T.nlevels; l++) {

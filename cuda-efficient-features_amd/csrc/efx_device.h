@@ -206,6 +206,7 @@ struct DetectLaunch {
     const LevelTable* h_table;  // host copy (same contents)
     TileHdr* hdr;
     Corner* cand;
+    uint32_t* cand_xy;          // coordinates of the FAST corners, indexed like `cand` (fast_kernel -> harris_kernel)
     Corner* cmax;               // strongest corner of every 16x16 cell (quick test of the NMS)
     Corner* surv;
     Counters* counters;
