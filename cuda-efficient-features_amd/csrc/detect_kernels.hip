@@ -322,8 +322,14 @@ __global__ __launch_bounds__(NT) void resize_kernel(
 // own loads.  Here the grid is only as large as the chip holds at once; a workgroup walks through tiles and issues the
 // (range-checked, branch-free) buffer loads of its NEXT tile into registers before it computes the current one from
 // LDS, so the memory latency is hidden behind arithmetic.  The barriers in the loop order LDS traffic only
-// (__syncthreads() would also wait for the loads in flight).  Requirements checked by the host: aligned source,
-// footprint <= 32 dwords x 80 rows (scale factors up to ~1.22; others use resize_kernel).
+// (__syncthreads() would also wait for the loads in flight).
+// The kernel is bound by VALU issue, and a third of its instructions used to be per-tile set-up (tile geometry, the x
+// weights of a lane's four columns, the row table: float expressions that do not depend on the pixels).  They now come
+// from the resize plan the host builds once per geometry with the same expressions (ResizePlanLevel, efx_api.cpp): a
+// scalar load per tile, three 16-byte loads per lane, one per row.
+// Requirements checked by the host: aligned source, footprint <= 32 dwords x 80 rows (scale factors up to ~1.22; others
+// use resize_kernel).  LDS: 80 rows of RS_LP bytes (a lane stages dword j0 of rows r0 + 8 p unconditionally: lanes and
+// rows outside the footprint read beyond the resource or unused pixels and land in padding), then the row table.
 // ================================================================================================
 __device__ __forceinline__ void efx_lds_barrier()
 {
@@ -332,18 +338,23 @@ __device__ __forceinline__ void efx_lds_barrier()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+#define RS_LP 132                                           // LDS row pitch: 33 dwords (rows one bank apart)
+#define RS_ROWS 80
+#define RS_YTAB (RS_LP * RS_ROWS)                           // 10560: 16-byte aligned
+
 __global__ __launch_bounds__(256) void resize_stream_kernel(
     const uint8_t* __restrict__ src, int spitch, int rows, int cols,
-    uint8_t* __restrict__ dst, int dpitch, int drows, int dcols, float fx, float fy, int tiles_x, int tiles_y, int lpitch, int ytab_off,
+    uint8_t* __restrict__ dst, int dpitch, int drows, int dcols, int tiles_x, int tiles_y,
+    const int* __restrict__ xtab, int W, const int4* __restrict__ ytab_g, const int4* __restrict__ ttab,
     Counters* __restrict__ zero, int zero_levels)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int NP = 10;                                  // 8 rows per pass, up to 80 footprint rows
+    constexpr int NP = RS_ROWS / 8;                         // 8 rows per pass
     const int tid = threadIdx.x;
     if (zero && blockIdx.x == 0) efx_zero_counters(zero, zero_levels, tid, 256);
     // XCD x owns the x-th contiguous eighth of the tiles, its workgroups stride through it
     const int ntiles = tiles_x * tiles_y;
-    const int W = gridDim.x / EFX_NXCD, xcd = blockIdx.x % EFX_NXCD, wg = blockIdx.x / EFX_NXCD;
+    const int Wg = gridDim.x / EFX_NXCD, xcd = blockIdx.x % EFX_NXCD, wg = blockIdx.x / EFX_NXCD;
     const int cq_ = ntiles / EFX_NXCD, cr_ = ntiles % EFX_NXCD;
     const int c0 = xcd < cr_ ? xcd * (cq_ + 1) : cr_ * (cq_ + 1) + (xcd - cr_) * cq_;
     const int c1 = c0 + cq_ + (xcd < cr_ ? 1 : 0);
@@ -353,79 +364,57 @@ __global__ __launch_bounds__(256) void resize_stream_kernel(
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src), 0, (rows - 1) * spitch + ((cols + 3) & ~3), 0x00020000);
     const int j0 = tid & 31, r0 = tid >> 5;
-    struct Geo { int ox0, oy0, ox1, oy1, sx1, sy0, ax0, ndw, nrow; };
-    auto geo_of = [&](int t) -> Geo {
-        Geo g;
-        const int tx = t % tiles_x, ty = t / tiles_x;
-        g.ox0 = tx * EFX_TILE; g.oy0 = ty * EFX_TILE;
-        g.ox1 = min(g.ox0 + EFX_TILE, dcols); g.oy1 = min(g.oy0 + EFX_TILE, drows);
-        const int sx0 = min((int)floorf((float)g.ox0 * fx), cols - 1);
-        g.sy0 = min((int)floorf((float)g.oy0 * fy), rows - 1);
-        g.sx1 = min(min((int)floorf((float)(g.ox1 - 1) * fx), cols - 1) + 1, cols - 1);
-        const int sy1 = min(min((int)floorf((float)(g.oy1 - 1) * fy), rows - 1) + 1, rows - 1);
-        g.ax0 = sx0 & ~3;
-        g.ndw = ((g.sx1 - g.ax0) >> 2) + 1; g.nrow = sy1 - g.sy0 + 1;
-        return g;
-    };
+    const int lane_off = r0 * spitch + 4 * j0;              // this lane's dword within a footprint
+    uint8_t* stage = smem + r0 * RS_LP + 4 * j0;
     uint32_t pf[NP];
-    auto issue = [&](const Geo& g) {
+    auto issue = [&](const int4 g) {
+        // lanes beyond the footprint's dwords read beyond the resource: the hardware range check returns 0, no branch
+        const int base = j0 < (g.z & 0xff) ? g.x * spitch + g.y + lane_off : 0x7ffffff0;
 #pragma unroll
-        for (int p = 0; p < NP; p++) {
-            const int r = r0 + 8 * p;
-            // lanes / rows outside the footprint read beyond the resource: the hardware range check returns 0, no branch
-            const int off = (j0 < g.ndw && r < g.nrow) ? (g.sy0 + r) * spitch + g.ax0 + 4 * j0 : 0x7ffffff0;
-            pf[p] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0);
-        }
+        for (int p = 0; p < NP; p++) pf[p] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, base, 8 * p * spitch, 0);
     };
 
-    Geo g = geo_of(tile);
+    int4 g = ttab[tile];
     issue(g);
+    const int cq = tid & 15, rq = tid >> 4;                 // 16 lanes x 4 outputs per row, 16 rows per pass
+    const bool dst4 = ((((uintptr_t)dst) | (uintptr_t)dpitch) & 3u) == 0;
     for (;;) {
+        const int sy0 = g.x, ax0 = g.y;
+        const int ox0 = (g.w & 0xffff) * EFX_TILE, oy0 = (g.w >> 16) * EFX_TILE;
+        const int ox1 = min(ox0 + EFX_TILE, dcols), oy1 = min(oy0 + EFX_TILE, drows);
         // ---- the prefetched footprint and the per-row table -> LDS ----
 #pragma unroll
-        for (int p = 0; p < NP; p++) {
-            const int r = r0 + 8 * p;
-            if (j0 < g.ndw && r < g.nrow) *reinterpret_cast<uint32_t*>(smem + r * lpitch + 4 * j0) = pf[p];
-        }
-        int4* ytab = reinterpret_cast<int4*>(smem + ytab_off);
+        for (int p = 0; p < NP; p++) *reinterpret_cast<uint32_t*>(stage + 8 * p * RS_LP) = pf[p];
         if (tid < EFX_TILE) {
-            const int oy = min(g.oy0 + tid, drows - 1);
-            const float sy = (float)oy * fy;
-            int y1 = (int)floorf(sy);
-            if (y1 > rows - 1) y1 = rows - 1;
-            const int y2 = y1 + 1;
-            const int y2r = y2 < rows - 1 ? y2 : rows - 1;
-            ytab[tid] = make_int4((y1 - g.sy0) * lpitch, (y2r - g.sy0) * lpitch, __float_as_int((float)y2 - sy), __float_as_int(sy - (float)y1));
+            int4 yt = ytab_g[oy0 + tid];
+            yt.x = (yt.x - sy0) * RS_LP; yt.y = (yt.y - sy0) * RS_LP;
+            reinterpret_cast<int4*>(smem + RS_YTAB)[tid] = yt;
         }
+        // x weights and source columns of this lane's four outputs (the clamped +1 neighbour is the next LDS byte)
+        const int oxq = ox0 + 4 * cq;
+        const int4 x1 = *reinterpret_cast<const int4*>(xtab + oxq);
+        const float4 wx0 = *reinterpret_cast<const float4*>(xtab + W + oxq);
+        const float4 wx1 = *reinterpret_cast<const float4*>(xtab + 2 * W + oxq);
         efx_lds_barrier();
-        if (g.sx1 == cols - 1) {                            // replicated +1 neighbour of the last source column (S5 clamp)
-            for (int r = tid; r < g.nrow; r += 256) smem[r * lpitch + (cols - g.ax0)] = smem[r * lpitch + (cols - 1 - g.ax0)];
+        if (g.z >> 16) {                                    // replicated +1 neighbour of the last source column (S5 clamp)
+            const int nrow = (g.z >> 8) & 0xff;
+            for (int r = tid; r < nrow; r += 256) smem[r * RS_LP + (cols - ax0)] = smem[r * RS_LP + (cols - 1 - ax0)];
             efx_lds_barrier();
         }
         // ---- next tile's loads go out now and land while this tile is computed ----
-        const int tnext = tile + W;
+        const int tnext = tile + Wg;
         const bool more = tnext < c1;
-        Geo gn = g;
-        if (more) { gn = geo_of(tnext); issue(gn); }
+        int4 gn = g;
+        if (more) { gn = ttab[tnext]; issue(gn); }
 
         // ---- this tile: the arithmetic of resize_kernel ----
-        const int cq = tid & 15, rq = tid >> 4;
-        const int oxq = g.ox0 + 4 * cq;
-        if (oxq < g.ox1) {
-            float wx0[4], wx1[4]; int lc[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int ox = min(oxq + k, dcols - 1);
-                const float sx = (float)ox * fx;
-                int x1 = (int)floorf(sx);
-                if (x1 > cols - 1) x1 = cols - 1;
-                const int x2 = x1 + 1;
-                wx0[k] = (float)x2 - sx; wx1[k] = sx - (float)x1;
-                lc[k] = x1 - g.ax0;
-            }
-            const bool full4 = oxq + 4 <= g.ox1 && ((((uintptr_t)dst) | (uintptr_t)dpitch) & 3u) == 0;
-            for (int oy = g.oy0 + rq; oy < g.oy1; oy += 16) {
-                const int4 yt = ytab[oy - g.oy0];
+        if (oxq < ox1) {
+            const int lc[4] = { x1.x - ax0, x1.y - ax0, x1.z - ax0, x1.w - ax0 };
+            const float wa[4] = { wx0.x, wx0.y, wx0.z, wx0.w }, wb[4] = { wx1.x, wx1.y, wx1.z, wx1.w };
+            const bool full4 = oxq + 4 <= ox1 && dst4;
+            const int4* ytab = reinterpret_cast<const int4*>(smem + RS_YTAB);
+            for (int oy = oy0 + rq; oy < oy1; oy += 16) {
+                const int4 yt = ytab[oy - oy0];
                 const float wy0 = __int_as_float(yt.z), wy1 = __int_as_float(yt.w);
                 const uint8_t* ra = smem + yt.x;
                 const uint8_t* rb = smem + yt.y;
@@ -434,16 +423,16 @@ __global__ __launch_bounds__(256) void resize_stream_kernel(
                 for (int k = 0; k < 4; k++) {
                     const uint8_t* pa = ra + lc[k];
                     const uint8_t* pb = rb + lc[k];
-                    float out = (float)pa[0] * (wx0[k] * wy0);
-                    out = out + (float)pa[1] * (wx1[k] * wy0);
-                    out = out + (float)pb[0] * (wx0[k] * wy1);
-                    out = out + (float)pb[1] * (wx1[k] * wy1);
+                    float out = (float)pa[0] * (wa[k] * wy0);
+                    out = out + (float)pa[1] * (wb[k] * wy0);
+                    out = out + (float)pb[0] * (wa[k] * wy1);
+                    out = out + (float)pb[1] * (wb[k] * wy1);
                     packed = __builtin_amdgcn_cvt_pk_u8_f32(out, k, packed);
                 }
                 uint8_t* d = dst + (size_t)oy * dpitch + oxq;
                 if (full4) *reinterpret_cast<uint32_t*>(d) = packed;
                 else
-                    for (int k = 0; k < 4; k++) if (oxq + k < g.ox1) d[k] = (uint8_t)(packed >> (8 * k));
+                    for (int k = 0; k < 4; k++) if (oxq + k < ox1) d[k] = (uint8_t)(packed >> (8 * k));
             }
         }
         if (!more) break;
@@ -1702,7 +1691,8 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
         const bool prof = a.prof.begin(100 + s, stream);
         const int ntiles = N.tiles_x * N.tiles_y;
         const bool no_stream = a.knobs.no_resize_stream != 0;     // EFX_NO_RESIZE_STREAM (tests): force the one-tile-per-workgroup kernel
-        if (aligned && sw <= 128 && sh <= 80 && !no_stream) {
+        const ResizePlanLevel* R = a.rplan_lv ? &a.rplan_lv[s + 1] : nullptr;
+        if (aligned && R && R->W != 0 && a.rplan && !no_stream) {
             // streamed variant: a grid the chip holds at once (8 workgroups of 256 threads per CU), a multiple of the 8 XCDs
             static int s_slots = 0;
             if (s_slots == 0) {
@@ -1711,9 +1701,10 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
                 s_slots = cus * 8;
             }
             const int per_xcd = std::min(s_slots / EFX_NXCD, (ntiles + EFX_NXCD - 1) / EFX_NXCD);
-            hipLaunchKernelGGL(resize_stream_kernel, dim3(per_xcd * EFX_NXCD), dim3(256), lds, stream, src, spitch, L.rows, L.cols,
-                               a.pyramid + N.img_off, N.pitch, N.rows, N.cols, N.fx, N.fy, N.tiles_x, N.tiles_y, lpitch, ytab_off,
-                               zeroed ? nullptr : a.counters, H.nlevels);
+            hipLaunchKernelGGL(resize_stream_kernel, dim3(per_xcd * EFX_NXCD), dim3(256), RS_YTAB + EFX_TILE * 16, stream, src, spitch, L.rows, L.cols,
+                               a.pyramid + N.img_off, N.pitch, N.rows, N.cols, N.tiles_x, N.tiles_y,
+                               reinterpret_cast<const int*>(a.rplan + R->x_off), R->W, reinterpret_cast<const int4*>(a.rplan + R->y_off),
+                               reinterpret_cast<const int4*>(a.rplan + R->t_off), zeroed ? nullptr : a.counters, H.nlevels);
         } else
         hipLaunchKernelGGL((resize_kernel<256>), dim3(ntiles), dim3(256), lds, stream, src, spitch, L.rows, L.cols, aligned,
                            a.pyramid + N.img_off, N.pitch, N.rows, N.cols, N.fx, N.fy, N.tiles_x, N.tiles_y, lpitch, ytab_off,

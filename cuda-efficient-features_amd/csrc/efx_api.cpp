@@ -284,6 +284,7 @@ struct efx_context {
     efx_params g_p;
     LevelTable h_table;
     DevBuf d_table, pyramid, hdr, cand, cmax, surv, counters, kp4, kp_level, img, kps, descout, count, maskbuf;
+    DevBuf rplan; ResizePlanLevel rplan_lv[EFX_MAX_LEVELS];        // resize plan (tables of resize_stream_kernel)
     size_t cand_slots = 0;          // records in `cand`; the coordinate-only array of the same length follows them
     Summary* h_mirror = nullptr;    // host copy of the last frame's summary, filled on demand by fetch_summary()
     int n_out_max = 0;              // sum of the active levels' quotas
@@ -301,7 +302,7 @@ struct efx_context {
 
     ~efx_context()
     {
-        d_table.release(); pyramid.release(); hdr.release(); cand.release(); cmax.release(); surv.release(); counters.release();
+        rplan.release(); d_table.release(); pyramid.release(); hdr.release(); cand.release(); cmax.release(); surv.release(); counters.release();
         kp4.release(); kp_level.release(); img.release(); kps.release(); descout.release(); count.release(); maskbuf.release();
         delete h_mirror;
         for (hipEvent_t e : prof_start) (void)hipEventDestroy(e);
@@ -430,6 +431,64 @@ int build_geometry(efx_context* c, int rows, int cols)
         }
         HIP_TRY(c->err, hipMemcpy(c->d_table.p, blob.data(), blob.size(), hipMemcpyHostToDevice));
     }
+    // resize plan: per destination level the column / row / tile tables of resize_stream_kernel (spec S5 expressions)
+    {
+        std::vector<int> blob;
+        auto fbits = [](float f) { int i; memcpy(&i, &f, 4); return i; };
+        memset(c->rplan_lv, 0, sizeof(c->rplan_lv));
+        for (int s = 1; s < p.nlevels; s++) {
+            const LevelDev& P = T.lv[s - 1];
+            const LevelDev& N = T.lv[s];
+            if (N.rows <= 0 || N.cols <= 0 || P.rows <= 0 || P.cols <= 0) continue;
+            const int W = N.tiles_x * EFX_TILE, Hh = N.tiles_y * EFX_TILE;
+            ResizePlanLevel& R = c->rplan_lv[s];
+            R.W = W;
+            R.x_off = (unsigned)(blob.size() * 4);
+            blob.resize(blob.size() + 3 * (size_t)W);
+            int* xt = blob.data() + R.x_off / 4;
+            for (int i = 0; i < W; i++) {
+                const int ox = i < N.cols - 1 ? i : N.cols - 1;
+                const float sx = (float)ox * N.fx;
+                int x1 = (int)floorf(sx);
+                if (x1 > P.cols - 1) x1 = P.cols - 1;
+                const int x2 = x1 + 1;
+                xt[i] = x1; xt[W + i] = fbits((float)x2 - sx); xt[2 * W + i] = fbits(sx - (float)x1);
+            }
+            R.y_off = (unsigned)(blob.size() * 4);
+            blob.resize(blob.size() + 4 * (size_t)Hh);
+            int* yt = blob.data() + R.y_off / 4;
+            for (int i = 0; i < Hh; i++) {
+                const int oy = i < N.rows - 1 ? i : N.rows - 1;
+                const float sy = (float)oy * N.fy;
+                int y1 = (int)floorf(sy);
+                if (y1 > P.rows - 1) y1 = P.rows - 1;
+                const int y2 = y1 + 1;
+                const int y2r = y2 < P.rows - 1 ? y2 : P.rows - 1;
+                yt[4 * i] = y1; yt[4 * i + 1] = y2r; yt[4 * i + 2] = fbits((float)y2 - sy); yt[4 * i + 3] = fbits(sy - (float)y1);
+            }
+            R.t_off = (unsigned)(blob.size() * 4);
+            blob.resize(blob.size() + 4 * (size_t)N.tiles_x * N.tiles_y);
+            int* tt = blob.data() + R.t_off / 4;
+            for (int ty = 0; ty < N.tiles_y; ty++)
+                for (int tx = 0; tx < N.tiles_x; tx++) {
+                    const int ox0 = tx * EFX_TILE, oy0 = ty * EFX_TILE;
+                    const int ox1 = std::min(ox0 + EFX_TILE, N.cols), oy1 = std::min(oy0 + EFX_TILE, N.rows);
+                    const int sx0 = std::min((int)floorf((float)ox0 * N.fx), P.cols - 1), sy0 = std::min((int)floorf((float)oy0 * N.fy), P.rows - 1);
+                    const int sx1 = std::min(std::min((int)floorf((float)(ox1 - 1) * N.fx), P.cols - 1) + 1, P.cols - 1);
+                    const int sy1 = std::min(std::min((int)floorf((float)(oy1 - 1) * N.fy), P.rows - 1) + 1, P.rows - 1);
+                    const int ax0 = sx0 & ~3, ndw = ((sx1 - ax0) >> 2) + 1, nrow = sy1 - sy0 + 1;
+                    int* q = tt + 4 * ((size_t)ty * N.tiles_x + tx);
+                    q[0] = sy0; q[1] = ax0;
+                    q[2] = (ndw & 0xff) | ((nrow & 0xff) << 8) | ((sx1 == P.cols - 1 ? 1 : 0) << 16);
+                    q[3] = tx | (ty << 16);
+                    if (ndw > 32 || nrow > 80) R.W = 0;          // footprint beyond what the streamed kernel stages: no plan
+                }
+        }
+        if (!blob.empty()) {
+            HIP_TRY(c->err, c->rplan.reserve(blob.size() * 4));
+            HIP_TRY(c->err, hipMemcpy(c->rplan.p, blob.data(), blob.size() * 4, hipMemcpyHostToDevice));
+        }
+    }
     c->g_rows = rows; c->g_cols = cols; c->g_p = p; c->g_arena_full = c->arena_full;
     return EFX_OK;
 }
@@ -459,6 +518,7 @@ int detect_common(efx_context* c, const uint8_t* d_image, int rows, int cols, si
     a.d_table = static_cast<const LevelTable*>(c->d_table.p);
     a.h_table = &c->h_table;
     a.hdr = static_cast<TileHdr*>(c->hdr.p);
+    a.rplan = static_cast<const unsigned char*>(c->rplan.p); a.rplan_lv = c->rplan_lv;
     a.cand = static_cast<Corner*>(c->cand.p);
     a.cand_xy = reinterpret_cast<uint32_t*>(a.cand + c->cand_slots);
     a.surv = static_cast<Corner*>(c->surv.p);
@@ -894,7 +954,7 @@ int efx_debug_rerun(efx_context* ctx, int stages, int* surv_totals, int nlevels_
 size_t efx_device_bytes(const efx_context* ctx)
 {
     if (!ctx) return 0;
-    const DevBuf* b[] = { &ctx->d_table, &ctx->pyramid, &ctx->hdr, &ctx->cand, &ctx->cmax, &ctx->surv, &ctx->counters, &ctx->kp4,
+    const DevBuf* b[] = { &ctx->rplan, &ctx->d_table, &ctx->pyramid, &ctx->hdr, &ctx->cand, &ctx->cmax, &ctx->surv, &ctx->counters, &ctx->kp4,
                           &ctx->kp_level, &ctx->img, &ctx->kps, &ctx->descout, &ctx->count, &ctx->maskbuf, &ctx->desc.params,
                           &ctx->desc.responses, &ctx->desc.kp4, &ctx->desc.img, &ctx->desc.desc };
     size_t t = 0;

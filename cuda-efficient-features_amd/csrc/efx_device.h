@@ -198,7 +198,15 @@ struct ProfRec {
     }
 };
 
+// Resize plan of one destination level (resize_stream_kernel): everything about a tile / column / row that does not
+// depend on the pixels, computed once per geometry on the host with the kernel's own float expressions (spec S5).
+//   x table  3 x W words (W = tiles_x * 64): source column x1 | weight of x1 | weight of x1 + 1, per destination column
+//   y table  int4 per destination row (tiles_y * 64): source rows y1, min(y1 + 1, rows - 1) | weights as float bits
+//   tile table  int4 per tile: sy0 | ax0 | ndw + (nrow << 8) + (touches the last source column << 16) | tx + (ty << 16)
+struct ResizePlanLevel { unsigned x_off, y_off, t_off; int W; };      // byte offsets into DetectLaunch::rplan; W == 0: no plan
+
 struct DetectLaunch {
+    const unsigned char* rplan; const ResizePlanLevel* rplan_lv;      // device blob, host index by destination level
     const uint8_t* img0;        // level 0 (caller's image)
     int pitch0;
     uint8_t* pyramid;           // levels >= 1
