@@ -85,10 +85,11 @@ __global__ __launch_bounds__(256) void bad_kernel(
             // 7x7 sigma-2 Gaussian of the window (spec S6) on packed fp32 FMAs; the quantised pixels go straight into
             // the integral's source (zero outside the frame)
             efx_blur_window_lds<256>(img, pitch, rows, cols, wx0, wy0, S, raw, hb, taps0, taps1, taps2, taps3, tid,
-                [&](int r, int c, int q0, int q1) {
+                [&](int r0, int i, int c, uint32_t pk) {
+                    const int r = r0 + i;
                     const bool rin = (wy0 + r) < rows;
-                    I[(r + 1) * IP + (c + 1)] = (rin && (wx0 + c) < cols) ? q0 : 0;
-                    I[(r + 1) * IP + (c + 2)] = (rin && (wx0 + c + 1) < cols) ? q1 : 0;
+                    I[(r + 1) * IP + (c + 1)] = (rin && (wx0 + c) < cols) ? (int)(pk & 0xffu) : 0;
+                    I[(r + 1) * IP + (c + 2)] = (rin && (wx0 + c + 1) < cols) ? (int)(pk >> 8) : 0;
                 });
         } else {
             for (int r = wid; r < S; r += 4) {
@@ -228,13 +229,12 @@ __global__ __launch_bounds__(256) void bad_det_kernel(
     if (fits) {
         const bool inside = wx0 + S <= cols && wy0 + S <= rows;  // frames smaller than the window: zero beyond the frame
         efx_blur_window_lds<256>(img, pitch, rows, cols, wx0, wy0, S, raw, hb, taps0, taps1, taps2, taps3, tid,
-            [&](int r, int c, int p0, int p1) {
+            [&](int r0, int i, int c, uint32_t pk) {
                 if (!inside) {
-                    const bool rin = (wy0 + r) < rows;
-                    p0 = (rin && (wx0 + c) < cols) ? p0 : 0;
-                    p1 = (rin && (wx0 + c + 1) < cols) ? p1 : 0;
+                    const bool rin = (wy0 + r0 + i) < rows;
+                    pk &= ((rin && (wx0 + c) < cols) ? 0xffu : 0u) | ((rin && (wx0 + c + 1) < cols) ? 0xff00u : 0u);
                 }
-                *reinterpret_cast<uint16_t*>(pix + r * S + c) = (uint16_t)(p0 | (p1 << 8));
+                *reinterpret_cast<uint16_t*>(pix + r0 * S + c + i * S) = (uint16_t)pk;
             });
         __syncthreads();
         // window-local integral: row prefix from the u8 plane (wave 0; the zero border is written by wave 1), then column prefix

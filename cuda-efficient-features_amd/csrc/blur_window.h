@@ -52,8 +52,9 @@ __device__ __forceinline__ int efx_reflect101(int p, int len)
 }
 
 // Blurs the window [wx0, wx0 + S) x [wy0, wy0 + S) of `img`.  All NT threads of the workgroup must call it (it
-// contains two barriers; the caller synchronises before reading what `store` wrote).  store(r, c, q0, q1) receives the
-// blurred, rounded (half-even) and saturated pixels of row r at columns c and c + 1 (c even, r < S).
+// contains two barriers; the caller synchronises before reading what `store` wrote).  store(r0, i, c, pk) receives the
+// blurred, rounded (half-even) and saturated pixels of row r0 + i (i a compile-time constant after unrolling) at columns
+// c and c + 1 (c even, r0 + i < S) as the two low bytes of pk.
 template <int NT, class Store>
 __device__ __forceinline__ void efx_blur_window_lds(const uint8_t* __restrict__ img, int pitch, int rows, int cols, int wx0, int wy0,
                                                     int S, uint8_t* raw, float* hb, float taps0, float taps1, float taps2, float taps3,
@@ -146,9 +147,10 @@ __device__ __forceinline__ void efx_blur_window_lds(const uint8_t* __restrict__ 
                 efx_f32x2 acc = v[i] * tp[0];
 #pragma unroll
                 for (int jt = 1; jt < 7; jt++) acc = __builtin_elementwise_fma(v[i + jt], (efx_f32x2)(tp[jt]), acc);
-                // both pixels through one pack chain: a store that re-packs them gets (pk & 0xffff) for free
+                // both pixels through one pack chain: the store receives them packed (low byte: column c, next: c + 1;
+                // the upper half is zero), with the row split into the item's first row and the unrolled offset
                 const uint32_t pk = __builtin_amdgcn_cvt_pk_u8_f32(acc.y, 1, __builtin_amdgcn_cvt_pk_u8_f32(acc.x, 0, 0u));
-                if (r < S) store(r, c, (int)(pk & 0xffu), (int)((pk >> 8) & 0xffu));
+                if (r < S) store(CR * rg, i, c, pk);
             }
         }
     }

@@ -165,8 +165,8 @@ __global__ __launch_bounds__(256) void patch_sift_kernel(
 
     if (BLUR && fits) {
         efx_blur_window_lds<256>(img, pitch, rows, cols, wx0, wy0, S, raw, hb, taps0, taps1, taps2, taps3, tid,
-            [&](int r, int c, int q0, int q1) {
-                *reinterpret_cast<uint16_t*>(win + r * WP + c) = (uint16_t)(q0 | (q1 << 8));      // c is even
+            [&](int r0, int i, int c, uint32_t pk) {
+                *reinterpret_cast<uint16_t*>(win + r0 * WP + c + i * WP) = (uint16_t)pk;         // c is even
             });
     }
     if (!BLUR && staged) {

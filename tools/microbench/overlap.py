@@ -24,7 +24,9 @@ def run(kind, ns, reps=24):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(reps): one(i)
+    t1 = time.perf_counter()
     torch.cuda.synchronize()
+    run.enqueue_ms = (t1 - t0) / reps * 1e3                 # host time to enqueue one frame's launches
     return (time.perf_counter() - t0) / reps * 1e3
 for kind in ('detect', 'compute', 'both'):
-    print(kind, ' '.join(f'{ns} streams {run(kind, ns):.4f} ms' for ns in (1, 2, 3)))
+    print(kind, ' '.join(f'{ns} streams {run(kind, ns):.4f} ms (host enqueue {run.enqueue_ms:.4f})' for ns in (1, 2, 3)))
