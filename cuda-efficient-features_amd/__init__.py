@@ -28,7 +28,7 @@ STATUS_NAMES = {0: "EFX_OK", -1: "EFX_ERR_BAD_ARG", -2: "EFX_ERR_UNSUPPORTED", -
 EFX_ERR_OVERFLOW = -6
 
 ABI_SYMBOLS = [
-    "efx_default_params", "efx_create", "efx_destroy", "efx_device_bytes", "efx_last_error", "efx_version",
+    "efx_default_params", "efx_create", "efx_destroy", "efx_device_bytes", "efx_trim_memory", "efx_cached_bytes", "efx_last_error", "efx_version",
     "efx_set_max_features", "efx_get_max_features", "efx_set_scale_factor", "efx_get_scale_factor",
     "efx_set_nlevels", "efx_get_nlevels", "efx_set_first_level", "efx_get_first_level",
     "efx_set_fast_threshold", "efx_get_fast_threshold", "efx_set_nonmax_radius", "efx_get_nonmax_radius",
@@ -111,6 +111,8 @@ def lib():
                                             C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]
         L.efx_last_count.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.efx_device_bytes.restype = C.c_size_t
+        L.efx_trim_memory.restype = C.c_size_t; L.efx_trim_memory.argtypes = []
+        L.efx_cached_bytes.restype = C.c_size_t; L.efx_cached_bytes.argtypes = []
         L.efx_device_bytes.argtypes = [C.c_void_p]
         L.efx_last_level_stats.argtypes = [C.c_void_p, C.POINTER(LevelStats), C.c_int, C.POINTER(C.c_int)]
         L.efx_detect.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
@@ -566,6 +568,15 @@ class Batch:
                                                       self._desc, dp, cap, self._cnt)
         if rc != EFX_OK:
             raise EfxError(rc, "batch: " + lib().efx_last_error(self._det0._h).decode())
+
+
+def trimMemory():
+    """Returns the device blocks cached from destroyed / regrown contexts to the driver; bytes released."""
+    return int(lib().efx_trim_memory())
+
+
+def cachedBytes():
+    return int(lib().efx_cached_bytes())
 
 
 def cvtGray(image, out=None, stream=None):

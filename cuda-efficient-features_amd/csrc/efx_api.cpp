@@ -17,6 +17,7 @@
 #include <new>
 #include <algorithm>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #ifdef EFX_DEBUG_BUILD
@@ -38,15 +39,65 @@ namespace {
 
 thread_local std::string g_create_error;
 
+// Process-wide cache of device blocks.  A context's buffers come from it and go back to it; memory returns to the driver
+// only through efx_trim_memory().  Contexts that are created and destroyed in a loop therefore run on the SAME device
+// pages: no hipMalloc / hipFree (each an implicit device-wide synchronisation and a page-table change) on that path, and
+// the one situation in which the 16-process stress showed wrong frames -- the first kernels on freshly mapped memory while
+// many processes oversubscribe the GPU, DESIGN.md section 7 -- does not arise after a process's first context.
+struct BlockCache {
+    struct Block { void* p; size_t bytes; };
+    std::mutex m;
+    std::vector<Block> free_blocks;
+    // smallest cached block of at least n bytes that wastes at most 1/16 (or no block: allocate)
+    void* take(size_t n, size_t* got)
+    {
+        std::lock_guard<std::mutex> g(m);
+        int best = -1;
+        for (int i = 0; i < (int)free_blocks.size(); i++)
+            if (free_blocks[i].bytes >= n && free_blocks[i].bytes <= n + n / 16 + 256 && (best < 0 || free_blocks[i].bytes < free_blocks[best].bytes)) best = i;
+        if (best < 0) return nullptr;
+        void* p = free_blocks[best].p; *got = free_blocks[best].bytes;
+        free_blocks.erase(free_blocks.begin() + best);
+        return p;
+    }
+    // the cache keeps at most EFX_BLOCK_CACHE_MB (default 4096): beyond that the oldest blocks go back to the driver
+    void give(void* p, size_t bytes)
+    {
+        static const size_t cap = [] { const char* v = getenv("EFX_BLOCK_CACHE_MB"); return (size_t)(v ? atoll(v) : 4096) << 20; }();
+        std::lock_guard<std::mutex> g(m);
+        free_blocks.push_back({ p, bytes });
+        size_t t = 0;
+        for (const Block& b : free_blocks) t += b.bytes;
+        while (t > cap && !free_blocks.empty()) { t -= free_blocks.front().bytes; (void)hipFree(free_blocks.front().p); free_blocks.erase(free_blocks.begin()); }
+    }
+    size_t trim()
+    {
+        std::lock_guard<std::mutex> g(m);
+        size_t t = 0;
+        for (const Block& b : free_blocks) { t += b.bytes; (void)hipFree(b.p); }
+        free_blocks.clear();
+        return t;
+    }
+    size_t cached() { std::lock_guard<std::mutex> g(m); size_t t = 0; for (const Block& b : free_blocks) t += b.bytes; return t; }
+};
+static BlockCache& block_cache() { static BlockCache* c = new BlockCache; return *c; }      // never destroyed: contexts may outlive statics
+
 struct DevBuf {                     // grow-only device allocation
     void* p = nullptr;
     size_t bytes = 0;
     hipError_t reserve(size_t n)
     {
         if (n <= bytes) return hipSuccess;
-        if (p) { hipError_t e = hipFree(p); p = nullptr; bytes = 0; if (e != hipSuccess) return e; }
+        release();
+        size_t got = 0;
+        p = block_cache().take(n, &got);
+        if (p) { bytes = got; return hipSuccess; }
         hipError_t e = hipMalloc(&p, n);
-        if (e == hipSuccess) bytes = n;
+        if (e != hipSuccess) {                       // out of memory with blocks of other sizes cached: give them back, once
+            (void)hipGetLastError();
+            if (block_cache().trim() > 0) e = hipMalloc(&p, n);
+        }
+        if (e == hipSuccess) bytes = n; else p = nullptr;
         // EFX_POISON=1 (tests): fill every new allocation with a pattern, so that a kernel that reads memory nobody wrote
         // fails the parity tests deterministically instead of once in 10^5 frames (fresh allocations are zero pages,
         // recycled ones hold a previous frame's data)
@@ -54,7 +105,15 @@ struct DevBuf {                     // grow-only device allocation
         if (e == hipSuccess && poison) { e = hipMemset(p, 0xA5, n); if (e == hipSuccess) e = hipDeviceSynchronize(); }   // before any non-blocking stream touches it
         return e;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    // The block may still be in use by kernels in flight (hipFree used to wait for them implicitly): wait, then cache it.
+    void release()
+    {
+        if (!p) return;
+        (void)hipDeviceSynchronize();
+        static const bool no_cache = getenv("EFX_NO_BLOCK_CACHE") != nullptr;
+        if (no_cache) (void)hipFree(p); else block_cache().give(p, bytes);
+        p = nullptr; bytes = 0;
+    }
 };
 
 struct Describer {                  // cuda::BAD / cuda::HashSIFT state
@@ -950,6 +1009,9 @@ int efx_debug_rerun(efx_context* ctx, int stages, int* surv_totals, int nlevels_
     return EFX_OK;
 }
 #endif
+
+size_t efx_trim_memory(void) { (void)hipDeviceSynchronize(); return block_cache().trim(); }
+size_t efx_cached_bytes(void) { return block_cache().cached(); }
 
 size_t efx_device_bytes(const efx_context* ctx)
 {

@@ -96,6 +96,12 @@ int efx_create(const efx_params* p, efx_context** out);         /* EfficientFeat
 int efx_destroy(efx_context* ctx);
 /* Device memory the context holds (pyramid, tile headers, corner / survivor arenas, keypoint lists), in bytes. */
 size_t efx_device_bytes(const efx_context* ctx);                              /* ~EfficientFeatures, .cpp:413-415 */
+/* Destroyed (and regrown) contexts and describers hand their device blocks to a process-wide cache that later contexts draw
+   from (no hipMalloc / hipFree in a create-destroy loop; the reference's DeviceBuffer arena, src/device_buffer.cpp:29-69, is
+   per object).  efx_trim_memory returns the cached blocks to the driver and reports their bytes; efx_cached_bytes reports
+   them.  The cache holds at most EFX_BLOCK_CACHE_MB (environment, default 4096); EFX_NO_BLOCK_CACHE=1 disables it. */
+size_t efx_trim_memory(void);
+size_t efx_cached_bytes(void);
 const char* efx_last_error(const efx_context* ctx);             /* ctx may be NULL: last create() error */
 int efx_version(void);
 
