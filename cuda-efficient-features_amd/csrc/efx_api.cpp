@@ -45,27 +45,27 @@ thread_local std::string g_create_error;
 // the one situation in which the 16-process stress showed wrong frames -- the first kernels on freshly mapped memory while
 // many processes oversubscribe the GPU, DESIGN.md section 7 -- does not arise after a process's first context.
 struct BlockCache {
-    struct Block { void* p; size_t bytes; };
+    struct Block { void* p; size_t bytes; int dev; };      // blocks belong to the device that was current when they were allocated
     std::mutex m;
     std::vector<Block> free_blocks;
     // smallest cached block of at least n bytes that wastes at most 1/16 (or no block: allocate)
-    void* take(size_t n, size_t* got)
+    void* take(size_t n, size_t* got, int dev)
     {
         std::lock_guard<std::mutex> g(m);
         int best = -1;
         for (int i = 0; i < (int)free_blocks.size(); i++)
-            if (free_blocks[i].bytes >= n && free_blocks[i].bytes <= n + n / 16 + 256 && (best < 0 || free_blocks[i].bytes < free_blocks[best].bytes)) best = i;
+            if (free_blocks[i].dev == dev && free_blocks[i].bytes >= n && free_blocks[i].bytes <= n + n / 16 + 256 && (best < 0 || free_blocks[i].bytes < free_blocks[best].bytes)) best = i;
         if (best < 0) return nullptr;
         void* p = free_blocks[best].p; *got = free_blocks[best].bytes;
         free_blocks.erase(free_blocks.begin() + best);
         return p;
     }
     // the cache keeps at most EFX_BLOCK_CACHE_MB (default 4096): beyond that the oldest blocks go back to the driver
-    void give(void* p, size_t bytes)
+    void give(void* p, size_t bytes, int dev)
     {
         static const size_t cap = [] { const char* v = getenv("EFX_BLOCK_CACHE_MB"); return (size_t)(v ? atoll(v) : 4096) << 20; }();
         std::lock_guard<std::mutex> g(m);
-        free_blocks.push_back({ p, bytes });
+        free_blocks.push_back({ p, bytes, dev });
         size_t t = 0;
         for (const Block& b : free_blocks) t += b.bytes;
         while (t > cap && !free_blocks.empty()) { t -= free_blocks.front().bytes; (void)hipFree(free_blocks.front().p); free_blocks.erase(free_blocks.begin()); }
@@ -85,12 +85,14 @@ static BlockCache& block_cache() { static BlockCache* c = new BlockCache; return
 struct DevBuf {                     // grow-only device allocation
     void* p = nullptr;
     size_t bytes = 0;
+    int dev = 0;                    // device the block lives on
     hipError_t reserve(size_t n)
     {
         if (n <= bytes) return hipSuccess;
         release();
         size_t got = 0;
-        p = block_cache().take(n, &got);
+        (void)hipGetDevice(&dev);
+        p = block_cache().take(n, &got, dev);
         if (p) { bytes = got; return hipSuccess; }
         hipError_t e = hipMalloc(&p, n);
         if (e != hipSuccess) {                       // out of memory with blocks of other sizes cached: give them back, once
@@ -111,7 +113,7 @@ struct DevBuf {                     // grow-only device allocation
         if (!p) return;
         (void)hipDeviceSynchronize();
         static const bool no_cache = getenv("EFX_NO_BLOCK_CACHE") != nullptr;
-        if (no_cache) (void)hipFree(p); else block_cache().give(p, bytes);
+        if (no_cache) (void)hipFree(p); else block_cache().give(p, bytes, dev);
         p = nullptr; bytes = 0;
     }
 };
