@@ -29,6 +29,7 @@ persist = '--persist' in sys.argv or '--persist-ctx' in sys.argv
 persist_img = '--persist' in sys.argv or '--persist-img' in sys.argv
 det = None
 d_img0 = torch.from_numpy(img).cuda()
+d_mask = None if mask is None else torch.from_numpy(mask).cuda()
 for rep in range(reps):
     if det is None or not persist:
         det = cef.EfficientFeatures.create(kw["nfeatures"], kw["scale_factor"], kw["nlevels"], kw["first_level"], kw["fast_threshold"], kw["nonmax_radius"], max(desc_type, 0))
@@ -40,7 +41,7 @@ for rep in range(reps):
     use_b = alt and (rep & 1)
     if use_b: d_img = d_img_b
     want = list((ref_b if use_b else ref)['stats']['n_after_nms']); want_c = list((ref_b if use_b else ref)['stats']['n_candidates'])
-    kps, desc, cnt = det.detectAndComputeAsync(d_img)
+    kps, desc, cnt = det.detectAndComputeAsync(d_img, mask=d_mask) if d_mask is not None else det.detectAndComputeAsync(d_img)
     torch.cuda.synchronize()
     if (rep == 0 or '--always' in sys.argv) and hasattr(cef.lib(), 'efx_debug_rerun'):
         import ctypes
