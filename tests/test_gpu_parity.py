@@ -249,6 +249,25 @@ def test_hashsift_vectors_equal_fixed_point_model_bit_exact(cef, torch_mod, orac
     assert rows_off.size == 0, f"{rows_off.size} of 4000 vectors differ from the fixed-point model: {rows_off[:8]}"
 
 
+@pytest.mark.parametrize("offset,pitch", [(0, 640), (3, 777), (1, 642)])
+def test_hashsift_window_paths(cef, torch_mod, oracle, offset, pitch):
+    """compute-only HashSIFT stages a keypoint's raw window in LDS as aligned dwords; images whose base or pitch is not
+    4-byte aligned and keypoints whose window exceeds 120 px gather from memory instead.  All paths against the
+    fixed-point model of the device arithmetic, bit for bit, with keypoint sizes from 3 to 150 in one call."""
+    img = synth.synth_frame(400, 601, seed=5)
+    big = np.zeros((400, max(pitch, 601 + offset)), np.uint8)
+    big[:, offset:offset + 601] = img
+    d = _dev(torch_mod, big)[:, offset:offset + 601]
+    kps = synth.random_keypoints(400, 601, 1500, seed=29)
+    kps[:, 2] = np.resize(np.array([3, 9.5, 31, 31, 31, 48, 64, 80, 100, 150], np.float32), kps.shape[0])
+    hs = cef.HashSIFT.create(1.0, cef.HashSIFT.SIZE_256_BITS)
+    resp, _ = hs.debug(d, _dev(torch_mod, kps), max_size=150.0)
+    torch_mod.cuda.synchronize()
+    want = oracle.hashsift_responses_fixedpoint(img, kps)
+    rows_off = np.nonzero((resp.cpu().numpy() != want).any(axis=1))[0]
+    assert rows_off.size == 0, f"{rows_off.size} of 1500 vectors differ from the fixed-point model: {rows_off[:8]}, sizes {kps[rows_off[:8], 2]}"
+
+
 @pytest.mark.parametrize("desc_type", [2, 3])
 def test_detect_and_compute_hashsift(cef, torch_mod, oracle, desc_type):
     img = synth.synth_frame(480, 640, seed=1002)
