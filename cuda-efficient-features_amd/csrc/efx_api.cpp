@@ -203,7 +203,7 @@ int describer_init(Describer& d, int kind, int nbits, float scale)
         for (int j = 0; j < nbits; j++)
             for (int k = 0; k < 129; k++) w[(size_t)j * HS_KPAD + k] = (float)w64[(size_t)j * 129 + k];
         // Gaussian pixel weights of computePatchSIFT (hash_sift.cpp:220-224,247): host expf, same call as the CPU code.  Stored
-        // x 2^16 (exact): the kernel's histogram is 16.16 fixed point and a power of two commutes with all its products
+        // x 2^17 (exact): the kernel's histogram is 15.17 fixed point and a power of two commutes with all its products
         const float kp_scale = 1.f / 6;
         const float kp_radius = kp_scale * (float)32 * 0.5f;
         const float kernel_sigma = 0.5f * (float)4 * 3.f * kp_radius;
@@ -216,7 +216,7 @@ int describer_init(Describer& d, int kind, int nbits, float scale)
                 const int x = 8 * (cell & 3) + (wq & 7), y = 8 * (cell >> 2) + (wq >> 3) + 2 * k;
                 if (x >= 30 || y >= 30) continue;
                 const float ddx = (float)x - cx, ddy = (float)y - cy;
-                w[(size_t)nbits * HS_KPAD + k * 256 + t] = 65536.f * expf(dist_scale * (ddx * ddx + ddy * ddy));
+                w[(size_t)nbits * HS_KPAD + k * 256 + t] = 131072.f * expf(dist_scale * (ddx * ddx + ddy * ddy));
             }
         // orientation bin scaleO * atan2f(dy, dx) and magnitude sqrtf(dx^2 + dy^2) of every integer gradient
         // (hash_sift.cpp:171,254-258), interleaved: one 8-byte gather per pixel

@@ -111,12 +111,12 @@ __device__ __forceinline__ uint32_t hs_round_half_up(float x)
 // 128-byte line per clock, and the 64 pixels of a wave lie in 12+ image rows whatever the lane mapping -- which is why
 // the window is staged in LDS by row-coalesced loads first (50 line look-ups per keypoint instead of 450); votes 50 us.
 // Everything that does not depend on the pixel is hoisted: a thread's four patch pixels share their column (warp: x,
-// m00 x, m10 x; votes: x, cf, column offset), the 16.16 scale rides in the weight table (stored in the threads' own order:
+// m00 x, m10 x; votes: x, cf, column offset), the 2^17 fixed-point scale rides in the weight table (stored in the threads' own order:
 // one coalesced load), the magnitude sqrtf(dx^2 + dy^2) in the orientation table, rounding to fixed point is one instruction.
 template <bool BLUR, int SF>
 __global__ __launch_bounds__(256) void patch_sift_kernel(
     const HsRec* __restrict__ rec, const int* __restrict__ d_count, int n, int smax,
-    const float* __restrict__ vote_weight16 /*4 x 256: weight x 65536 of pixel k of thread t*/,
+    const float* __restrict__ vote_weight16 /*4 x 256: weight x 2^17 of pixel k of thread t*/,
     const float2* __restrict__ grad_lut /*511*511 {orientation bin, magnitude}*/,
     float taps0, float taps1, float taps2, float taps3,
     uint16_t* __restrict__ responses /* n x HS_KB bf16 */, float* __restrict__ dbg_responses /* n x 129 or null */, int dbg_arg)
@@ -124,9 +124,10 @@ __global__ __launch_bounds__(256) void patch_sift_kernel(
     const int dbg = EFX_DBG(dbg_arg);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ uint8_t s_patch[32 * 32];
-    // Histogram in 16.16 fixed point (order-independent integer sums).  A pixel votes for TWO adjacent orientation bins of
+    // Histogram in 15.17 fixed point (order-independent integer sums; a bin collects at most 64 pixel-weights x 361 of
+    // magnitude < 2^15, so 17 fractional bits fill an unsigned 32-bit counter).  A pixel votes for TWO adjacent orientation bins of
     // each of four cells: the pair goes out as ONE 64-bit LDS atomic on two packed 32-bit counters (a counter stays below
-    // 2^31, so nothing carries from the low into the high one).  Slot p of a cell holds the pair (p, p + 1), p = 0 .. 8; a
+    // 2^32, so nothing carries from the low into the high one).  Slot p of a cell holds the pair (p, p + 1), p = 0 .. 8; a
     // bin is the sum of its two homes.  Half the atomics of one counter per bin.
     __shared__ unsigned long long s_h64[6 * 6 * 9];
     __shared__ float s_rf[32];
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(256) void patch_sift_kernel(
                 const efx_u32x2 gw = __builtin_amdgcn_raw_buffer_load_b64(lut_rsrc, (idy * 511 + idx + 255 * 512) * 8, 0, 0);
                 const float2 g = dbg == 7 ? make_float2(3.f + 0.01f * (float)(idx + idy), (float)(idx * idx + idy * idy))
                                           : make_float2(__uint_as_float(gw.x), __uint_as_float(gw.y));
-                const float mag = (dbg == 8 ? 32768.f : vote_weight16[k * 256 + tid]) * g.y;   // x 65536: exact, commutes with every product below
+                const float mag = (dbg == 8 ? 32768.f : vote_weight16[k * 256 + tid]) * g.y;   // x 2^17: exact, commutes with every product below
                 const float fo = floorf(g.x);
                 const float of = g.x - fo;
                 const int oi = (int)fo & 7;                                             // bins -4 .. 4 -> 4 .. 7, 0 .. 4
@@ -264,8 +265,8 @@ __global__ __launch_bounds__(256) void patch_sift_kernel(
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const float b1 = of * a4[q], b0 = a4[q] - b1;
-                    // 16.16 fixed point, rounded half up (contributions are >= 0; a bin collects at most 64 pixel-weights x 361
-                    // of magnitude: < 2^15).  A bin holds hundreds of gray levels, so 2^-17 per vote is ~1e-7 relative.
+                    // 15.17 fixed point, rounded half up (contributions are >= 0).  A bin holds hundreds of gray levels, so 2^-18
+                    // per vote is ~1e-7 relative.
                     const unsigned long long pair = (unsigned long long)hs_round_half_up(b0) | ((unsigned long long)hs_round_half_up(b1) << 32);
                     if (dbg == 6) sink += pair;
                     else atomicAdd(reinterpret_cast<unsigned long long*>(home + ((q >> 1) * 6 + (q & 1)) * 72), pair);
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(256) void patch_sift_kernel(
     // fixed point -> float, circular fold of the 10 orientation bins into 8 (hash_sift.cpp:293-308: ph[0] += ph[8], ph[1] += ph[9])
     auto bin_of = [&](const unsigned long long* hc, int k) -> float {
         const uint32_t v = (k < 9 ? (uint32_t)hc[k] : 0u) + (k >= 1 ? (uint32_t)(hc[k - 1] >> 32) : 0u);      // pairs (k, k+1) and (k-1, k)
-        return (float)v * (1.f / 65536.f);               // one rounding (u32 -> f32), the power of two is exact
+        return (float)v * (1.f / 131072.f);              // one rounding (u32 -> f32), the power of two is exact
     };
     auto element = [&](int e) -> float {
         const int r = e >> 5, c = (e >> 3) & 3, k = e & 7;

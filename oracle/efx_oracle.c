@@ -266,7 +266,7 @@ static void hs_normalize(float* d, int n)
 
 /* computePatchSIFT, hash_sift.cpp:200-331 (STEP1_PYRAMID is false: no patch blur) */
 /* fixed_point != 0: the histogram is summed as the HIP kernel does it (hashsift_kernels.hip): every vote is converted
- * to 16.16 fixed point (rounded to nearest) and added as an integer (order independent), the bin is converted back to
+ * to 15.17 fixed point (rounded half up) and added as an integer (order independent), the bin is converted back to
  * float at the end; the two 128-term sums of squares of the normalisation are added in the device's tree order.
  * This is a CPU MODEL OF THE DEVICE ARITHMETIC used to (a) check the kernel bit for bit and (b) quantify how far that
  * arithmetic is from the reference's sequentially rounded float sums (fixed_point == 0). */
@@ -300,9 +300,9 @@ static void hs_patch_sift(const uint8_t* patch, float* desc /*128*/, float kp_sc
     uint64_t h64[HS_R_BINS + 2][HS_C_BINS + 2][HS_ORI_BINS + 2];
     memset(hist, 0, sizeof(hist));
     memset(h64, 0, sizeof(h64));
-    /* fixed_point: the device's histogram arithmetic -- 16.16 fixed point, every vote rounded half up (floor(v * 2^16 + 1/2),
+    /* fixed_point: the device's histogram arithmetic -- 15.17 fixed point, every vote rounded half up (floor(v * 2^17 + 1/2),
      * the sum formed exactly), integer sums (order independent), cuda-efficient-features_amd/csrc/hashsift_kernels.hip */
-#define HS_VOTE(R, Cc, O, V) do { if (fixed_point) h64[R][Cc][O] += (uint64_t)(uint32_t)floor((double)((V) * 65536.f) + 0.5); \
+#define HS_VOTE(R, Cc, O, V) do { if (fixed_point) h64[R][Cc][O] += (uint64_t)(uint32_t)floor((double)((V) * 131072.f) + 0.5); \
         else hist[R][Cc][O] += (V); } while (0)
 
     /* HistBin, hash_sift.cpp:162-184 */
@@ -359,7 +359,7 @@ static void hs_patch_sift(const uint8_t* patch, float* desc /*128*/, float kp_sc
     if (fixed_point)
         for (int r = 0; r < HS_R_BINS + 2; r++)
             for (int c = 0; c < HS_C_BINS + 2; c++)
-                for (int o = 0; o < HS_ORI_BINS + 2; o++) hist[r][c][o] = (float)((double)(uint32_t)h64[r][c][o] * (1.0 / 65536.0));
+                for (int o = 0; o < HS_ORI_BINS + 2; o++) hist[r][c][o] = (float)((double)(uint32_t)h64[r][c][o] * (1.0 / 131072.0));
     /* circular orientation fold + copy, hash_sift.cpp:293-308 */
     for (int r = 0; r < HS_R_BINS; r++)
         for (int c = 0; c < HS_C_BINS; c++) {

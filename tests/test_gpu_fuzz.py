@@ -67,7 +67,10 @@ def _case(seed):
 
 
 def _hashsift_tol(nbits, n):
-    return 2 * max(1, n // 100)
+    # 1.4e-5 of the 129-vector elements differ from the CPU reference by one unit (15.17 fixed-point histogram against
+    # sequentially rounded float sums); such an element flips the bits whose projection is within one
+    # weight of zero -- usually none, now and then three or four of one descriptor
+    return max(4, 2 * (n // 100))
 
 
 # EFX_FUZZ_CASES / EFX_FUZZ_FIRST widen the sweep from the command line (the committed default keeps the suite fast)
