@@ -138,6 +138,7 @@ def main():
     if args.dry_run:
         return dry_run(args, rank, world)
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes on this host driver (before HIP starts)
     import torch
     import cef_loader
     cef = cef_loader.load()
