@@ -329,9 +329,9 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 struct efx_describer { Describer d; };
 
 struct efx_matcher {
-    DevBuf scratch, a_idx, a_dist, b_idx, b_dist;
+    DevBuf scratch, expanded, a_idx, a_dist, b_idx, b_dist;
     std::string err;
-    ~efx_matcher() { scratch.release(); a_idx.release(); a_dist.release(); b_idx.release(); b_dist.release(); }
+    ~efx_matcher() { scratch.release(); expanded.release(); a_idx.release(); a_dist.release(); b_idx.release(); b_dist.release(); }
 };
 
 struct efx_context {
@@ -1517,6 +1517,20 @@ static int knn2_run(efx_matcher* m, const uint8_t* q, size_t qp, int nq, const u
                     int* idx, int* dist, hipStream_t stream)
 {
     if (nq == 0) return EFX_OK;
+    static const bool no_mfma = getenv("EFX_MATCH_NO_MFMA") != nullptr;       // tests: force the popcount kernel
+    if (nq >= 128 && nt >= 64 && !no_mfma) {
+        // large sets: the distance matrix as an int8 GEMM on the matrix cores (match_kernels.hip)
+        int nchunks = 1024 / ((nq + 255) / 256);
+        if (nchunks < 1) nchunks = 1;
+        if (nchunks > 64) nchunks = 64;
+        const int ntiles = (nt + 31) / 32;
+        if (nchunks > ntiles) nchunks = ntiles;
+        HIP_TRY(m->err, m->scratch.reserve((size_t)nchunks * nq * 16));
+        HIP_TRY(m->err, m->expanded.reserve(efx_knn2_mfma_scratch(nq, nt, db)));
+        hipError_t e = efx_launch_knn2_mfma(q, qp, nq, t, tp, nt, db, m->expanded.p, m->scratch.p, nchunks, idx, dist, stream);
+        if (e != hipSuccess) return set_err(m->err, EFX_ERR_HIP, "knn launch failed: %s", hipGetErrorString(e));
+        return EFX_OK;
+    }
     // enough (query block, train chunk) pairs to fill the chip: ~4 workgroups per CU
     int nchunks = 1024 / ((nq + 255) / 256);
     if (nchunks < 1) nchunks = 1;

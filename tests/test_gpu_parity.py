@@ -338,9 +338,10 @@ def test_determinism(cef, torch_mod):
 
 # ---- brute-force Hamming matcher ----
 @pytest.mark.parametrize("nbytes", [32, 64])
-@pytest.mark.parametrize("nq,nt", [(1000, 1300), (257, 3), (5, 1), (300, 300)])
+@pytest.mark.parametrize("nq,nt", [(1000, 1300), (257, 3), (5, 1), (300, 300), (4097, 3001), (129, 65), (2500, 64)])
 def test_matcher_knn2_and_crosscheck(cef, torch_mod, nbytes, nq, nt):
-    """knnMatch(k=2) and crossCheck match are exact (integer distances, ties to the lower train index)."""
+    """knnMatch(k=2) and crossCheck match are exact (integer distances, ties to the lower train index).  Sets of at least
+    128 x 64 descriptors go through the int8 matrix-core kernel, smaller ones through the popcount kernel."""
     from oracle import matcher_oracle as MO
     rng = np.random.default_rng(nq * 7 + nt + nbytes)
     q = rng.integers(0, 256, size=(nq, nbytes), dtype=np.uint8)
@@ -361,6 +362,19 @@ def test_matcher_knn2_and_crosscheck(cef, torch_mod, nbytes, nq, nt):
     torch_mod.cuda.synchronize()
     wm, wd = MO.crosscheck(q, t)
     assert np.array_equal(mm.cpu().numpy(), wm) and np.array_equal(md.cpu().numpy(), wd)
+
+
+def test_matcher_paths_agree(cef, torch_mod, monkeypatch):
+    """The popcount kernel and the matrix-core kernel give the same answer on a set with many distance ties."""
+    rng = np.random.default_rng(99)
+    q = rng.integers(0, 256, size=(3000, 64), dtype=np.uint8)
+    t = np.concatenate([q[::3], q[::5], rng.integers(0, 256, size=(700, 64), dtype=np.uint8)])     # duplicates: ties everywhere
+    m = cef.BFMatcher.create(cef.BFMatcher.NORM_HAMMING)
+    idx, dist = m.knnMatch(_dev(torch_mod, q), _dev(torch_mod, t), 2)
+    torch_mod.cuda.synchronize()
+    from oracle import matcher_oracle as MO
+    widx, wdist = MO.knn2(q, t)
+    assert np.array_equal(dist.cpu().numpy(), wdist) and np.array_equal(idx.cpu().numpy(), widx)
 
 
 def test_matcher_on_detected_descriptors(cef, torch_mod):
