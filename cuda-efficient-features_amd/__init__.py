@@ -35,7 +35,7 @@ ABI_SYMBOLS = [
     "efx_set_descriptor_type", "efx_get_descriptor_type",
     "efx_descriptor_size", "efx_descriptor_dtype", "efx_default_norm",
     "efx_detect_async", "efx_detect_and_compute_async", "efx_compute_async", "efx_compute_kp4_async",
-    "efx_last_count", "efx_last_level_stats",
+    "efx_last_count", "efx_last_level_stats", "efx_overflow_events",
     "efx_detect", "efx_compute", "efx_detect_and_compute", "efx_convert",
     "efx_bad_create", "efx_hashsift_create", "efx_describer_destroy", "efx_describer_descriptor_size",
     "efx_describer_last_error", "efx_describer_compute_kp4_async", "efx_describer_compute_async",
@@ -110,6 +110,7 @@ def lib():
         L.efx_compute_kp4_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_int,
                                             C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]
         L.efx_last_count.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        L.efx_overflow_events.restype = C.c_int; L.efx_overflow_events.argtypes = [C.c_void_p]
         L.efx_device_bytes.restype = C.c_size_t
         L.efx_trim_memory.restype = C.c_size_t; L.efx_trim_memory.argtypes = []
         L.efx_cached_bytes.restype = C.c_size_t; L.efx_cached_bytes.argtypes = []
@@ -330,6 +331,10 @@ class EfficientFeatures:
         n = C.c_int(0)
         self._check(lib().efx_last_count(self._h, C.byref(n)))
         return n.value
+
+    def overflowEvents(self):
+        """Frames of this context that were void because they overflowed the density-sized arenas (include/efx.h)."""
+        return int(lib().efx_overflow_events(self._h))
 
     def lastLevelStats(self):
         st = (LevelStats * 32)()
@@ -568,6 +573,12 @@ class Batch:
                                                       self._desc, dp, cap, self._cnt)
         if rc != EFX_OK:
             raise EfxError(rc, "batch: " + lib().efx_last_error(self._det0._h).decode())
+
+    def overflowEvents(self):
+        """Void frames (arena overflow) over all contexts of the batch: a caller that reads the count tensors directly
+        checks this after a step -- non-zero means frames with N == 0 that must be run again (the contexts have enlarged
+        their arenas by the next run())."""
+        return sum(d.overflowEvents() for d in self._keep[0])
 
 
 def trimMemory():

@@ -835,7 +835,7 @@ __global__ __launch_bounds__(256) void fast_kernel(
             s_start = total > 0 ? atomicAdd(&cnt->cand_total[l][tile & (EFX_NSUB - 1)].v, total) : 0;
             // the arenas are sized for a corner density, not for the worst case (efx_api.cpp, build_geometry): a frame that
             // does not fit is void -- every later kernel of the frame returns at once, N = 0, the host enlarges the arenas
-            if ((unsigned)(s_start + total) > L.cand_sub_cap) cnt->sum.overflow = 1;
+            if ((unsigned)(s_start + total) > L.cand_sub_cap) efx_raise_overflow(T, cnt);
         }
         __syncthreads();
 
@@ -861,7 +861,7 @@ __global__ __launch_bounds__(256) void fast_kernel(
 __global__ __launch_bounds__(64) void harris_kernel(
     const LevelTable* __restrict__ T, const uint8_t* __restrict__ img0, int pitch0, int aligned0,
     const uint8_t* __restrict__ pyramid, const uint32_t* __restrict__ cand_xy_all, Corner* __restrict__ cand_all, Corner* __restrict__ cmax_all,
-    TileHdr* __restrict__ hdr_all, const Counters* __restrict__ cnt, int dbg_arg)
+    TileHdr* __restrict__ hdr_all, Counters* __restrict__ cnt, int dbg_arg)
 {
     const int dbg = EFX_DBG(dbg_arg);
     __shared__ unsigned long long s_cellmax[EFX_CELLS_PER_TILE];
@@ -905,6 +905,10 @@ __global__ __launch_bounds__(64) void harris_kernel(
     const bool aligned = l == 0 ? aligned0 != 0 : true;
     const TileHdr& h = hdr_all[L.tile_base + tile];
     const int total = h.cell_off[EFX_CELLS_PER_TILE];
+    if (total > EFX_TILE * EFX_TILE || (size_t)h.cand_start + (size_t)total > (size_t)L.cand_sub_cap) {      // header out of range: void frame
+        if (lane == 0) efx_raise_overflow(T, cnt);
+        return;
+    }
     const size_t first = L.cand_base + (size_t)(tile & (EFX_NSUB - 1)) * L.cand_sub_cap + h.cand_start;
     Corner* cand = cand_all + first;
     const uint32_t* cand_xy = cand_xy_all + first;
@@ -913,6 +917,10 @@ __global__ __launch_bounds__(64) void harris_kernel(
     for (int k = lane; k < total; k += 64) {
         const uint32_t xy = cand_xy[k];
         const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
+        // a coordinate that is not of this tile was never written by fast_kernel (stores of freshly
+        // mapped arenas lost under heavy oversubscription): the frame is void like an overflowed one -- the host reruns
+        // it -- instead of a memory fault here or in nms_kernel
+        if ((x >> 6) != tx || (y >> 6) != ty || x >= L.cols || y >= L.rows) { efx_raise_overflow(T, cnt); continue; }
         const uint8_t* c = src + (size_t)y * spitch + x;
         const float resp = (dbg & 4) ? 1.f : (aligned ? harris_rows(c - 4 * spitch - 4, spitch) : harris_bytes(c, spitch));
         Corner rec; rec.xy = xy; rec.resp = resp;
@@ -997,6 +1005,19 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
     Corner cm; cm.xy = 0u; cm.resp = 0.f;
     if (lane < 36) cm = cmax_all[L.cmax_base + (size_t)cy * (L.tiles_x * 4) + cx];
     __syncthreads();                                     // s_nb is read below
+    {
+        // the nine headers address the corner arena: ranges that do not fit it void the frame (see harris_kernel)
+        bool bad = false;
+        if (lane < 9) {
+            const TileHdr* nh = reinterpret_cast<const TileHdr*>(&s_nb[lane][0]);
+            const unsigned tot = nh->cell_off[EFX_CELLS_PER_TILE];
+            bad = tot > (unsigned)(EFX_TILE * EFX_TILE) || (size_t)nh->cand_start + tot > (size_t)L.cand_sub_cap;
+        }
+        if (__ballot(bad) != 0ull) {
+            if (lane == 0) efx_raise_overflow(T, cnt);
+            return;
+        }
+    }
     if (lane < 36) {
         if (capped) {
             // a cell of a tile that is cut by the cap may hold invalid corners: its maximum must not suppress anything,
@@ -1151,8 +1172,14 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
         bool hard = false, sure = false;
         int need = 0x1ff;                                     // neighbour cells the exact scan has to walk (all, unless phase A knows better)
         Corner me; me.xy = 0; me.resp = 0.f;
+        if (k < n_valid) me = own[k];
+        // range check (see harris_kernel): a record that is not of this tile would index LDS and the arenas out of range;
+        // the frame is void (wave-uniform exit: the workgroup is this wave)
+        if (__ballot(k < n_valid && ((int)((me.xy & 0xffff) >> 6) != tx || (int)(me.xy >> 22) != ty)) != 0ull) {
+            if (lane == 0) efx_raise_overflow(T, cnt);
+            return;
+        }
         if (k < n_valid) {
-            me = own[k];
             const int mx = me.xy & 0xffff, my = me.xy >> 16;
             const int bx1 = mx / EFX_CELL, by1 = my / EFX_CELL;
             hard = true;
@@ -1219,7 +1246,7 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
     int start = 0;
     if (lane == 0 && nsurv > 0) {
         start = atomicAdd(&cnt->surv_total[l][tile & (EFX_NSUB - 1)].v, nsurv);
-        if ((unsigned)(start + nsurv) > L.surv_sub_cap) cnt->sum.overflow = 1;      // void frame, see fast_kernel
+        if ((unsigned)(start + nsurv) > L.surv_sub_cap) efx_raise_overflow(T, cnt);      // void frame, see fast_kernel
     }
     start = __shfl(start, 0, 64);
     // second pass: write the survivors in canonical order

@@ -60,21 +60,37 @@ struct BlockCache {
         free_blocks.erase(free_blocks.begin() + best);
         return p;
     }
-    // the cache keeps at most EFX_BLOCK_CACHE_MB (default 4096): beyond that the oldest blocks go back to the driver
+    // the cache keeps at most EFX_BLOCK_CACHE_MB (default 1024: three 8K contexts; 0 switches it off): beyond that the oldest
+    // blocks go back to the driver.  Memory held here is invisible to other allocators of the process (PyTorch's caching
+    // allocator, ...): efx_trim_memory() returns it, INTEGRATION.md section 4
     void give(void* p, size_t bytes, int dev)
     {
-        static const size_t cap = [] { const char* v = getenv("EFX_BLOCK_CACHE_MB"); return (size_t)(v ? atoll(v) : 4096) << 20; }();
+        static const size_t cap = [] { const char* v = getenv("EFX_BLOCK_CACHE_MB"); return (size_t)(v ? atoll(v) : 1024) << 20; }();
         std::lock_guard<std::mutex> g(m);
         free_blocks.push_back({ p, bytes, dev });
         size_t t = 0;
         for (const Block& b : free_blocks) t += b.bytes;
-        while (t > cap && !free_blocks.empty()) { t -= free_blocks.front().bytes; (void)hipFree(free_blocks.front().p); free_blocks.erase(free_blocks.begin()); }
+        while (t > cap && !free_blocks.empty()) {
+            const Block b = free_blocks.front();
+            free_blocks.erase(free_blocks.begin());
+            t -= b.bytes;
+            free_on(b.p, b.dev);
+        }
+    }
+    // hipFree on the device the block lives on (a process may drive several GPUs)
+    static void free_on(void* p, int dev)
+    {
+        int cur = -1;
+        (void)hipGetDevice(&cur);
+        if (cur != dev) (void)hipSetDevice(dev);
+        (void)hipFree(p);
+        if (cur != dev && cur >= 0) (void)hipSetDevice(cur);
     }
     size_t trim()
     {
         std::lock_guard<std::mutex> g(m);
         size_t t = 0;
-        for (const Block& b : free_blocks) { t += b.bytes; (void)hipFree(b.p); }
+        for (const Block& b : free_blocks) { t += b.bytes; free_on(b.p, b.dev); }
         free_blocks.clear();
         return t;
     }
@@ -107,19 +123,25 @@ struct DevBuf {                     // grow-only device allocation
         if (e == hipSuccess && poison) { e = hipMemset(p, 0xA5, n); if (e == hipSuccess) e = hipDeviceSynchronize(); }   // before any non-blocking stream touches it
         return e;
     }
-    // The block may still be in use by kernels in flight (hipFree used to wait for them implicitly): wait, then cache it.
+    // The block may still be in use by kernels in flight ON ITS OWN DEVICE (hipFree used to wait for them implicitly): wait
+    // there -- not on whatever device is current: one process may drive several GPUs -- then cache it.
     void release()
     {
         if (!p) return;
+        int cur = -1;
+        (void)hipGetDevice(&cur);
+        if (cur != dev) (void)hipSetDevice(dev);
         (void)hipDeviceSynchronize();
         static const bool no_cache = getenv("EFX_NO_BLOCK_CACHE") != nullptr;
         if (no_cache) (void)hipFree(p); else block_cache().give(p, bytes, dev);
+        if (cur != dev && cur >= 0) (void)hipSetDevice(cur);
         p = nullptr; bytes = 0;
     }
 };
 
 struct Describer {                  // cuda::BAD / cuda::HashSIFT state
     int dbg_hs = 0;                 // EFX_DEBUG_HS, read when the describer is created (EFX_DEBUG_BUILD builds only)
+    int no_raw = 0;                 // EFX_BAD_NO_RAW (variant knob), read when the describer is created
     size_t hs_wb_off = 0;           // HashSIFT: byte offset of the bf16 weight terms inside `params`
     int kind = 0;                   // 0 BAD, 1 HashSIFT
     int nbits = 256;
@@ -157,6 +179,7 @@ int describer_init(Describer& d, int kind, int nbits, float scale)
 {
     d.kind = kind; d.nbits = nbits; d.scale = scale;
     d.dbg_hs = efx_read_knobs().dbg_hs;
+    d.no_raw = getenv("EFX_BAD_NO_RAW") != nullptr;
     if (kind == 0) {
         // BAD_Impl ctor, bad.cpp:300-317 / loadBoxPairParams, cuda_bad.cu:318-334 (per-instance here)
         const unsigned char* blob = nbits == 256 ? efx_blob_bad256 : efx_blob_bad512;
@@ -276,6 +299,7 @@ int describer_run(Describer& d, std::string& err, DescribeLaunch a, float* dbg_r
         HIP_TRY(err, d.responses.reserve((size_t)a.n * sizeof(Affine)));
         a.bad_affine = d.responses.p;
         a.bad_det_tables = 1;            // describer_init builds ubox for d.scale and size 31
+        a.bad_no_raw = d.no_raw;
         hipError_t e = efx_launch_bad(a, static_cast<const BadParamsDev*>(d.params.p), d.reach, stream);
         if (e == hipErrorInvalidValue) return set_err(err, EFX_ERR_UNSUPPORTED, "keypoint size %.1f needs a window larger than the 160 KB LDS", a.max_size);
         if (e != hipSuccess) return set_err(err, EFX_ERR_HIP, "BAD launch failed: %s", hipGetErrorString(e));
@@ -329,6 +353,7 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 struct efx_describer { Describer d; };
 
 struct efx_matcher {
+    bool no_mfma = getenv("EFX_MATCH_NO_MFMA") != nullptr;        // variant knob (tests: force the popcount kernel), read when the matcher is created
     DevBuf scratch, expanded, a_idx, a_dist, b_idx, b_dist;
     std::string err;
     ~efx_matcher() { scratch.release(); expanded.release(); a_idx.release(); a_dist.release(); b_idx.release(); b_dist.release(); }
@@ -351,6 +376,9 @@ struct efx_context {
     int n_out_max = 0;              // sum of the active levels' quotas
     bool arena_full = false;        // corner / survivor arenas sized for the worst case (set after a frame overflowed them)
     bool g_arena_full = false;      // ... as the cached geometry was built
+    int* h_overflow = nullptr;      // sticky overflow word: pinned host memory the kernels store to (LevelTable::host_overflow)
+    int* d_overflow = nullptr;      // ... its device address
+    int overflow_events = 0;        // frames that were void because of it (efx_overflow_events)
     DetectLaunch last_launch;       // investigation (efx_debug_rerun): the last frame's launch arguments
     bool has_frame = false;
     const uint8_t* last_img0 = nullptr; int last_pitch0 = 0;
@@ -366,6 +394,7 @@ struct efx_context {
         rplan.release(); d_table.release(); pyramid.release(); hdr.release(); cand.release(); cmax.release(); surv.release(); counters.release();
         kp4.release(); kp_level.release(); img.release(); kps.release(); descout.release(); count.release(); maskbuf.release();
         delete h_mirror;
+        if (h_overflow) (void)hipHostFree(h_overflow);
         for (hipEvent_t e : prof_start) (void)hipEventDestroy(e);
         for (hipEvent_t e : prof_stop) (void)hipEventDestroy(e);
     }
@@ -393,6 +422,18 @@ int build_geometry(efx_context* c, int rows, int cols)
     LevelTable& T = c->h_table;
     memset(&T, 0, sizeof(T));
     T.nlevels = p.nlevels;
+    if (!c->h_overflow) {
+        // best effort: without the word the overflow is still reported through efx_last_count / efx_last_level_stats
+        void* hp = nullptr; void* dp = nullptr;
+        if (hipHostMalloc(&hp, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
+            c->h_overflow = static_cast<int*>(hp); c->d_overflow = static_cast<int*>(dp);
+            *c->h_overflow = 0;
+        } else {
+            if (hp) (void)hipHostFree(hp);
+            (void)hipGetLastError();
+        }
+    }
+    T.host_overflow = c->d_overflow;
 
     int quota[EFX_MAX_LEVELS];
     {
@@ -554,6 +595,20 @@ int build_geometry(efx_context* c, int rows, int cols)
     return EFX_OK;
 }
 
+// An earlier frame of this context overflowed the density-sized arenas (it was void: N = 0).  The kernels left a sticky
+// word in host memory; a caller that only ever reads d_count never calls efx_last_count, so the enlargement happens here,
+// at the start of the next call, without a synchronisation.  (A frame still in flight may set the word again after it was
+// cleared: harmless, the arenas are already at their worst-case size by then.)
+void consume_sticky_overflow(efx_context* c)
+{
+    if (!c->h_overflow) return;
+    volatile int* w = c->h_overflow;
+    if (*w == 0) return;
+    *w = 0;
+    c->overflow_events++;
+    c->arena_full = true;
+}
+
 int detect_common(efx_context* c, const uint8_t* d_image, int rows, int cols, size_t pitch,
                   void* d_keypoints, size_t kps_pitch, uint8_t* d_desc, size_t desc_pitch,
                   int capacity, int* d_count, hipStream_t stream, const uint8_t* d_mask = nullptr, size_t mask_pitch = 0)
@@ -566,6 +621,7 @@ int detect_common(efx_context* c, const uint8_t* d_image, int rows, int cols, si
     if (d_desc && desc_pitch < (size_t)efx_descriptor_size(c)) return set_err(c->err, EFX_ERR_BAD_ARG, "desc_pitch smaller than the descriptor");
     int rc = validate_params(c->p, c->err);
     if (rc) return rc;
+    consume_sticky_overflow(c);
     rc = build_geometry(c, rows, cols);
     if (rc) return rc;
     const int cap_alloc = capacity > 0 ? capacity : 1;
@@ -704,11 +760,17 @@ int describe_5xn(Describer& d, std::string& err, const uint8_t* d_image, int row
     if (n < 0) return set_err(err, EFX_ERR_BAD_ARG, "n must be >= 0");
     if (n == 0) return EFX_OK;
     if (!d_keypoints || kps_pitch < (size_t)n * 4) return set_err(err, EFX_ERR_BAD_ARG, "bad keypoint matrix");   // CV_Assert(rows == 5), .cpp:111
-    HIP_TRY(err, d.kp4.reserve((size_t)n * sizeof(float4)));
-    hipError_t e = efx_launch_convert_keypoints(d_keypoints, kps_pitch, n, static_cast<float4*>(d.kp4.p), stream);
-    if (e != hipSuccess) return set_err(err, EFX_ERR_HIP, "convertKeypoints failed: %s", hipGetErrorString(e));
-    return describe_single(d, err, d_image, rows, cols, pitch, static_cast<const float4*>(d.kp4.p), n, (float)EFX_PATCH_SIZE,
-                           d_desc, desc_pitch, nullptr, nullptr, stream, 1);
+    // getKeypointsMat -> convertKeypointsKernel (.cpp:102-115, .cu:250-263): the describers' record kernels read the 5 x n
+    // matrix themselves (size forced to 31), so the conversion is not a launch of its own
+    if (!d_image || rows <= 0 || cols <= 0 || pitch < (size_t)cols) return set_err(err, EFX_ERR_BAD_ARG, "bad image arguments");
+    if (d_desc && desc_pitch < (size_t)(d.nbits / 8)) return set_err(err, EFX_ERR_BAD_ARG, "desc_pitch smaller than the descriptor");
+    DescribeLaunch dl;
+    memset(&dl, 0, sizeof(dl));
+    dl.img0 = d_image; dl.pitch0 = (int)pitch; dl.rows0 = rows; dl.cols0 = cols;
+    dl.kps5 = static_cast<const uint8_t*>(d_keypoints); dl.kps5_pitch = kps_pitch;
+    dl.n = n; dl.blur = 0; dl.max_size = (float)EFX_PATCH_SIZE; dl.uniform_size = 1;
+    dl.desc = d_desc; dl.desc_pitch = desc_pitch;
+    return describer_run(d, err, dl, nullptr, nullptr, stream);
 }
 
 int describe_host(Describer& d, std::string& err, const uint8_t* h_image, int rows, int cols, size_t pitch,
@@ -905,6 +967,7 @@ static int check_overflow(const efx_context* ctx)
     if (!ctx->h_mirror->overflow) return EFX_OK;
     efx_context* c = const_cast<efx_context*>(ctx);
     c->arena_full = true;
+    if (c->h_overflow && *(volatile int*)c->h_overflow) { *(volatile int*)c->h_overflow = 0; c->overflow_events++; }
     return set_err(c->err, EFX_ERR_OVERFLOW, "the frame had more FAST corners / NMS survivors than the scratch arenas hold (they are sized "
                    "for a corner density of 1/8); the arenas are enlarged to the worst case from the next call on: repeat the call");
 }
@@ -1011,6 +1074,8 @@ int efx_debug_rerun(efx_context* ctx, int stages, int* surv_totals, int nlevels_
     return EFX_OK;
 }
 #endif
+
+int efx_overflow_events(const efx_context* ctx) { return ctx ? ctx->overflow_events : 0; }
 
 size_t efx_trim_memory(void) { (void)hipDeviceSynchronize(); return block_cache().trim(); }
 size_t efx_cached_bytes(void) { return block_cache().cached(); }
@@ -1517,8 +1582,7 @@ static int knn2_run(efx_matcher* m, const uint8_t* q, size_t qp, int nq, const u
                     int* idx, int* dist, hipStream_t stream)
 {
     if (nq == 0) return EFX_OK;
-    static const bool no_mfma = getenv("EFX_MATCH_NO_MFMA") != nullptr;       // tests: force the popcount kernel
-    if (nq >= 128 && nt >= 64 && !no_mfma) {
+    if (nq >= 128 && nt >= 64 && !m->no_mfma) {
         // large sets: the distance matrix as an int8 GEMM on the matrix cores (match_kernels.hip)
         int nchunks = 1024 / ((nq + 255) / 256);
         if (nchunks < 1) nchunks = 1;

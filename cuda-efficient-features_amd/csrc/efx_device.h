@@ -46,6 +46,11 @@ struct LevelDev {
 struct LevelTable {
     int nlevels;
     int total_tiles;
+    // Sticky "a frame overflowed the density-sized arenas" word in pinned, device-mapped HOST memory (null: none).  The
+    // kernels that raise Summary::overflow also store 1 here (system scope); the host looks at it -- a plain load, no
+    // synchronisation -- at the start of the context's next call and enlarges the arenas, so that an asynchronous caller who
+    // never asks for the summary does not lose every dense frame (efx_api.cpp, detect_common)
+    int* host_overflow;
     LevelDev lv[EFX_MAX_LEVELS];
 };
 
@@ -77,6 +82,25 @@ struct Counters {               // zeroed at the start of every frame
     unsigned long long thresh[EFX_MAX_LEVELS];   // selection threshold key per level
     Summary sum;
 };
+
+#if defined(__HIPCC__)
+// Keypoint i of a describe call: from the float4 list, or straight from the caller's 5 x n matrix with the rule of
+// convertKeypointsKernel (cuda_efficient_features.cu:250-263): x, y from the packed shorts, size forced to 31, angle row
+__device__ __forceinline__ float4 efx_load_keypoint(const float4* __restrict__ kp4, const uint8_t* __restrict__ kps5, size_t kps5_pitch, int i)
+{
+    if (!kps5) return kp4[i];
+    const uint32_t loc = *reinterpret_cast<const uint32_t*>(kps5 + 4 * (size_t)i);
+    const float ang = *reinterpret_cast<const float*>(kps5 + 2 * kps5_pitch + 4 * (size_t)i);
+    return make_float4((float)(short)(loc & 0xffff), (float)(short)(loc >> 16), 31.f, ang);
+}
+
+// the frame is void (arena overflow, or arena contents that fail their range checks): device flag + the host's sticky word
+__device__ __forceinline__ void efx_raise_overflow(const LevelTable* T, Counters* cnt)
+{
+    cnt->sum.overflow = 1;
+    if (T->host_overflow) __hip_atomic_store(T->host_overflow, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+#endif
 
 // One packed word per tile behind the level table: level | tx << 5 | ty << 15.  The level field must hold EFX_MAX_LEVELS
 // values; tx, ty < 32768 / 64 = 512 (images are at most 32767 px per side).
@@ -239,6 +263,8 @@ struct DescribeLaunch {
     const uint8_t* img0; int pitch0; int rows0, cols0;     // image for level index 0 / single-image mode
     const uint8_t* pyramid; const LevelTable* d_table;     // null in single-image mode
     const float4* kp4; const int* kp_level;                // kp_level null -> all keypoints on img0
+    const uint8_t* kps5; size_t kps5_pitch;                // non-null: the keypoints are the caller's 5 x n matrix (computeAsync): the
+                                                           // record kernels read it directly (convertKeypointsKernel's rule: size 31), kp4 is unused
     const int* d_count;                                    // device N (null -> use n)
     int n;                                                 // grid size (upper bound of N)
     int blur;                                              // 1: 7x7 sigma-2 Gaussian first (detectAndCompute)
@@ -248,6 +274,8 @@ struct DescribeLaunch {
     uint8_t* desc; size_t desc_pitch;
     void* bad_affine;                                      // BAD scratch: n x 80 bytes (per-keypoint affine map + window geometry)
     int bad_det_tables;                                    // BadParamsDev::ubox was built for this describer scale and size 31
+    int bad_no_raw;                                        // EFX_BAD_NO_RAW (variant knob, read when the describer is created; parity tests):
+                                                           // computeAsync through the generic one-workgroup-per-keypoint kernel
     int affine_ready;                                      // bad_affine already holds this call's records (written by angle_kernel)
     int dbg_hs;                                            // EFX_DEBUG_HS (EFX_DEBUG_BUILD builds only)
     ProfRec prof;

@@ -1,23 +1,28 @@
-// hashsift_kernels.hip -- HashSIFT descriptor for gfx950: PatchSIFT 129-vectors + fp32 MFMA projection.
+// hashsift_kernels.hip -- HashSIFT descriptor for gfx950: PatchSIFT 129-vectors + bf16 matrix-core projection.
 //
 // Arithmetic: the reference CPU descriptor, modules/efficient_features/src/hash_sift.cpp
 //   rectifyPatch / warpAffineLinear :68-138, HistBin :162-184, distribute :193-198,
 //   computePatchSIFT :200-331, normalize :150-160, matmulAndSign :353-378.
 //
 // MI355X design
-//   * one workgroup per keypoint; the (optionally Gaussian-blurred, spec S6) window the rotated 32x32
-//     patch can touch is staged in LDS, so detectAndCompute needs no global blur pass;
-//   * the 6x6x10 gradient histogram is accumulated in 32.32 FIXED POINT with LDS integer atomics, one lane per
-//     pixel: integer addition is associative, so the result does not depend on the order the lanes arrive in
-//     (the reference's CUDA kernel adds floats with shared-memory atomics, cuda_hash_sift.cu:282-289, and is
-//     order-nondeterministic), and it is at least as accurate as the CPU loop's sequentially rounded float
-//     sums (hash_sift.cpp:233-290): the two differ by a last-place rounding that changes 1.5e-6 of the
-//     129-vector elements by one unit (measured over 40 000 keypoints), 1/60 of the stated tolerance;
-//   * the Gaussian pixel weights expf(...) (30x30) and the orientation bins scaleO*atan2f(dy,dx) (511x511
-//     integer gradients) are tables computed on the host with the same libm calls the CPU code makes;
-//     sqrtf is IEEE; cosf/sinf of the keypoint angle are glibc's (glibc_sincosf.h, bit-identical to the host libm);
-//   * projection T = R[N x 129] . W^T is the one real GEMM of the path: v_mfma_f32_32x32x2_f32 (exact fp32
-//     FMA chain), fused with the sign test and MSB-first bit packing (no T matrix in HBM, no separate
+//   * a lane per keypoint writes its record (rectifying affine map, level image, window: hs_record_kernel), then one
+//     workgroup per keypoint; the (optionally Gaussian-blurred, spec S6) window the rotated 32x32 patch can touch is
+//     staged in LDS, so detectAndCompute needs no global blur pass;
+//   * the 6x6x10 gradient histogram is accumulated in 15.17 FIXED POINT with LDS integer atomics, one lane per pixel; the
+//     two orientation bins a pixel votes for in a cell are two 32-bit counters packed into ONE 64-bit atomic (a bin
+//     collects < 2^15, so 17 fractional bits never carry into the neighbour); a vote is floor(v * 2^17 + 1/2).  Integer
+//     addition is associative, so the result does not depend on the order the lanes arrive in (the reference's CUDA
+//     kernel adds floats with shared-memory atomics, cuda_hash_sift.cu:282-289, and is order-nondeterministic).
+//     Against the CPU loop's sequentially rounded float sums (hash_sift.cpp:233-290) 1.4e-5 of the 129-vector elements
+//     differ by one unit and 2e-5 of the descriptor bytes (40 000 keypoints; the reference's own GPU-vs-CPU bound is 1e-4
+//     of the bytes, tests/descriptor_test.cpp:72; the 32.32 counters of round 1 gave 1.5e-6 at twice the atomics:
+//     DESIGN.md section 3 has the trade);
+//   * the Gaussian pixel weights expf(...) (30x30) and orientation bin + magnitude of a gradient (511x511 integer
+//     gradients: scaleO*atan2f(dy,dx), sqrtf) are tables computed on the host with the same libm calls the CPU code
+//     makes; cosf/sinf of the keypoint angle are glibc's (glibc_sincosf.h, bit-identical to the host libm);
+//   * projection T = R[N x 129] . W^T is the one real GEMM of the path: v_mfma_f32_32x32x16_bf16 with W split on the host
+//     into three bf16 terms whose sum is W exactly and R (integers 0..255, and 1) exact in bf16, so every product is
+//     exact in the fp32 accumulator; fused with the sign test and MSB-first bit packing (no T matrix in HBM, no separate
 //     binarize pass as in cuda_hash_sift.cu:414-435).
 
 #include "efx_device.h"
@@ -50,13 +55,13 @@ static_assert(sizeof(HsRec) == 64, "one record per 64-byte line");
 __global__ __launch_bounds__(256) void hs_record_kernel(
     const uint8_t* __restrict__ img0, int pitch0, int rows0, int cols0,
     const uint8_t* __restrict__ pyramid, const LevelTable* __restrict__ T,
-    const float4* __restrict__ kp4, const int* __restrict__ kp_level, const int* __restrict__ d_count, int n,
+    const float4* __restrict__ kp4, const uint8_t* __restrict__ kps5, size_t kps5_pitch, const int* __restrict__ kp_level, const int* __restrict__ d_count, int n,
     float crop_scale, int smax, int sfixed, int dword_rows, HsRec* __restrict__ rec)
 {
     const int count = d_count ? min(*d_count, n) : n;
     const int kid = blockIdx.x * 256 + threadIdx.x;
     if (kid >= count) return;
-    const float4 kp = kp4[kid];
+    const float4 kp = efx_load_keypoint(kp4, kps5, kps5_pitch, kid);
     HsRec A;
     A.img = img0; A.pitch = pitch0; A.rows = rows0; A.cols = cols0;
     if (kp_level) {
@@ -446,13 +451,13 @@ hipError_t efx_launch_hashsift(const DescribeLaunch& a, const HashSiftDev& h, hi
     float t[7];
     efx_gaussian_taps_host(t);
     const int dbg = a.dbg_hs;
-    const float* mag = h.W + (size_t)h.nbits * HS_KPAD;    // the pixel weights (x 2^16, in the vote loop's thread order) are stored behind W
+    const float* mag = h.W + (size_t)h.nbits * HS_KPAD;    // the pixel weights (x 2^17, in the vote loop's thread order) are stored behind W
     const float2* lut = reinterpret_cast<const float2*>(mag + 1024);      // followed by the 511x511 {orientation bin, magnitude} table
     static_assert(sizeof(HsRec) == EFX_HS_REC_BYTES, "scratch sizing in efx_api.cpp");
     HsRec* rec = static_cast<HsRec*>(h.records);
     const bool fixed48 = a.blur && S == 48 && a.uniform_size;
     hipLaunchKernelGGL(hs_record_kernel, dim3((a.n + 255) / 256), dim3(256), 0, stream, a.img0, a.pitch0, a.rows0, a.cols0,
-                       a.pyramid, a.d_table, a.kp4, a.kp_level, a.d_count, a.n, a.scale_factor, S, fixed48 ? 48 : 0, a.blur ? 0 : 1, rec);
+                       a.pyramid, a.d_table, a.kp4, a.kps5, a.kps5_pitch, a.kp_level, a.d_count, a.n, a.scale_factor, S, fixed48 ? 48 : 0, a.blur ? 0 : 1, rec);
     if (fixed48) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_sift_kernel<true, 48>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((patch_sift_kernel<true, 48>), dim3(a.n), dim3(256), lds, stream, rec, a.d_count, a.n, S, mag, lut,

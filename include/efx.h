@@ -38,8 +38,9 @@ typedef enum efx_status {
     EFX_ERR_HIP = -3,           /* a HIP runtime call failed (the reference only printf's: cuda_macro.h:23-28) */
     EFX_ERR_NO_DEVICE = -4,
     EFX_ERR_NOMEM = -5,
-    EFX_ERR_OVERFLOW = -6       /* the frame had more FAST corners / NMS survivors than the context's scratch arenas hold
-                                 * (see efx_last_count); the arenas have been enlarged, repeat the call */
+    EFX_ERR_OVERFLOW = -6       /* the frame had more FAST corners / NMS survivors than the context's scratch arenas hold: it
+                                 * is VOID (N = 0).  The arenas are enlarged to the worst case before the context's next
+                                 * frame: repeat the call ("arena overflow contract" at efx_detect_async) */
 } efx_status;
 
 /* cuda_efficient_features.h:39-45 */
@@ -99,7 +100,9 @@ size_t efx_device_bytes(const efx_context* ctx);                              /*
 /* Destroyed (and regrown) contexts and describers hand their device blocks to a process-wide cache that later contexts draw
    from (no hipMalloc / hipFree in a create-destroy loop; the reference's DeviceBuffer arena, src/device_buffer.cpp:29-69, is
    per object).  efx_trim_memory returns the cached blocks to the driver and reports their bytes; efx_cached_bytes reports
-   them.  The cache holds at most EFX_BLOCK_CACHE_MB (environment, default 4096); EFX_NO_BLOCK_CACHE=1 disables it. */
+   them.  The cache holds at most EFX_BLOCK_CACHE_MB (environment, default 1024); EFX_NO_BLOCK_CACHE=1 disables it.  Cached
+   blocks are invisible to other allocators of the process: a deployment that shares the GPU with one (PyTorch, ...) calls
+   efx_trim_memory() after tearing contexts down.  Blocks are waited for and freed on the device they were allocated on. */
 size_t efx_trim_memory(void);
 size_t efx_cached_bytes(void);
 const char* efx_last_error(const efx_context* ctx);             /* ctx may be NULL: last create() error */
@@ -125,7 +128,17 @@ int efx_default_norm(const efx_context* ctx);      /* 6 == cv::NORM_HAMMING, .cp
  * d_keypoints: 5 x capacity matrix (layout above).  d_count: device int receiving N (<= capacity).
  * The mask argument of the reference is accepted and ignored there (.cpp:225-250); it has no parameter here.
  * No host synchronisation happens inside; once the stream has been synchronised, efx_last_count() and
- * efx_last_level_stats() fetch N and the per-level counts from the device (one small blocking copy per call). */
+ * efx_last_level_stats() fetch N and the per-level counts from the device (one small blocking copy per call).
+ *
+ * Arena overflow contract (every asynchronous detect entry point: efx_detect_async, efx_detect_and_compute_async,
+ * efx_detect_and_compute_masked_async).  Levels above 2 Mpx get corner / survivor arenas sized for a corner DENSITY (1/8
+ * of the pixels; the reference keeps at most 1/10, .cpp:252), not for the worst case.  A frame that does not fit is void:
+ * *d_count == 0, nothing is emitted or described.  The device leaves a sticky flag, and the NEXT call on the context --
+ * whichever entry point -- enlarges the arenas to the worst case before it launches, without a synchronisation; so at most
+ * the frames already enqueued when the first dense frame ran are lost, never "every dense frame".  A caller who must not
+ * lose a frame polls efx_last_count() after synchronising: it returns EFX_ERR_OVERFLOW for a void frame (repeat the
+ * call); efx_overflow_events() counts the void frames seen so far.  The synchronous entry points (efx_detect, ...) rerun
+ * the frame by themselves. */
 int efx_detect_async(efx_context* ctx, const uint8_t* d_image, int rows, int cols, size_t pitch,
                      void* d_keypoints, size_t kps_pitch, int capacity, int* d_count, void* stream);
 
@@ -149,8 +162,11 @@ int efx_compute_kp4_async(efx_context* ctx, const uint8_t* d_image, int rows, in
                           const float* d_kp4, int n, float max_size,
                           uint8_t* d_descriptors, size_t desc_pitch, void* stream);
 
-/* N of the last detect / detectAndCompute on this context (valid after the stream was synchronised). */
+/* N of the last detect / detectAndCompute on this context (valid after the stream was synchronised).  Returns
+ * EFX_ERR_OVERFLOW when that frame was void because it overflowed the scratch arenas (contract at efx_detect_async). */
 int efx_last_count(const efx_context* ctx, int* n);
+/* Frames of this context found void by arena overflow so far (host-side count, no device access). */
+int efx_overflow_events(const efx_context* ctx);
 /* Per-level counters of the last detect call (valid after the stream was synchronised). */
 int efx_last_level_stats(const efx_context* ctx, efx_level_stats* stats, int max_levels, int* nlevels);
 

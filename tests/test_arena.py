@@ -78,3 +78,28 @@ def test_synchronous_api_reruns_by_itself(cef, oracle):
     k = oracle.unpack_keypoints(ref["kps"])
     assert len(kps) == ref["n"] > 0
     assert np.array_equal(kps["x"], k["x"].astype(np.float32)) and np.array_equal(kps["y"], k["y"].astype(np.float32))
+
+
+def test_async_only_caller_recovers_without_polling(cef, oracle):
+    """a caller that reads d_count directly and never asks for the summary.  The first dense frame is void; the
+    device leaves a sticky flag that the context's NEXT call consumes (no synchronisation, no efx_last_count): the arenas
+    are enlarged and the second frame is exact."""
+    import torch
+    img = synth.noise_frame(1300, 1900, seed=13)
+    d_img = torch.from_numpy(img).cuda()
+    det = cef.EfficientFeatures.create(3000, dtype=cef.EfficientFeatures.BAD_256)
+    kps, desc, cnt = det.detectAndComputeAsync(d_img)
+    torch.cuda.synchronize()
+    assert int(cnt.item()) == 0 and det.overflowEvents() == 0      # void; nobody has looked yet
+    small = det.deviceBytes()
+    kps, desc, cnt = det.detectAndComputeAsync(d_img)              # consumes the flag, enlarges, runs
+    torch.cuda.synchronize()
+    n = int(cnt.item())
+    assert det.overflowEvents() == 1 and det.deviceBytes() > small
+    prev = oracle.set_threads(32)
+    ref = oracle.detect_and_compute(img, nfeatures=3000, desc_type=oracle.BAD_256)
+    oracle.set_threads(prev)
+    assert n == ref["n"] > 0
+    assert np.array_equal(kps[:, :n].cpu().numpy().view(np.uint32), ref["kps"].view(np.uint32))
+    assert np.array_equal(desc[:n].cpu().numpy(), ref["desc"])
+    assert det.lastCount() == n                                     # no stale EFX_ERR_OVERFLOW

@@ -104,7 +104,14 @@ def test_c4_4k_40k_compute_hashsift512(cef, threaded_oracle, c34):
     want_resp = threaded_oracle.hashsift_responses(c34["img"], c34["kp4"])
     want_T, want_desc = threaded_oracle.hashsift_project(want_resp, 512)
     d = np.abs(resp - want_resp)
-    assert d.max() <= HS_VEC_MAX and (d > 0).mean() <= HS_VEC_FRAC
+    elem_rate, byte_rate = float((d > 0).mean()), float(np.count_nonzero(desc != want_desc)) / desc.size
+    # measured rates of the 15.17 fixed-point histogram against the CPU float sums (DESIGN.md section 3 records them;
+    # `pytest -s` shows them): the bound asserted here is 3x tighter than the stated tolerance, so an accuracy
+    # regression shows up before the reference's 1e-4 is reached
+    print(f"\nC4 HashSIFT512 vs CPU reference arithmetic: {elem_rate:.2e} of the 129-vector elements differ by one unit, "
+          f"{byte_rate:.2e} of the descriptor bytes differ ({workloads.N40K} keypoints)")
+    assert d.max() <= HS_VEC_MAX and elem_rate <= HS_VEC_FRAC
+    assert elem_rate <= 3e-5 and byte_rate <= 4e-5
     same = (d == 0).all(axis=1)
     assert np.abs(T[same] - want_T[same]).max() <= HS_T_ABS_TOL
     bits = np.unpackbits(desc, axis=1).astype(bool)

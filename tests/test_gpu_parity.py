@@ -196,6 +196,55 @@ def test_compute_async_5xn_forces_size_31(cef, torch_mod, oracle):
     assert np.array_equal(desc.cpu().numpy(), want)
 
 
+def _matrix_5xn(torch_mod, rows, cols, n, seed):
+    """A 5 x n keypoint matrix as detectAsync writes it: integer positions anywhere in the frame (corners and borders
+    included), every angle convention; SIZE / OCTAVE rows hold values computeAsync must ignore (.cu:250-263)."""
+    k = synth.random_keypoints(rows, cols, n, seed=seed)
+    x = np.floor(k[:, 0]).astype(np.int64).clip(0, cols - 1); y = np.floor(k[:, 1]).astype(np.int64).clip(0, rows - 1)
+    x[:4] = [0, cols - 1, 0, cols - 1]; y[:4] = [0, 0, rows - 1, rows - 1]
+    m = np.zeros((5, n), dtype=np.float32)
+    m[0] = ((x & 0xffff) | ((y & 0xffff) << 16)).astype(np.uint32).view(np.float32)
+    m[1] = 1.0
+    m[2] = k[:, 3]
+    m[3] = np.arange(n, dtype=np.int32).view(np.float32) % 7
+    m[4] = 77.0
+    kp4 = np.stack([x.astype(np.float32), y.astype(np.float32), np.full(n, 31, np.float32), k[:, 3]], axis=1)
+    return torch_mod.from_numpy(m).cuda(), kp4
+
+
+@pytest.mark.parametrize("nbits", [256, 512])
+@pytest.mark.parametrize("rows,cols,offset,pitch", [(480, 640, 0, 640), (203, 301, 0, 304), (203, 301, 1, 303), (40, 61, 0, 64),
+                                                    (47, 200, 0, 200), (300, 45, 2, 46)])
+def test_compute_async_wave_per_keypoint_kernel(cef, torch_mod, oracle, monkeypatch, nbits, rows, cols, offset, pitch):
+    """Config C3's kernel (bad_raw_kernel: computeAsync on detector-sized keypoints, a wave per keypoint): equals the
+    oracle bit for bit on frames larger and SMALLER than the 48 x 48 window, on unaligned bases / pitches (byte path), for
+    border and corner keypoints; and equals the generic one-workgroup-per-keypoint kernel (EFX_BAD_NO_RAW)."""
+    rng = np.random.default_rng(rows * 1000 + cols)
+    img = synth.synth_frame(rows, cols, seed=rows + cols) if min(rows, cols) >= 64 else rng.integers(0, 256, (rows, cols), dtype=np.uint8)
+    buf = torch_mod.zeros(rows * pitch + 16, dtype=torch_mod.uint8, device="cuda")
+    d_img = buf[offset:offset + rows * pitch].view(rows, pitch)[:, :cols]
+    d_img.copy_(torch_mod.from_numpy(img).cuda())
+    n = 1500
+    d_kps, kp4 = _matrix_5xn(torch_mod, rows, cols, n, seed=nbits + rows)
+    dtype = cef.EfficientFeatures.BAD_256 if nbits == 256 else cef.EfficientFeatures.BAD_512
+    monkeypatch.delenv("EFX_BAD_NO_RAW", raising=False)
+    det = cef.EfficientFeatures.create(n, dtype=dtype)
+    monkeypatch.setenv("EFX_BAD_NO_RAW", "1")
+    det_generic = cef.EfficientFeatures.create(n, dtype=dtype)
+    monkeypatch.delenv("EFX_BAD_NO_RAW")
+    desc = det.computeAsync(d_img, d_kps)
+    desc2 = det_generic.computeAsync(d_img, d_kps)
+    torch_mod.cuda.synchronize()
+    want = oracle.bad_compute(img, kp4, nbits)
+    assert np.array_equal(desc.cpu().numpy(), want)
+    assert torch_mod.equal(desc, desc2)
+    # unaligned descriptor rows (byte stores)
+    out = torch_mod.zeros((n, nbits // 8 + 3), dtype=torch_mod.uint8, device="cuda")[:, 3:]
+    det.computeAsync(d_img, d_kps, descriptors=out)
+    torch_mod.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), want)
+
+
 # ---- HashSIFT: float tolerance before thresholding ----
 HS_T_ABS_TOL = 2e-3      # |T_hip - T_oracle| for identical 129-vectors: fp32 FMA chain (MFMA) vs double accumulation
                          # of 129 products; |T| is typically ~15, at most ~400; measured max 2.2e-4
@@ -365,13 +414,21 @@ def test_matcher_knn2_and_crosscheck(cef, torch_mod, nbytes, nq, nt):
 
 
 def test_matcher_paths_agree(cef, torch_mod, monkeypatch):
-    """The popcount kernel and the matrix-core kernel give the same answer on a set with many distance ties."""
+    """The popcount kernel and the matrix-core kernel give the same answer on a set with many distance ties.  The knob is
+    read when a matcher is created, so both kernels run in this process on the same inputs."""
     rng = np.random.default_rng(99)
     q = rng.integers(0, 256, size=(3000, 64), dtype=np.uint8)
     t = np.concatenate([q[::3], q[::5], rng.integers(0, 256, size=(700, 64), dtype=np.uint8)])     # duplicates: ties everywhere
-    m = cef.BFMatcher.create(cef.BFMatcher.NORM_HAMMING)
-    idx, dist = m.knnMatch(_dev(torch_mod, q), _dev(torch_mod, t), 2)
+    monkeypatch.delenv("EFX_MATCH_NO_MFMA", raising=False)
+    m_mfma = cef.BFMatcher.create(cef.BFMatcher.NORM_HAMMING)
+    monkeypatch.setenv("EFX_MATCH_NO_MFMA", "1")
+    m_pop = cef.BFMatcher.create(cef.BFMatcher.NORM_HAMMING)
+    monkeypatch.delenv("EFX_MATCH_NO_MFMA")
+    dq, dt = _dev(torch_mod, q), _dev(torch_mod, t)
+    idx, dist = m_mfma.knnMatch(dq, dt, 2)
+    idx2, dist2 = m_pop.knnMatch(dq, dt, 2)
     torch_mod.cuda.synchronize()
+    assert torch_mod.equal(idx, idx2) and torch_mod.equal(dist, dist2)
     from oracle import matcher_oracle as MO
     widx, wdist = MO.knn2(q, t)
     assert np.array_equal(dist.cpu().numpy(), wdist) and np.array_equal(idx.cpu().numpy(), widx)

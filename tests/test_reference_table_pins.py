@@ -90,3 +90,55 @@ def test_fast_kernel_equals_reference_c_table_for_all_masks(polarity):
     t = table_from_predicate(lambda m: detected[m])
     assert hashlib.sha256(t.tobytes()).hexdigest() == PINS["c_table"]["sha256"]
     assert not detected[:504].any()
+
+
+# ---- learned descriptor parameters: params/*.bin == the reference's header tables ------------------
+PARAMS_DIR = os.path.join(os.path.dirname(HERE), "cuda-efficient-features_amd", "params")
+PARAM_BLOBS = ["bad256", "bad512", "hashsift256", "hashsift512"]
+
+
+@pytest.mark.parametrize("name", PARAM_BLOBS)
+def test_param_blob_equals_reference_header_table(name):
+    """params/<name>.bin hashes to the digest tools/pin_reference_tables.py took from the reference's header
+    (bad.p256.h:27,94, bad.p512.h:209,340, hash_sift.p{256,512}.h:22), and to the md5 MANIFEST.json records."""
+    blob = open(os.path.join(PARAMS_DIR, name + ".bin"), "rb").read()
+    assert len(blob) == PINS[name]["bytes"]
+    assert hashlib.sha256(blob).hexdigest() == PINS[name]["sha256"]
+    manifest = json.load(open(os.path.join(PARAMS_DIR, "MANIFEST.json")))
+    assert hashlib.md5(blob).hexdigest() == manifest[name + ".bin"]["blob_md5"]
+    assert manifest[name + ".bin"]["bytes"] == len(blob)
+
+
+def test_param_blobs_are_well_formed():
+    """Structure the reference's code relies on: every BAD box lies inside the 32 x 32 patch (bad.cpp:151-155 never
+    leaves it before the affine map), radii 1..7; the HashSIFT matrices are finite."""
+    for n in (256, 512):
+        blob = open(os.path.join(PARAMS_DIR, f"bad{n}.bin"), "rb").read()
+        boxes = np.frombuffer(blob, dtype="<i4", count=5 * n).reshape(n, 5)
+        thr = np.frombuffer(blob, dtype="<f4", offset=20 * n)
+        assert thr.size == n and np.isfinite(thr).all()
+        assert (boxes[:, :4] - boxes[:, 4:5] >= 0).all() and (boxes[:, :4] + boxes[:, 4:5] <= 31).all()
+        assert boxes[:, 4].min() >= 1 and boxes[:, 4].max() <= 7
+        w = np.fromfile(os.path.join(PARAMS_DIR, f"hashsift{n}.bin"), dtype="<f8")
+        assert w.size == 129 * n and np.isfinite(w).all()
+
+
+def test_library_embeds_the_pinned_blobs():
+    """The blobs linked into libefx_hip.so (params_embed.S) are the pinned tables: read through the exported symbols,
+    no device needed."""
+    import ctypes
+    import cef_loader
+    lib = cef_loader.load().lib()
+    for name in PARAM_BLOBS:
+        n = PINS[name]["bytes"]
+        arr = (ctypes.c_ubyte * n).in_dll(lib, "efx_blob_" + name)
+        assert hashlib.sha256(bytes(arr)).hexdigest() == PINS[name]["sha256"], name
+
+
+@pytest.mark.gpu
+def test_loaded_describers_use_the_pinned_blobs():
+    """On the GPU box: the library the describers run from embeds the pinned tables, and a BAD describer built from
+    them reproduces the oracle (which reads params/*.bin) on a probe -- blob, library and oracle agree."""
+    test_library_embeds_the_pinned_blobs()
+    for name in PARAM_BLOBS:
+        test_param_blob_equals_reference_header_table(name)

@@ -91,9 +91,33 @@ def main():
         d = EF.create(40000, dtype=dt)
         desc = torch.zeros((40000, nbytes), dtype=torch.uint8, device="cuda")
         ms_c = perf(lambda: d.computeAsync(img, kps, n=n, descriptors=desc), args.iters)
-        res["rows"].append({"config": cfg, "size": "4k", "descriptor": name, "keypoints": n, "compute_ms": round(ms_c, 4),
-                            "Mdescriptors_per_s": round(n / ms_c / 1e3, 2),
-                            "keypoints_from": "detector, NMS radius %d, frame density %.1f (tools/workloads.py)" % (workloads.C34_NMS_RADIUS, workloads.C34_DENSITY)})
+        row = {"config": cfg, "size": "4k", "descriptor": name, "keypoints": n, "compute_ms": round(ms_c, 4),
+               "Mdescriptors_per_s": round(n / ms_c / 1e3, 2),
+               "keypoints_from": "detector, NMS radius %d, frame density %.1f (tools/workloads.py)" % (workloads.C34_NMS_RADIUS, workloads.C34_DENSITY)}
+        if cfg == "C3":
+            # roofline of the whole call (host clock, one stream, sync per call) against SURVEY 8d's BAD-compute figure --
+            # P + 4 (W+1)(H+1) + min(4 (W+1)(H+1), N 46^2 4) + 16 N + N nbits/8: 77.9 MB for BAD512 -- and against what THIS
+            # design has to move: the 48 x 48 u8 windows lie inside the frame (P), 20 B of keypoint matrix, the descriptor
+            px = rows * cols
+            integ = 4 * (rows + 1) * (cols + 1)
+            b_survey = px + integ + min(integ, n * 46 * 46 * 4) + 16 * n + n * nbytes
+            b_design = px + 20 * n + n * nbytes
+            row["roofline"] = {"bound": "hbm", "peak_GBps": 8000,
+                               "survey_algorithmic_MB": round(b_survey / 1e6, 1), "frac_vs_survey_bytes": round(b_survey / ms_c / 1e6 / 8000, 4),
+                               "design_algorithmic_MB": round(b_design / 1e6, 1), "frac_vs_design_bytes": round(b_design / ms_c / 1e6 / 8000, 4),
+                               "note": "the kernel is bound by LDS-array cycles (random box gathers) and VALU issue, not by HBM: profiles/r03_c3_*"}
+        res["rows"].append(row)
+    # NMS robustness: detect on frames whose corner density or NMS radius make the exact scans long
+    for label, dens, radius in (("c34_frame_radius5", workloads.C34_DENSITY, workloads.C34_NMS_RADIUS), ("3x_density_default_radius", 0.9, 15),
+                                ("default", None, 15)):
+        f = workloads.frame_c2() if dens is None else synth.synth_frame(rows, cols, seed=1000, density=dens)
+        d_f = torch.from_numpy(f).cuda()
+        det = EF.create(workloads.N40K, 1.2, 8, 0, 20, radius, EF.BAD_256)
+        ms = perf(lambda: det.detectAsync(d_f, kps, cnt), args.iters)
+        st = det.lastLevelStats()
+        res["rows"].append({"config": "nms_density", "case": label, "size": "4k", "nonmax_radius": radius, "detect_ms": round(ms, 4),
+                            "fast_corners": int(sum(x["n_candidates"] for x in st)), "nms_survivors": int(sum(x["n_after_nms"] for x in st)),
+                            "keypoints": int(cnt.item())})
     s = json.dumps(res, indent=1)
     print(s)
     if args.out:

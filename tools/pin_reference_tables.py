@@ -8,7 +8,15 @@ is copied into the repo -- only SHA-256 digests and lengths are written):
            mask m with popcount > 8 up as  c_table[(m >> 3) - 63] & (1 << (m & 7))
   U_MAX    modules/cuda_efficient_features/src/cuda_efficient_features.cu:143   17 ints; IC_Angle's row half-widths
 
-tests/test_reference_table_pins.py regenerates both from the oracle's own predicates and compares the digests; the GPU
+and the four learned descriptor parameter tables, parsed here with this file's own parser (not
+tools/extract_params.py's) and hashed in the canonical layout of params/*.bin:
+
+  bad{256,512}       modules/efficient_features/src/bad.p256.h:27,94 / bad.p512.h:209,340
+                     int32[N][5] {x1, x2, y1, y2, radius} then float32[N] thresholds (double literal -> float)
+  hashsift{256,512}  modules/efficient_features/src/hash_sift.p{256,512}.h   float64[N][129]
+
+tests/test_reference_table_pins.py checks params/*.bin (and, on the GPU box, the blobs embedded in libefx_hip.so) against
+these digests.  It regenerates the two detector tables from the oracle's own predicates and compares the digests; the GPU
 test drives fast_kernel with ring patterns for all 65 536 masks x both polarities against the same predicate.
 """
 import hashlib
@@ -20,6 +28,7 @@ import sys
 import numpy as np
 
 REF = "/root/reference/modules/cuda_efficient_features/src"
+REF_CPU = "/root/reference/modules/efficient_features/src"
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "reference_table_pins.json")
 
 
@@ -42,6 +51,62 @@ def c_table_bytes_from_predicate(has_arc9):
     return t
 
 
+def c_tokens(path):
+    """The header as a flat token stream with comments removed (numbers, identifiers, punctuation)."""
+    text = open(path, encoding="utf-8", errors="replace").read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", " ", text)
+    return text
+
+
+def numbers_of(path, name):
+    """All numeric literals of the initialiser of array `name`, in order, and the line the array starts at."""
+    raw = open(path, encoding="utf-8", errors="replace").read()
+    text = c_tokens(path)
+    i = text.find(name)
+    if i < 0:
+        raise SystemExit(f"{name} not found in {path}")
+    i = text.index("=", i)
+    depth, j = 0, text.index("{", i)
+    k = j
+    while True:
+        ch = text[k]
+        depth += ch == "{"
+        depth -= ch == "}"
+        if depth == 0:
+            break
+        k += 1
+    body = text[j:k + 1]
+    nums = re.findall(r"[-+]?(?:\d+\.\d*(?:[eE][-+]?\d+)?|\.\d+(?:[eE][-+]?\d+)?|\d+[eE][-+]?\d+|\d+)", body)
+    line = raw[:raw.find(name)].count("\n") + 1
+    return nums, line
+
+
+def pin_descriptor_tables(pins):
+    for n in (256, 512):
+        path = os.path.join(REF_CPU, f"bad.p{n}.h")
+        boxes, l1 = numbers_of(path, f"box_pair_params_{n}")
+        thr, l2 = numbers_of(path, f"thresholds_{n}")
+        assert len(boxes) == 5 * n and len(thr) == n, (len(boxes), len(thr))
+        blob = np.array([int(v) for v in boxes], dtype="<i4").tobytes() + \
+            np.array([float(v) for v in thr], dtype=np.float64).astype("<f4").tobytes()
+        # the copy the CUDA module compiles is the same table
+        b2, _ = numbers_of(os.path.join(REF, f"bad.p{n}.h"), f"box_pair_params_{n}")
+        t2, _ = numbers_of(os.path.join(REF, f"bad.p{n}.h"), f"thresholds_{n}")
+        assert b2 == boxes and t2 == thr
+        pins[f"bad{n}"] = {"source": f"modules/efficient_features/src/bad.p{n}.h:{l1},{l2}", "bytes": len(blob),
+                           "layout": "int32[N][5] {x1,x2,y1,y2,radius} + float32[N] thresholds, little endian",
+                           "sha256": hashlib.sha256(blob).hexdigest()}
+        path = os.path.join(REF_CPU, f"hash_sift.p{n}.h")
+        vals, l3 = numbers_of(path, f"HASH_SIFT_{n}_VALS")
+        assert len(vals) == 129 * n, len(vals)
+        v2, _ = numbers_of(os.path.join(REF, f"hash_sift.p{n}.h"), f"HASH_SIFT_{n}_VALS")
+        assert v2 == vals
+        blob = np.array([float(v) for v in vals], dtype="<f8").tobytes()
+        pins[f"hashsift{n}"] = {"source": f"modules/efficient_features/src/hash_sift.p{n}.h:{l3}", "bytes": len(blob),
+                                "layout": "float64[N][129] row-major, little endian", "sha256": hashlib.sha256(blob).hexdigest()}
+
+
 def main():
     ctab, l1 = parse_array(os.path.join(REF, "cuda_fast.cu"), "c_table")
     umax, l2 = parse_array(os.path.join(REF, "cuda_efficient_features.cu"), "U_MAX")
@@ -59,6 +124,7 @@ def main():
                         "equals_arc9_predicate": bool(np.array_equal(ctab, regen))},
             "U_MAX": {"source": "modules/cuda_efficient_features/src/cuda_efficient_features.cu:%d" % l2, "len": int(umax.size),
                       "dtype": "int32 little endian", "sha256": hashlib.sha256(umax.tobytes()).hexdigest()}}
+    pin_descriptor_tables(pins)
     json.dump(pins, open(OUT, "w"), indent=1)
     print(json.dumps(pins, indent=1))
 
