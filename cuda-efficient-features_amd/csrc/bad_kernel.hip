@@ -18,14 +18,19 @@
 
 namespace {
 
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 
 // computeBadResponse for a keypoint near the frame border (bad.cpp:166-251): boxes clamped to the frame, float means.
 // I: window-local integral with IP ints per row (zero beyond the frame), window [wx0, wx0 + S) x [wy0, wy0 + S);
 // fw x fh: integral dimensions of the whole frame.
-__device__ __forceinline__ bool bad_border_bit(const Affine& A, uint2 bq, const int* I, int IP, int S, int wx0, int wy0, int fw, int fh)
+// T = uint16_t: the integral is kept modulo 2^16 (every box sum is below 2^16: bad_raw_kernel), the sums are reduced likewise.
+template <class T>
+__device__ __forceinline__ bool bad_border_bit(const Affine& A, uint2 bq, const T* I, int IP, int S, int wx0, int wy0, int fw, int fh)
 {
+    constexpr int M = sizeof(T) == 2 ? 0xffff : -1;
     const float x1f = (float)(bq.x & 31u), x2f = (float)((bq.x >> 5) & 31u);
     const float y1f = (float)((bq.x >> 10) & 31u), y2f = (float)((bq.x >> 15) & 31u);
     // transform, bad.cpp:151-155: CV_ROUNDNUM(x) = (int)(x + 0.5f)
@@ -41,7 +46,7 @@ __device__ __forceinline__ bool bad_border_bit(const Affine& A, uint2 bq, const 
     int ay2 = cy1 + r + 1; if (ay2 <= 0) ay2 = 1; else if (ay2 >= fh) ay2 = fh - 1;
     int lx1 = clampi(ax1 - wx0, 0, S), ly1 = clampi(ay1 - wy0, 0, S);
     int lx2 = clampi(ax2 - wx0, 0, S), ly2 = clampi(ay2 - wy0, 0, S);
-    const float sum1 = (float)(I[ly1 * IP + lx1] + I[ly2 * IP + lx2] - I[ly1 * IP + lx2] - I[ly2 * IP + lx1]);
+    const float sum1 = (float)(((int)I[ly1 * IP + lx1] + (int)I[ly2 * IP + lx2] - (int)I[ly1 * IP + lx2] - (int)I[ly2 * IP + lx1]) & M);
     const int area1 = (ay2 - ay1) * (ax2 - ax1);
     const float avg1 = sum1 / (float)area1;
 
@@ -51,10 +56,47 @@ __device__ __forceinline__ bool bad_border_bit(const Affine& A, uint2 bq, const 
     int by2 = cy2 + r + 1; if (by2 <= 0) by2 = 1; else if (by2 >= fh) by2 = fh - 1;
     lx1 = clampi(bx1 - wx0, 0, S); ly1 = clampi(by1 - wy0, 0, S);
     lx2 = clampi(bx2 - wx0, 0, S); ly2 = clampi(by2 - wy0, 0, S);
-    const float sum2 = (float)(I[ly1 * IP + lx1] + I[ly2 * IP + lx2] - I[ly1 * IP + lx2] - I[ly2 * IP + lx1]);
+    const float sum2 = (float)(((int)I[ly1 * IP + lx1] + (int)I[ly2 * IP + lx2] - (int)I[ly1 * IP + lx2] - (int)I[ly2 * IP + lx1]) & M);
     const int area2 = (by2 - by1) * (bx2 - bx1);
     const float avg2 = sum2 / (float)area2;
     return (avg1 - avg2) <= thr;
+}
+
+// The integral of the detector-sized kernels (bad_det_kernel, bad_raw_kernel): u16 entries modulo 2^16, BAD_J_PITCH per row
+#define BAD_J_PITCH 50
+
+// One box pair of the integer fast path (bad.cpp:365-393) from the per-pair table BadParamsDev::ubox: both boxes go through
+// the affine map as ONE packed-fp32 sequence (bad.cpp:151-155: ((m00 x + m01 y) + m02) + 0.5f, truncated -- the same IEEE
+// operations, two per instruction); Jb = byte address of the modulo-2^16 integral, wbase = -(wy0 JP + wx0) 2.
+//   byte address of entry (cy - r' - wy0, cx - r' - wx0) = (cy JP + cx) 2 + [.y + wbase],  .y = -2 r' (JP + 1)
+//   .z = 2 side | (2 JP side) << 16: byte strides to the box's right / lower corners;  .w = bits of thr * side^2
+struct BadTaps { int a_tl, b_tl, side2, sideJ2; };        // byte offsets into the integral of one box pair
+__device__ __forceinline__ BadTaps bad_ubox_taps(const Affine& A, uint4 q, int wbase)
+{
+    constexpr int JP = BAD_J_PITCH;
+    const efx_f32x2 xs = { (float)(q.x & 0xffu), (float)((q.x >> 16) & 0xffu) };          // x1, x2
+    const efx_f32x2 ys = { (float)((q.x >> 8) & 0xffu), (float)(q.x >> 24) };             // y1, y2
+    const efx_f32x2 half2 = { 0.5f, 0.5f };
+    const efx_f32x2 cxf = (((efx_f32x2)(A.m00) * xs + (efx_f32x2)(A.m01) * ys) + (efx_f32x2)(A.m02)) + half2;
+    const efx_f32x2 cyf = (((efx_f32x2)(A.m10) * xs + (efx_f32x2)(A.m11) * ys) + (efx_f32x2)(A.m12)) + half2;
+    const int cx1 = (int)cxf.x, cx2 = (int)cxf.y, cy1 = (int)cyf.x, cy2 = (int)cyf.y;
+    const int pbase = (int)q.y + wbase;
+    BadTaps t;
+    t.side2 = (int)(q.z & 0xffffu); t.sideJ2 = (int)(q.z >> 16);
+    // 24-bit multiplies (v_mul_lo_u32 is quarter rate): level coordinates are below 2^15
+    t.a_tl = (__mul24(cy1, JP) + cx1) * 2 + pbase; t.b_tl = (__mul24(cy2, JP) + cx2) * 2 + pbase;
+    return t;
+}
+__device__ __forceinline__ bool bad_taps_bit(const BadTaps& t, uint32_t thr_bits, const unsigned char* Jb)
+{
+    auto at = [&](int o) -> int { return (int)*reinterpret_cast<const uint16_t*>(Jb + o); };
+    const int sa = (at(t.a_tl) + at(t.a_tl + t.side2 + t.sideJ2) - at(t.a_tl + t.side2) - at(t.a_tl + t.sideJ2)) & 0xffff;
+    const int sb = (at(t.b_tl) + at(t.b_tl + t.side2 + t.sideJ2) - at(t.b_tl + t.side2) - at(t.b_tl + t.sideJ2)) & 0xffff;
+    return (float)(sa - sb) <= __uint_as_float(thr_bits);
+}
+__device__ __forceinline__ bool bad_ubox_bit(const Affine& A, uint4 q, const unsigned char* Jb, int wbase)
+{
+    return bad_taps_bit(bad_ubox_taps(A, q, wbase), q.w, Jb);
 }
 
 // rectifyBoxes etc. for keypoint lists that do not come from the detector (bad_affine.h)
@@ -232,7 +274,9 @@ __global__ __launch_bounds__(256) void bad_kernel(
 //     sequence (v_pk_mul_f32 / v_pk_add_f32: the same IEEE operations, two per instruction);
 //   * the level's image pointer / pitch / size ride in the Affine record (one dependent load before the window loads);
 //   * the blur's column pass writes a u8 plane (2 pixels per ds_write_b16 instead of two ds_write_b32); the integral's
-//     row pass reads a row as three conflict-free ds_read_b128 and unpacks with SDWA adds; I aliases the dead hb;
+//     row pass reads a row as three conflict-free ds_read_b128 and unpacks with SDWA adds; the integral is kept modulo
+//     2^16 (round 3: box sums are below 2^16), two columns per dword, column prefix in place on v_pk_add_u16 -- half the
+//     LDS traffic of the int32 integral; it aliases the dead hb;
 //   * a wave packs its 64 bits with two scalar bit reversals and one 8-byte store.
 // Measured and dropped: blur item lists limited to the disc the boxes can reach (71 % of the pixels, but the 3-row apron
 // leaves 195 of 216 row-pass items: no wave is saved and the compacted order costs bank conflicts).
@@ -242,8 +286,8 @@ __global__ __launch_bounds__(256) void bad_det_kernel(
     float taps0, float taps1, float taps2, float taps3, uint8_t* __restrict__ desc, size_t desc_pitch)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int S = 48, IP = S + 1;
-    constexpr int PIX_OFF = 3248, HB_OFF = PIX_OFF + S * S;      // raw [0, 3248) | pix [3248, 5552) | hb / I [5552, ...)
+    constexpr int S = 48, JP = BAD_J_PITCH, JD = JP / 2;
+    constexpr int PIX_OFF = 3248, HB_OFF = PIX_OFF + S * S;      // raw [0, 3248) | pix [3248, 5552) | hb / J [5552, ...)
     static_assert(HB_OFF % 16 == 0 && PIX_OFF % 16 == 0, "LDS regions are 16-byte aligned");
 
     const int tid = threadIdx.x;
@@ -262,8 +306,21 @@ __global__ __launch_bounds__(256) void bad_det_kernel(
     uint8_t* raw = smem;
     uint8_t* pix = smem + PIX_OFF;
     float* hb = reinterpret_cast<float*>(smem + HB_OFF);
-    int* I = reinterpret_cast<int*>(smem + HB_OFF);              // (S+1) x (S+1), aliases hb (dead after the column pass)
+    // The window-local integral, MODULO 2^16 (every box of the table has at most 16 x 16 pixels -- BadParamsDev::ubox_max_side,
+    // checked by the launcher -- so a box sum is below 2^16 and (tl + br - tr - bl) mod 2^16 IS the sum): 49 rows of 50 u16,
+    // two columns per dword; aliases hb (dead after the blur's column pass)
+    uint32_t* Jd = reinterpret_cast<uint32_t*>(smem + HB_OFF);
+    const uint16_t* J = reinterpret_cast<const uint16_t*>(smem + HB_OFF);
 
+    // A workgroup's life is a chain of dependent phases (record -> window loads -> blur rows -> blur columns -> integral rows
+    // -> integral columns -> boxes), a CU holds eight workgroups, and the kernel takes (keypoints / 2048) x that life time:
+    // what shortens the chain shortens the kernel, whatever the instruction counts (the int32 -> u16 integral halved the
+    // integral's LDS traffic and changed nothing).  So: the box taps' addresses -- they need the record, not the pixels --
+    // are worked out while the window loads are in flight; the integral's prefix chains are cut in two (two lanes per row,
+    // two lanes per column pair, the second adds the first one's total).
+    const int wbase = -(wy0 * JP + wx0) * 2;
+    const bool border = (A.border & 1) != 0;
+    BadTaps t0 = { 0, 0, 0, 0 }, t1 = { 0, 0, 0, 0 };
     if (fits) {
         const bool inside = wx0 + S <= cols && wy0 + S <= rows;  // frames smaller than the window: zero beyond the frame
         efx_blur_window_lds<256>(img, pitch, rows, cols, wx0, wy0, S, raw, hb, taps0, taps1, taps2, taps3, tid,
@@ -273,90 +330,80 @@ __global__ __launch_bounds__(256) void bad_det_kernel(
                     pk &= ((rin && (wx0 + c) < cols) ? 0xffu : 0u) | ((rin && (wx0 + c + 1) < cols) ? 0xff00u : 0u);
                 }
                 *reinterpret_cast<uint16_t*>(pix + r0 * S + c + i * S) = (uint16_t)pk;
+            },
+            [&]() {
+                if (!border) { t0 = bad_ubox_taps(A, q0, wbase); if (nbits > 256) t1 = bad_ubox_taps(A, q1, wbase); }
             });
         __syncthreads();
-        // window-local integral: row prefix from the u8 plane (wave 0; the zero border is written by wave 1), then column prefix
-        if (tid < S) {
-            const uint4* row = reinterpret_cast<const uint4*>(pix + tid * S);
-            const uint4 w0 = row[0], w1 = row[1], w2 = row[2];
-            const uint32_t w[12] = { w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w };
-            int* p = I + (tid + 1) * IP + 1;
+        // row prefix from the u8 plane: P'[r][x] = sum of row r left of column x, x = 0 .. 49, as 25 packed pairs into plane
+        // row r + 1.  Two lanes per row (waves 0 and 1: 96 lanes), 24 pixels each; the second adds the first one's total
+        // (its neighbour lane: DPP row_shr:1).  Wave 2 writes the zero row.
+        if (tid < 2 * S) {
+            const int row = tid >> 1, half = tid & 1;
+            const uint2* src = reinterpret_cast<const uint2*>(pix + row * S + 24 * half);
+            const uint2 w0 = src[0], w1 = src[1], w2 = src[2];
+            const uint32_t w[6] = { w0.x, w0.y, w1.x, w1.y, w2.x, w2.y };
+            uint32_t out[12];
             int run = 0;
 #pragma unroll
-            for (int c = 0; c < S; c++) { run += (int)((w[c >> 2] >> (8 * (c & 3))) & 0xffu); p[c] = run; }
-        } else if (tid >= 64 && tid < 64 + IP) {
-            I[tid - 64] = 0; I[(tid - 64) * IP] = 0;
+            for (int j = 0; j < 12; j++) {
+                const int lo = run;
+                run += (int)((w[(2 * j) >> 2] >> (8 * ((2 * j) & 3))) & 0xffu);
+                const int hi = run;
+                run += (int)((w[(2 * j + 1) >> 2] >> (8 * ((2 * j + 1) & 3))) & 0xffu);
+                out[j] = (uint32_t)lo | ((uint32_t)hi << 16);
+            }
+            const int left = __builtin_amdgcn_update_dpp(0, run, 0x111, 0xf, 0xf, true);     // row_shr:1: the total of lane - 1
+            uint32_t* p = Jd + (row + 1) * JD + 12 * half;
+            if (half) {
+                const u16x2 off = { (unsigned short)left, (unsigned short)left };
+#pragma unroll
+                for (int j = 0; j < 12; j++) p[j] = __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, out[j]) + off));
+                p[12] = (uint32_t)(left + run);                   // x = 48: the row total (x = 49 is padding)
+            } else {
+#pragma unroll
+                for (int j = 0; j < 12; j++) p[j] = out[j];
+            }
+        } else if (tid >= 128 && tid < 128 + JD) {
+            Jd[tid - 128] = 0u;
         }
         __syncthreads();
-        if (tid < S) {
-            int* p = I + IP + 1 + tid;
-            int run = 0;
+        // column prefix IN PLACE (v_pk_add_u16, modulo 2^16): wave 0, lane = column pair + 32 x (upper / lower 24 rows); the
+        // lower half adds the upper half's total (lane - 32: ds_bpermute)
+        if (tid < 64) {
+            const int cp = tid & 31, seg = tid >> 5;
+            uint32_t v[24];
+            u16x2 run = { 0, 0 };
+            if (cp < JD) {
 #pragma unroll
-            for (int r = 0; r < S; r++) { run += p[r * IP]; p[r * IP] = run; }
+                for (int i = 0; i < 24; i++) v[i] = Jd[(24 * seg + i + 1) * JD + cp];
+#pragma unroll
+                for (int i = 0; i < 24; i++) { run = run + __builtin_bit_cast(u16x2, v[i]); v[i] = __builtin_bit_cast(uint32_t, run); }
+            }
+            const uint32_t upper = (uint32_t)__builtin_amdgcn_ds_bpermute(((tid - 32) & 63) * 4, (int)__builtin_bit_cast(uint32_t, run));
+            if (cp < JD) {
+                const u16x2 off = seg ? __builtin_bit_cast(u16x2, upper) : (u16x2){ 0, 0 };
+#pragma unroll
+                for (int i = 0; i < 24; i++)
+                    Jd[(24 * seg + i + 1) * JD + cp] = __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, v[i]) + off));
+            }
         }
     }
     __syncthreads();
 
-    const bool border = (A.border & 1) != 0;
     const int fw = cols + 1, fh = rows + 1;       // integral image dims of the full frame
     const bool wide_store = ((((uintptr_t)desc) | desc_pitch) & 7u) == 0;
-    const int wbase = -(wy0 * IP + wx0) * 4;
 
     for (int b0 = 0; b0 < nbits; b0 += 256) {
         const int b = b0 + tid;
         bool bit = false;
         if (fits) {
             if (border) {
-                const uint2 bq = P->box[b];
-                const float x1f = (float)(bq.x & 31u), x2f = (float)((bq.x >> 5) & 31u);
-                const float y1f = (float)((bq.x >> 10) & 31u), y2f = (float)((bq.x >> 15) & 31u);
-                const int cx1 = (int)((A.m00 * x1f + A.m01 * y1f + A.m02) + 0.5f);
-                const int cy1 = (int)((A.m10 * x1f + A.m11 * y1f + A.m12) + 0.5f);
-                const int cx2 = (int)((A.m00 * x2f + A.m01 * y2f + A.m02) + 0.5f);
-                const int cy2 = (int)((A.m10 * x2f + A.m11 * y2f + A.m12) + 0.5f);
-                const int r = (int)((A.s * (float)(bq.x >> 20)) + 0.5f);
-                const float thr = __uint_as_float(bq.y);
-                // computeBadResponse, bad.cpp:166-251: boxes clamped to the frame, float means
-                int ax1 = cx1 - r; if (ax1 < 0) ax1 = 0; else if (ax1 >= fw - 1) ax1 = fw - 2;
-                int ay1 = cy1 - r; if (ay1 < 0) ay1 = 0; else if (ay1 >= fh - 1) ay1 = fh - 2;
-                int ax2 = cx1 + r + 1; if (ax2 <= 0) ax2 = 1; else if (ax2 >= fw) ax2 = fw - 1;
-                int ay2 = cy1 + r + 1; if (ay2 <= 0) ay2 = 1; else if (ay2 >= fh) ay2 = fh - 1;
-                int lx1 = clampi(ax1 - wx0, 0, S), ly1 = clampi(ay1 - wy0, 0, S);
-                int lx2 = clampi(ax2 - wx0, 0, S), ly2 = clampi(ay2 - wy0, 0, S);
-                const float sum1 = (float)(I[ly1 * IP + lx1] + I[ly2 * IP + lx2] - I[ly1 * IP + lx2] - I[ly2 * IP + lx1]);
-                const int area1 = (ay2 - ay1) * (ax2 - ax1);
-                const float avg1 = sum1 / (float)area1;
-
-                int bx1 = cx2 - r; if (bx1 < 0) bx1 = 0; else if (bx1 >= fw - 1) bx1 = fw - 2;
-                int by1 = cy2 - r; if (by1 < 0) by1 = 0; else if (by1 >= fh - 1) by1 = fh - 2;
-                int bx2 = cx2 + r + 1; if (bx2 <= 0) bx2 = 1; else if (bx2 >= fw) bx2 = fw - 1;
-                int by2 = cy2 + r + 1; if (by2 <= 0) by2 = 1; else if (by2 >= fh) by2 = fh - 1;
-                lx1 = clampi(bx1 - wx0, 0, S); ly1 = clampi(by1 - wy0, 0, S);
-                lx2 = clampi(bx2 - wx0, 0, S); ly2 = clampi(by2 - wy0, 0, S);
-                const float sum2 = (float)(I[ly1 * IP + lx1] + I[ly2 * IP + lx2] - I[ly1 * IP + lx2] - I[ly2 * IP + lx1]);
-                const int area2 = (by2 - by1) * (bx2 - bx1);
-                const float avg2 = sum2 / (float)area2;
-                bit = (avg1 - avg2) <= thr;
+                bit = bad_border_bit<uint16_t>(A, P->box[b], J, JP, S, wx0, wy0, fw, fh);
             } else {
                 // integer fast path, bad.cpp:365-393.  Not within 27 px of the frame edge: the window is not clamped by
                 // the frame and R >= s * reach + 1 puts every tap inside it (no clamps, spec S9 is vacuous here).
-                const uint4 q = b0 == 0 ? q0 : q1;
-                const efx_f32x2 xs = { (float)(q.x & 0xffu), (float)((q.x >> 16) & 0xffu) };          // x1, x2
-                const efx_f32x2 ys = { (float)((q.x >> 8) & 0xffu), (float)(q.x >> 24) };             // y1, y2
-                // transform, bad.cpp:151-155: ((m00 x + m01 y) + m02) + 0.5f, truncated -- both boxes per instruction
-                const efx_f32x2 half2 = { 0.5f, 0.5f };
-                const efx_f32x2 cxf = (((efx_f32x2)(A.m00) * xs + (efx_f32x2)(A.m01) * ys) + (efx_f32x2)(A.m02)) + half2;
-                const efx_f32x2 cyf = (((efx_f32x2)(A.m10) * xs + (efx_f32x2)(A.m11) * ys) + (efx_f32x2)(A.m12)) + half2;
-                const int cx1 = (int)cxf.x, cx2 = (int)cxf.y, cy1 = (int)cyf.x, cy2 = (int)cyf.y;
-                // byte address of integral entry (cy - r' - wy0, cx - r' - wx0): (cy * IP + cx) * 4 + [(-r') (IP + 1) 4 + wbase]
-                const int pbase = (int)q.y * (IP + 1) + wbase;
-                const int side4 = (int)(q.z & 0xffffu), sideIP4 = (int)(q.z >> 16);
-                const int a_tl = (cy1 * IP + cx1) * 4 + pbase, b_tl = (cy2 * IP + cx2) * 4 + pbase;
-                const unsigned char* Ib = smem + HB_OFF;
-                auto at = [&](int off) -> int { return *reinterpret_cast<const int*>(Ib + off); };
-                const int area_resp = at(a_tl) + at(a_tl + side4 + sideIP4) - at(a_tl + side4) - at(a_tl + sideIP4)
-                                    - at(b_tl) - at(b_tl + side4 + sideIP4) + at(b_tl + side4) + at(b_tl + sideIP4);
-                bit = (float)area_resp <= __uint_as_float(q.w);
+                bit = bad_taps_bit(b0 == 0 ? t0 : t1, b0 == 0 ? q0.w : q1.w, smem + HB_OFF);
             }
         }
         // 64 consecutive box pairs -> 8 bytes, bit i -> byte i / 8, MSB first (bad.cpp:349,368)
@@ -379,27 +426,32 @@ __global__ __launch_bounds__(256) void bad_det_kernel(
 // BASELINE config C3, cuda_efficient_features.cpp:220-223 -> cuda_bad.cpp:46-70 -> computeBADKernel cuda_bad.cu:246-316).
 // No blur means no phase that wants 256 lanes, so ONE WAVE owns a keypoint and a 256-thread workgroup runs four of them
 // independently: no workgroup barrier anywhere (a wave's LDS operations complete in order), and the waves of a CU sit in
-// different phases -- window loads (vector memory), prefix sums (VALU + LDS writes), box gathers (LDS reads) overlap.
+// different phases -- window loads (vector memory), prefix sums (VALU + LDS stores), box gathers (LDS reads) overlap.
+// The integral is kept MODULO 2^16: a box of the table has at most 16 x 16 pixels (BadParamsDev::ubox_max_side, checked by
+// the launcher), so every box sum is below 2^16 and (tl + br - tr - bl) mod 2^16 IS the sum.  Half the LDS (4.9 KB per
+// wave: 32 waves per CU instead of 16), and the column prefix runs on packed pairs.
 //   window   48 rows x 13 aligned dwords through a buffer resource (range-checked: zero beyond the image), row-coalesced
-//            (13 consecutive lanes = one row), into LDS rows of 13 dwords (odd pitch: conflict-free row-per-lane reads)
+//            (16 lanes per row), into LDS rows of 13 dwords (odd pitch: conflict-free row-per-lane reads)
 //   rows     lane r: its row as 13 ds_read_b32 + v_alignbyte, exclusive prefix on SDWA byte adds, written as 25 packed u16
-//            pairs (a row prefix is at most 48 * 255): P'[r][x] = sum of the row's pixels left of column x
-//   columns  lane j < 25: columns 2j, 2j + 1 of the integral J (pitch 50 ints, so the pair is one aligned ds_write_b64);
-//            one ds_read_b32 per row.  P' aliases the SECOND half of J: row r + 1 of J never reaches a P' row that is still
-//            to be read (200 (r + 2) <= 5000 + 100 (r + 1)), so a wave needs 9.8 KB and a CU holds 16 waves
-//   boxes    the per-pair table of the detector path (BadParamsDev::ubox), 64 pairs per step, the wave's ballot is the
-//            descriptor word; lane i keeps word i and the descriptor leaves as one 8-byte store per lane
+//            pairs into plane row r + 1: P'[r][x] = sum of the row's pixels left of column x (x = 0 .. 49)
+//   columns  lane j < 25: columns 2j, 2j + 1, IN PLACE: row r + 1 <- row r + row r + 1 (one ds_read_b32, one v_pk_add_u16,
+//            one ds_write_b32 per row); row 0 is zero.  The staged window aliases the plane (it is in registers by then)
+//   boxes    the per-pair table of the detector path (BadParamsDev::ubox, loaded before anything that depends on the
+//            keypoint), 64 pairs per step, ds_read_u16 gathers; the wave's ballot is the descriptor word, lane i keeps
+//            word i and the descriptor leaves as one 8-byte store per lane
+// Measured (MI355X, C3: 40 000 keypoints of a 4K frame, profiles/r03_c3_*): the kernel is bound by the LDS pipe -- the
+// random box gathers cost 3.4 cycles per 32 lanes in bank conflicts -- with the VALU 60 % busy beside it.
 // ================================================================================================
-#define BAD_RAW_JP 50                                     // ints per integral row
-#define BAD_RAW_P_OFF 5000                                // byte offset of the u16 row-prefix plane inside the integral's storage
-#define BAD_RAW_WAVE_LDS 9808                             // 49 * 50 * 4 = 9800, rounded to 16
+#define BAD_RAW_JP BAD_J_PITCH                             // u16 entries per integral row (25 dwords)
+#define BAD_RAW_WAVE_LDS 4912                             // 49 * 50 * 2 = 4900, rounded to 16
 
+template <int NIT>            // descriptor words of 64 bits: 4 (BAD256) or 8 (BAD512)
 __global__ __launch_bounds__(256) void bad_raw_kernel(
     const int* __restrict__ d_count, int n, const BadParamsDev* __restrict__ P, const Affine* __restrict__ aff,
     uint8_t* __restrict__ desc, size_t desc_pitch)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int S = 48, JP = BAD_RAW_JP;
+    constexpr int S = 48, JP = BAD_RAW_JP, JD = JP / 2;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int count = d_count ? min(*d_count, n) : n;
@@ -409,13 +461,16 @@ __global__ __launch_bounds__(256) void bad_raw_kernel(
     if (kid >= count) return;                                         // wave-uniform
 
     unsigned char* wbuf = smem + wave * BAD_RAW_WAVE_LDS;
-    uint32_t* rawdw = reinterpret_cast<uint32_t*>(wbuf);               // 48 x 13 dwords
-    uint32_t* Pq = reinterpret_cast<uint32_t*>(wbuf + BAD_RAW_P_OFF);  // 48 x 25 dwords (50 u16)
-    int* J = reinterpret_cast<int*>(wbuf);                             // 49 x 50 ints
+    uint32_t* rawdw = reinterpret_cast<uint32_t*>(wbuf);               // 48 x 13 dwords, dead before the plane is written
+    uint32_t* Jd = reinterpret_cast<uint32_t*>(wbuf);                  // 49 x 25 dwords: the integral, two u16 columns per dword
+    const uint16_t* J = reinterpret_cast<const uint16_t*>(wbuf);
 
+    // the per-pair table does not depend on the keypoint: requested first, its latency hides behind the window loads
+    uint4 q[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; it++) q[it] = P->ubox[it * 64 + lane];
     const Affine A = aff[kid];                                         // wave-uniform address: scalar loads
     const uint8_t* img = A.img; const int pitch = A.pitch, rows = A.rows, cols = A.cols;
-    const int nbits = P->nbits;
     const bool fits = A.S != 0;
     const int wx0 = A.wx0, wy0 = A.wy0;
 
@@ -424,14 +479,16 @@ __global__ __launch_bounds__(256) void bad_raw_kernel(
         const int off = aligned ? (wx0 & 3) : 0;
         if (aligned) {
             // rows are pitch bytes apart and at least roundup4(cols) of them are memory we may read (our own levels are
-            // padded; a caller's 4-byte aligned image has pitch >= roundup4(cols))
+            // padded; a caller's 4-byte aligned image has pitch >= roundup4(cols)); beyond the image the range check gives 0
             const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(img), 0, (rows - 1) * pitch + ((cols + 3) & ~3), 0x00020000);
-            const int gbase = wy0 * pitch + (wx0 & ~3);
+            // 16 lanes per row (13 of them load), 4 rows per step: no division, one offset add per step
+            const int k = lane & 15, r4 = lane >> 4;
+            int goff = wy0 * pitch + (wx0 & ~3) + r4 * pitch + 4 * k;
+            uint32_t* dst = rawdw + r4 * 13 + k;
 #pragma unroll
-            for (int it = 0; it < 10; it++) {
-                const int idx = it * 64 + lane;
-                const int r = idx / 13, k = idx - r * 13;
-                if (idx < S * 13) rawdw[idx] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, gbase + r * pitch + 4 * k, 0, 0);
+            for (int it = 0; it < 12; it++) {
+                if (k < 13) dst[it * 52] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, goff, 0, 0);
+                goff += 4 * pitch;
             }
         } else {
             // caller's image with an unaligned base or pitch: bytes, zero beyond the frame
@@ -445,7 +502,7 @@ __global__ __launch_bounds__(256) void bad_raw_kernel(
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // ---- row prefix (lane = row) ----
-        uint32_t out[25];
+        uint32_t out[JD];
         if (lane < S) {
             uint32_t d[13], w[12];
 #pragma unroll
@@ -465,7 +522,7 @@ __global__ __launch_bounds__(256) void bad_raw_kernel(
             }
             int run = 0;
 #pragma unroll
-            for (int j = 0; j < 25; j++) {
+            for (int j = 0; j < JD; j++) {
                 const int lo = run;
                 if (2 * j < S) run += (int)((w[(2 * j) >> 2] >> (8 * ((2 * j) & 3))) & 0xffu);
                 const int hi = run;
@@ -473,27 +530,29 @@ __global__ __launch_bounds__(256) void bad_raw_kernel(
                 out[j] = (uint32_t)lo | ((uint32_t)hi << 16);
             }
         }
-        // every lane has read its raw row (program order) before the prefix plane -- which does not overlap the raw rows --
-        // is written
+        // every lane has its raw row in registers (program order; a wave's LDS operations complete in order) before the
+        // plane, which aliases the staged window, is written
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         if (lane < S) {
 #pragma unroll
-            for (int j = 0; j < 25; j++) Pq[lane * 25 + j] = out[j];
+            for (int j = 0; j < JD; j++) Jd[(lane + 1) * JD + j] = out[j];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // ---- column prefix (lane = column pair) ----
-        if (lane < 25) {
-            *reinterpret_cast<uint2*>(J + 2 * lane) = make_uint2(0u, 0u);
-            int run0 = 0, run1 = 0;
+        // ---- column prefix in place (lane = column pair), modulo 2^16 per column ----
+        if (lane < JD) {
+            Jd[lane] = 0u;
+            u16x2 run = { 0, 0 };
 #pragma unroll
             for (int r0 = 0; r0 < S; r0 += 8) {
                 uint32_t v[8];
 #pragma unroll
-                for (int i = 0; i < 8; i++) v[i] = Pq[(r0 + i) * 25 + lane];
+                for (int i = 0; i < 8; i++) v[i] = Jd[(r0 + i + 1) * JD + lane];
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
-                    run0 += (int)(v[i] & 0xffffu); run1 += (int)(v[i] >> 16);
-                    *reinterpret_cast<uint2*>(J + (r0 + i + 1) * JP + 2 * lane) = make_uint2((uint32_t)run0, (uint32_t)run1);
+                    run = run + __builtin_bit_cast(u16x2, v[i]);
+                    Jd[(r0 + i + 1) * JD + lane] = __builtin_bit_cast(uint32_t, run);
                 }
             }
         }
@@ -503,37 +562,25 @@ __global__ __launch_bounds__(256) void bad_raw_kernel(
 
     const bool border = (A.border & 1) != 0;
     const int fw = cols + 1, fh = rows + 1;
-    const int wbase = -(wy0 * JP + wx0) * 4;
+    const int wbase = -(wy0 * JP + wx0) * 2;
     uint32_t mlo = 0u, mhi = 0u;
-    for (int it = 0; it * 64 < nbits; it++) {
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
         const int b = it * 64 + lane;
         bool bit = false;
         if (fits) {
             if (border) {
-                bit = bad_border_bit(A, P->box[b], J, JP, S, wx0, wy0, fw, fh);
+                bit = bad_border_bit<uint16_t>(A, P->box[b], J, JP, S, wx0, wy0, fw, fh);
             } else {
                 // integer fast path, bad.cpp:365-393; the window holds every tap (bad_det_kernel has the argument)
-                const uint4 q = P->ubox[b];
-                const efx_f32x2 xs = { (float)(q.x & 0xffu), (float)((q.x >> 16) & 0xffu) };          // x1, x2
-                const efx_f32x2 ys = { (float)((q.x >> 8) & 0xffu), (float)(q.x >> 24) };             // y1, y2
-                const efx_f32x2 half2 = { 0.5f, 0.5f };
-                const efx_f32x2 cxf = (((efx_f32x2)(A.m00) * xs + (efx_f32x2)(A.m01) * ys) + (efx_f32x2)(A.m02)) + half2;
-                const efx_f32x2 cyf = (((efx_f32x2)(A.m10) * xs + (efx_f32x2)(A.m11) * ys) + (efx_f32x2)(A.m12)) + half2;
-                const int cx1 = (int)cxf.x, cx2 = (int)cxf.y, cy1 = (int)cyf.x, cy2 = (int)cyf.y;
-                const int pbase = (int)q.y * (JP + 1) + wbase;                // q.y = -4 r'
-                const int side4 = (int)(q.z & 0xffffu), sideJ4 = side4 * JP;
-                const int a_tl = (cy1 * JP + cx1) * 4 + pbase, b_tl = (cy2 * JP + cx2) * 4 + pbase;
-                auto at = [&](int o) -> int { return *reinterpret_cast<const int*>(wbuf + o); };
-                const int area_resp = at(a_tl) + at(a_tl + side4 + sideJ4) - at(a_tl + side4) - at(a_tl + sideJ4)
-                                    - at(b_tl) - at(b_tl + side4 + sideJ4) + at(b_tl + side4) + at(b_tl + sideJ4);
-                bit = (float)area_resp <= __uint_as_float(q.w);
+                bit = bad_ubox_bit(A, q[it], wbuf, wbase);
             }
         }
         const unsigned long long m = __ballot(bit);
         if (lane == it) { mlo = (uint32_t)m; mhi = (uint32_t)(m >> 32); }
     }
     // bit i -> byte i / 8, MSB first (bad.cpp:349,368): lane i holds bits 64 i .. 64 i + 63
-    if (lane * 64 < nbits) {
+    if (lane < NIT) {
         uint8_t* o = desc + (size_t)kid * desc_pitch + lane * 8;
         const uint32_t lo = __builtin_bswap32(__brev(mlo)), hi = __builtin_bswap32(__brev(mhi));
         if (((((uintptr_t)desc) | desc_pitch) & 7u) == 0) *reinterpret_cast<uint2*>(o) = make_uint2(lo, hi);
@@ -580,7 +627,7 @@ hipError_t efx_launch_bad(const DescribeLaunch& a, const BadParamsDev* d_params,
         hipLaunchKernelGGL(bad_affine_kernel, dim3((a.n + 255) / 256), dim3(256), 0, stream, a.kp4, a.kps5, a.kps5_pitch, a.kp_level, a.d_table, a.img0, a.pitch0, a.pyramid, a.rows0, a.cols0,
                            a.d_count, a.n, a.scale_factor, reach, S, sfixed, aff);
     if (a.blur) {
-        if (S == 48 && a.uniform_size && max_size == (float)EFX_PATCH_SIZE && a.kp_level && a.bad_det_tables) {
+        if (S == 48 && a.uniform_size && max_size == (float)EFX_PATCH_SIZE && a.kp_level && a.bad_det_tables == 2) {
             // detector keypoints: the per-pair table of BadParamsDev was built for exactly this s; LDS: raw | pix | hb / I
             const size_t lds_det = 3248 + 48 * 48 + BlurGeom(48).hb_bytes();
             hipLaunchKernelGGL(bad_det_kernel, dim3(a.n), dim3(256), lds_det, stream, a.d_count, a.n, d_params, aff, t[0], t[1], t[2], t[3],
@@ -599,10 +646,14 @@ hipError_t efx_launch_bad(const DescribeLaunch& a, const BadParamsDev* d_params,
                            a.d_table, a.kp4, a.kp_level, a.d_count, a.n, a.scale_factor, S, d_params, aff, t[0], t[1], t[2], t[3],
                            a.desc, a.desc_pitch);
     } else {
-        if (S == 48 && a.uniform_size && max_size == (float)EFX_PATCH_SIZE && a.bad_det_tables && !a.bad_no_raw) {
+        if (S == 48 && a.uniform_size && max_size == (float)EFX_PATCH_SIZE && a.bad_det_tables == 2 && !a.bad_no_raw) {
             // computeAsync on detector-sized keypoints: a wave per keypoint, four keypoints per workgroup
-            hipLaunchKernelGGL(bad_raw_kernel, dim3((a.n + 3) / 4), dim3(256), 4 * BAD_RAW_WAVE_LDS, stream, a.d_count, a.n, d_params, aff,
-                               a.desc, a.desc_pitch);
+            if (a.nbits == 256)
+                hipLaunchKernelGGL(bad_raw_kernel<4>, dim3((a.n + 3) / 4), dim3(256), 4 * BAD_RAW_WAVE_LDS, stream, a.d_count, a.n, d_params, aff,
+                                   a.desc, a.desc_pitch);
+            else
+                hipLaunchKernelGGL(bad_raw_kernel<8>, dim3((a.n + 3) / 4), dim3(256), 4 * BAD_RAW_WAVE_LDS, stream, a.d_count, a.n, d_params, aff,
+                                   a.desc, a.desc_pitch);
             return hipGetLastError();
         }
         if (S == 48 && a.uniform_size) {

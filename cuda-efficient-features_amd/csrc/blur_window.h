@@ -55,10 +55,14 @@ __device__ __forceinline__ int efx_reflect101(int p, int len)
 // contains two barriers; the caller synchronises before reading what `store` wrote).  store(r0, i, c, pk) receives the
 // blurred, rounded (half-even) and saturated pixels of row r0 + i (i a compile-time constant after unrolling) at columns
 // c and c + 1 (c even, r0 + i < S) as the two low bytes of pk.
-template <int NT, class Store>
+struct EfxNoOverlap { __device__ __forceinline__ void operator()() const {} };
+
+// overlap(): work of the caller that does not depend on the window (a describer's per-keypoint set-up); it is placed between
+// the issue of the window's global loads and their first use, i.e. it runs while the loads are in flight.
+template <int NT, class Store, class Overlap = EfxNoOverlap>
 __device__ __forceinline__ void efx_blur_window_lds(const uint8_t* __restrict__ img, int pitch, int rows, int cols, int wx0, int wy0,
                                                     int S, uint8_t* raw, float* hb, float taps0, float taps1, float taps2, float taps3,
-                                                    int tid, Store store)
+                                                    int tid, Store store, Overlap overlap = Overlap())
 {
     const BlurGeom g_(S);
     constexpr int RO = BlurGeom::RO, CR = BlurGeom::CR, NV = BlurGeom::NV, ND = BlurGeom::ND;
@@ -74,11 +78,30 @@ __device__ __forceinline__ void efx_blur_window_lds(const uint8_t* __restrict__ 
         const int sh = ndw <= 16 ? 4 : (ndw <= 32 ? 5 : 6);      // lanes per row: 16 / 32 / 64
         const int j = tid & ((1 << sh) - 1), r0 = tid >> sh, rstep = NT >> sh;
         const uint8_t* base = img + (size_t)(wy0 - 3) * pitch + ((wx0 - 3) & ~3);
-        for (int jj = j; jj < ndw; jj += (1 << sh))
-            for (int r = r0; r < RP; r += rstep)
-                *reinterpret_cast<uint32_t*>(raw + r * RPB + 4 * jj) =
-                    *reinterpret_cast<const uint32_t*>(base + (size_t)r * pitch + 4 * jj);
+        if (sh == 4 && RP <= 4 * rstep) {
+            // the common shape (S = 48: 54 rows of 15 dwords, 16 rows per step): all of a thread's loads are issued before
+            // the caller's overlap() work and before the first store
+            uint32_t v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int r = r0 + k * rstep;
+                v[k] = (j < ndw && r < RP) ? *reinterpret_cast<const uint32_t*>(base + (size_t)r * pitch + 4 * j) : 0u;
+            }
+            overlap();
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int r = r0 + k * rstep;
+                if (j < ndw && r < RP) *reinterpret_cast<uint32_t*>(raw + r * RPB + 4 * j) = v[k];
+            }
+        } else {
+            overlap();
+            for (int jj = j; jj < ndw; jj += (1 << sh))
+                for (int r = r0; r < RP; r += rstep)
+                    *reinterpret_cast<uint32_t*>(raw + r * RPB + 4 * jj) =
+                        *reinterpret_cast<const uint32_t*>(base + (size_t)r * pitch + 4 * jj);
+        }
     } else {
+        overlap();
         for (int r = tid >> 6; r < RP; r += NT / 64) {
             const int gy = efx_reflect101(wy0 - 3 + r, rows);
             const uint8_t* src = img + (size_t)gy * pitch;
@@ -120,13 +143,20 @@ __device__ __forceinline__ void efx_blur_window_lds(const uint8_t* __restrict__ 
                 for (int jt = 1; jt < 7; jt++) acc = __builtin_elementwise_fma(v[i + jt], (efx_f32x2)(tp[jt]), acc);
                 o[i] = acc;
             }
-            float2* d0 = reinterpret_cast<float2*>(hb + (2 * rp) * HP + RO * g);
-            float2* d1 = reinterpret_cast<float2*>(hb + (2 * rp + 1) * HP + RO * g);
+            // o[i] = (row 2 rp, row 2 rp + 1) of column RO g + i: neighbouring columns of a row sit in different register
+            // pairs, so the stores are written dword by dword (ds_write2_b32 takes any two registers; a float2 store would
+            // cost a v_mov per value to line the registers up)
+            // (written as ds_write2_b32 by hand: the compiler merges adjacent dword stores into ds_write_b64 + moves)
+            const uint32_t a0 = (uint32_t)(uintptr_t)(hb + (2 * rp) * HP + RO * g);       // LDS byte address: low half of the generic address
+            const uint32_t a1 = (uint32_t)(uintptr_t)(hb + (2 * rp + 1) * HP + RO * g);
 #pragma unroll
             for (int i = 0; i < RO / 2; i++) {
-                d0[i] = make_float2(o[2 * i].x, o[2 * i + 1].x);
-                d1[i] = make_float2(o[2 * i].y, o[2 * i + 1].y);
+                asm volatile("ds_write2_b32 %0, %1, %2 offset0:%3 offset1:%4" :: "v"(a0), "v"(o[2 * i].x), "v"(o[2 * i + 1].x), "n"(2 * i), "n"(2 * i + 1) : "memory");
+                asm volatile("ds_write2_b32 %0, %1, %2 offset0:%3 offset1:%4" :: "v"(a1), "v"(o[2 * i].y), "v"(o[2 * i + 1].y), "n"(2 * i), "n"(2 * i + 1) : "memory");
             }
+            // the compiler does not count hand-written LDS operations: without this the barrier below is not preceded by
+            // a wait for them
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     }
     __syncthreads();

@@ -142,6 +142,7 @@ struct DevBuf {                     // grow-only device allocation
 struct Describer {                  // cuda::BAD / cuda::HashSIFT state
     int dbg_hs = 0;                 // EFX_DEBUG_HS, read when the describer is created (EFX_DEBUG_BUILD builds only)
     int no_raw = 0;                 // EFX_BAD_NO_RAW (variant knob), read when the describer is created
+    int ubox_max_side = 0;          // BAD: largest box edge of the detector-keypoint table
     size_t hs_wb_off = 0;           // HashSIFT: byte offset of the bf16 weight terms inside `params`
     int kind = 0;                   // 0 BAD, 1 HashSIFT
     int nbits = 256;
@@ -205,16 +206,20 @@ int describer_init(Describer& d, int kind, int nbits, float scale)
             const float sz = (float)EFX_PATCH_SIZE;
             const float su = scale * sz / (0.5f * (float)(32 + 32));            // == Affine.s of bad_affine_kernel
             h->ubox_s = su;
+            h->ubox_max_side = 0;
             for (int i = 0; i < nbits; i++) {
                 const int x1 = boxes[5 * i + 0], x2 = boxes[5 * i + 1], y1 = boxes[5 * i + 2], y2 = boxes[5 * i + 3], r = boxes[5 * i + 4];
                 const int rs = (int)((su * (float)r) + 0.5f);
                 const int side = 1 + (rs << 1);
+                if (side > h->ubox_max_side) h->ubox_max_side = side;
                 const float ts = thr[i] * (float)(side * side);
                 uint32_t tsb; memcpy(&tsb, &ts, 4);
-                h->ubox[i] = make_uint4((uint32_t)(x1 | (y1 << 8) | (x2 << 16) | (y2 << 24)), (uint32_t)(-4 * rs),
-                                        (uint32_t)(4 * side) | ((uint32_t)(4 * 49 * side) << 16), tsb);
+                // byte offsets in the detector-sized kernels' integral: u16 entries, 50 per row (BAD_J_PITCH, bad_kernel.hip)
+                h->ubox[i] = make_uint4((uint32_t)(x1 | (y1 << 8) | (x2 << 16) | (y2 << 24)), (uint32_t)(-2 * rs * (50 + 1)),
+                                        (uint32_t)(2 * side) | ((uint32_t)(2 * 50 * side) << 16), tsb);
             }
         }
+        d.ubox_max_side = h->ubox_max_side;
         hipError_t e = d.params.reserve(sizeof(BadParamsDev));
         if (e == hipSuccess) e = hipMemcpy(d.params.p, h, sizeof(BadParamsDev), hipMemcpyHostToDevice);
         delete h;
@@ -291,6 +296,7 @@ int describer_init(Describer& d, int kind, int nbits, float scale)
 int describer_run(Describer& d, std::string& err, DescribeLaunch a, float* dbg_resp, float* dbg_T, hipStream_t stream)
 {
     a.scale_factor = d.scale;
+    a.nbits = d.nbits;
     a.dbg_hs = d.dbg_hs;
     if (a.n <= 0) return EFX_OK;
     const bool prof = a.prof.begin(10, stream);
@@ -298,7 +304,7 @@ int describer_run(Describer& d, std::string& err, DescribeLaunch a, float* dbg_r
     if (d.kind == 0) {
         HIP_TRY(err, d.responses.reserve((size_t)a.n * sizeof(Affine)));
         a.bad_affine = d.responses.p;
-        a.bad_det_tables = 1;            // describer_init builds ubox for d.scale and size 31
+        a.bad_det_tables = d.ubox_max_side <= 16 ? 2 : 1;      // describer_init builds ubox for d.scale and size 31
         a.bad_no_raw = d.no_raw;
         hipError_t e = efx_launch_bad(a, static_cast<const BadParamsDev*>(d.params.p), d.reach, stream);
         if (e == hipErrorInvalidValue) return set_err(err, EFX_ERR_UNSUPPORTED, "keypoint size %.1f needs a window larger than the 160 KB LDS", a.max_size);

@@ -139,11 +139,12 @@ struct BadParamsDev {           // per-context copy of the learned tables (no pr
     // Detector keypoints (size 31, describer scale s.t. the window is 48 x 48): everything about a box pair that does not
     // depend on the keypoint, worked out once on the host with the float expressions of bad.cpp:151-155,393
     //   .x = x1 | y1 << 8 | x2 << 16 | y2 << 24          (v_cvt_f32_ubyteN)
-    //   .y = -4 r'            r' = (int)(s r + 0.5f), the scaled radius
-    //   .z = 4 side | (4 * 49 side) << 16               side = 2 r' + 1; byte strides in the 49-int integral rows
+    //   .y = -2 r' (50 + 1)   r' = (int)(s r + 0.5f), the scaled radius: byte offset of the box's top-left entry from its centre's
+    //   .z = 2 side | (2 * 50 side) << 16               side = 2 r' + 1; byte strides in the integral (u16 entries, 50 per row)
     //   .w = bits of thr * (float)(side * side)
     uint4 ubox[512];
     float ubox_s;               // the s the table was built for (scale_factor * 31 / 32)
+    int ubox_max_side;          // largest box edge 2 r' + 1 of the table (<= 16: every box sum fits 16 bits, bad_raw_kernel)
 };
 
 #if defined(__HIPCC__)
@@ -273,7 +274,8 @@ struct DescribeLaunch {
     int uniform_size;                                      // 1: every keypoint has size == max_size (detector output)
     uint8_t* desc; size_t desc_pitch;
     void* bad_affine;                                      // BAD scratch: n x 80 bytes (per-keypoint affine map + window geometry)
-    int bad_det_tables;                                    // BadParamsDev::ubox was built for this describer scale and size 31
+    int nbits;                                             // descriptor bits (256 / 512)
+    int bad_det_tables;                                    // 1: BadParamsDev::ubox was built for this describer scale and size 31; 2: and no box edge exceeds 16
     int bad_no_raw;                                        // EFX_BAD_NO_RAW (variant knob, read when the describer is created; parity tests):
                                                            // computeAsync through the generic one-workgroup-per-keypoint kernel
     int affine_ready;                                      // bad_affine already holds this call's records (written by angle_kernel)
