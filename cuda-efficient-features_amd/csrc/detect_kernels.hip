@@ -1269,6 +1269,12 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
 // (response desc, raster asc) finds the quota-th largest key; then the selected survivors of every tile
 // are counted and scanned in canonical tile order to give each tile its output offset.
 // ================================================================================================
+// INVESTIGATION (-DEFX_SEL_TIMING builds only): thread 0 of level 0's workgroup prints its phase times (10 ns ticks)
+#ifdef EFX_SEL_TIMING
+#define SEL_T(i) do { if (l == 0 && tid == 0) sel_t[i] = wall_clock64(); } while (0)
+#else
+#define SEL_T(i) do { } while (0)
+#endif
 #define SEL_BITS 12
 #define SEL_BINS (1 << SEL_BITS)
 #define SEL_MAX_TILES 12288          // per-tile counts of one level in LDS (48 KB); larger levels take the tile-parallel path
@@ -1277,10 +1283,13 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
 #define SEL_LIST_CAP 4096            // keys of the threshold's bin that are ranked in LDS; more (thousands of near-equal responses): radix passes
 #define SEL_LDS_BYTES (SEL_TOP_BINS * 4)      // dynamic LDS: the histogram; later the candidate list / the per-tile counts
 
-// One workgroup per level.  The level's survivors were written by nms_kernel on all eight XCDs and are read here through
-// ONE CU's L2: every dependent step over them is a trip to memory (~2 us), and that -- not arithmetic -- is what the
-// kernel's time is made of.  Round 3: TWO passes over the survivors instead of up to seven, two steps' loads (16 per
-// thread) in flight at a time:
+// One workgroup per level.  What the kernel's time is made of (level 0 of the 8K benchmark frame, 22 593 survivors,
+// -DEFX_SEL_TIMING build, tools/microbench/sel_timing.sh): launch 4.5 us, counters 3.5, pass 1 5.3, threshold bin 2.3,
+// pass 2 + ranking 7.4, tile scan 1.3, header stores 0.9.  A pass over the survivors costs ~5 us whatever feeds it -- keys
+// held in registers, one batch of 24 loads or three of 8, sub-arrays interleaved against TLB misses were all measured and
+// changed nothing: it is 1024 threads' per-key instructions on ONE CU (16 waves on 4 SIMDs) plus one trip to memory.  So
+// the lever is the NUMBER of passes -- round 3: TWO instead of up to seven (31.6 -> 26 us) -- and spreading a level over
+// several workgroups would need three grid-wide hand-offs through memory (~2.5 us each across XCDs), i.e. no gain:
 //   1  histogram of the top 15 key bits (128 KB of LDS counters) -> the bin b* that holds the quota-th largest key, and how
 //      many keys of that bin are wanted;
 //   2  keys above b* are selected for sure: they are counted into their tiles at once; the keys OF b* (a few dozen on real
@@ -1307,6 +1316,10 @@ __global__ __launch_bounds__(1024) void select_kernel(const LevelTable* __restri
     const int l = blockIdx.x;
     const LevelDev& L = T->lv[l];
     const int tid = threadIdx.x;
+#ifdef EFX_SEL_TIMING
+    unsigned long long sel_t[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+#endif
+    SEL_T(0);
 
     // output base of this level: sum over lower levels of min(survivors, quota)  (.cpp:292-314)
     int base = 0, all = 0;
@@ -1322,6 +1335,7 @@ __global__ __launch_bounds__(1024) void select_kernel(const LevelTable* __restri
         if (l == T->nlevels - 1) cnt->level_out_base[T->nlevels] = all;
         if (l == 0) { const int n = all < capacity ? all : capacity; cnt->sum.n_out = n; if (d_count) *d_count = n; }
     }
+    SEL_T(1);
     if (!L.active) { if (tid == 0) { cnt->sum.kept[l] = 0; cnt->thresh[l] = 0; } return; }
     if (cnt->sum.overflow) {
         // void frame (arena overflow): N = 0, nothing is selected, emitted or described
@@ -1340,23 +1354,26 @@ __global__ __launch_bounds__(1024) void select_kernel(const LevelTable* __restri
     const int ntiles = L.tiles_x * L.tiles_y;
     const bool tiles_in_lds = ntiles <= SEL_MAX_TILES;
 
-    // one pass over the level's survivors: entries i and i + 1024 of all 8 sub-arrays per step (16 independent loads in
-    // flight: one memory round trip per 16 384 survivors)
+    // one pass over the level's survivors: entries i, i + 1024, i + 2048 of all 8 sub-arrays per step -- 24 independent loads
+    // in flight, ONE memory round trip for levels of up to 3072 survivors per sub-array (every level of the benchmark
+    // frames).  The loads are unconditional (index clamped into the sub-array: the arena is ours whatever the counts say),
+    // so that they are not serialised by exec-mask bookkeeping; what lies beyond a count is skipped afterwards.
+    constexpr int SEL_BATCH = 3;
+    const uint2* surv2 = reinterpret_cast<const uint2*>(surv);
+    const unsigned capm1 = L.surv_sub_cap - 1u;
     auto for_each_key = [&](auto&& f) {
-        for (int i = tid; i < nmaxsub; i += 2048) {
-            Corner c[2][EFX_NSUB];
+        for (int i0 = 0; i0 < nmaxsub; i0 += SEL_BATCH * 1024) {
+            uint2 c[SEL_BATCH][EFX_NSUB];
 #pragma unroll
-            for (int h = 0; h < 2; h++)
-#pragma unroll
-                for (int sub = 0; sub < EFX_NSUB; sub++) {
-                    c[h][sub].xy = 0u; c[h][sub].resp = 0.f;
-                    if (i + 1024 * h < nsub[sub]) c[h][sub] = surv[(size_t)sub * L.surv_sub_cap + i + 1024 * h];
-                }
-#pragma unroll
-            for (int h = 0; h < 2; h++)
+            for (int h = 0; h < SEL_BATCH; h++)
 #pragma unroll
                 for (int sub = 0; sub < EFX_NSUB; sub++)
-                    if (i + 1024 * h < nsub[sub]) f(efx_select_key(c[h][sub].xy, c[h][sub].resp), c[h][sub].xy);
+                    c[h][sub] = surv2[(unsigned)sub * L.surv_sub_cap + min((unsigned)(i0 + tid + 1024 * h), capm1)];
+#pragma unroll
+            for (int h = 0; h < SEL_BATCH; h++)
+#pragma unroll
+                for (int sub = 0; sub < EFX_NSUB; sub++)
+                    if (i0 + tid + 1024 * h < nsub[sub]) f(efx_select_key(c[h][sub].x, __uint_as_float(c[h][sub].y)), c[h][sub].x);
         }
     };
     auto tile_of = [&](uint32_t xy) -> int { return (int)((xy >> 16) >> 6) * L.tiles_x + (int)((xy & 0xffffu) >> 6); };
@@ -1374,6 +1391,7 @@ __global__ __launch_bounds__(1024) void select_kernel(const LevelTable* __restri
         __syncthreads();
         for_each_key([&](unsigned long long k, uint32_t) { atomicAdd(&s_hist[(int)(k >> (64 - SEL_TOP_BITS))], 1); });
         __syncthreads();
+        SEL_T(2);
         // walk the bins from the top: thread t owns the 32 bins [hi - 32 t - 31, hi - 32 t]
         {
             constexpr int PER = SEL_TOP_BINS / 1024;
@@ -1385,13 +1403,18 @@ __global__ __launch_bounds__(1024) void select_kernel(const LevelTable* __restri
                 sum += v.x + v.y + v.z + v.w;
             }
             int tot;
-            int before = block_excl_scan<16>(sum, s_scan, &tot);
-            if (before < L.quota && L.quota <= before + sum) {
-                for (int j = 0; j < PER; j++) {
-                    const int c = s_hist[top - j];
-                    if (L.quota <= before + c) { s_bin = top - j; s_rem = L.quota - before; s_n = c; break; }
-                    before += c;
-                }
+            const int before = block_excl_scan<16>(sum, s_scan, &tot);
+            if (before < L.quota && L.quota <= before + sum) { s_bin = top; s_rem = L.quota - before; }     // the owner of the bin
+            __syncthreads();
+            if (tid < 64) {
+                // its 32 bins, from the top, one per lane of wave 0
+                const int b = s_bin - tid;
+                const int c = tid < PER ? s_hist[b] : 0;
+                const int incl = wave_incl_scan(c);
+                const int want = s_rem;
+                const bool hit = tid < PER && incl - c < want && want <= incl;
+                __builtin_amdgcn_wave_barrier();
+                if (hit) { s_bin = b; s_rem = want - (incl - c); s_n = c; }
             }
         }
         __syncthreads();
@@ -1400,6 +1423,7 @@ __global__ __launch_bounds__(1024) void select_kernel(const LevelTable* __restri
         unsigned long long prefix = (unsigned long long)bin;     // decided high bits, right-aligned
         int decided = SEL_TOP_BITS;
         __syncthreads();                                         // the histogram's storage is reused below
+        SEL_T(3);
         if (remaining == in_bin) {
             thresh = prefix << (64 - decided);                   // every key of the bin is wanted: its lower edge
         } else if (in_bin <= SEL_LIST_CAP) {
@@ -1508,6 +1532,7 @@ __global__ __launch_bounds__(1024) void select_kernel(const LevelTable* __restri
         __syncthreads();
     }
     if (tid == 0) cnt->thresh[l] = thresh;
+    SEL_T(4);
 
     // ---- selected survivors per tile (unless pass 2 has counted them), exclusive scan in canonical tile order ----
     TileHdr* hl = hdr + L.tile_base;
@@ -1521,6 +1546,7 @@ __global__ __launch_bounds__(1024) void select_kernel(const LevelTable* __restri
             for_each_key([&](unsigned long long k, uint32_t xy) { if (k >= thresh) atomicAdd(&s_cnt[tile_of(xy)], 1); });
         }
         __syncthreads();
+        SEL_T(5);
         // exclusive scan over the tiles: a thread owns a contiguous chunk
         const int chunk = (ntiles + 1023) / 1024;
         const int t0 = tid * chunk, t1 = min(t0 + chunk, ntiles);
@@ -1528,6 +1554,7 @@ __global__ __launch_bounds__(1024) void select_kernel(const LevelTable* __restri
         for (int t = t0; t < t1; t++) local += s_cnt[t];
         int tot;
         int pre = block_excl_scan<16>(local, s_scan, &tot);
+        SEL_T(6);
         for (int t = t0; t < t1; t++) { hl[t].out_off = (uint32_t)(base + pre); pre += s_cnt[t]; }
         running = tot;
     } else {
@@ -1545,6 +1572,13 @@ __global__ __launch_bounds__(1024) void select_kernel(const LevelTable* __restri
             running += tot;
         }
     }
+    SEL_T(7);
+#ifdef EFX_SEL_TIMING
+    if (l == 0 && tid == 0)
+        printf("select l0 ticks(10ns): base %llu | pass1 %llu | bin %llu | pass2+rank %llu | count %llu | scan %llu | hdr %llu | total %llu\n",
+               sel_t[1] - sel_t[0], sel_t[2] - sel_t[1], sel_t[3] - sel_t[2], sel_t[4] - sel_t[3], sel_t[5] - sel_t[4], sel_t[6] - sel_t[5],
+               sel_t[7] - sel_t[6], sel_t[7] - sel_t[0]);
+#endif
     if (tid == 0) {
         cnt->sum.kept[l] = running;
         cnt->sum.surv[l] = n;
