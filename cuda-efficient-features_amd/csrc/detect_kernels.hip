@@ -1060,6 +1060,22 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
     const int ncell = span * span;
     const int grp = lane >> 3, sub = lane & 7;
 
+    // one cell's list [nb, ne) walked by the 8 lanes of a group, four entries per lane in flight (a long list is a chain of
+    // dependent trips to L2 otherwise: dense frames).  Entries past the end are clamped onto the last one (harmless repeats).
+    auto walk_list = [&](unsigned nbase, int nb, int ne, const Corner& m, int mx, int my, bool& kill) {
+        const Corner* lst = cand + (size_t)nbase;
+        for (int j = nb + sub; j < ne; j += 32) {
+            Corner o[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) o[u] = lst[min(j + 8 * u, ne - 1)];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int dx = mx - (int)(o[u].xy & 0xffff), dy = my - (int)(o[u].xy >> 16);
+                kill |= (o[u].xy != m.xy && m.resp <= o[u].resp && dx * dx + dy * dy < image_radius);
+            }
+        }
+    };
+
     // phase B over the hard corners collected so far
     auto scan_hard = [&](int nh) {
         for (int h0 = 0; h0 < nh; h0 += 8) {
@@ -1101,13 +1117,7 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
                     const unsigned a0 = (unsigned)__shfl((int)lbase[0], src, 64), a1 = (unsigned)__shfl((int)lbase[1], src, 64);
                     const int nb = i < 8 ? b0 : b1, ne = i < 8 ? e0 : e1;
                     const unsigned nbase = i < 8 ? a0 : a1;
-                    if (gneed) {
-                        for (int j = nb + sub; j < ne; j += 8) {
-                            const Corner o = cand[(size_t)nbase + j];
-                            const int dx = mx - (int)(o.xy & 0xffff), dy = my - (int)(o.xy >> 16);
-                            kill |= (o.xy != m.xy && m.resp <= o.resp && dx * dx + dy * dy < image_radius);
-                        }
-                    }
+                    if (gneed) walk_list(nbase, nb, ne, m, mx, my, kill);
                     gneed &= ~(1u << i);
                     // one suppressor is enough: a group whose corner is dead stops walking (most hard corners of a
                     // dense tile die in the first list)
@@ -1134,6 +1144,10 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
                         lbase[q] = (unsigned)(nt & (EFX_NSUB - 1)) * L.cand_sub_cap + nh2->cand_start;
                         // a cell whose strongest corner is weaker than this corner cannot suppress it: skip the cell
                         if (quick_ok && le[q] > lb[q] && cmax[by * gwp + bx].resp < m.resp) le[q] = lb[q];
+                        // nor can a cell whose nearest pixel is not inside the radius
+                        const int ex = max(max(bx * EFX_CELL - mx, mx - (bx * EFX_CELL + EFX_CELL - 1)), 0);
+                        const int ey = max(max(by * EFX_CELL - my, my - (by * EFX_CELL + EFX_CELL - 1)), 0);
+                        if (ex * ex + ey * ey >= image_radius) le[q] = lb[q];
                     }
                 }
                 // bit i of gneed <-> cell c0+i still has a list to walk (group-uniform)
@@ -1147,13 +1161,7 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
                     const unsigned a0 = (unsigned)__shfl((int)lbase[0], src, 64), a1 = (unsigned)__shfl((int)lbase[1], src, 64);
                     const int nb = i < 8 ? b0 : b1, ne = i < 8 ? e0 : e1;
                     const unsigned nbase = i < 8 ? a0 : a1;
-                    if (gneed) {
-                        for (int j = nb + sub; j < ne; j += 8) {
-                            const Corner o = cand[(size_t)nbase + j];
-                            const int dx = mx - (int)(o.xy & 0xffff), dy = my - (int)(o.xy >> 16);
-                            kill |= (o.xy != m.xy && m.resp <= o.resp && dx * dx + dy * dy < image_radius);
-                        }
-                    }
+                    if (gneed) walk_list(nbase, nb, ne, m, mx, my, kill);
                     gneed &= gneed - 1u;
                     if (((unsigned)(__ballot(kill) >> (grp * 8)) & 0xffu) != 0u) gneed = 0u;       // one suppressor is enough
                 }
@@ -1193,15 +1201,23 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
 #pragma unroll
                     for (int q = 0; q < 9; q++) o[q] = s_cm[ci + q / 3][cj + q % 3];
                     int kill = 0, rival = 0;
+                    // A neighbouring cell matters only if its nearest pixel is inside the radius (round 3): with a small
+                    // radius most corners are too far from most of the eight neighbours -- radius 5: 2.3 cells on
+                    // average instead of 9 -- and dense frames stop walking lists that cannot hold a suppressor.
+                    // gx[k], gy[k]: squared gap to the cell column / row k - 1 (0 for the own cell)
+                    const int px = mx & (EFX_CELL - 1), py = my & (EFX_CELL - 1);
+                    const int gx[3] = { (px + 1) * (px + 1), 0, (EFX_CELL - px) * (EFX_CELL - px) };
+                    const int gy[3] = { (py + 1) * (py + 1), 0, (EFX_CELL - py) * (EFX_CELL - py) };
 #pragma unroll
                     for (int q = 0; q < 9; q++) {
                         const uint32_t oxy = o[q].xy & ~EFX_CMAX_TIE;
                         const int dx = mx - (int)(oxy & 0xffff), dy = my - (int)(oxy >> 16);
                         const int other = (int)(oxy != me.xy);
                         const int ge = other & (int)(me.resp <= o[q].resp);
+                        const int near = (int)(gx[q % 3] + gy[q / 3] < image_radius);
                         // cell q holds a corner at least as strong: the exact scan must walk it.  That includes the cell whose
                         // maximum this corner is, when another corner of the cell has the same response (ties suppress)
-                        rival |= (ge | ((other ^ 1) & (int)(o[q].xy >> 31))) << q;
+                        rival |= (near & (ge | ((other ^ 1) & (int)(o[q].xy >> 31)))) << q;
                         kill |= ge & (int)(dx * dx + dy * dy < image_radius);
                     }
                     hard = kill == 0;
