@@ -334,22 +334,30 @@ __global__ __launch_bounds__(256) void patch_sift_kernel(
 // first version used).  R is integer valued (0..255 and the leading 1): exact in bf16.  W is split on the host into three
 // bf16 terms whose sum is W exactly, so every product R * W_t is exact in the fp32 accumulator and T differs from the
 // fp32 FMA chain only by the order / rounding of the accumulation (well inside the stated 2e-3 tolerance on T).
-// A wave owns 32 output bits and keeps their 3 x 9 B-operands (W terms x K steps) in registers for its whole life, then
-// walks 32-keypoint tiles of R: 9 sixteen-byte loads per lane, 27 MFMAs, sign test by ballot, packed bits out -- no T
-// matrix in HBM, no separate binarize pass (cuda_hash_sift.cu:414-435).
+// A wave owns 32 output bits and keeps their 3 x 9 weight operands (W terms x K steps) in registers for its whole life; the
+// four waves of a workgroup (128 adjacent bits) walk 64-keypoint tiles of R that the workgroup stages in LDS once.  Per tile
+// and wave: 54 MFMAs on two alternating accumulators, sign + pack in the lanes, one 16-byte store per keypoint -- no T
+// matrix in HBM, no separate binarize pass (cuda_hash_sift.cu:414-435).  One wave per SIMD (the kernel wants ~270 registers).
 // Operand layout: lane l holds row / column (l & 31) and the 8 consecutive k of half (l >> 5) of the K step, for A and B
 // alike, so whatever order the hardware contracts the 16 k of a step in, A and B elements meet at equal k.
+// Round 3 (C4, 40 000 keypoints x 512 bits, tools/microbench/hs_timing.sh): 26.8 -> 22.3 us.  What it was made of: a
+// one-accumulator MFMA chain (dependency-paced: 28 % of the matrix pipe), 32 ballots per tile funnelled through SGPRs, and --
+// once those were gone -- v_cmp + v_cndmask pairs the compiler made of the sign test (22 cycles each).  Per tile now: stage +
+// fetch 0.33 us, LDS reads + MFMAs 0.8 us (the pipe's own 54 x 32 cycles), pack 0.3 us, barrier + store 0.2 us; launch and
+// prologue (weights) 5.8 us.
 // ================================================================================================
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // lane `lane` (a constant) of `old` := the wave-uniform `sval`
 #define efx_writelane(sval, old, lane) ([&]() { uint32_t o_ = (old); asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(o_) : "s"(sval), "n"(lane)); return o_; }())
 
-__global__ __launch_bounds__(256) void project_sign_kernel(const uint16_t* __restrict__ Rm, const uint16_t* __restrict__ Wb,
+#ifndef HS_PROJ_WAVES
+#define HS_PROJ_WAVES 1          // waves per SIMD the kernel is compiled for (register budget 512 / waves)
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HS_PROJ_WAVES, HS_PROJ_WAVES))) void project_sign_kernel(const uint16_t* __restrict__ Rm, const uint16_t* __restrict__ Wb,
                                                            const int* __restrict__ d_count, int n, int nbits,
                                                            uint8_t* __restrict__ desc, size_t desc_pitch, float* __restrict__ dbg_T)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t s_bits[2][32][4];     // [buffer][row of the tile][wave]: 128 bits per row
     const int count = d_count ? min(*d_count, n) : n;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     // the waves that share a row group (one per column tile) run on ONE XCD: they read the same rows of R through one L2
@@ -359,68 +367,141 @@ __global__ __launch_bounds__(256) void project_sign_kernel(const uint16_t* __res
     const int mgroup = gw / ntn, nmgroups = (gridDim.x * 4) / ntn;
     const int li = lane & 31, lk = lane >> 5;
     constexpr int KS = HS_KB / 16;                                // 9 K steps
-    // this wave's weights: b[t][ks] = W_t[n0 + (li ^ 7)][16 ks + 8 lk .. + 8].  Lane li takes output bit n0 + (li ^ 7): a descriptor
-    // byte holds its 8 bits MSB first (hash_sift.cpp:367-374), so the 32 signs of a row, in lane order, ARE its 4 bytes
+    // The product is formed TRANSPOSED, T^T = W R^T: the weights are the MFMA's A operand (rows = output bits), the keypoints
+    // its B operand (columns), so lane (li, lk) ends up with 16 projections of ONE keypoint -- rows i = (r & 3) + 8 (r >> 2)
+    // + 4 lk of the C tile in register r -- and packs their signs itself, two VALU operations per value, instead of 32
+    // ballots per tile funnelled through SGPRs (round 2: a third of the kernel's time).  The packed word of a keypoint is
+    // bit b = r + 16 lk; a descriptor byte holds its 8 bits MSB first (hash_sift.cpp:367-374), i.e. descriptor bit p is bit
+    // 8 (p / 8) + 7 - p % 8 of the little-endian word, so MFMA row i carries W row n0 + p(b(i)):
+    const int r_of_li = (li & 3) + 4 * (li >> 3), bword = r_of_li + 16 * ((li >> 2) & 1);
+    const int wrow = n0 + 8 * (bword >> 3) + 7 - (bword & 7);
+    // this wave's weights: b[t][ks] = W_t[wrow][16 ks + 8 lk .. + 8]
     bf16x8 b[3][KS];
 #pragma unroll
     for (int t = 0; t < 3; t++) {
-        const uint4* p = reinterpret_cast<const uint4*>(Wb + ((size_t)t * nbits + n0 + (li ^ 7)) * HS_KB + 8 * lk);
+        const uint4* p = reinterpret_cast<const uint4*>(Wb + ((size_t)t * nbits + wrow) * HS_KB + 8 * lk);
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) b[t][ks] = __builtin_bit_cast(bf16x8, p[2 * ks]);
     }
-    const int mtiles = (count + 31) >> 5;
-    // the next row tile of R is in flight while this one is multiplied; two waves per SIMD cover the rest of the latency
-    auto load_tile = [&](int mt, uint4 (&dst)[KS]) {
-        const int arow = max(min(mt * 32 + li, count - 1), 0);
-        const uint4* pa = reinterpret_cast<const uint4*>(Rm + (size_t)arow * HS_KB + 8 * lk);
+    // A workgroup's four waves multiply the SAME rows of R (by four column tiles), so a 64-row tile is fetched once per
+    // workgroup into LDS (round 3; every wave used to fetch its 32 rows for itself).  Thread t fetches 16-byte pieces t,
+    // t + 256, ... of the tile (64 rows x 18 pieces); the next tile's pieces are in flight while this one is multiplied.  LDS
+    // rows are 304 bytes apart: the 16 lanes of a ds_read_b128 group land on 16 distinct 4-bank slots.
+    // Each wave multiplies the tile's two 32-row halves into TWO accumulators, alternating: an MFMA on the accumulator of
+    // the MFMA before it is dependency-paced (the one-accumulator chain of round 2 ran at 28 % of the matrix pipe: 75 cycles
+    // per 32-cycle instruction, profiles/r03_hashsift_pmc.txt), two alternating chains issue back to back.
+    const int stiles = (count + 63) >> 6;
+    constexpr int APITCH = 304, NPIECE = 64 * 18, NFETCH = (NPIECE + 255) / 256;
+    __shared__ __attribute__((aligned(16))) unsigned char s_a[2][64 * APITCH];
+    __shared__ __attribute__((aligned(16))) uint32_t s_bits[2][64][4];      // [buffer][row of the tile][wave]: 128 bits per row
+    auto fetch_tile = [&](int st, uint4 (&dst)[NFETCH]) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ks++) dst[ks] = pa[2 * ks];
+        for (int u = 0; u < NFETCH; u++) {
+            const int idx = (int)threadIdx.x + 256 * u;
+            const int row = idx / 18, piece = idx - row * 18;
+            const int arow = max(min(st * 64 + row, count - 1), 0);
+            dst[u] = make_uint4(0u, 0u, 0u, 0u);
+            if (idx < NPIECE) dst[u] = *reinterpret_cast<const uint4*>(Rm + (size_t)arow * HS_KB + 8 * piece);
+        }
     };
-    uint4 nxt[KS];
-    load_tile(mgroup, nxt);
     // 16-byte stores of a row's 128 bits need a 16-byte aligned destination
     const bool wide = desc != nullptr && (((reinterpret_cast<uintptr_t>(desc) | desc_pitch) & 15u) == 0);
-    int buf = 0;
-    for (int mt = mgroup; mt < mtiles; mt += nmgroups, buf ^= 1) {
-        const int m0 = mt * 32;
-        bf16x8 a[KS];
+    auto stage_tile = [&](int b_, const uint4 (&src)[NFETCH]) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ks++) a[ks] = __builtin_bit_cast(bf16x8, nxt[ks]);
-        if (mt + nmgroups < mtiles) load_tile(mt + nmgroups, nxt);
-        f32x16 acc = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-        // smallest terms first: the fp32 accumulator rounds them in before the large ones arrive.  (Three independent
-        // accumulators, one per term, were measured slower: 44 against 29 us.)
+        for (int u = 0; u < NFETCH; u++) {
+            const int idx = (int)threadIdx.x + 256 * u;
+            const int row = idx / 18, piece = idx - row * 18;
+            if (idx < NPIECE) *reinterpret_cast<uint4*>(&s_a[b_][row * APITCH + 16 * piece]) = src[u];
+        }
+    };
+    // ONE barrier per tile.  While tile i is multiplied out of buffer b, the same instruction stream moves tile i + 1 from
+    // registers into buffer b ^ 1 and requests tile i + 2 (a handful of LDS stores and loads between 54 MFMAs: they ride in
+    // the matrix pipe's shadow); the tile's sign words go to s_bits[b]; after the barrier 64 threads store them.
+#ifdef HS_PROJ_TIMING
+#define HSP_T(i) do { __builtin_amdgcn_sched_barrier(0); if (blockIdx.x == 0 && threadIdx.x == 0) hsp_t[i] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+    unsigned long long hsp_t[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    int hsp_iter = 0;
+#else
+#define HSP_T(i) do { } while (0)
+#endif
+    HSP_T(0);
+    uint4 nxt[NFETCH];
+    if (mgroup >= stiles) return;                                     // workgroup-uniform
+    fetch_tile(mgroup, nxt);
+    stage_tile(0, nxt);
+    if (mgroup + nmgroups < stiles) fetch_tile(mgroup + nmgroups, nxt);
+    __syncthreads();
+    HSP_T(1);
+    int buf = 0;
+    for (int st = mgroup; st < stiles; st += nmgroups, buf ^= 1) {
+        HSP_T(2);
+        const bool more = st + nmgroups < stiles;
+        if (more) stage_tile(buf ^ 1, nxt);          // its readers (tile i - 1) are past the barrier that ended tile i - 1
+        if (st + 2 * nmgroups < stiles) fetch_tile(st + 2 * nmgroups, nxt);
+        HSP_T(3);
+        const unsigned char* a0p = &s_a[buf][li * APITCH + 16 * lk];
+        const unsigned char* a1p = a0p + 32 * APITCH;
+        f32x16 acc0 = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, acc1 = acc0;
+        // smallest terms first: the fp32 accumulators round them in before the large ones arrive
 #pragma unroll
         for (int t = 2; t >= 0; t--)
 #pragma unroll
-            for (int ks = 0; ks < KS; ks++) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], b[t][ks], acc, 0, 0, 0);
-        // C layout 32x32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).  The sign bits of a row are a
-        // ballot half; lane `row` collects its row's 32 bits (v_writelane_b32: no compares, no selects)
-        uint32_t mine = 0u;
+            for (int ks = 0; ks < KS; ks++) {
+                const bf16x8 a0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(a0p + 32 * ks));
+                const bf16x8 a1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(a1p + 32 * ks));
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[t][ks], a0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[t][ks], a1, acc1, 0, 0, 0);
+            }
+        // C layout 32x32: col = lane & 31 (keypoint), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (output bit, permuted
+        // as above).  sign(T > 0) = clamp((int)bits, 0, 1): one v_med3_i32, then one v_lshl_or_b32 per value.
+        const int m0 = st * 64;
+        HSP_T(4);
+        uint32_t word[2];
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int row = (r & 3) + 8 * (r >> 2);
-            const unsigned long long ba = __ballot(acc[r] > 0.f);
+        for (int h = 0; h < 2; h++) {
+            const f32x16& acc = h ? acc1 : acc0;
+            uint32_t half = 0u;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                // clamp((int)bits, 0, 1) as ONE v_med3_i32 (written by hand: the compiler turns it into v_cmp + v_cndmask,
+                // and a v_cndmask behind the compare that feeds it costs ~22 cycles here, profiles/valu_rate.txt)
+                int sgn;
+                asm("v_med3_i32 %0, %1, 0, 1" : "=v"(sgn) : "v"(__float_as_uint(acc[r])));
+                half |= (uint32_t)sgn << r;
+            }
             if (dbg_T) {
-                const int i = m0 + row + 4 * lk;
-                if (i < count) dbg_T[(size_t)i * nbits + n0 + (li ^ 7)] = acc[r];
-            }
-            mine = efx_writelane(__builtin_amdgcn_readfirstlane((uint32_t)ba), mine, row);
-            mine = efx_writelane(__builtin_amdgcn_readfirstlane((uint32_t)(ba >> 32)), mine, row + 4);
-        }
-        if (desc != nullptr) {
-            if (wide) {
-                // the workgroup's four waves hold 128 adjacent bits of the same 32 rows: one 16-byte store per row
-                if (lane < 32) s_bits[buf][lane][wid] = mine;
-                __syncthreads();
-                if (threadIdx.x < 32 && m0 + (int)threadIdx.x < count) {
-                    const uint4 v = *reinterpret_cast<const uint4*>(&s_bits[buf][threadIdx.x][0]);
-                    *reinterpret_cast<uint4*>(desc + (size_t)(m0 + threadIdx.x) * desc_pitch + (n0 & ~127) / 8) = v;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int i = m0 + 32 * h + li, bb = r + 16 * lk;
+                    if (i < count) dbg_T[(size_t)i * nbits + n0 + 8 * (bb >> 3) + 7 - (bb & 7)] = acc[r];
                 }
-            } else if (lane < 32 && m0 + lane < count) {
-                *reinterpret_cast<unsigned*>(desc + (size_t)(m0 + lane) * desc_pitch + n0 / 8) = mine;
             }
+            const uint32_t other = (uint32_t)__shfl_xor((int)half, 32, 64);       // the keypoint's other 16 bits (lane ^ 32)
+            word[h] = half | (other << 16);                                         // valid in lanes 0 .. 31 (lk == 0)
         }
+        HSP_T(5);
+        if (wide) {
+            // the workgroup's four waves hold 128 adjacent bits of the same 64 rows: one 16-byte store per row
+            if (lane < 32) { s_bits[buf][lane][wid] = word[0]; s_bits[buf][32 + lane][wid] = word[1]; }
+            __syncthreads();
+            HSP_T(6);
+            if (threadIdx.x < 64 && m0 + (int)threadIdx.x < count) {
+                const uint4 v = *reinterpret_cast<const uint4*>(&s_bits[buf][threadIdx.x][0]);
+                *reinterpret_cast<uint4*>(desc + (size_t)(m0 + threadIdx.x) * desc_pitch + (n0 & ~127) / 8) = v;
+            }
+        } else {
+            if (desc != nullptr && lane < 32) {
+                if (m0 + lane < count) *reinterpret_cast<unsigned*>(desc + (size_t)(m0 + lane) * desc_pitch + n0 / 8) = word[0];
+                if (m0 + 32 + lane < count) *reinterpret_cast<unsigned*>(desc + (size_t)(m0 + 32 + lane) * desc_pitch + n0 / 8) = word[1];
+            }
+            __syncthreads();                        // the tile staged for the next trip is complete
+        }
+#ifdef HS_PROJ_TIMING
+        HSP_T(7);
+        if (blockIdx.x == 0 && threadIdx.x == 0 && hsp_iter++ < 3)
+            printf("proj wg0 ticks(10ns): prologue %llu | stage+fetch %llu | lds+mfma %llu | pack %llu | bits+barrier %llu | store %llu\n",
+                   hsp_t[1] - hsp_t[0], hsp_t[3] - hsp_t[2], hsp_t[4] - hsp_t[3], hsp_t[5] - hsp_t[4], hsp_t[6] - hsp_t[5], hsp_t[7] - hsp_t[6]);
+#endif
     }
 }
 
@@ -472,10 +553,10 @@ hipError_t efx_launch_hashsift(const DescribeLaunch& a, const HashSiftDev& h, hi
                            t[0], t[1], t[2], t[3], h.responses, h.dbg_responses, dbg);
     }
     if (a.desc || h.dbg_T) {
-        // persistent waves: 2 per SIMD (the weights occupy 108 VGPRs), each owning one 32-bit column tile
+        // persistent waves: HS_PROJ_WAVES per SIMD (the weights occupy 108 VGPRs), each owning one 32-bit column tile
         const int ntn = h.nbits / 32;
-        int nblk = 512 / ntn * ntn;                            // 2048 waves on 1024 SIMDs, a multiple of the column tiles
-        const int need = (((a.n + 31) / 32) * ntn + 3) / 4;     // never more waves than (row tile, column tile) pairs
+        int nblk = (256 * HS_PROJ_WAVES) / ntn * ntn;          // one workgroup (four waves) per CU and wave slot, a multiple of the column tiles
+        const int need = (((a.n + 63) / 64) * ntn + 3) / 4;     // never more waves than (row tile, column tile) pairs
         if (nblk > need) nblk = (need + ntn - 1) / ntn * ntn;
         hipLaunchKernelGGL(project_sign_kernel, dim3(nblk), dim3(256), 0, stream,
                            h.responses, h.Wb, a.d_count, a.n, h.nbits, a.desc, a.desc_pitch, h.dbg_T);
