@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256) void patch_sift_kernel(
 // alike, so whatever order the hardware contracts the 16 k of a step in, A and B elements meet at equal k.
 // Round 3 (C4, 40 000 keypoints x 512 bits, tools/microbench/hs_timing.sh): 26.8 -> 22.3 us.  What it was made of: a
 // one-accumulator MFMA chain (dependency-paced: 28 % of the matrix pipe), 32 ballots per tile funnelled through SGPRs, and --
-// once those were gone -- v_cmp + v_cndmask pairs the compiler made of the sign test (22 cycles each).  Per tile now: stage +
+// once those were gone -- v_cmp / s_nop / v_cndmask triples the compiler made of the sign test.  Per tile now: stage +
 // fetch 0.33 us, LDS reads + MFMAs 0.8 us (the pipe's own 54 x 32 cycles), pack 0.3 us, barrier + store 0.2 us; launch and
 // prologue (weights) 5.8 us.
 // ================================================================================================
@@ -463,8 +463,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HS_PROJ_WAV
             uint32_t half = 0u;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                // clamp((int)bits, 0, 1) as ONE v_med3_i32 (written by hand: the compiler turns it into v_cmp + v_cndmask,
-                // and a v_cndmask behind the compare that feeds it costs ~22 cycles here, profiles/valu_rate.txt)
+                // clamp((int)bits, 0, 1) as ONE v_med3_i32, written by hand: the compiler makes v_cmp + s_nop + v_cndmask + v_or3
+                // of it (a VALU write of VCC needs wait states before the select reads it): 0.62 -> 0.3 us per tile
                 int sgn;
                 asm("v_med3_i32 %0, %1, 0, 1" : "=v"(sgn) : "v"(__float_as_uint(acc[r])));
                 half |= (uint32_t)sgn << r;

@@ -40,6 +40,17 @@ KERNEL(k_lshl_or, "v_lshl_or_b32 %0, %1, 3, %0")
 KERNEL(k_sad, "v_sad_u8 %0, %1, %2, %0")
 KERNEL(k_dpp, "v_add_u32_dpp %0, %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf")
 KERNEL(k_cndmask, "v_cndmask_b32 %0, %1, %0, vcc")
+// round 3: what exactly is slow about a select -- the mask read, the encoding, or the compare that feeds it?
+KERNEL(k_cndmask_s, "v_cndmask_b32_e64 %0, %1, %0, s[20:21]")
+KERNEL(k_addc, "v_addc_co_u32 %0, vcc, %0, %1, vcc")
+KERNEL(k_addc_s, "v_addc_co_u32_e64 %0, s[22:23], %0, %1, s[20:21]")
+KERNEL(k_cmp_vcc, "v_cmp_lt_u32 vcc, %0, %1")
+KERNEL(k_cmp_s, "v_cmp_lt_u32_e64 s[20:21], %0, %1")
+KERNEL(k_cmp_cnd, "v_cmp_lt_u32 vcc, %0, %1\n v_cndmask_b32 %0, %1, %0, vcc")
+KERNEL(k_cmp_addc, "v_cmp_lt_u32 vcc, %0, %1\n v_addc_co_u32 %0, vcc, %0, %1, vcc")
+KERNEL(k_readlane, "v_readlane_b32 s24, %0, 3")
+KERNEL(k_writelane, "v_writelane_b32 %0, s24, 3")
+KERNEL(k_alignbit, "v_alignbit_b32 %0, %0, %1, 31")
 // packed fp32 needs register pairs
 __global__ __launch_bounds__(256) void k_pk_fma_f32(unsigned* out) {
     typedef float f2 __attribute__((ext_vector_type(2)));
@@ -71,6 +82,6 @@ int main() {
 #define R(k) run(#k, k, d, ghz)
     R(k_add); R(k_add3); R(k_mul24); R(k_mad24); R(k_mullo); R(k_perm); R(k_alignbyte); R(k_pk_add_u16); R(k_pk_sub_i16); R(k_pk_lshl);
     R(k_pk_mad_u16); R(k_dot2c); R(k_dot4c); R(k_min_sdwa); R(k_min); R(k_med3); R(k_fma); R(k_cvt_ub); R(k_cvt_pk_u8); R(k_bfe); R(k_lshl_or);
-    R(k_sad); R(k_dpp); R(k_cndmask); R(k_pk_fma_f32);
+    R(k_sad); R(k_dpp); R(k_cndmask); R(k_cndmask_s); R(k_addc); R(k_addc_s); R(k_cmp_vcc); R(k_cmp_s); R(k_cmp_cnd); R(k_cmp_addc); R(k_readlane); R(k_writelane); R(k_alignbit); R(k_pk_fma_f32);
     return 0;
 }
