@@ -269,8 +269,25 @@ def main():
         iso_chain = chain_ms_per_frame(ms2, lvl2)
         dom = max(iso, key=lambda k: iso[k]["avg_launch_ms"]) if iso else None
 
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r02_counters.json"))) if os.path.exists(os.path.join(ROOT, "profiles", "r02_counters.json")) else {}
-        roof = {"bound": "hbm", "kernel": dom, "achieved": iso[dom]["achieved"] if dom else None, "peak": HBM_PEAK_GBS,
+        # PMC-derived figures (traffic, VALU, LDS) are not measured in this run: they come from the newest committed
+        # profiles/rNN_counters.json -- and only when that file was collected from THIS tree's kernel sources (its
+        # source_sha256 stamp, tools/counters_json.py); otherwise they are null with the reason
+        import glob
+        from tools import counters_json as cj
+        cfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_counters.json")))
+        prof_all = json.load(open(cfiles[-1])) if cfiles else {}
+        stamp, here = prof_all.get("source_sha256"), cj.source_digests(ROOT)
+        counters_ok = bool(prof_all) and stamp == here
+        prof = prof_all if counters_ok else {}
+        counters_info = {"file": os.path.relpath(cfiles[-1], ROOT) if cfiles else None, "commit": prof_all.get("git_head"),
+                         "sources_match_this_tree": counters_ok}
+        if not counters_ok:
+            counters_info["why_null"] = ("no counters file" if not prof_all else "no source stamp in the counters file" if not stamp else
+                                         "kernel sources changed since the counters were collected: " +
+                                         ", ".join(k for k in here if (stamp or {}).get(k) != here[k]))
+        roof = {"bound": "hbm", "bound_that_binds": "valu (instruction issue; see roofline.valu -- every kernel of the path issues "
+                                                    "more than ~5 lane-operations per byte, DESIGN.md section 9)",
+                "counters": counters_info, "kernel": dom, "achieved": iso[dom]["achieved"] if dom else None, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": iso[dom]["frac"] if dom else None,
                 "traffic": (prof.get("traffic_bytes_per_launch", {}) or {}).get(dom),
                 "algorithmic_bytes_per_launch": iso[dom]["algorithmic_bytes"] if dom else None,
@@ -340,9 +357,12 @@ def main():
                           "frames_each_once": sorted(sum(all_frames, [])) == list(range(F * world)), "streams_per_gpu": NS,
                           "keypoints_per_frame": round(nkp / F, 1), "parallelism": f"frames sharded over {world} GPU(s)"},
                "roofline": roof}
-        roof["profiles"] = {"frac / kernels_isolated (one stream)": "profiles/r02_kernel_stats.csv",
-                            "live (the default command, three frames in flight)": "profiles/r02_kernel_stats_3streams.csv",
-                            "traffic, valu, lds": "profiles/r02_counters.json <- profiles/r02_pmc_sq.txt, r02_pmc_lds.txt, r02_traffic.json, valu_rate.txt"}
+        tag = os.path.basename(cfiles[-1])[:3] if cfiles else "rNN"
+        roof["profiles"] = {"frac / kernels_isolated (one stream)": "profiles/%s_kernel_stats.csv" % tag,
+                            "live (the default command, three frames in flight)": "profiles/%s_kernel_stats_3streams.csv" % tag,
+                            "traffic, valu, lds": "profiles/%s_counters.json <- profiles/%s_pmc_sq.txt, %s_pmc_lds.txt, %s_traffic.json, valu_rate.txt" % (tag, tag, tag, tag)}
+        if not counters_ok:
+            roof["valu"] = None; roof["lds"] = None
 
         # The reference's own protocol (samples/sample_benchmark.cpp:39-52: 1 warm-up, then N x {detectAndComputeAsync;
         # stream.waitForCompletion()}): one frame at a time on one stream, host wait included.  This is the figure that

@@ -4,7 +4,9 @@
 # one stream and the default three), SQ / LDS counters and HBM traffic (separate --pmc passes), the issue-rate and
 # workgroup-rate micro-benchmarks, <tag>_counters.json (what bench.py's roofline.valu / lds / traffic read), the bench.py
 # line, the BASELINE.json configurations, HashSIFT / matcher kernel stats.  Copy the files into profiles/ afterwards.
+# usage: tools/collect_round.sh <tag> [git commit of the tree]   (the box has no .git: pass `git rev-parse HEAD` from the build container)
 tag=${1:-rXX}
+export EFX_GIT_HEAD=${2:-${EFX_GIT_HEAD:-unknown}}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out
 rocprofv3 --kernel-trace --stats -d $O/prof_$tag -o bench -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --streams 1 > $O/bench_$tag.log 2>&1

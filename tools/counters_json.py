@@ -7,10 +7,24 @@ usage: tools/counters_json.py <pmc_sq.txt> <pmc_lds.txt> <traffic.json> <valu_ra
   traffic.json               tools/traffic_json.py (FETCH_SIZE / WRITE_SIZE passes)
   valu_rate.txt              stdout of tools/microbench/valu_rate (cycles per wave-instruction per SIMD)
 Per-launch figures are totals / dispatches; per-frame figures use fast_kernel's dispatch count (one per frame)."""
+import hashlib
 import json
+import os
 import re
 import statistics
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the sources of the kernels the counters describe: bench.py refuses the counters when these differ from the running tree
+HEADLINE_SOURCES = ["detect_kernels.hip", "bad_kernel.hip", "blur_window.h", "bad_affine.h", "efx_device.h"]
+
+
+def source_digests(root=ROOT):
+    d = {}
+    for f in HEADLINE_SOURCES:
+        path = os.path.join(root, "cuda-efficient-features_amd", "csrc", f)
+        d[f] = hashlib.sha256(open(path, "rb").read()).hexdigest() if os.path.exists(path) else None
+    return d
 
 
 def parse_pmc(path):
@@ -49,8 +63,10 @@ def main(sq_path, lds_path, traffic_path, valu_path, out_path):
     clock = float(re.search(r"clock ([\d.]+) GHz", txt).group(1))
     cyc = {m.group(1): float(m.group(2)) for m in re.finditer(r"^(k_\w+)\s+[\d.]+ us\s+->\s+([\d.]+) cycles", txt, re.M)}
     # the single-rate 32-bit / packed-16 integer instructions the detector kernels are made of (not v_pk_fma_f32, not v_mul_lo)
-    ref = statistics.median(v for k, v in cyc.items() if k not in ("k_pk_fma_f32", "k_mullo"))
-    res = {"note": __doc__.split("\n")[0], "frames_profiled": frames, "clock_ghz": clock,
+    # (nor the round-3 probes: k_cndmask reads a never-written VCC, the k_cmp_* pairs are two instructions per slot)
+    ref = statistics.median(v for k, v in cyc.items() if k not in ("k_pk_fma_f32", "k_mullo", "k_cndmask", "k_cmp_cnd", "k_cmp_addc"))
+    res = {"note": __doc__.split("\n")[0], "git_head": os.environ.get("EFX_GIT_HEAD", "unknown (set EFX_GIT_HEAD)"),
+           "source_sha256": source_digests(), "frames_profiled": frames, "clock_ghz": clock,
            "cycles_per_wave_instr": round(ref, 3), "cycles_per_wave_instr_by_instruction": cyc,
            "issue_peak_wave_instr_per_s": 1024 * clock * 1e9 / ref,
            "valu_wave_instr_per_launch": valu_launch, "valu_wave_instr_per_frame": round(valu_frame),
