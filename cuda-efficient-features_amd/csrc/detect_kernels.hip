@@ -905,10 +905,12 @@ __global__ __launch_bounds__(64) void harris_kernel(
     const bool aligned = l == 0 ? aligned0 != 0 : true;
     const TileHdr& h = hdr_all[L.tile_base + tile];
     const int total = h.cell_off[EFX_CELLS_PER_TILE];
+#ifndef EFX_NO_RANGE_CHECKS
     if (total > EFX_TILE * EFX_TILE || (size_t)h.cand_start + (size_t)total > (size_t)L.cand_sub_cap) {      // header out of range: void frame
         if (lane == 0) efx_raise_overflow(T, cnt);
         return;
     }
+#endif
     const size_t first = L.cand_base + (size_t)(tile & (EFX_NSUB - 1)) * L.cand_sub_cap + h.cand_start;
     Corner* cand = cand_all + first;
     const uint32_t* cand_xy = cand_xy_all + first;
@@ -916,15 +918,21 @@ __global__ __launch_bounds__(64) void harris_kernel(
     __syncthreads();
     const uint32_t tile_xy = ((uint32_t)tx << 6) | ((uint32_t)ty << 22);      // what the tile bits of a coordinate word must be
     for (int k = lane; k < total; k += 64) {
-        const uint32_t xy = cand_xy[k];
-        const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
+        const uint32_t xy_in = cand_xy[k];
         // a coordinate that is not of this tile was never written by fast_kernel (stores of freshly
-        // mapped arenas lost under heavy oversubscription): the frame is void like an overflowed one -- the host reruns
-        // it -- instead of a memory fault here or in nms_kernel
-        if (((xy ^ tile_xy) & 0xffc0ffc0u) != 0u || y >= L.rows) { efx_raise_overflow(T, cnt); continue; }
+        // mapped arenas lost under heavy oversubscription).  Here it is only forced into the tile (a no-op for a valid one:
+        // three instructions; raising the void-frame flag here cost 5 us of the kernel's 57), so that nothing faults; the
+        // record keeps the word as it was read, and nms_kernel -- which checks every record it owns -- voids the frame.
+#ifdef EFX_NO_RANGE_CHECKS                                   // INVESTIGATION builds: what the checks cost
+        const uint32_t xy = xy_in;
+        const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
+#else
+        const uint32_t xy = (xy_in & 0x003f003fu) | tile_xy;
+        const int x = (int)(xy & 0xffffu), y = min((int)(xy >> 16), L.rows - 1);
+#endif
         const uint8_t* c = src + (size_t)y * spitch + x;
         const float resp = (dbg & 4) ? 1.f : (aligned ? harris_rows(c - 4 * spitch - 4, spitch) : harris_bytes(c, spitch));
-        Corner rec; rec.xy = xy; rec.resp = resp;
+        Corner rec; rec.xy = xy_in; rec.resp = resp;
         cand[k] = rec;                                      // whole records: full-line stores (fast_kernel's coordinate array likewise)
         // strongest corner of the 16x16 cell: 64-bit max of (response key, xy).  A corner that finds its own response
         // already there has an equal twin in the cell; if that response ends up being the cell's maximum, the NMS quick
