@@ -332,7 +332,12 @@ __global__ __launch_bounds__(256) void bad_det_kernel(
                 *reinterpret_cast<uint16_t*>(pix + r0 * S + c + i * S) = (uint16_t)pk;
             },
             [&]() {
-                if (!border) { t0 = bad_ubox_taps(A, q0, wbase); if (nbits > 256) t1 = bad_ubox_taps(A, q1, wbase); }
+                // pinned BEHIND the window loads: the taps are pure arithmetic and the same on every path of the loader, so
+                // the compiler hoists them above it -- where they wait for the table's loads before the window's loads have
+                // even been issued -- unless something they depend on is defined here
+                int wb = wbase;
+                asm volatile("" : "+s"(wb) : : "memory");
+                if (!border) { t0 = bad_ubox_taps(A, q0, wb); if (nbits > 256) t1 = bad_ubox_taps(A, q1, wb); }
             });
         __syncthreads();
         // row prefix from the u8 plane: P'[r][x] = sum of row r left of column x, x = 0 .. 49, as 25 packed pairs into plane

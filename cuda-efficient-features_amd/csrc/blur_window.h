@@ -80,12 +80,17 @@ __device__ __forceinline__ void efx_blur_window_lds(const uint8_t* __restrict__ 
         const uint8_t* base = img + (size_t)(wy0 - 3) * pitch + ((wx0 - 3) & ~3);
         if (sh == 4 && RP <= 4 * rstep) {
             // the common shape (S = 48: 54 rows of 15 dwords, 16 rows per step): all of a thread's loads are issued before
-            // the caller's overlap() work and before the first store
+            // the caller's overlap() work and before the first store.  Through a buffer resource: 32-bit offsets, no
+            // predicates (rows / dwords past the window are inside the image or range-checked to zero, and not stored), and
+            // -- unlike loads through the generic pointer -- counted in issue order, so that the overlap() work waits for
+            // ITS operands only, not for these loads
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(img), 0, rows * pitch, 0x00020000);
+            int goff = (wy0 - 3 + r0) * pitch + ((wx0 - 3) & ~3) + 4 * j;
             uint32_t v[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const int r = r0 + k * rstep;
-                v[k] = (j < ndw && r < RP) ? *reinterpret_cast<const uint32_t*>(base + (size_t)r * pitch + 4 * j) : 0u;
+                v[k] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, goff, 0, 0);
+                goff += rstep * pitch;
             }
             overlap();
 #pragma unroll
