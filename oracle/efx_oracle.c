@@ -287,8 +287,12 @@ static void hs_normalize_tree128(float* d)
     for (int i = 0; i < 128; i++) d[i] = d[i] * scale;
 }
 
+/* fixed_point: bit 0 = fixed-point histogram, bit 1 = tree-ordered norms (the device model is 3; 1 and 2 isolate the two
+ * differences from the reference arithmetic: efxo_hashsift_responses_model) */
 static void hs_patch_sift(const uint8_t* patch, float* desc /*128*/, float kp_scale, int fixed_point)
 {
+    const int tree_norm = (fixed_point >> 1) & 1;
+    fixed_point &= 1;
     const int h = 32, w = 32, dh = h - 2, dw = w - 2;
     const float kp_radius = kp_scale * (float)h * 0.5f;
     const float kernel_sigma = 0.5f * (float)HS_C_BINS * HS_SCL_FCTR * kp_radius;
@@ -368,9 +372,9 @@ static void hs_patch_sift(const uint8_t* patch, float* desc /*128*/, float kp_sc
             ph[1] += ph[HS_ORI_BINS + 1];
             for (int k = 0; k < HS_ORI_BINS; k++) desc[(r * HS_R_BINS + c) * HS_ORI_BINS + k] = ph[k];
         }
-    if (fixed_point) hs_normalize_tree128(desc); else hs_normalize(desc, 128);          /* step 7 */
+    if (tree_norm) hs_normalize_tree128(desc); else hs_normalize(desc, 128);          /* step 7 */
     for (int i = 0; i < 128; i++) desc[i] = desc[i] < HS_MAG_TH ? desc[i] : HS_MAG_TH;   /* step 8 */
-    if (fixed_point) hs_normalize_tree128(desc); else hs_normalize(desc, 128);
+    if (tree_norm) hs_normalize_tree128(desc); else hs_normalize(desc, 128);
     for (int k = 0; k < 128; k++) desc[k] = (float)sat_u8_f(HS_INT_FACTOR * desc[k]);   /* step 9 */
 }
 
@@ -400,7 +404,22 @@ void efxo_hashsift_responses_fixedpoint(const uint8_t* img, int rows, int cols, 
         float* r = responses + (size_t)i * 129;
         r[0] = 1;
         efxo_hashsift_patch(img, rows, cols, stride, kps + 4 * i, crop_scale, patch);
-        hs_patch_sift(patch, r + 1, kp_scale, 1);
+        hs_patch_sift(patch, r + 1, kp_scale, 3);
+    }
+}
+
+/* mode: bit 0 = fixed-point histogram, bit 1 = tree-ordered norms (0 = the reference arithmetic, 3 = the device model) */
+void efxo_hashsift_responses_model(const uint8_t* img, int rows, int cols, int stride,
+                                   const float* kps, int n, float crop_scale, int mode, float* responses)
+{
+    const float kp_scale = 1.f / 6;
+    EFXO_PAR
+    for (int i = 0; i < n; i++) {
+        uint8_t patch[32 * 32];
+        float* r = responses + (size_t)i * 129;
+        r[0] = 1;
+        efxo_hashsift_patch(img, rows, cols, stride, kps + 4 * i, crop_scale, patch);
+        hs_patch_sift(patch, r + 1, kp_scale, mode & 3);
     }
 }
 

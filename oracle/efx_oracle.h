@@ -151,6 +151,9 @@ void efxo_set_threads(int n);
 int efxo_get_threads(void);
 
 /* CPU model of the HIP kernel's fixed-point histogram sums (test infrastructure for the HashSIFT tolerance) */
+/* mode: bit 0 = fixed-point histogram, bit 1 = tree-ordered norms: isolates the two differences of the device arithmetic */
+void efxo_hashsift_responses_model(const uint8_t* img, int rows, int cols, int stride,
+                                   const float* kps, int n, float crop_scale, int mode, float* responses);
 void efxo_hashsift_responses_fixedpoint(const uint8_t* img, int rows, int cols, int stride,
                                         const float* kps, int n, float crop_scale, float* responses);
 

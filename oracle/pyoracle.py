@@ -119,6 +119,16 @@ def hashsift_responses_fixedpoint(img, kps, crop_scale=1.0):
     return resp
 
 
+def hashsift_responses_model(img, kps, mode, crop_scale=1.0):
+    """mode: bit 0 = fixed-point histogram, bit 1 = tree-ordered norms (0 = reference arithmetic, 3 = device model)."""
+    img = _u8(img)
+    kps = np.ascontiguousarray(kps, dtype=np.float32).reshape(-1, 4)
+    resp = np.zeros((kps.shape[0], 129), dtype=np.float32)
+    lib().efxo_hashsift_responses_model(_p(img), img.shape[0], img.shape[1], img.strides[0], _p(kps), kps.shape[0],
+                                        C.c_float(crop_scale), int(mode), _p(resp))
+    return resp
+
+
 def hashsift_project(resp, nbits):
     resp = np.ascontiguousarray(resp, dtype=np.float32).reshape(-1, 129)
     W = load_hashsift_weights(nbits)

@@ -66,12 +66,21 @@ def _case(seed):
     return img, mask, desc_type, kw
 
 
-def _hashsift_tol(nbits, n):
-    # the stated bound (the reference's own GPU-vs-CPU tolerance, tests/descriptor_test.cpp:72): 1e-4
-    # of the descriptor BYTES.  The floor of 4 bytes is one event: a 129-vector element that differs from the CPU float
-    # sums by one unit (2e-5 of the elements, section 3) flips the bits whose projection lies within one weight of zero
-    # -- usually none, now and then three or four bytes of ONE descriptor -- and a small case has fewer than 10 000 bytes
-    return max(4, int(1e-4 * n * (nbits // 8)))
+# HashSIFT tolerance.  The stated bound (the reference's own GPU-vs-CPU tolerance,
+# tests/descriptor_test.cpp:72) is a FRACTION of the descriptor bytes of a whole data set: 1e-4.  It is asserted as such over
+# everything this module compares (test_zz_hashsift_bytes_over_the_sweep).  A single case is small and its mismatches come in
+# events -- a 129-vector element that differs from the CPU float sums by one unit (the device adds the norm's 128 squares in
+# a tree, the CPU serially: section 3) flips the bits whose projection lies within one weight of zero, usually none, now and
+# then three or four bytes of ONE descriptor -- so the per-case bound is the stated fraction plus ONE such event.  (Found by
+# the round-3 sweep: seed 103188, 1935 keypoints x 64 bytes, 13 differing bytes against int(1e-4 x bytes) = 12.)
+_HS_TOTAL = {"bytes": 0, "bad": 0}
+
+
+def _hashsift_check(nbad, nbits, n, info):
+    nbytes = max(n, 0) * (nbits // 8)
+    _HS_TOTAL["bytes"] += nbytes
+    _HS_TOTAL["bad"] += nbad
+    assert nbad <= int(1e-4 * nbytes) + 4, f"{info}: {nbad} of {nbytes} HashSIFT descriptor bytes differ"
 
 
 # EFX_FUZZ_CASES / EFX_FUZZ_FIRST widen the sweep from the command line (the committed default keeps the suite fast)
@@ -114,7 +123,7 @@ def test_fuzz_detect_and_compute(cef, torch_mod, oracle, seed):
         d = desc[:n].cpu().numpy()
         assert d.shape == ref["desc"].shape, info
         nbad = int(np.count_nonzero(d != ref["desc"]))
-        assert nbad <= _hashsift_tol(256 if desc_type == 2 else 512, max(n, 1)), f"{info}: {nbad} descriptor bytes differ"
+        _hashsift_check(nbad, 256 if desc_type == 2 else 512, n, info)
 
 
 @pytest.mark.parametrize("seed", range(_FIRST, _FIRST + max(_N // 2, 1)))
@@ -150,7 +159,7 @@ def test_fuzz_compute(cef, oracle, seed):
         got = cef.HashSIFT.create(scale, enum).compute(img, kps)
         want = oracle.hashsift_compute(img, kps, nbits, crop_scale=scale)
         nbad = int(np.count_nonzero(got != want))
-        assert nbad <= _hashsift_tol(nbits, n), f"{info} HashSIFT{nbits}: {nbad} bytes differ"
+        _hashsift_check(nbad, nbits, n, info)
 
 
 @pytest.mark.parametrize("seed", range(_FIRST, _FIRST + max(_N // 3, 1)))
@@ -186,7 +195,7 @@ def test_fuzz_provided_keypoints(cef, torch_mod, oracle, seed):
         assert np.array_equal(got, want), f"{info}: rows {np.nonzero((got != want).any(axis=1))[0][:6].tolist()} differ"
     else:
         nbad = int(np.count_nonzero(got != want))
-        assert nbad <= _hashsift_tol(0, n), f"{info}: {nbad} bytes differ"
+        _hashsift_check(nbad, 256 if dt == 2 else 512, n, info)
 
 
 def test_every_small_frame_size(cef, torch_mod, oracle):
@@ -206,3 +215,13 @@ def test_every_small_frame_size(cef, torch_mod, oracle):
         assert n == ref["n"], (rows, cols)
         assert np.array_equal(kps[:, :n].cpu().numpy().view(np.uint32), ref["kps"].view(np.uint32)), (rows, cols)
         assert np.array_equal(desc[:n].cpu().numpy(), ref["desc"]), (rows, cols)
+
+
+def test_zz_hashsift_bytes_over_the_sweep():
+    """The stated HashSIFT tolerance over everything the fuzz tests of this process compared: at most 1e-4 of the
+    descriptor bytes differ from the CPU reference arithmetic (descriptor_test.cpp:72); measured 2e-5."""
+    if _HS_TOTAL["bytes"] == 0:
+        pytest.skip("no HashSIFT case ran in this process")
+    rate = _HS_TOTAL["bad"] / _HS_TOTAL["bytes"]
+    print(f"\nHashSIFT over the sweep: {_HS_TOTAL['bad']} of {_HS_TOTAL['bytes']} bytes differ ({rate:.2e})")
+    assert _HS_TOTAL["bad"] <= max(4, int(1e-4 * _HS_TOTAL["bytes"]))
