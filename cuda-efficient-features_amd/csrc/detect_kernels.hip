@@ -1072,6 +1072,16 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
     // dependent trips to L2 otherwise: dense frames).  Entries past the end are clamped onto the last one (harmless repeats).
     auto walk_list = [&](unsigned nbase, int nb, int ne, const Corner& m, int mx, int my, bool& kill) {
         const Corner* lst = cand + (size_t)nbase;
+        if (__ballot(ne - nb > 8) == 0ull) {
+            // every list of this step fits one entry per lane (sparse frames: nearly always): one load, no clamping
+            const int j = nb + sub;
+            if (j < ne) {
+                const Corner o = lst[j];
+                const int dx = mx - (int)(o.xy & 0xffff), dy = my - (int)(o.xy >> 16);
+                kill |= (o.xy != m.xy && m.resp <= o.resp && dx * dx + dy * dy < image_radius);
+            }
+            return;
+        }
         for (int j = nb + sub; j < ne; j += 32) {
             Corner o[4];
 #pragma unroll
@@ -1695,20 +1705,23 @@ __global__ __launch_bounds__(64) void emit_kernel(const LevelTable* __restrict__
 // radius-15 disc (31 columns), loop over the 31 rows: every row is one coalesced 31-byte read.  The integer
 // moments are order-independent, the wave reduction gives exactly the reference's m_01 / m_10.
 // ================================================================================================
-__global__ __launch_bounds__(256) void angle_kernel(const LevelTable* __restrict__ T, const int* __restrict__ d_count, int capacity,
+#define ANGLE_KP 8              // keypoints per workgroup (two per wave): the double-precision tail runs on ANGLE_KP lanes of ONE wave
+__global__ __launch_bounds__(ANGLE_KP * 32) void angle_kernel(const LevelTable* __restrict__ T, const int* __restrict__ d_count, int capacity,
                                                     const uint8_t* __restrict__ img0, int pitch0, const uint8_t* __restrict__ pyramid,
                                                     float4* __restrict__ kp4, const int* __restrict__ kp_level,
                                                     uint8_t* __restrict__ kps, size_t kps_pitch,
                                                     Affine* __restrict__ aff, float bad_scale, float bad_reach, int bad_smax, int bad_sfixed)
 {
-    // two keypoints per wave (31 of each 32 lanes hold one patch column), 8 per workgroup; neighbouring keypoints
-    // (canonical order) stay on the same XCD: their patches share L2 lines
+    // two keypoints per wave (31 of each 32 lanes hold one patch column), ANGLE_KP per workgroup.  (Round 3 measured 32 per
+    // workgroup -- the double-precision tail below, ~700 instructions, is issued once per workgroup whatever the number of
+    // its lanes at work, 3.5 M of the kernel's 6 M wave-instructions: 19.1 -> 20.8 us isolated, frame rate unchanged; kept
+    // at 8.)  Neighbouring keypoints (canonical order) stay on the same XCD: their patches share L2 lines
     const int lane = threadIdx.x & 31;
     const int count = min(*d_count, capacity);
-    const int ngroups = (count + 7) >> 3;                 // the grid is sized for the capacity
+    const int ngroups = (count + ANGLE_KP - 1) / ANGLE_KP;   // the grid is sized for the capacity
     if ((int)blockIdx.x >= ngroups) return;
     const int group = xcd_chunked(blockIdx.x, ngroups);  // chunked over the groups that exist: all XCDs busy at any count
-    const int kid = group * 8 + (threadIdx.x >> 5);
+    const int kid = group * ANGLE_KP + (threadIdx.x >> 5);
     const bool act = kid < count;
     const float4 kp = act ? kp4[kid] : make_float4(0.f, 0.f, 0.f, 0.f);
     const int l = act ? kp_level[kid] : 0;
@@ -1738,11 +1751,11 @@ __global__ __launch_bounds__(256) void angle_kernel(const LevelTable* __restrict
 #pragma unroll
     for (int d = 16; d >= 1; d >>= 1) { m10 += __shfl_xor(m10, d, 64); m01 += __shfl_xor(m01, d, 64); }
     // the double-precision atan2 (spec S7) is ~100 instructions: the 8 keypoints of the workgroup share one pass of it
-    __shared__ int s_m[8][2];
+    __shared__ int s_m[ANGLE_KP][2];
     if (lane == 0) { s_m[threadIdx.x >> 5][0] = m01; s_m[threadIdx.x >> 5][1] = m10; }
     __syncthreads();
-    const int k8 = group * 8 + threadIdx.x;
-    if (threadIdx.x < 8 && k8 < count) {
+    const int k8 = group * ANGLE_KP + threadIdx.x;
+    if (threadIdx.x < ANGLE_KP && k8 < count) {
         const float angle = atan2_deg(s_m[threadIdx.x][0], s_m[threadIdx.x][1]);
         kp4[k8].w = angle;
         if (kps) *reinterpret_cast<float*>(kps + 2 * kps_pitch + 4 * (size_t)k8) = angle;
@@ -1983,7 +1996,7 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
         for (int s = 0; s < H.nlevels; s++) if (H.lv[s].active) nmax += H.lv[s].quota;
         if (nmax > a.capacity) nmax = a.capacity;
         if (nmax > 0)
-            hipLaunchKernelGGL(angle_kernel, dim3((nmax + 7) / 8), dim3(256), 0, stream, a.d_table, a.d_count, a.capacity,
+            hipLaunchKernelGGL(angle_kernel, dim3((nmax + ANGLE_KP - 1) / ANGLE_KP), dim3(ANGLE_KP * 32), 0, stream, a.d_table, a.d_count, a.capacity,
                                a.img0, a.pitch0, a.pyramid, a.kp4, a.kp_level, (uint8_t*)a.d_keypoints, a.kps_pitch,
                                static_cast<Affine*>(a.bad_affine), a.bad_scale, a.bad_reach, a.bad_smax, a.bad_sfixed);
     }
