@@ -159,6 +159,11 @@ public:
                                 static_cast<uint8_t*>(descriptors.data()), descriptors.step, stream));
     }
     int lastCount() const { int n = 0; check(efx_last_count(ctx_, &n)); return n; }
+    // frames of this object that were void because they overflowed the density-sized scratch arenas (include/efx.h, "arena
+    // overflow contract": the next call enlarges the arenas by itself; lastCount() throws EFX_ERR_OVERFLOW for such a frame)
+    int overflowEvents() const { return efx_overflow_events(ctx_); }
+    // device blocks of destroyed objects are cached process-wide (at most EFX_BLOCK_CACHE_MB, default 1 GB): give them back
+    static size_t trimMemory() { return efx_trim_memory(); }
 
     // convert (cuda_efficient_features.cpp:323-349): downloads the 5 x n matrix and fills KeyPoints
     void convert(const DeviceMatrix& gpu_keypoints, int n, std::vector<KeyPoint>& keypoints) const

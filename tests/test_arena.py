@@ -103,3 +103,23 @@ def test_async_only_caller_recovers_without_polling(cef, oracle):
     assert np.array_equal(kps[:, :n].cpu().numpy().view(np.uint32), ref["kps"].view(np.uint32))
     assert np.array_equal(desc[:n].cpu().numpy(), ref["desc"])
     assert det.lastCount() == n                                     # no stale EFX_ERR_OVERFLOW
+
+
+def test_batch_reports_void_frames(cef):
+    """The batched entry point with callers that only read the count tensors: Batch.overflowEvents() tells them that
+    frames came back void (N = 0) and must be run again; the second run is complete."""
+    import torch
+    img = torch.from_numpy(synth.noise_frame(1300, 1900, seed=14)).cuda()
+    n = 2
+    dets = [cef.EfficientFeatures.create(2000, dtype=cef.EfficientFeatures.BAD_256) for _ in range(n)]
+    streams = [torch.cuda.Stream() for _ in range(n)]
+    kps = [torch.zeros((5, 2000), dtype=torch.float32, device="cuda") for _ in range(n)]
+    desc = [torch.zeros((2000, 32), dtype=torch.uint8, device="cuda") for _ in range(n)]
+    cnt = [torch.zeros(1, dtype=torch.int32, device="cuda") for _ in range(n)]
+    b = cef.Batch(dets, streams, [img] * n, kps, desc, cnt, 2000)
+    b.run(); torch.cuda.synchronize()
+    assert [int(c.item()) for c in cnt] == [0, 0] and b.overflowEvents() == 0        # void, nobody has looked yet
+    b.run(); torch.cuda.synchronize()                                                # every context consumes its flag first
+    assert b.overflowEvents() == n
+    assert all(int(c.item()) > 0 for c in cnt) and int(cnt[0].item()) == int(cnt[1].item())
+    assert torch.equal(kps[0], kps[1]) and torch.equal(desc[0], desc[1])
