@@ -98,6 +98,13 @@ struct BlockCache {
 };
 static BlockCache& block_cache() { static BlockCache* c = new BlockCache; return *c; }      // never destroyed: contexts may outlive statics
 
+// Who waits before a block is handed back.  A context knows the streams it has launched on: while one of its calls (or its
+// destructor) is on the stack, a block it releases waits for THOSE streams only -- a regrow under the overflow path used to
+// stall every stream of the process (hipDeviceSynchronize in every release).  Owners that do not track streams (stand-alone
+// describers, the matcher, the uploader) keep the device-wide wait.
+struct Quiesce { void (*fn)(void*); void* arg; bool done; };
+thread_local Quiesce* tl_quiesce = nullptr;
+
 struct DevBuf {                     // grow-only device allocation
     void* p = nullptr;
     size_t bytes = 0;
@@ -131,7 +138,8 @@ struct DevBuf {                     // grow-only device allocation
         int cur = -1;
         (void)hipGetDevice(&cur);
         if (cur != dev) (void)hipSetDevice(dev);
-        (void)hipDeviceSynchronize();
+        if (tl_quiesce) { if (!tl_quiesce->done) { tl_quiesce->fn(tl_quiesce->arg); tl_quiesce->done = true; } }
+        else (void)hipDeviceSynchronize();
         static const bool no_cache = getenv("EFX_NO_BLOCK_CACHE") != nullptr;
         if (no_cache) (void)hipFree(p); else block_cache().give(p, bytes, dev);
         if (cur != dev && cur >= 0) (void)hipSetDevice(cur);
@@ -153,7 +161,8 @@ struct Describer {                  // cuda::BAD / cuda::HashSIFT state
     DevBuf kp4;                     // float4 keypoints for the stand-alone / compute paths
     DevBuf img, desc;               // staging for the host entry points
     std::string err;
-    ~Describer() { params.release(); responses.release(); kp4.release(); img.release(); desc.release(); }
+    void release_all() { params.release(); responses.release(); kp4.release(); img.release(); desc.release(); }
+    ~Describer() { release_all(); }
 };
 
 int set_err(std::string& dst, int code, const char* fmt, ...)
@@ -382,6 +391,7 @@ struct efx_context {
     int n_out_max = 0;              // sum of the active levels' quotas
     bool arena_full = false;        // corner / survivor arenas sized for the worst case (set after a frame overflowed them)
     bool g_arena_full = false;      // ... as the cached geometry was built
+    std::vector<hipStream_t> streams;   // streams this context has launched on since it last waited for them (ctx_quiesce)
     int* h_overflow = nullptr;      // sticky overflow word: pinned host memory the kernels store to (LevelTable::host_overflow)
     int* d_overflow = nullptr;      // ... its device address
     int overflow_events = 0;        // frames that were void because of it (efx_overflow_events)
@@ -395,16 +405,39 @@ struct efx_context {
     int prof_stride = 1, prof_calls = 0;   // record events on every prof_stride-th detect call only
     unsigned prof_skip = 0;                // launch groups that are not timed (efx_profile_set_groups)
 
+    static void quiesce_cb(void* p)
+    {
+        efx_context* c = static_cast<efx_context*>(p);
+        bool ok = true;
+        for (hipStream_t st : c->streams) ok = ok && hipStreamSynchronize(st) == hipSuccess;
+        if (!ok) { (void)hipGetLastError(); (void)hipDeviceSynchronize(); }      // e.g. a stream the caller has destroyed meanwhile
+        c->streams.clear();
+    }
+    void note_stream(hipStream_t st) { for (hipStream_t q : streams) if (q == st) return; streams.push_back(st); }
     ~efx_context()
     {
+        Quiesce q = { &efx_context::quiesce_cb, this, false };
+        Quiesce* prev = tl_quiesce;
+        tl_quiesce = &q;
+        desc.release_all();                                // the describer's blocks are this context's: same wait
         rplan.release(); d_table.release(); pyramid.release(); hdr.release(); cand.release(); cmax.release(); surv.release(); counters.release();
         kp4.release(); kp_level.release(); img.release(); kps.release(); descout.release(); count.release(); maskbuf.release();
         delete h_mirror;
         if (h_overflow) (void)hipHostFree(h_overflow);
         for (hipEvent_t e : prof_start) (void)hipEventDestroy(e);
         for (hipEvent_t e : prof_stop) (void)hipEventDestroy(e);
+        tl_quiesce = prev;
     }
 };
+
+namespace {
+// while one of these is alive on the calling thread, blocks released by `c` (regrow, describer rebuild) wait for c's streams
+struct QuiesceScope {
+    Quiesce q; Quiesce* prev;
+    explicit QuiesceScope(efx_context* c) : q{ &efx_context::quiesce_cb, c, false }, prev(tl_quiesce) { tl_quiesce = &q; }
+    ~QuiesceScope() { tl_quiesce = prev; }
+};
+}
 
 namespace {
 
@@ -627,6 +660,8 @@ int detect_common(efx_context* c, const uint8_t* d_image, int rows, int cols, si
     if (d_desc && desc_pitch < (size_t)efx_descriptor_size(c)) return set_err(c->err, EFX_ERR_BAD_ARG, "desc_pitch smaller than the descriptor");
     int rc = validate_params(c->p, c->err);
     if (rc) return rc;
+    QuiesceScope quiesce(c);
+    c->note_stream(stream);
     consume_sticky_overflow(c);
     rc = build_geometry(c, rows, cols);
     if (rc) return rc;
@@ -711,6 +746,8 @@ int compute_provided(efx_context* c, const uint8_t* d_image, int rows, int cols,
     if (!d_desc || desc_pitch < (size_t)efx_descriptor_size(c)) return set_err(c->err, EFX_ERR_BAD_ARG, "bad descriptor buffer");
     int rc = validate_params(c->p, c->err);
     if (rc) return rc;
+    QuiesceScope quiesce(c);
+    c->note_stream(stream);
     rc = build_geometry(c, rows, cols);
     if (rc) return rc;
     HIP_TRY(c->err, c->kp4.reserve((size_t)n * sizeof(float4)));
@@ -944,6 +981,8 @@ int efx_compute_async(efx_context* ctx, const uint8_t* d_image, int rows, int co
                       const void* d_keypoints, size_t kps_pitch, int n, uint8_t* d_descriptors, size_t desc_pitch, void* stream)
 {
     if (!ctx) return EFX_ERR_BAD_ARG;
+    QuiesceScope quiesce(ctx);
+    ctx->note_stream((hipStream_t)stream);
     return describe_5xn(ctx->desc, ctx->err, d_image, rows, cols, pitch, d_keypoints, kps_pitch, n, d_descriptors, desc_pitch, (hipStream_t)stream);
 }
 
@@ -951,6 +990,8 @@ int efx_compute_kp4_async(efx_context* ctx, const uint8_t* d_image, int rows, in
                           const float* d_kp4, int n, float max_size, uint8_t* d_descriptors, size_t desc_pitch, void* stream)
 {
     if (!ctx) return EFX_ERR_BAD_ARG;
+    QuiesceScope quiesce(ctx);
+    ctx->note_stream((hipStream_t)stream);
     return describe_single(ctx->desc, ctx->err, d_image, rows, cols, pitch, reinterpret_cast<const float4*>(d_kp4), n, max_size,
                            d_descriptors, desc_pitch, nullptr, nullptr, (hipStream_t)stream);
 }
