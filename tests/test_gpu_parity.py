@@ -245,6 +245,19 @@ def test_compute_async_wave_per_keypoint_kernel(cef, torch_mod, oracle, monkeypa
     assert np.array_equal(out.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 67])
+def test_compute_async_few_keypoints(cef, torch_mod, oracle, n):
+    """The wave-per-keypoint kernel runs four keypoints per workgroup: counts that do not fill the last workgroup, and the
+    device count (N) smaller than the matrix."""
+    img = synth.synth_frame(300, 400, seed=8)
+    d_img = _dev(torch_mod, img)
+    d_kps, kp4 = _matrix_5xn(torch_mod, 300, 400, 80, seed=n)
+    det = cef.EfficientFeatures.create(80, dtype=cef.EfficientFeatures.BAD_512)
+    desc = det.computeAsync(d_img, d_kps, n=n)
+    torch_mod.cuda.synchronize()
+    assert np.array_equal(desc.cpu().numpy(), oracle.bad_compute(img, kp4[:n], 512))
+
+
 # ---- HashSIFT: float tolerance before thresholding ----
 HS_T_ABS_TOL = 2e-3      # |T_hip - T_oracle| for identical 129-vectors: fp32 FMA chain (MFMA) vs double accumulation
                          # of 129 products; |T| is typically ~15, at most ~400; measured max 2.2e-4
