@@ -858,7 +858,10 @@ __global__ __launch_bounds__(256) void fast_kernel(
 // row -- measured faster than staging the tile in LDS again (117 vs 130 us per 8K frame).
 // Also leaves the strongest corner of every 16x16 cell (the quick test of the NMS kernel).
 // ================================================================================================
-__global__ __launch_bounds__(64) void harris_kernel(
+// NW waves per tile (round 3, as nms_kernel): frames whose tiles do not fill the chip by themselves spread a tile's corners
+// over several waves (the corners are independent; the per-cell maxima meet in LDS atomics).
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void harris_kernel(
     const LevelTable* __restrict__ T, const uint8_t* __restrict__ img0, int pitch0, int aligned0,
     const uint8_t* __restrict__ pyramid, const uint32_t* __restrict__ cand_xy_all, Corner* __restrict__ cand_all, Corner* __restrict__ cmax_all,
     TileHdr* __restrict__ hdr_all, Counters* __restrict__ cnt, int dbg_arg)
@@ -866,9 +869,10 @@ __global__ __launch_bounds__(64) void harris_kernel(
     const int dbg = EFX_DBG(dbg_arg);
     __shared__ unsigned long long s_cellmax[EFX_CELLS_PER_TILE];
     __shared__ unsigned s_celltie[EFX_CELLS_PER_TILE];     // largest response key that two corners of the cell share
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x;                           // 0 .. 64 NW - 1: a corner slot of the round, not the hardware lane
     if (cnt->sum.overflow) return;                          // void frame (arena overflow in fast_kernel)
     if ((int)blockIdx.x >= T->total_tiles) {
+        if (lane >= 64) return;                             // the tile-rank scan below is one wave's work
         // One extra workgroup per level: canonical rank of every tile's first corner = exclusive scan of the tile counts
         // in tile order, needed to apply the 10 % cap deterministically (spec S2).  Only consulted (and only computed)
         // when the level has more corners than its cap, i.e. on pathological frames; it rides in this launch because a
@@ -917,7 +921,7 @@ __global__ __launch_bounds__(64) void harris_kernel(
     if (lane < EFX_CELLS_PER_TILE) { s_cellmax[lane] = 0ull; s_celltie[lane] = 0u; }
     __syncthreads();
     const uint32_t tile_xy = ((uint32_t)tx << 6) | ((uint32_t)ty << 22);      // what the tile bits of a coordinate word must be
-    for (int k = lane; k < total; k += 64) {
+    for (int k = lane; k < total; k += 64 * NW) {
         const uint32_t xy_in = cand_xy[k];
         // a coordinate that is not of this tile was never written by fast_kernel (stores of freshly
         // mapped arenas lost under heavy oversubscription).  Here it is only forced into the tile (a no-op for a valid one:
@@ -969,16 +973,31 @@ __global__ __launch_bounds__(64) void harris_kernel(
 //   survivors are compacted by ballot in canonical order and appended to the level's survivor array.
 // ================================================================================================
 #define NMS_HCAP 256
+#ifndef EFX_NMS_WIDE_TILES
+#define EFX_NMS_WIDE_TILES 2048      // frames with at most this many tiles (FHD and below) run four waves per tile
+#endif
+#ifndef EFX_NMS_MID_TILES
+#define EFX_NMS_MID_TILES 8192       // ... up to this many (4K): EFX_NMS_MID_NW waves per tile
+#endif
+#ifndef EFX_NMS_MID_NW
+#define EFX_NMS_MID_NW 2
+#endif
 
-__global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ T, TileHdr* __restrict__ hdr,
+// NW waves per tile (round 3).  One wave per tile fills the chip when a frame has tens of thousands of tiles (8K: 25 500);
+// a 4K frame has 6 400 and an FHD frame 1 650, and then the kernel takes as long as its densest tile's ONE wave needs for
+// all of that tile's rounds.  With NW = 4 the rounds of 64 corners go round-robin over four waves, each with its own list
+// of hard corners (the exact scans are wave-local as before); the survivor bits meet in s_keep, wave 0 compacts.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void nms_kernel(const LevelTable* __restrict__ T, TileHdr* __restrict__ hdr,
                                                  const Corner* __restrict__ cand_all, const Corner* __restrict__ cmax_all,
                                                  Corner* __restrict__ surv_all, Counters* __restrict__ cnt, int radius, int dbg_arg)
 {
     const int dbg = EFX_DBG(dbg_arg);
-    __shared__ Corner s_hme[NMS_HCAP];
-    __shared__ uint16_t s_hidx[NMS_HCAP];
-    __shared__ uint16_t s_hneed[NMS_HCAP];                 // block_radius 1: the cells (bit q = cell q of the 3x3) that hold a rival
+    __shared__ Corner s_hme_all[NW][NMS_HCAP];
+    __shared__ uint16_t s_hidx_all[NW][NMS_HCAP];
+    __shared__ uint16_t s_hneed_all[NW][NMS_HCAP];         // block_radius 1: the cells (bit q = cell q of the 3x3) that hold a rival
     __shared__ unsigned long long s_keep[64];            // survivor bits of round r (64 rounds = 4096 corners = a full tile)
+    __shared__ int s_void;                               // a wave found a record that is not of this tile: nothing is written
     __shared__ __attribute__((aligned(64))) uint32_t s_nb[9][16];   // TileHdr of the 3x3 neighbouring tiles
     __shared__ Corner s_cm[6][6];                        // cell maxima of the tile's 4x4 cells + one ring (block_radius 1)
 
@@ -990,11 +1009,17 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
     const int tile = gt - L.tile_base;
     TileHdr* hl = hdr + L.tile_base;
     const Corner* cand = cand_all + L.cand_base;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    Corner* s_hme = s_hme_all[wv]; uint16_t* s_hidx = s_hidx_all[wv]; uint16_t* s_hneed = s_hneed_all[wv];
     if (cnt->sum.overflow) return;                          // void frame (arena overflow in fast_kernel)
 
-    s_keep[lane] = 0ull;
-    for (int i = lane; i < 9 * 16; i += 64) {
+    // A wave beyond the tile's corners (most tiles of a sparse frame have fewer than 64 * NW) leaves at once: its slot is
+    // free after one load instead of after the tile.  (s_barrier waits for the waves of the workgroup that have not
+    // terminated; the prologue below is wave 0's.)
+    if (NW > 1 && wv > 0 && 64 * wv >= (int)hl[tile].cell_off[EFX_CELLS_PER_TILE]) return;
+    if (tid < 64) s_keep[tid] = 0ull;
+    if (tid == 0) s_void = 0;
+    for (int i = tid; i < 9 * 16 && tid < 64; i += 64) {
         const int t = i >> 4, w = i & 15;
         const int ntx = tx - 1 + (t % 3), nty = ty - 1 + (t / 3);
         uint32_t v = 0u;
@@ -1010,12 +1035,13 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
     // the cell maxima are fetched in the same memory round trip as the headers (both only need the tile's coordinates)
     // clamped exactly as the quick test clamps its cell coordinates
     const int gw_ = (L.cols + EFX_CELL - 1) / EFX_CELL, gh_ = (L.rows + EFX_CELL - 1) / EFX_CELL;
-    const int cy = min(max(ty * 4 - 1 + lane / 6, 0), gh_ - 1), cx = min(max(tx * 4 - 1 + lane % 6, 0), gw_ - 1);
+    const int cy = min(max(ty * 4 - 1 + tid / 6, 0), gh_ - 1), cx = min(max(tx * 4 - 1 + tid % 6, 0), gw_ - 1);
     Corner cm; cm.xy = 0u; cm.resp = 0.f;
-    if (lane < 36) cm = cmax_all[L.cmax_base + (size_t)cy * (L.tiles_x * 4) + cx];
+    if (tid < 36) cm = cmax_all[L.cmax_base + (size_t)cy * (L.tiles_x * 4) + cx];
     __syncthreads();                                     // s_nb is read below
     {
         // the nine headers address the corner arena: ranges that do not fit it void the frame (see harris_kernel)
+        // (every wave evaluates the same nine headers: the exit is workgroup-uniform)
         bool bad = false;
         if (lane < 9) {
             const TileHdr* nh = reinterpret_cast<const TileHdr*>(&s_nb[lane][0]);
@@ -1023,11 +1049,11 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
             bad = tot > (unsigned)(EFX_TILE * EFX_TILE) || (size_t)nh->cand_start + tot > (size_t)L.cand_sub_cap;
         }
         if (__ballot(bad) != 0ull) {
-            if (lane == 0) efx_raise_overflow(T, cnt);
+            if (tid == 0) efx_raise_overflow(T, cnt);
             return;
         }
     }
-    if (lane < 36) {
+    if (tid < 36) {
         if (capped) {
             // a cell of a tile that is cut by the cap may hold invalid corners: its maximum must not suppress anything,
             // but the cell may still hold a valid rival -> "infinitely strong, infinitely far": never kills, always
@@ -1035,7 +1061,7 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
             const TileHdr* nh = reinterpret_cast<const TileHdr*>(&s_nb[((cy >> 2) - ty + 1) * 3 + ((cx >> 2) - tx + 1)][0]);
             if ((int)nh->cand_rank + (int)nh->cell_off[EFX_CELLS_PER_TILE] > L.cap) { cm.xy = 0x7fff7fffu; cm.resp = __int_as_float(0x7f800000); }
         }
-        s_cm[lane / 6][lane % 6] = cm;
+        s_cm[tid / 6][tid % 6] = cm;
     }
     __syncthreads();
     // header of the tile that holds cell (bx, by): the LDS copy when it is a neighbour (always, up to radius 64)
@@ -1193,8 +1219,11 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
         }
     };
 
+    // LDS traffic of one wave is ordered; the hard-corner lists are wave-local: wave-level fences are all the loop needs
+    auto wave_sync = [&]() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
     int nh = 0;
-    for (int k0 = 0; k0 < n_valid; k0 += 64) {
+    bool foreign = false;
+    for (int k0 = 64 * wv; k0 < n_valid; k0 += 64 * NW) {
         const int k = k0 + lane;
         bool hard = false, sure = false;
         int need = 0x1ff;                                     // neighbour cells the exact scan has to walk (all, unless phase A knows better)
@@ -1203,8 +1232,9 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
         // range check (see harris_kernel): a record that is not of this tile would index LDS and the arenas out of range;
         // the frame is void (wave-uniform exit: the workgroup is this wave)
         if (__ballot(k < n_valid && ((int)((me.xy & 0xffff) >> 6) != tx || (int)(me.xy >> 22) != ty)) != 0ull) {
-            if (lane == 0) efx_raise_overflow(T, cnt);
-            return;
+            if (lane == 0) { efx_raise_overflow(T, cnt); s_void = 1; }
+            foreign = true;
+            break;                                           // this wave stops; the workgroup meets at the barrier below
         }
         if (k < n_valid) {
             const int mx = me.xy & 0xffff, my = me.xy >> 16;
@@ -1267,14 +1297,16 @@ __global__ __launch_bounds__(64) void nms_kernel(const LevelTable* __restrict__ 
             s_hneed[pos] = (uint16_t)need;
         }
         nh += __popcll(hm);
-        if (nh > NMS_HCAP - 64 || k0 + 64 >= n_valid) {
-            __syncthreads();
+        if (nh > NMS_HCAP - 64 || k0 + 64 * NW >= n_valid) {
+            wave_sync();
             if (dbg != 2) scan_hard(nh);
             nh = 0;
-            __syncthreads();
+            wave_sync();
         }
     }
-    if (dbg == 3) return;
+    (void)foreign;
+    __syncthreads();                                     // every wave's survivor bits are in s_keep
+    if (dbg == 3 || wv != 0 || s_void) return;
     // lane r holds the survivor ballot of round r
     const unsigned long long my_round_mask = s_keep[lane];
     const int nsurv = __shfl(wave_incl_scan(__popcll(my_round_mask)), 63, 64);
@@ -1965,14 +1997,29 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
         a.prof.end(prof, 0, stream);
         EFX_TRACE_POINT("fast");
         prof = a.prof.begin(1, stream);
-        hipLaunchKernelGGL(harris_kernel, dim3(H.total_tiles + H.nlevels), dim3(64), 0, stream, a.d_table, a.img0, a.pitch0, aligned0, a.pyramid,
-                           a.cand_xy, a.cand, a.cmax, a.hdr, a.counters, a.knobs.dbg & 15);
+        if (H.total_tiles <= EFX_NMS_WIDE_TILES)
+            hipLaunchKernelGGL(harris_kernel<4>, dim3(H.total_tiles + H.nlevels), dim3(256), 0, stream, a.d_table, a.img0, a.pitch0, aligned0, a.pyramid,
+                               a.cand_xy, a.cand, a.cmax, a.hdr, a.counters, a.knobs.dbg & 15);
+        else if (H.total_tiles <= EFX_NMS_MID_TILES)
+            hipLaunchKernelGGL(harris_kernel<EFX_NMS_MID_NW>, dim3(H.total_tiles + H.nlevels), dim3(64 * EFX_NMS_MID_NW), 0, stream, a.d_table, a.img0, a.pitch0, aligned0, a.pyramid,
+                               a.cand_xy, a.cand, a.cmax, a.hdr, a.counters, a.knobs.dbg & 15);
+        else
+            hipLaunchKernelGGL(harris_kernel<1>, dim3(H.total_tiles + H.nlevels), dim3(64), 0, stream, a.d_table, a.img0, a.pitch0, aligned0, a.pyramid,
+                               a.cand_xy, a.cand, a.cmax, a.hdr, a.counters, a.knobs.dbg & 15);
         a.prof.end(prof, 1, stream);
         EFX_TRACE_POINT("harris");
     }
     bool prof = a.prof.begin(2, stream);
-    hipLaunchKernelGGL(nms_kernel, dim3(H.total_tiles), dim3(64), 0, stream, a.d_table, a.hdr, a.cand, a.cmax, a.surv,
-                       a.counters, a.nonmax_radius, a.knobs.dbg >> 4);
+    // several waves per tile when the tiles alone do not fill the chip (256 CUs x 32 waves)
+    if (H.total_tiles <= EFX_NMS_WIDE_TILES)
+        hipLaunchKernelGGL(nms_kernel<4>, dim3(H.total_tiles), dim3(256), 0, stream, a.d_table, a.hdr, a.cand, a.cmax, a.surv,
+                           a.counters, a.nonmax_radius, a.knobs.dbg >> 4);
+    else if (H.total_tiles <= EFX_NMS_MID_TILES)
+        hipLaunchKernelGGL(nms_kernel<EFX_NMS_MID_NW>, dim3(H.total_tiles), dim3(64 * EFX_NMS_MID_NW), 0, stream, a.d_table, a.hdr, a.cand, a.cmax, a.surv,
+                           a.counters, a.nonmax_radius, a.knobs.dbg >> 4);
+    else
+        hipLaunchKernelGGL(nms_kernel<1>, dim3(H.total_tiles), dim3(64), 0, stream, a.d_table, a.hdr, a.cand, a.cmax, a.surv,
+                           a.counters, a.nonmax_radius, a.knobs.dbg >> 4);
     a.prof.end(prof, 2, stream);
     EFX_TRACE_POINT("nms");
     prof = a.prof.begin(3, stream);
@@ -2017,10 +2064,10 @@ hipError_t efx_debug_rerun_stages(const DetectLaunch& a, int stages, hipStream_t
     hipError_t e = hipMemsetAsync(&a.counters->surv_total[0][0], 0, sizeof(a.counters->surv_total), stream);
     if (e != hipSuccess) return e;
     if (stages & 1)
-        hipLaunchKernelGGL(harris_kernel, dim3(H.total_tiles + H.nlevels), dim3(64), 0, stream, a.d_table, a.img0, a.pitch0, aligned0, a.pyramid,
+        hipLaunchKernelGGL(harris_kernel<1>, dim3(H.total_tiles + H.nlevels), dim3(64), 0, stream, a.d_table, a.img0, a.pitch0, aligned0, a.pyramid,
                            a.cand_xy, a.cand, a.cmax, a.hdr, a.counters, 0);
     if (stages & 2)
-        hipLaunchKernelGGL(nms_kernel, dim3(H.total_tiles), dim3(64), 0, stream, a.d_table, a.hdr, a.cand, a.cmax, a.surv,
+        hipLaunchKernelGGL(nms_kernel<1>, dim3(H.total_tiles), dim3(64), 0, stream, a.d_table, a.hdr, a.cand, a.cmax, a.surv,
                            a.counters, a.nonmax_radius, 0);
     return hipGetLastError();
 }
