@@ -1866,9 +1866,29 @@ static bool plan_tower(const LevelTable& H, int last, const uint8_t* img0, int p
     // (8K levels 4..7) does not pay: those levels are as large as a 4K pyramid and the tower recomputes ~1.7x the pixels.
     if ((long long)H.lv[0].rows * H.lv[0].cols > EFX_TOWER_MAX_PX) return false;
     if (no_tower) return false;                               // EFX_NO_TOWER (tests): exercise the per-level kernels on small frames
+    // Tile edge of the top level.  The kernel is a chain of dependent levels, so a workgroup's time hardly shrinks with
+    // its tile; what counts is how the workgroups (1024 threads, at most two per CU) spread over the 256 CUs.  Measured
+    // (tower time per edge, tools/microbench/tower_tt.sh): VGA 12: 14.1 us (180 WGs), 32: 19.2 (30); 720p 20: 16.4 (198),
+    // 32: 19.7 (84), 12: 19.1 (510); FHD 28: 20.6 (220), 32: 22.6 (170), 24: 25.6 (299); 2.7K 36: 28.0 (252), 32: 32.9 (336);
+    // 4K 36: 41 (510), 32: 48.4 (646 = a full round and a mostly empty one), 40: 44.5 (432).  Hence: the smallest edge
+    // whose tiles fit ONE workgroup per CU; when that needs an edge above 40, the smallest edge from 32 up that fits two
+    // per CU; otherwise 32.  EFX_TOWER_TT pins the edge (investigation).
+    static const int tt_pin = getenv("EFX_TOWER_TT") ? atoi(getenv("EFX_TOWER_TT")) : 0;
+    const LevelDev& Ltop = H.lv[last];
+    auto tiles_of = [&](int tt) { return ((Ltop.cols + tt - 1) / tt) * ((Ltop.rows + tt - 1) / tt); };
+    int cand[16], ncand = 0;
+    if (tt_pin > 0) cand[ncand++] = tt_pin;
+    else {
+        for (int tt = 12; tt <= 40 && ncand == 0; tt += 4) if (tiles_of(tt) <= 256) cand[ncand++] = tt;
+        for (int tt = 32; tt <= 48 && ncand == 0; tt += 4) if (tiles_of(tt) <= 512) cand[ncand++] = tt;
+        if (ncand == 0 || cand[0] != 32) cand[ncand++] = 32;                // the fallback when the LDS plan of the first choice is too large
+    }
+    int pick = -1;
+    TowerArgs best; size_t best_lds = 0;
+    for (int ci = 0; ci < ncand && pick < 0; ci++)
     for (int s0 = 0; s0 == 0; s0++) {
         const LevelDev& Lt = H.lv[last];
-        const int tt = 32;
+        const int tt = cand[ci];
         const int ntx = (Lt.cols + tt - 1) / tt, nty = (Lt.rows + tt - 1) / tt;
         int maxw[EFX_MAX_LEVELS] = { 0 }, maxh[EFX_MAX_LEVELS] = { 0 };
         for (int dim = 0; dim < 2; dim++) {
@@ -1901,16 +1921,18 @@ static bool plan_tower(const LevelTable& H, int last, const uint8_t* img0, int p
         }
         bufA = (bufA + 15) & ~(size_t)15; bufB = (bufB + 15) & ~(size_t)15;
         const size_t lds = bufA + bufB + 2 * (size_t)yrows * 16;
-        if (lds > 64 * 1024) return false;                    // too deep for this scale factor: one launch per level
+        if (lds > 78 * 1024) break;                           // this edge does not fit two workgroups per CU
         const uint8_t* src = s0 == 0 ? img0 : nullptr;
         const int spitch = s0 == 0 ? pitch0 : H.lv[s0].pitch;
-        out->s0 = s0; out->top = last; out->tt = tt; out->tiles_x = ntx; out->tiles_y = nty;
-        out->bufA = 0; out->bufB = (int)bufA; out->ytab_off = (int)(bufA + bufB); out->ytab_rows = yrows;
-        out->aligned0 = s0 > 0 ? 1 : ((((uintptr_t)src | (uintptr_t)spitch) & 3u) == 0 && (H.lv[0].cols & 3) == 0);
-        *lds_out = lds;
-        return true;
+        TowerArgs t;
+        t.s0 = s0; t.top = last; t.tt = tt; t.tiles_x = ntx; t.tiles_y = nty;
+        t.bufA = 0; t.bufB = (int)bufA; t.ytab_off = (int)(bufA + bufB); t.ytab_rows = yrows;
+        t.aligned0 = s0 > 0 ? 1 : ((((uintptr_t)src | (uintptr_t)spitch) & 3u) == 0 && (H.lv[0].cols & 3) == 0);
+        best = t; best_lds = lds; pick = ci;
     }
-    return false;
+    if (best_lds == 0) return false;                          // too deep for this scale factor: one launch per level
+    *out = best; *lds_out = best_lds;
+    return true;
 }
 
 hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
@@ -1973,6 +1995,8 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
     }
     if (use_tower) {
         const bool prof = a.prof.begin(100 + tw.s0, stream);
+        if (tw_lds > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pyramid_tower_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tw_lds);
         hipLaunchKernelGGL((pyramid_tower_kernel<1024>), dim3(tw.tiles_x * tw.tiles_y), dim3(1024), tw_lds, stream, a.d_table, a.img0,
                            a.pitch0, a.pyramid, tw, zeroed ? nullptr : a.counters);
         zeroed = true;

@@ -62,9 +62,10 @@ def _assert_same_keypoints(got, ref):
         assert bad.size == 0, f"{name} row differs at {bad[:8]} (of {bad.size}); got {got['kps'][row][bad[:4]]} want {ref['kps'][row][bad[:4]]}"
 
 
-@pytest.mark.parametrize("shape", [(480, 640), (501, 703), (1080, 1920)])
+@pytest.mark.parametrize("shape", [(480, 640), (501, 703), (720, 1280), (1080, 1920), (1520, 2704), (2160, 3840)])
 def test_pyramid_levels_bit_exact(cef, torch_mod, oracle, shape):
-    """Spec S5 resize chain (cuda_efficient_features.cpp:136-157)."""
+    """Spec S5 resize chain (cuda_efficient_features.cpp:136-157).  The shapes cover every tile edge the tower launch
+    picks (plan_tower: 12, 20, 28, 36 with one workgroup per CU, 36 with two)."""
     img = synth.synth_frame(shape[0], shape[1], seed=11)
     det = cef.EfficientFeatures.create(1000)
     d_img = _dev(torch_mod, img)            # level 0 aliases the caller's image: keep it alive

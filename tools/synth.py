@@ -6,7 +6,7 @@ background plus low-amplitude noise.  Frame k of the benchmark uses seed 1000+k.
 """
 import numpy as np
 
-SIZES = {"fhd": (1080, 1920), "4k": (2160, 3840), "8k": (4320, 7680)}
+SIZES = {"vga": (480, 640), "720p": (720, 1280), "fhd": (1080, 1920), "2.7k": (1520, 2704), "4k": (2160, 3840), "8k": (4320, 7680)}
 
 
 def synth_frame(rows, cols, seed=1000, density=0.3, noise=3):
