@@ -207,6 +207,31 @@ __device__ __forceinline__ void efx_zero_counters(Counters* __restrict__ c, int 
     for (int i = tid; i < nwords; i += nthreads) tail[i] = 0;
 }
 
+// Four horizontally adjacent outputs of the bilinear resize (spec S5), the arithmetic all three resize kernels share.
+// ra / rb: the two source rows in LDS, lc[k]: the LDS column of output k's left source pixel (its right neighbour is the
+// next byte), wa / wb: the x weights, wy0 / wy1: the y weights.  Per output the expression of the reference, term by term
+// (unfused multiplies and adds: -ffp-contract=off).
+// Measured and dropped (round 3, tools/microbench/bench_ab.sh): two outputs per instruction on packed fp32 lanes
+// (v_pk_mul_f32 / v_pk_add_f32: 42 instead of 64 VALU instructions per four outputs) -- kernel 11.10 vs 10.97 us, bench
+// line 106.6 vs 106.8 Mkeypoints/s; a pixel pair as ONE unaligned 16-bit LDS read -- 40 us instead of 11 (unaligned
+// ds_read_u16 is a slow path).
+__device__ __forceinline__ uint32_t resize_quad(const uint8_t* ra, const uint8_t* rb, const int (&lc)[4], const float (&wa)[4], const float (&wb)[4],
+                                                float wy0, float wy1)
+{
+    uint32_t packed = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint8_t* pa = ra + lc[k];
+        const uint8_t* pb = rb + lc[k];
+        float out = (float)pa[0] * (wa[k] * wy0);                    // == 0.f + ... exactly
+        out = out + (float)pa[1] * (wb[k] * wy0);
+        out = out + (float)pb[0] * (wa[k] * wy1);
+        out = out + (float)pb[1] * (wb[k] * wy1);
+        packed = __builtin_amdgcn_cvt_pk_u8_f32(out, k, packed);     // rint (half even) + saturate + pack
+    }
+    return packed;
+}
+
 // ================================================================================================
 // Kernel R: one 64x64 tile of pyramid level s+1 per workgroup, bilinear from level s (spec S5; the
 // cv::cuda::resize call of calcImagePyramid, cuda_efficient_features.cpp:154).  The source footprint of the
@@ -298,17 +323,7 @@ __global__ __launch_bounds__(NT) void resize_kernel(
         const float wy0 = __int_as_float(yt.z), wy1 = __int_as_float(yt.w);
         const uint8_t* ra = smem + yt.x;
         const uint8_t* rb = smem + yt.y;
-        uint32_t packed = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint8_t* pa = ra + lc[k];
-            const uint8_t* pb = rb + lc[k];
-            float out = (float)pa[0] * (wx0[k] * wy0);                  // == 0.f + ... exactly
-            out = out + (float)pa[1] * (wx1[k] * wy0);
-            out = out + (float)pb[0] * (wx0[k] * wy1);
-            out = out + (float)pb[1] * (wx1[k] * wy1);
-            packed = __builtin_amdgcn_cvt_pk_u8_f32(out, k, packed);     // rint (half even) + saturate + pack
-        }
+        const uint32_t packed = resize_quad(ra, rb, lc, wx0, wx1, wy0, wy1);
         uint8_t* d = dst + (size_t)oy * dpitch + oxq;
         if (full4) *reinterpret_cast<uint32_t*>(d) = packed;
         else
@@ -418,17 +433,7 @@ __global__ __launch_bounds__(256) void resize_stream_kernel(
                 const float wy0 = __int_as_float(yt.z), wy1 = __int_as_float(yt.w);
                 const uint8_t* ra = smem + yt.x;
                 const uint8_t* rb = smem + yt.y;
-                uint32_t packed = 0;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const uint8_t* pa = ra + lc[k];
-                    const uint8_t* pb = rb + lc[k];
-                    float out = (float)pa[0] * (wa[k] * wy0);
-                    out = out + (float)pa[1] * (wb[k] * wy0);
-                    out = out + (float)pb[0] * (wa[k] * wy1);
-                    out = out + (float)pb[1] * (wb[k] * wy1);
-                    packed = __builtin_amdgcn_cvt_pk_u8_f32(out, k, packed);
-                }
+                const uint32_t packed = resize_quad(ra, rb, lc, wa, wb, wy0, wy1);
                 uint8_t* d = dst + (size_t)oy * dpitch + oxq;
                 if (full4) *reinterpret_cast<uint32_t*>(d) = packed;
                 else
@@ -600,17 +605,7 @@ __global__ __launch_bounds__(NT) void pyramid_tower_kernel(const LevelTable* __r
                 const float wy0 = __int_as_float(t4.z), wy1 = __int_as_float(t4.w);
                 const uint8_t* ra = smem + sb + t4.x;
                 const uint8_t* rb = smem + sb + t4.y;
-                uint32_t packed = 0;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const uint8_t* pa = ra + lc[k];
-                    const uint8_t* pb = rb + lc[k];
-                    float out = (float)pa[0] * (wx0[k] * wy0);
-                    out = out + (float)pa[1] * (wx1[k] * wy0);
-                    out = out + (float)pb[0] * (wx0[k] * wy1);
-                    out = out + (float)pb[1] * (wx1[k] * wy1);
-                    packed = __builtin_amdgcn_cvt_pk_u8_f32(out, k, packed);
-                }
+                const uint32_t packed = resize_quad(ra, rb, lc, wx0, wx1, wy0, wy1);
                 if (keep) *reinterpret_cast<uint32_t*>(smem + db + i * lp1 + 4 * g) = packed;
                 const int oy = loy1 + i;
                 if (oy >= ownloy && oy < ownhiy) {
