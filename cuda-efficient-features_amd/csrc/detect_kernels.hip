@@ -732,52 +732,51 @@ __global__ __launch_bounds__(256) void fast_kernel(
                 R[i][0] = trow[i * (EFX_LP / 4) + 0]; R[i][1] = trow[i * (EFX_LP / 4) + 1]; R[i][2] = trow[i * (EFX_LP / 4) + 2];
             }
             const int gx0 = x0 + bx, gy0 = y0 + by;
-            // validity of the 16 pixels of the block (border mask, .cpp:176-182) as one 16-bit mask
-            unsigned xm = 0xffffu, ym = 0xffffu;
+            // validity of the 16 pixels of the block (border mask, .cpp:176-182) in the layout of qm below: column c of
+            // the block in byte c, row j at bit 7 - j of the byte
+            unsigned xm = 0xf0f0f0f0u, ym = 0xf0f0f0f0u;
             if (x0 < EFX_HALF_PATCH || x0 + EFX_TILE > cols - EFX_HALF_PATCH || y0 < EFX_HALF_PATCH || y0 + EFX_TILE > rows - EFX_HALF_PATCH) {
                 // only tiles that touch the 15-px border build the masks (workgroup-uniform branch)
                 xm = 0; ym = 0;
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    if ((gx0 + i) >= EFX_HALF_PATCH && (gx0 + i) < cols - EFX_HALF_PATCH) xm |= 0x1111u << i;
-                    if ((gy0 + i) >= EFX_HALF_PATCH && (gy0 + i) < rows - EFX_HALF_PATCH) ym |= 0xfu << (4 * i);
+                    if ((gx0 + i) >= EFX_HALF_PATCH && (gx0 + i) < cols - EFX_HALF_PATCH) xm |= 0xf0u << (8 * i);
+                    if ((gy0 + i) >= EFX_HALF_PATCH && (gy0 + i) < rows - EFX_HALF_PATCH) ym |= 0x80808080u >> i;
                 }
             }
-            // Two pixels per instruction on packed 16-bit lanes (v_perm_b32 widens byte pairs, v_pk_max/min_u16,
-            // saturating v_pk_sub_u16 instead of compares).  Two neighbouring compass points brighter than p+t
-            // <=> min(max(N,S), max(E,W)) > p+t, and the mirrored form for darker.
+            // Two pixels per instruction on packed 16-bit lanes (v_perm_b32 widens byte pairs, v_pk_max/min_i16).  Two
+            // neighbouring compass points brighter than p+t <=> min(max(N,S), max(E,W)) > p+t, and the mirrored form for
+            // darker; either one <=> max(bright - p, p - dark) > t, i.e. the SIGN of t - max(..) (all values within +-255).
+            // The sign bits of a row's four columns are the top bits of four bytes: one v_perm_b32 gathers them, one
+            // shift + one v_and_or_b32 drops them into qm (round 3: 91 instead of 112 instructions per 16 pixels).
             //   C[r][h]: columns (2h, 2h+1) of the block in footprint row r;  E/W: the pixels 3 to the right / left
-            const u16x2 thr2 = { (unsigned short)threshold, (unsigned short)threshold };
-            const u16x2 bias2 = { 0x7fff, 0x7fff };
-            u16x2 C[10][2];
+            const i16x2 thr2 = { (short)threshold, (short)threshold };
+            i16x2 C[10][2];
 #pragma unroll
             for (int r = 0; r < 10; r++) {
-                C[r][0] = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(0u, R[r][1], 0x0c010c00u));
-                C[r][1] = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(0u, R[r][1], 0x0c030c02u));
+                C[r][0] = __builtin_bit_cast(i16x2, __builtin_amdgcn_perm(0u, R[r][1], 0x0c010c00u));
+                C[r][1] = __builtin_bit_cast(i16x2, __builtin_amdgcn_perm(0u, R[r][1], 0x0c030c02u));
             }
-            unsigned acc = 0;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const uint32_t d0 = R[j + 3][0], d1 = R[j + 3][1], d2 = R[j + 3][2];
-                const u16x2 E[2] = { __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(d2, d1, 0x0c040c03u)),      // x+3 of columns 0,1
-                                     __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(d2, d1, 0x0c060c05u)) };    // x+3 of columns 2,3
-                const u16x2 W[2] = { __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(d1, d0, 0x0c020c01u)),      // x-3 of columns 0,1
-                                     __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(d1, d0, 0x0c040c03u)) };    // x-3 of columns 2,3
+                const i16x2 E[2] = { __builtin_bit_cast(i16x2, __builtin_amdgcn_perm(d2, d1, 0x0c040c03u)),      // x+3 of columns 0,1
+                                     __builtin_bit_cast(i16x2, __builtin_amdgcn_perm(d2, d1, 0x0c060c05u)) };    // x+3 of columns 2,3
+                const i16x2 W[2] = { __builtin_bit_cast(i16x2, __builtin_amdgcn_perm(d1, d0, 0x0c020c01u)),      // x-3 of columns 0,1
+                                     __builtin_bit_cast(i16x2, __builtin_amdgcn_perm(d1, d0, 0x0c040c03u)) };    // x-3 of columns 2,3
+                uint32_t sgn[2];
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
-                    const u16x2 p2 = C[j + 3][h], cn = C[j][h], cs = C[j + 6][h];
-                    const u16x2 bright = __builtin_elementwise_min(__builtin_elementwise_max(cs, cn), __builtin_elementwise_max(E[h], W[h]));
-                    const u16x2 dark = __builtin_elementwise_max(__builtin_elementwise_min(cs, cn), __builtin_elementwise_min(E[h], W[h]));
-                    // bright > p + t  <=>  sat(bright - (p + t)) != 0;   dark < p - t  <=>  sat(sat(p - t) - dark) != 0
-                    const u16x2 pb = __builtin_elementwise_sub_sat(bright, (u16x2)(p2 + thr2));
-                    const u16x2 pd = __builtin_elementwise_sub_sat(__builtin_elementwise_sub_sat(p2, thr2), dark);
-                    // nonzero (<= 0x1ff) -> 1 without compares: bit 15 of x + 0x7fff
-                    const u16x2 pass = (u16x2)(((u16x2)(pb | pd) + bias2) >> 15);
-                    // even columns land in the low half of acc, odd columns in the high half (same bit position)
-                    acc |= __builtin_bit_cast(uint32_t, pass) << (4 * j + 2 * h);
+                    const i16x2 p2 = C[j + 3][h], cn = C[j][h], cs = C[j + 6][h];
+                    const i16x2 bright = __builtin_elementwise_min(__builtin_elementwise_max(cs, cn), __builtin_elementwise_max(E[h], W[h]));
+                    const i16x2 dark = __builtin_elementwise_max(__builtin_elementwise_min(cs, cn), __builtin_elementwise_min(E[h], W[h]));
+                    const i16x2 m = __builtin_elementwise_max((i16x2)(bright - p2), (i16x2)(p2 - dark));
+                    sgn[h] = __builtin_bit_cast(uint32_t, (i16x2)(thr2 - m));      // bit 15 / 31 set <=> the pixel passes
                 }
+                // bytes 1, 3 of sgn[0] (columns 0, 1) and of sgn[1] (columns 2, 3) -> bytes 0 .. 3
+                const uint32_t f = __builtin_amdgcn_perm(sgn[1], sgn[0], 0x07050301u);
+                qm |= (f >> j) & (0x80808080u >> j);
             }
-            qm = (acc | (acc >> 15)) & 0xffffu;
             qm &= xm & ym;
             if (dbg & 2) qm = 0;
         }
@@ -788,9 +787,9 @@ __global__ __launch_bounds__(256) void fast_kernel(
         {
             int pos = block_excl_scan<4>(qcnt, s_scan, &nq);
             while (qm) {
-                const int b = __ffs(qm) - 1;
+                const int b = __ffs(qm) - 1;                 // column b >> 3, row 7 - (b & 7) of the block
                 qm &= qm - 1;
-                s_list[pos++] = (uint16_t)((bx + (b & 3)) | ((by + (b >> 2)) << 8));
+                s_list[pos++] = (uint16_t)((bx + (b >> 3)) | ((by + 7 - (b & 7)) << 8));
             }
         }
         __syncthreads();
@@ -1098,8 +1097,8 @@ __global__ __launch_bounds__(64 * NW) void nms_kernel(const LevelTable* __restri
             const int j = nb + sub;
             if (j < ne) {
                 const Corner o = lst[j];
-                const int dx = mx - (int)(o.xy & 0xffff), dy = my - (int)(o.xy >> 16);
-                kill |= (o.xy != m.xy && m.resp <= o.resp && dx * dx + dy * dy < image_radius);
+                const i16x2 d = __builtin_bit_cast(i16x2, m.xy) - __builtin_bit_cast(i16x2, o.xy);
+                kill |= (o.xy != m.xy && m.resp <= o.resp && __builtin_amdgcn_sdot2(d, d, 0, false) < image_radius);
             }
             return;
         }
@@ -1109,8 +1108,8 @@ __global__ __launch_bounds__(64 * NW) void nms_kernel(const LevelTable* __restri
             for (int u = 0; u < 4; u++) o[u] = lst[min(j + 8 * u, ne - 1)];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                const int dx = mx - (int)(o[u].xy & 0xffff), dy = my - (int)(o[u].xy >> 16);
-                kill |= (o[u].xy != m.xy && m.resp <= o[u].resp && dx * dx + dy * dy < image_radius);
+                const i16x2 d = __builtin_bit_cast(i16x2, m.xy) - __builtin_bit_cast(i16x2, o[u].xy);
+                kill |= (o[u].xy != m.xy && m.resp <= o[u].resp && __builtin_amdgcn_sdot2(d, d, 0, false) < image_radius);
             }
         }
     };
@@ -1243,7 +1242,8 @@ __global__ __launch_bounds__(64 * NW) void nms_kernel(const LevelTable* __restri
                     const int cj = bx1 - tx * 4, ci = by1 - ty * 4;      // this corner's cell inside the tile, 0..3
 #pragma unroll
                     for (int q = 0; q < 9; q++) o[q] = s_cm[ci + q / 3][cj + q % 3];
-                    int kill = 0, rival = 0;
+                    bool kill = false;
+                    int rival = 0;
                     // A neighbouring cell matters only if its nearest pixel is inside the radius (round 3): with a small
                     // radius most corners are too far from most of the eight neighbours -- radius 5: 2.3 cells on
                     // average instead of 9 -- and dense frames stop walking lists that cannot hold a suppressor.
@@ -1251,19 +1251,27 @@ __global__ __launch_bounds__(64 * NW) void nms_kernel(const LevelTable* __restri
                     const int px = mx & (EFX_CELL - 1), py = my & (EFX_CELL - 1);
                     const int gx[3] = { (px + 1) * (px + 1), 0, (EFX_CELL - px) * (EFX_CELL - px) };
                     const int gy[3] = { (py + 1) * (py + 1), 0, (EFX_CELL - py) * (EFX_CELL - py) };
+                    // The kernel is bound by instruction issue and this loop was 60 % of its VALU instructions (round 3,
+                    // tools/microbench/stage_insts.sh: 14.8 M of 24.3 M): the squared distance is one v_pk_sub_i16 + one
+                    // v_dot2_i32_i16 on the packed coordinate word (|dx|, |dy| < 2^15; an empty cell's 0x7fffffff gives
+                    // a huge distance and a response no corner is below), the conditions stay booleans (compares into
+                    // lane masks, combined on the scalar unit) instead of 0 / 1 integers.
+                    const i16x2 mev = __builtin_bit_cast(i16x2, me.xy);
 #pragma unroll
                     for (int q = 0; q < 9; q++) {
                         const uint32_t oxy = o[q].xy & ~EFX_CMAX_TIE;
-                        const int dx = mx - (int)(oxy & 0xffff), dy = my - (int)(oxy >> 16);
-                        const int other = (int)(oxy != me.xy);
-                        const int ge = other & (int)(me.resp <= o[q].resp);
-                        const int near = (int)(gx[q % 3] + gy[q / 3] < image_radius);
+                        const i16x2 d = mev - __builtin_bit_cast(i16x2, oxy);
+                        const int d2 = __builtin_amdgcn_sdot2(d, d, 0, false);
+                        const bool other = oxy != me.xy;
+                        const bool ge = other && me.resp <= o[q].resp;
+                        const bool near = q == 4 || gx[q % 3] + gy[q / 3] < image_radius;
                         // cell q holds a corner at least as strong: the exact scan must walk it.  That includes the cell whose
                         // maximum this corner is, when another corner of the cell has the same response (ties suppress)
-                        rival |= (near & (ge | ((other ^ 1) & (int)(o[q].xy >> 31)))) << q;
-                        kill |= ge & (int)(dx * dx + dy * dy < image_radius);
+                        const bool tie = !other && (int)o[q].xy < 0;
+                        if (near && (ge || tie)) rival |= 1 << q;
+                        kill = kill || (ge && d2 < image_radius);
                     }
-                    hard = kill == 0;
+                    hard = !kill;
                     need = rival;
                     // stronger than every neighbouring cell maximum: nothing in the neighbourhood can suppress it, so
                     // it survives without the exact scan (most true survivors are such local maxima)
