@@ -61,6 +61,22 @@ __device__ __forceinline__ int block_excl_scan(int v, int* scratch, int* total)
     return r;
 }
 
+// The same for four waves with ONE barrier: every wave reads the four wave totals (one 16-byte LDS read) and adds up the
+// ones before it (wave-uniform selects).  `scratch`: four ints, 16-byte aligned, not reused by the caller before its
+// next barrier.
+__device__ __forceinline__ int block_excl_scan4(int v, int* scratch, int* total)
+{
+    const int lane = lane_id();
+    const int wid = threadIdx.x >> 6;
+    const int incl = wave_incl_scan(v);
+    if (lane == 63) scratch[wid] = incl;
+    __syncthreads();
+    const int4 t = *reinterpret_cast<const int4*>(scratch);
+    *total = (t.x + t.y) + (t.z + t.w);
+    const int before = (wid > 0 ? t.x : 0) + (wid > 1 ? t.y : 0) + (wid > 2 ? t.z : 0);
+    return before + incl - v;
+}
+
 // ------------------------------------------------------------------------------------------------
 // FAST-9 segment test on an LDS tile (cuda_fast.cu:33-222).  c points at the centre pixel, P = LDS pitch.
 // Circle order as cuda_fast.cu:179-207: k=0 at (0,+3) walking towards +x.
@@ -685,8 +701,9 @@ __global__ __launch_bounds__(256) void fast_kernel(
     const int dbg = EFX_DBG(dbg_arg);
     __shared__ __attribute__((aligned(16))) uint32_t s_tile[EFX_LT * (EFX_LP / 4)];
     __shared__ unsigned long long s_bitmap[EFX_TILE];
-    __shared__ uint16_t s_list[EFX_TILE * EFX_TILE];     // phase 1-2: per-wave quick-test survivors; phase 3+: corner list
-    __shared__ int s_scan[8];
+    __shared__ uint16_t s_list[EFX_TILE * EFX_TILE];     // quick-test survivors (block << 5 | bit), read by the full test and by the append
+    __shared__ __attribute__((aligned(16))) int s_scan[8];     // two one-barrier scans: [0, 4) and [4, 8)
+    __shared__ uint16_t s_rowoff[256];                          // phase 3: corners before row rr of cell c (canonical order), index 16 c + rr
     __shared__ int s_celloff[EFX_CELLS_PER_TILE + 1];
     __shared__ int s_start;
 
@@ -785,11 +802,14 @@ __global__ __launch_bounds__(256) void fast_kernel(
         const int qcnt = __popc(qm);
         int nq;
         {
-            int pos = block_excl_scan<4>(qcnt, s_scan, &nq);
+            int pos = block_excl_scan4(qcnt, s_scan, &nq);
+            // an entry names the lane's block (tid) and the bit; phase 2 decodes it once per survivor -- this loop runs as
+            // often as the fullest block of the wave has survivors, for all 64 lanes (round 3: 14 -> 8 instructions per trip)
+            const unsigned tag = (unsigned)tid << 5;
             while (qm) {
                 const int b = __ffs(qm) - 1;                 // column b >> 3, row 7 - (b & 7) of the block
                 qm &= qm - 1;
-                s_list[pos++] = (uint16_t)((bx + (b >> 3)) | ((by + 7 - (b & 7)) << 8));
+                s_list[pos++] = (uint16_t)(tag | (unsigned)b);
             }
         }
         __syncthreads();
@@ -797,7 +817,8 @@ __global__ __launch_bounds__(256) void fast_kernel(
         //      the 64x64 bitmap ----
         for (int idx = tid; idx < ((dbg & 8) ? 0 : nq); idx += 256) {
             const int e = s_list[idx];
-            const int lx = e & 0xff, ly = e >> 8;
+            const int blk = e >> 5, b = e & 31;              // block (blk & 15, blk >> 4) of 4 x 4 pixels, see phase 1
+            const int lx = ((blk & 15) << 2) + (b >> 3), ly = ((blk >> 4) << 2) + 7 - (b & 7);
             bool corner = fast9_survivor_lds<EFX_LP>(tb + (ly + EFX_HALO) * EFX_LP + lx + EFX_HALO, threshold);
             if (corner && mask) {
                 // spec S12: the level-0 mask is sampled where the keypoint will be reported (scalePoints, .cu:236-248)
@@ -810,22 +831,17 @@ __global__ __launch_bounds__(256) void fast_kernel(
         }
         __syncthreads();
 
-        // ---- phase 3: canonical enumeration (spec S1): cell-major, raster inside the 16x16 cell ----
+        // ---- phase 3: canonical enumeration (spec S1): cell-major, raster inside the 16x16 cell.  Thread 16 c + rr counts
+        //      row rr of cell c; the scan gives the number of corners before that row ----
         const int cell = tid >> 4, rr = tid & 15;
         const int cy = cell >> 2, cx = cell & 3;
         const int brow = cy * 16 + rr;
-        unsigned bits = (unsigned)(s_bitmap[brow] >> (cx * 16)) & 0xffffu;
-        const int cntb = __popc(bits);
-        const int pre = block_excl_scan<4>(cntb, s_scan, &total);
+        const unsigned bits = (unsigned)(s_bitmap[brow] >> (cx * 16)) & 0xffffu;
+        const int pre = block_excl_scan4(__popc(bits), s_scan + 4, &total);
+        s_rowoff[tid] = (uint16_t)pre;
         if (rr == 0) s_celloff[cell] = pre;
-        if (tid == 0) s_celloff[EFX_CELLS_PER_TILE] = total;
-        int pos = pre;
-        while (bits) {
-            const int b = __ffs(bits) - 1;
-            bits &= bits - 1;
-            s_list[pos++] = (uint16_t)((cx * 16 + b) | (brow << 8));
-        }
         if (tid == 0) {
+            s_celloff[EFX_CELLS_PER_TILE] = total;
             s_start = total > 0 ? atomicAdd(&cnt->cand_total[l][tile & (EFX_NSUB - 1)].v, total) : 0;
             // the arenas are sized for a corner density, not for the worst case (efx_api.cpp, build_geometry): a frame that
             // does not fit is void -- every later kernel of the frame returns at once, N = 0, the host enlarges the arenas
@@ -833,12 +849,23 @@ __global__ __launch_bounds__(256) void fast_kernel(
         }
         __syncthreads();
 
-        // ---- phase 4: append the corner coordinates to the level's corner array (responses: harris_kernel) ----
+        // ---- phase 4: append the corner coordinates to the level's corner array (responses: harris_kernel).  The lanes
+        //      walk the survivor list of phase 1 again; a survivor whose bit is set is a corner and its place is the count
+        //      before its row + the set bits left of it in the row.  (Until round 3 every row's thread wrote its corners to
+        //      an LDS list in a loop that ran as often as the fullest row of the wave had corners, and a second loop copied
+        //      the list out: ~130 instructions per tile more.) ----
         const int start = s_start;
-        for (int k = tid; k < total; k += 256) {
-            const int lx = s_list[k] & 0xff, ly = s_list[k] >> 8;
-            if ((unsigned)(start + k) < L.cand_sub_cap)
-                cand_xy[(size_t)(tile & (EFX_NSUB - 1)) * L.cand_sub_cap + start + k] = (uint32_t)(x0 + lx) | ((uint32_t)(y0 + ly) << 16);
+        for (int idx = tid; idx < nq; idx += 256) {
+            const int e = s_list[idx];
+            const int blk = e >> 5, b = e & 31;
+            const int lx = ((blk & 15) << 2) + (b >> 3), ly = ((blk >> 4) << 2) + 7 - (b & 7);
+            const unsigned word = reinterpret_cast<const unsigned*>(s_bitmap)[ly * 2 + (lx >> 5)];
+            if ((word >> (lx & 31)) & 1u) {
+                const unsigned rowbits = (word >> (lx & 16)) & 0xffffu;            // the row of the corner's 16 x 16 cell
+                const int k = (int)s_rowoff[((((ly >> 4) << 2) + (lx >> 4)) << 4) + (ly & 15)] + __popc(rowbits & ((1u << (lx & 15)) - 1u));
+                if ((unsigned)(start + k) < L.cand_sub_cap)
+                    cand_xy[(size_t)(tile & (EFX_NSUB - 1)) * L.cand_sub_cap + start + k] = (uint32_t)(x0 + lx) | ((uint32_t)(y0 + ly) << 16);
+            }
         }
         TileHdr* h = hdr + tile;
         if (tid <= EFX_CELLS_PER_TILE) h->cell_off[tid] = (uint16_t)s_celloff[tid];
