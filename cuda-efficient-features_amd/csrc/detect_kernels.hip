@@ -1066,11 +1066,15 @@ __global__ __launch_bounds__(64 * NW) void nms_kernel(const LevelTable* __restri
     for (int sub = 0; sub < EFX_NSUB; sub++) lvl_total += cnt->cand_total[l][sub].v;
     const bool capped = lvl_total > L.cap;              // only then the canonical ranks were computed
     // the cell maxima are fetched in the same memory round trip as the headers (both only need the tile's coordinates)
-    // clamped exactly as the quick test clamps its cell coordinates
+    // a cell beyond the grid is an EMPTY cell (harris_kernel's encoding: no coordinate, the lowest response): the
+    // neighbourhood of IsMaxPoint is clipped to the grid (.cu:70-73), so such a cell holds nothing -- and phase A may rely on
+    // "a neighbouring cell's maximum is never this corner itself"
     const int gw_ = (L.cols + EFX_CELL - 1) / EFX_CELL, gh_ = (L.rows + EFX_CELL - 1) / EFX_CELL;
-    const int cy = min(max(ty * 4 - 1 + tid / 6, 0), gh_ - 1), cx = min(max(tx * 4 - 1 + tid % 6, 0), gw_ - 1);
-    Corner cm; cm.xy = 0u; cm.resp = 0.f;
-    if (tid < 36) cm = cmax_all[L.cmax_base + (size_t)cy * (L.tiles_x * 4) + cx];
+    const int cyu = ty * 4 - 1 + tid / 6, cxu = tx * 4 - 1 + tid % 6;
+    const int cy = min(max(cyu, 0), gh_ - 1), cx = min(max(cxu, 0), gw_ - 1);
+    Corner cm; cm.xy = 0xffffffffu; cm.resp = -3.0e38f;
+    const bool cell_exists = cyu == cy && cxu == cx;
+    if (tid < 36 && cell_exists) cm = cmax_all[L.cmax_base + (size_t)cy * (L.tiles_x * 4) + cx];
     __syncthreads();                                     // s_nb is read below
     {
         // the nine headers address the corner arena: ranges that do not fit it void the frame (see harris_kernel)
@@ -1087,7 +1091,7 @@ __global__ __launch_bounds__(64 * NW) void nms_kernel(const LevelTable* __restri
         }
     }
     if (tid < 36) {
-        if (capped) {
+        if (capped && cell_exists) {
             // a cell of a tile that is cut by the cap may hold invalid corners: its maximum must not suppress anything,
             // but the cell may still hold a valid rival -> "infinitely strong, infinitely far": never kills, always
             // sends the corner to the exact scan of that cell (whose list is clipped at the cap)
@@ -1301,14 +1305,20 @@ __global__ __launch_bounds__(64 * NW) void nms_kernel(const LevelTable* __restri
                         const uint32_t oxy = o[q].xy & ~EFX_CMAX_TIE;
                         const i16x2 d = mev - __builtin_bit_cast(i16x2, oxy);
                         const int d2 = __builtin_amdgcn_sdot2(d, d, 0, false);
-                        const bool other = oxy != me.xy;
-                        const bool ge = other && me.resp <= o[q].resp;
-                        const bool near = q == 4 || gx[q % 3] + gy[q / 3] < image_radius;
-                        // cell q holds a corner at least as strong: the exact scan must walk it.  That includes the cell whose
-                        // maximum this corner is, when another corner of the cell has the same response (ties suppress)
-                        const bool tie = !other && (int)o[q].xy < 0;
-                        if (near && (ge || tie)) rival |= 1 << q;
-                        kill = kill || (ge && d2 < image_radius);
+                        if (q == 4) {
+                            // the corner's own cell: its maximum may be this corner.  Then the exact scan must still walk the
+                            // cell when another corner of it has the same response (ties suppress)
+                            const bool other = oxy != me.xy;
+                            const bool ge = other && me.resp <= o[q].resp;
+                            if (ge || (!other && (int)o[q].xy < 0)) rival |= 1 << q;
+                            kill = kill || (ge && d2 < image_radius);
+                        } else {
+                            // a neighbouring cell's maximum is another corner (cells beyond the grid are empty, see the prologue)
+                            const bool ge = me.resp <= o[q].resp;
+                            // cell q holds a corner at least as strong: the exact scan must walk it
+                            if (ge && gx[q % 3] + gy[q / 3] < image_radius) rival |= 1 << q;
+                            kill = kill || (ge && d2 < image_radius);
+                        }
                     }
                     hard = !kill;
                     need = rival;
