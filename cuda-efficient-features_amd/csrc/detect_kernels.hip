@@ -1789,17 +1789,21 @@ __global__ __launch_bounds__(64) void emit_kernel(const LevelTable* __restrict__
 // radius-15 disc (31 columns), loop over the 31 rows: every row is one coalesced 31-byte read.  The integer
 // moments are order-independent, the wave reduction gives exactly the reference's m_01 / m_10.
 // ================================================================================================
-#define ANGLE_KP 8              // keypoints per workgroup (two per wave): the double-precision tail runs on ANGLE_KP lanes of ONE wave
+#define ANGLE_KP 8              // keypoints per workgroup (two per wave)
 __global__ __launch_bounds__(ANGLE_KP * 32) void angle_kernel(const LevelTable* __restrict__ T, const int* __restrict__ d_count, int capacity,
                                                     const uint8_t* __restrict__ img0, int pitch0, const uint8_t* __restrict__ pyramid,
-                                                    float4* __restrict__ kp4, const int* __restrict__ kp_level,
-                                                    uint8_t* __restrict__ kps, size_t kps_pitch,
-                                                    Affine* __restrict__ aff, float bad_scale, float bad_reach, int bad_smax, int bad_sfixed)
+                                                    float4* __restrict__ kp4, const int* __restrict__ kp_level)
 {
-    // two keypoints per wave (31 of each 32 lanes hold one patch column), ANGLE_KP per workgroup.  (Round 3 measured 32 per
-    // workgroup -- the double-precision tail below, ~700 instructions, is issued once per workgroup whatever the number of
-    // its lanes at work, 3.5 M of the kernel's 6 M wave-instructions: 19.1 -> 20.8 us isolated, frame rate unchanged; kept
-    // at 8.)  Neighbouring keypoints (canonical order) stay on the same XCD: their patches share L2 lines
+    // The intensity-centroid moments m01, m10 of every keypoint's patch; two keypoints per wave (31 of each 32 lanes hold
+    // one patch column), ANGLE_KP per workgroup.  The moments are left in the .z / .w words of the keypoint's kp4 entry
+    // (integer bits); angle_tail_kernel turns them into the angle.  (Until round 3 the double-precision atan2 / cos / sin
+    // tail, ~1100 instructions, ran here on ANGLE_KP lanes of one wave per workgroup; now one LANE per keypoint of a dense
+    // launch runs it: 6.0 -> 4.3 + 0.2 M wave-instructions, 19.0 -> 15.9 us.)
+    // The kernel is bound by the bytes it makes the memory system fetch (31-byte rows at arbitrary alignment: 87 MB per 8K
+    // frame for 38 MB of pixels).  Measured and dropped (round 3): the patch as range-checked dwords, 8 lanes along a row,
+    // three v_dot4_u32_u8 per dword against (dx + 16), (dy + 16) and 1 inside the disc -- 2.1 M wave-instructions instead of
+    // 4.3, but 20.6 us and the same frame rate; one lane per patch ROW -- 3.0 M, every load touches 62 cache lines: 33 us.
+    // Neighbouring keypoints (canonical order) stay on the same XCD: their patches share L2 lines
     const int lane = threadIdx.x & 31;
     const int count = min(*d_count, capacity);
     const int ngroups = (count + ANGLE_KP - 1) / ANGLE_KP;   // the grid is sized for the capacity
@@ -1834,23 +1838,31 @@ __global__ __launch_bounds__(ANGLE_KP * 32) void angle_kernel(const LevelTable* 
     }
 #pragma unroll
     for (int d = 16; d >= 1; d >>= 1) { m10 += __shfl_xor(m10, d, 64); m01 += __shfl_xor(m01, d, 64); }
-    // the double-precision atan2 (spec S7) is ~100 instructions: the 8 keypoints of the workgroup share one pass of it
-    __shared__ int s_m[ANGLE_KP][2];
-    if (lane == 0) { s_m[threadIdx.x >> 5][0] = m01; s_m[threadIdx.x >> 5][1] = m10; }
-    __syncthreads();
-    const int k8 = group * ANGLE_KP + threadIdx.x;
-    if (threadIdx.x < ANGLE_KP && k8 < count) {
-        const float angle = atan2_deg(s_m[threadIdx.x][0], s_m[threadIdx.x][1]);
-        kp4[k8].w = angle;
-        if (kps) *reinterpret_cast<float*>(kps + 2 * kps_pitch + 4 * (size_t)k8) = angle;
-        if (aff) {
-            // the BAD describer's record of this keypoint, while its angle is in a register (saves bad_affine_kernel's launch)
-            float4 kq = kp4[k8]; kq.w = angle;
-            const int lv = kp_level[k8];
-            const LevelDev& L = T->lv[lv];
-            aff[k8] = efx_bad_affine(kq, lv == 0 ? img0 : pyramid + L.img_off, lv == 0 ? pitch0 : L.pitch, L.rows, L.cols, lv,
-                                     bad_scale, bad_reach, bad_smax, bad_sfixed);
-        }
+    if (act && lane == 0) *reinterpret_cast<int2*>(&kp4[kid].z) = make_int2(m10, m01);
+}
+
+// The angle from the moments (calcAngles, .cu:376-390; the double-precision atan2 of spec S7), one lane per keypoint; the
+// kp4 entry gets its size and angle, the caller's matrix its angle row and -- behind a BAD describer -- the keypoint's
+// record (rectifyBoxes' double cos / sin, bad_affine.h), which saves bad_affine_kernel's launch.
+__global__ __launch_bounds__(64) void angle_tail_kernel(const LevelTable* __restrict__ T, const int* __restrict__ d_count, int capacity,
+                                                        const uint8_t* __restrict__ img0, int pitch0, const uint8_t* __restrict__ pyramid,
+                                                        float4* __restrict__ kp4, const int* __restrict__ kp_level,
+                                                        uint8_t* __restrict__ kps, size_t kps_pitch,
+                                                        Affine* __restrict__ aff, float bad_scale, float bad_reach, int bad_smax, int bad_sfixed)
+{
+    const int count = min(*d_count, capacity);
+    const int k = (int)blockIdx.x * 64 + (int)threadIdx.x;
+    if (k >= count) return;
+    float4 kq = kp4[k];
+    const float angle = atan2_deg(__float_as_int(kq.w), __float_as_int(kq.z));
+    kq.z = (float)EFX_PATCH_SIZE; kq.w = angle;
+    kp4[k] = kq;
+    if (kps) *reinterpret_cast<float*>(kps + 2 * kps_pitch + 4 * (size_t)k) = angle;
+    if (aff) {
+        const int lv = kp_level[k];
+        const LevelDev& L = T->lv[lv];
+        aff[k] = efx_bad_affine(kq, lv == 0 ? img0 : pyramid + L.img_off, lv == 0 ? pitch0 : L.pitch, L.rows, L.cols, lv,
+                                bad_scale, bad_reach, bad_smax, bad_sfixed);
     }
 }
 
@@ -2118,10 +2130,13 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
         int nmax = 0;
         for (int s = 0; s < H.nlevels; s++) if (H.lv[s].active) nmax += H.lv[s].quota;
         if (nmax > a.capacity) nmax = a.capacity;
-        if (nmax > 0)
+        if (nmax > 0) {
             hipLaunchKernelGGL(angle_kernel, dim3((nmax + ANGLE_KP - 1) / ANGLE_KP), dim3(ANGLE_KP * 32), 0, stream, a.d_table, a.d_count, a.capacity,
+                               a.img0, a.pitch0, a.pyramid, a.kp4, a.kp_level);
+            hipLaunchKernelGGL(angle_tail_kernel, dim3((nmax + 63) / 64), dim3(64), 0, stream, a.d_table, a.d_count, a.capacity,
                                a.img0, a.pitch0, a.pyramid, a.kp4, a.kp_level, (uint8_t*)a.d_keypoints, a.kps_pitch,
                                static_cast<Affine*>(a.bad_affine), a.bad_scale, a.bad_reach, a.bad_smax, a.bad_sfixed);
+        }
     }
     a.prof.end(prof, 3, stream);
     EFX_TRACE_POINT("angle");
