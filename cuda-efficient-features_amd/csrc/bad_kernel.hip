@@ -281,6 +281,13 @@ __global__ __launch_bounds__(256) void bad_kernel(
 // Measured and dropped: blur item lists limited to the disc the boxes can reach (71 % of the pixels, but the 3-row apron
 // leaves 195 of 216 row-pass items: no wave is saved and the compacted order costs bank conflicts).
 // ================================================================================================
+// INVESTIGATION (-DBAD_DET_STOP=n builds, tools/microbench/bad_phases.sh): the kernel returns after phase n, so that the
+// instruction counters of successive builds give the phases' shares (results are NOT valid)
+#ifdef BAD_DET_STOP
+#define BAD_DET_PHASE(n) do { if (BAD_DET_STOP == (n)) return; } while (0)
+#else
+#define BAD_DET_PHASE(n) do { } while (0)
+#endif
 __global__ __launch_bounds__(256) void bad_det_kernel(
     const int* __restrict__ d_count, int n, const BadParamsDev* __restrict__ P, const Affine* __restrict__ aff,
     float taps0, float taps1, float taps2, float taps3, uint8_t* __restrict__ desc, size_t desc_pitch)
@@ -339,6 +346,10 @@ __global__ __launch_bounds__(256) void bad_det_kernel(
                 asm volatile("" : "+s"(wb) : : "memory");
                 if (!border) { t0 = bad_ubox_taps(A, q0, wb); if (nbits > 256) t1 = bad_ubox_taps(A, q1, wb); }
             });
+#ifdef BAD_DET_STOP
+        if (BAD_DET_STOP < 2) return;                           // the blur returned early (blur_window.h)
+#endif
+        BAD_DET_PHASE(2);                                       // record, window loads, taps, blur
         __syncthreads();
         // row prefix from the u8 plane: P'[r][x] = sum of row r left of column x, x = 0 .. 49, as 25 packed pairs into plane
         // row r + 1.  Two lanes per row (waves 0 and 1: 96 lanes), 24 pixels each; the second adds the first one's total
@@ -372,6 +383,7 @@ __global__ __launch_bounds__(256) void bad_det_kernel(
         } else if (tid >= 128 && tid < 128 + JD) {
             Jd[tid - 128] = 0u;
         }
+        BAD_DET_PHASE(3);                                       // + row prefix
         __syncthreads();
         // column prefix IN PLACE (v_pk_add_u16, modulo 2^16): wave 0, lane = column pair + 32 x (upper / lower 24 rows); the
         // lower half adds the upper half's total (lane - 32: ds_bpermute)
@@ -394,6 +406,7 @@ __global__ __launch_bounds__(256) void bad_det_kernel(
             }
         }
     }
+    BAD_DET_PHASE(4);                                           // + column prefix
     __syncthreads();
 
     const int fw = cols + 1, fh = rows + 1;       // integral image dims of the full frame

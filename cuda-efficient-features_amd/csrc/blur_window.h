@@ -113,6 +113,12 @@ __device__ __forceinline__ void efx_blur_window_lds(const uint8_t* __restrict__ 
             for (int c = tid & 63; c < RP; c += 64) raw[r * RPB + c] = src[efx_reflect101(wx0 - 3 + c, cols)];
         }
     }
+#if defined(BAD_DET_STOP)                                    // INVESTIGATION builds (bad_kernel.hip): stop after the window loads / the row pass
+#define EFX_BLUR_STOP(n) do { if (BAD_DET_STOP == (n)) return; } while (0)
+#else
+#define EFX_BLUR_STOP(n) do { } while (0)
+#endif
+    EFX_BLUR_STOP(0);
     __syncthreads();
     const float tp[7] = { taps0, taps1, taps2, taps3, taps2, taps1, taps0 };
     // ---- row pass: u8 -> float, acc = fma(tap_j, v_j, acc) for j = 0..6.  An item is RO consecutive outputs of TWO
@@ -164,6 +170,7 @@ __device__ __forceinline__ void efx_blur_window_lds(const uint8_t* __restrict__ 
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     }
+    EFX_BLUR_STOP(1);
     __syncthreads();
     // ---- column pass: float -> u8 (round half even, saturate: v_cvt_pk_u8_f32).  An item is CR consecutive rows of
     //      TWO adjacent columns (S is even): CR + 6 ds_read_b64, 7 CR v_pk_fma_f32.
