@@ -1790,9 +1790,14 @@ __global__ __launch_bounds__(64) void emit_kernel(const LevelTable* __restrict__
 // moments are order-independent, the wave reduction gives exactly the reference's m_01 / m_10.
 // ================================================================================================
 #define ANGLE_KP 8              // keypoints per workgroup (two per wave)
+// TAIL: the workgroup also turns its ANGLE_KP moments into angles (and records) itself, on ANGLE_KP lanes of one wave -- the
+// form for small frames, where a second launch costs more than those ~1100 serial instructions (FHD: 7 us against 4.8 + 4.6)
+template <bool TAIL>
 __global__ __launch_bounds__(ANGLE_KP * 32) void angle_kernel(const LevelTable* __restrict__ T, const int* __restrict__ d_count, int capacity,
                                                     const uint8_t* __restrict__ img0, int pitch0, const uint8_t* __restrict__ pyramid,
-                                                    float4* __restrict__ kp4, const int* __restrict__ kp_level)
+                                                    float4* __restrict__ kp4, const int* __restrict__ kp_level,
+                                                    uint8_t* __restrict__ kps, size_t kps_pitch,
+                                                    Affine* __restrict__ aff, float bad_scale, float bad_reach, int bad_smax, int bad_sfixed)
 {
     // The intensity-centroid moments m01, m10 of every keypoint's patch; two keypoints per wave (31 of each 32 lanes hold
     // one patch column), ANGLE_KP per workgroup.  The moments are left in the .z / .w words of the keypoint's kp4 entry
@@ -1838,7 +1843,28 @@ __global__ __launch_bounds__(ANGLE_KP * 32) void angle_kernel(const LevelTable* 
     }
 #pragma unroll
     for (int d = 16; d >= 1; d >>= 1) { m10 += __shfl_xor(m10, d, 64); m01 += __shfl_xor(m01, d, 64); }
-    if (act && lane == 0) *reinterpret_cast<int2*>(&kp4[kid].z) = make_int2(m10, m01);
+    if (!TAIL) {
+        if (act && lane == 0) *reinterpret_cast<int2*>(&kp4[kid].z) = make_int2(m10, m01);
+        return;
+    }
+    // the double-precision atan2 (spec S7) is ~100 instructions: the 8 keypoints of the workgroup share one pass of it
+    __shared__ int s_m[ANGLE_KP][2];
+    if (lane == 0) { s_m[threadIdx.x >> 5][0] = m01; s_m[threadIdx.x >> 5][1] = m10; }
+    __syncthreads();
+    const int k8 = group * ANGLE_KP + threadIdx.x;
+    if (threadIdx.x < ANGLE_KP && k8 < count) {
+        const float angle = atan2_deg(s_m[threadIdx.x][0], s_m[threadIdx.x][1]);
+        kp4[k8].w = angle;
+        if (kps) *reinterpret_cast<float*>(kps + 2 * kps_pitch + 4 * (size_t)k8) = angle;
+        if (aff) {
+            // the BAD describer's record of this keypoint, while its angle is in a register (saves bad_affine_kernel's launch)
+            float4 kq = kp4[k8]; kq.w = angle;
+            const int lv = kp_level[k8];
+            const LevelDev& L = T->lv[lv];
+            aff[k8] = efx_bad_affine(kq, lv == 0 ? img0 : pyramid + L.img_off, lv == 0 ? pitch0 : L.pitch, L.rows, L.cols, lv,
+                                     bad_scale, bad_reach, bad_smax, bad_sfixed);
+        }
+    }
 }
 
 // The angle from the moments (calcAngles, .cu:376-390; the double-precision atan2 of spec S7), one lane per keypoint; the
@@ -2130,9 +2156,14 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
         int nmax = 0;
         for (int s = 0; s < H.nlevels; s++) if (H.lv[s].active) nmax += H.lv[s].quota;
         if (nmax > a.capacity) nmax = a.capacity;
-        if (nmax > 0) {
-            hipLaunchKernelGGL(angle_kernel, dim3((nmax + ANGLE_KP - 1) / ANGLE_KP), dim3(ANGLE_KP * 32), 0, stream, a.d_table, a.d_count, a.capacity,
-                               a.img0, a.pitch0, a.pyramid, a.kp4, a.kp_level);
+        if (nmax > 0 && use_tower) {
+            // small frames (the ones whose pyramid is one tower launch): angles and records in the same launch
+            hipLaunchKernelGGL(angle_kernel<true>, dim3((nmax + ANGLE_KP - 1) / ANGLE_KP), dim3(ANGLE_KP * 32), 0, stream, a.d_table, a.d_count, a.capacity,
+                               a.img0, a.pitch0, a.pyramid, a.kp4, a.kp_level, (uint8_t*)a.d_keypoints, a.kps_pitch,
+                               static_cast<Affine*>(a.bad_affine), a.bad_scale, a.bad_reach, a.bad_smax, a.bad_sfixed);
+        } else if (nmax > 0) {
+            hipLaunchKernelGGL(angle_kernel<false>, dim3((nmax + ANGLE_KP - 1) / ANGLE_KP), dim3(ANGLE_KP * 32), 0, stream, a.d_table, a.d_count, a.capacity,
+                               a.img0, a.pitch0, a.pyramid, a.kp4, a.kp_level, nullptr, 0, nullptr, 0.f, 0.f, 0, 0);
             hipLaunchKernelGGL(angle_tail_kernel, dim3((nmax + 63) / 64), dim3(64), 0, stream, a.d_table, a.d_count, a.capacity,
                                a.img0, a.pitch0, a.pyramid, a.kp4, a.kp_level, (uint8_t*)a.d_keypoints, a.kps_pitch,
                                static_cast<Affine*>(a.bad_affine), a.bad_scale, a.bad_reach, a.bad_smax, a.bad_sfixed);
