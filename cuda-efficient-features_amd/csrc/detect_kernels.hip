@@ -247,14 +247,65 @@ __device__ __forceinline__ uint32_t resize_quad(const uint8_t* ra, const uint8_t
                                                 float wy0, float wy1)
 {
     uint32_t packed = 0;
+    // the right neighbour is read through an offset the compiler cannot see: it would merge the two byte reads into ONE
+    // unaligned ds_read_u16, which is a slow path of the LDS (measured: 40 us instead of 11 for a level)
+    int one = 1;
+    asm volatile("" : "+v"(one));
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const uint8_t* pa = ra + lc[k];
         const uint8_t* pb = rb + lc[k];
         float out = (float)pa[0] * (wa[k] * wy0);                    // == 0.f + ... exactly
-        out = out + (float)pa[1] * (wb[k] * wy0);
+        out = out + (float)pa[one] * (wb[k] * wy0);
         out = out + (float)pb[0] * (wa[k] * wy1);
-        out = out + (float)pb[1] * (wb[k] * wy1);
+        out = out + (float)pb[one] * (wb[k] * wy1);
+        packed = __builtin_amdgcn_cvt_pk_u8_f32(out, k, packed);     // rint (half even) + saturate + pack
+    }
+    return packed;
+}
+
+// The same four outputs with a quarter of the LDS instructions (round 3): the source pixels of outputs 0, 1 lie within 8
+// bytes of the dword that holds the first of them, those of outputs 2, 3 likewise (scale factors up to 4), so a row costs two
+// ds_read2_b32 instead of eight ds_read_u8, and one v_perm_b32 per window lines the four bytes up (left / right pixel of
+// output k, left / right of output k + 1) for v_cvt_f32_ubyte0..3.  The windows' offsets and byte selectors do not depend on
+// the row: resize_windows() once per lane and tile.  ra / rb must be 4-byte aligned (LDS row pitches are multiples of 4).
+struct ResizeWin { int offA, offB; uint32_t selA, selB; bool ok; };
+__device__ __forceinline__ ResizeWin resize_windows(const int (&lc)[4])
+{
+    ResizeWin w;
+    w.offA = lc[0] & ~3; w.offB = lc[2] & ~3;
+    const int a0 = lc[0] - w.offA, a1 = lc[1] - w.offA, b0 = lc[2] - w.offB, b1 = lc[3] - w.offB;
+    w.selA = (uint32_t)a0 | ((uint32_t)(a0 + 1) << 8) | ((uint32_t)a1 << 16) | ((uint32_t)(a1 + 1) << 24);
+    w.selB = (uint32_t)b0 | ((uint32_t)(b0 + 1) << 8) | ((uint32_t)b1 << 16) | ((uint32_t)(b1 + 1) << 24);
+    w.ok = a1 >= a0 && a1 + 1 <= 7 && b1 >= b0 && b1 + 1 <= 7;
+    return w;
+}
+__device__ __forceinline__ uint32_t resize_quad_win(const uint8_t* ra, const uint8_t* rb, const ResizeWin& w, const float (&wa)[4], const float (&wb)[4],
+                                                    float wy0, float wy1)
+{
+#ifdef EFX_RESIZE_NO_WIN                                     // INVESTIGATION builds (bench_ab.sh): the byte reads
+    {
+        const int a0 = (int)(w.selA & 7u), a1 = (int)((w.selA >> 16) & 7u), b0 = (int)(w.selB & 7u), b1 = (int)((w.selB >> 16) & 7u);
+        const int lc[4] = { w.offA + a0, w.offA + a1, w.offB + b0, w.offB + b1 };
+        return resize_quad(ra, rb, lc, wa, wb, wy0, wy1);
+    }
+#endif
+    const uint32_t* qa = reinterpret_cast<const uint32_t*>(ra + w.offA);
+    const uint32_t* qb = reinterpret_cast<const uint32_t*>(rb + w.offA);
+    const uint32_t* ta = reinterpret_cast<const uint32_t*>(ra + w.offB);
+    const uint32_t* tb = reinterpret_cast<const uint32_t*>(rb + w.offB);
+    const uint32_t a0 = qa[0], a1 = qa[1], b0 = qb[0], b1 = qb[1], c0 = ta[0], c1 = ta[1], d0 = tb[0], d1 = tb[1];
+    // bytes of pr[h][0]: left, right pixel of output 2h, left, right of output 2h + 1, in source row a; pr[h][1]: row b
+    const uint32_t pr[2][2] = { { __builtin_amdgcn_perm(a1, a0, w.selA), __builtin_amdgcn_perm(b1, b0, w.selA) },
+                                { __builtin_amdgcn_perm(c1, c0, w.selB), __builtin_amdgcn_perm(d1, d0, w.selB) } };
+    uint32_t packed = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t pa = pr[k >> 1][0] >> (16 * (k & 1)), pb = pr[k >> 1][1] >> (16 * (k & 1));
+        float out = (float)(pa & 0xffu) * (wa[k] * wy0);              // == 0.f + ... exactly
+        out = out + (float)((pa >> 8) & 0xffu) * (wb[k] * wy0);
+        out = out + (float)(pb & 0xffu) * (wa[k] * wy1);
+        out = out + (float)((pb >> 8) & 0xffu) * (wb[k] * wy1);
         packed = __builtin_amdgcn_cvt_pk_u8_f32(out, k, packed);     // rint (half even) + saturate + pack
     }
     return packed;
@@ -345,13 +396,15 @@ __global__ __launch_bounds__(NT) void resize_kernel(
         lc[k] = x1 - ax0;                                   // the clamped +1 neighbour is the next LDS byte
     }
     const bool full4 = oxq + 4 <= ox1 && ((((uintptr_t)dst) | (uintptr_t)dpitch) & 3u) == 0;
+    const ResizeWin win = resize_windows(lc);
+    const bool use_win = __ballot(!win.ok) == 0ull;
     const int4* ytab = reinterpret_cast<const int4*>(smem + ytab_off);
     for (int oy = oy0 + rq; oy < oy1; oy += NT / 16) {
         const int4 yt = ytab[oy - oy0];
         const float wy0 = __int_as_float(yt.z), wy1 = __int_as_float(yt.w);
         const uint8_t* ra = smem + yt.x;
         const uint8_t* rb = smem + yt.y;
-        const uint32_t packed = resize_quad(ra, rb, lc, wx0, wx1, wy0, wy1);
+        const uint32_t packed = use_win ? resize_quad_win(ra, rb, win, wx0, wx1, wy0, wy1) : resize_quad(ra, rb, lc, wx0, wx1, wy0, wy1);
         uint8_t* d = dst + (size_t)oy * dpitch + oxq;
         if (full4) *reinterpret_cast<uint32_t*>(d) = packed;
         else
@@ -455,13 +508,14 @@ __global__ __launch_bounds__(256) void resize_stream_kernel(
             const int lc[4] = { x1.x - ax0, x1.y - ax0, x1.z - ax0, x1.w - ax0 };
             const float wa[4] = { wx0.x, wx0.y, wx0.z, wx0.w }, wb[4] = { wx1.x, wx1.y, wx1.z, wx1.w };
             const bool full4 = oxq + 4 <= ox1 && dst4;
+            const ResizeWin win = resize_windows(lc);             // always valid here: the host sends scale factors up to ~1.22 only
             const int4* ytab = reinterpret_cast<const int4*>(smem + RS_YTAB);
             for (int oy = oy0 + rq; oy < oy1; oy += 16) {
                 const int4 yt = ytab[oy - oy0];
                 const float wy0 = __int_as_float(yt.z), wy1 = __int_as_float(yt.w);
                 const uint8_t* ra = smem + yt.x;
                 const uint8_t* rb = smem + yt.y;
-                const uint32_t packed = resize_quad(ra, rb, lc, wa, wb, wy0, wy1);
+                const uint32_t packed = resize_quad_win(ra, rb, win, wa, wb, wy0, wy1);
                 uint8_t* d = dst + (size_t)oy * dpitch + oxq;
                 if (full4) *reinterpret_cast<uint32_t*>(d) = packed;
                 else
@@ -628,12 +682,13 @@ __global__ __launch_bounds__(NT) void pyramid_tower_kernel(const LevelTable* __r
                 lc[k] = x1 - lox0;
             }
             const bool colfull = oxq >= ownlox && oxq + 4 <= ownhix;
+            const ResizeWin win = resize_windows(lc);             // always valid: plan_tower refuses scale factors above 3.5
             for (int i = rq; i < H; i += rstep) {
                 const int4 t4 = *reinterpret_cast<const int4*>(smem + yt + i * 16);
                 const float wy0 = __int_as_float(t4.z), wy1 = __int_as_float(t4.w);
                 const uint8_t* ra = smem + sb + t4.x;
                 const uint8_t* rb = smem + sb + t4.y;
-                const uint32_t packed = resize_quad(ra, rb, lc, wx0, wx1, wy0, wy1);
+                const uint32_t packed = resize_quad_win(ra, rb, win, wx0, wx1, wy0, wy1);
                 if (keep) *reinterpret_cast<uint32_t*>(smem + db + i * lp1 + 4 * g) = packed;
                 const int oy = loy1 + i;
                 if (oy >= ownloy && oy < ownhiy) {
@@ -1956,6 +2011,7 @@ static bool plan_tower(const LevelTable& H, int last, const uint8_t* img0, int p
     // (8K levels 4..7) does not pay: those levels are as large as a 4K pyramid and the tower recomputes ~1.7x the pixels.
     if ((long long)H.lv[0].rows * H.lv[0].cols > EFX_TOWER_MAX_PX) return false;
     if (no_tower) return false;                               // EFX_NO_TOWER (tests): exercise the per-level kernels on small frames
+    for (int s = 1; s <= last; s++) if (H.lv[s].fx > 3.5f || H.lv[s].fy > 3.5f) return false;     // resize_quad_win: source columns of neighbouring outputs within 8 bytes
     // Tile edge of the top level.  The kernel is a chain of dependent levels, so a workgroup's time hardly shrinks with
     // its tile; what counts is how the workgroups (1024 threads, at most two per CU) spread over the 256 CUs.  Measured
     // (tower time per edge, tools/microbench/tower_tt.sh): VGA 12: 14.1 us (180 WGs), 32: 19.2 (30); 720p 20: 16.4 (198),
