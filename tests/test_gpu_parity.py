@@ -651,7 +651,7 @@ def test_equal_responses_suppress_each_other(cef, torch_mod, oracle, period, rad
 
 
 @pytest.mark.parametrize("mode", ["tower", "chain_streamed", "chain_plain"])
-@pytest.mark.parametrize("shape,scale", [((480, 640), 1.2), ((501, 703), 1.2), ((333, 1111), 1.1), ((700, 900), 1.5)])
+@pytest.mark.parametrize("shape,scale", [((480, 640), 1.2), ((501, 703), 1.2), ((333, 1111), 1.1), ((700, 900), 1.5), ((600, 800), 2.0)])
 def test_pyramid_kernel_variants_bit_exact(cef, torch_mod, oracle, monkeypatch, mode, shape, scale):
     """The three ways a pyramid is produced -- one tower launch (small frames), the streamed per-level kernel and the
     one-tile-per-workgroup per-level kernel (large frames / other scale factors) -- give the same levels, bit for bit."""
