@@ -166,8 +166,9 @@ __device__ __forceinline__ float harris_rows(const uint8_t* p0, int P)
     const uint8_t* wb = p0 - sh;
     // Row by row (rolling, to keep the live register set small): E[j] = columns (2j, 2j+1) for j < 4,
     // E[4] = (8, 7); O[j] = columns (2j+1, 2j+2); H[j] = horizontal 1-2-1 sums at columns (2j+1, 2j+2);
-    // S = E(row-1) + E(row) vertical pair sums; V = S(r-1) + S(r) vertical 1-2-1 sums.
-    u16x2 Hm2[4], Hm1[4], Sm1[5], Em1[5];      // H(row-2), H(row-1), S(row-1), E(row-1)
+    // D[j] = E[j+1] - E[j] = horizontal differences p[x+1] - p[x-1] at the same columns (round 3: the vertical 1-2-1 of
+    // the differences instead of the difference of vertical 1-2-1 sums: 12 instead of 14 instructions per row).
+    u16x2 Hm2[4], Hm1[4], Dm2[4], Dm1[4];      // H(row-2), H(row-1), D(row-2), D(row-1)
     const u16x2 two2 = { 2, 2 };
     int sxx = 0, sxy = 0, syy = 0;
 #pragma unroll
@@ -176,7 +177,7 @@ __device__ __forceinline__ float harris_rows(const uint8_t* p0, int P)
         const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
         const uint32_t a = __builtin_amdgcn_alignbyte(w1, w0, sh), b = __builtin_amdgcn_alignbyte(w2, w1, sh);
         const uint32_t t = w2 >> (8 * sh);
-        u16x2 E[5], O[4], H[4], S[5];
+        u16x2 E[5], O[4], H[4], D[4];
         E[0] = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(b, a, 0x0c010c00u));
         E[1] = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(b, a, 0x0c030c02u));
         E[2] = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(b, a, 0x0c050c04u));
@@ -191,20 +192,16 @@ __device__ __forceinline__ float harris_rows(const uint8_t* p0, int P)
             // H = 2 * O + (E[j] + E[j+1]) as one v_pk_mad_u16 (the compiler turns the doubling into a separate shift)
             const u16x2 e = E[j] + E[j + 1];
             asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(H[j]) : "v"(O[j]), "v"(two2), "v"(e));
-        }
-        if (row >= 1) {
-#pragma unroll
-            for (int j = 0; j < 5; j++) S[j] = Em1[j] + E[j];
+            D[j] = E[j + 1] - E[j];                               // the high half of D[3] is p7 - p7 = 0: ix = 7 does not exist
         }
         if (row >= 2) {
-            // output row r = row - 1: dx = V[ix+2] - V[ix] (the high half of the j == 3 pair is V7 - V7 = 0),
-            // dy = H(r+1) - H(r-1)
-            u16x2 V[5];
-#pragma unroll
-            for (int j = 0; j < 5; j++) V[j] = Sm1[j] + S[j];
+            // output row r = row - 1: dx = D(r-1) + 2 D(r) + D(r+1), dy = H(r+1) - H(r-1)
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const i16x2 dx = __builtin_bit_cast(i16x2, (u16x2)(V[j + 1] - V[j]));
+                const u16x2 dsum = Dm2[j] + D[j];
+                u16x2 dxu;
+                asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(dxu) : "v"(Dm1[j]), "v"(two2), "v"(dsum));
+                const i16x2 dx = __builtin_bit_cast(i16x2, dxu);
                 uint32_t dyu = __builtin_bit_cast(uint32_t, (u16x2)(H[j] - Hm2[j]));
                 if (j == 3) dyu &= 0xffffu;                      // ix = 7 does not exist
                 const i16x2 dy = __builtin_bit_cast(i16x2, dyu);
@@ -214,9 +211,7 @@ __device__ __forceinline__ float harris_rows(const uint8_t* p0, int P)
             }
         }
 #pragma unroll
-        for (int j = 0; j < 4; j++) { Hm2[j] = Hm1[j]; Hm1[j] = H[j]; }
-#pragma unroll
-        for (int j = 0; j < 5; j++) { Sm1[j] = S[j]; Em1[j] = E[j]; }
+        for (int j = 0; j < 4; j++) { Hm2[j] = Hm1[j]; Hm1[j] = H[j]; Dm2[j] = Dm1[j]; Dm1[j] = D[j]; }
     }
     return harris_from_sums(sxx, sxy, syy);
 }
