@@ -459,10 +459,12 @@ __global__ __launch_bounds__(256) void resize_stream_kernel(
     uint8_t* stage = smem + r0 * RS_LP + 4 * j0;
     uint32_t pf[NP];
     auto issue = [&](const int4 g) {
-        // lanes beyond the footprint's dwords read beyond the resource: the hardware range check returns 0, no branch
+        // lanes beyond the footprint's dwords read beyond the resource: the hardware range check returns 0, no branch.  The
+        // row step is part of the per-lane offset: the check looks at that offset alone (a scalar offset is added to the
+        // address unchecked -- until round 3 the rows below the last image row were read from whatever follows the image)
         const int base = j0 < (g.z & 0xff) ? g.x * spitch + g.y + lane_off : 0x7ffffff0;
 #pragma unroll
-        for (int p = 0; p < NP; p++) pf[p] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, base, 8 * p * spitch, 0);
+        for (int p = 0; p < NP; p++) pf[p] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, base + 8 * p * spitch, 0, 0);
     };
 
     int4 g = ttab[tile];
@@ -714,6 +716,26 @@ __device__ __forceinline__ void load_tile_lds(uint32_t* s_tile, const uint8_t* _
     if (aligned) {
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src), 0, (rows - 1) * spitch + cols, 0x00020000);
         const int base = (y0 - EFX_HALO) * spitch + x0 - EFX_HALO;
+        if (NT == 256) {
+            // 9 pieces x 28 rows per pass (252 of the 256 threads), three passes: a thread's piece and row are worked out
+            // once, a pass adds 28 rows -- one addition for the global offset, an immediate for the LDS address
+            // (round 3: the running index cost a division by 9 and three multiply-adds per piece, 36 instructions per wave
+            // and tile; now 12)
+            const int r0 = tid / 9, c8 = tid - r0 * 9;
+            if (tid < 252) {
+                const int goff = base + r0 * spitch + c8 * 8;
+                uint8_t* l = reinterpret_cast<uint8_t*>(s_tile) + r0 * EFX_LP + c8 * 8;
+                // (the row step goes into the per-lane offset: the hardware range check looks at that offset alone, not at a
+                // scalar one added to it, and the halo rows above / below the image rely on the check)
+                const efx_u32x2 v0 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, goff, 0, 0);
+                const efx_u32x2 v1 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, goff + 28 * spitch, 0, 0);
+                const efx_u32x2 v2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, goff + 56 * spitch, 0, 0);
+                *reinterpret_cast<efx_u32x2*>(l) = v0;
+                *reinterpret_cast<efx_u32x2*>(l + 28 * EFX_LP) = v1;
+                if (r0 + 56 < EFX_LT) *reinterpret_cast<efx_u32x2*>(l + 56 * EFX_LP) = v2;
+            }
+            return;
+        }
         for (int i = tid; i < EFX_LT * 9; i += NT) {
             const int r = i / 9, c8 = i - r * 9;
             const efx_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, base + r * spitch + c8 * 8, 0, 0);
