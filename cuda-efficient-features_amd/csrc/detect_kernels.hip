@@ -1124,13 +1124,21 @@ __global__ __launch_bounds__(64 * NW) void nms_kernel(const LevelTable* __restri
     if (NW > 1 && wv > 0 && 64 * wv >= (int)hl[tile].cell_off[EFX_CELLS_PER_TILE]) return;
     if (tid < 64) s_keep[tid] = 0ull;
     if (tid == 0) s_void = 0;
-    for (int i = tid; i < 9 * 16 && tid < 64; i += 64) {
-        const int t = i >> 4, w = i & 15;
-        const int ntx = tx - 1 + (t % 3), nty = ty - 1 + (t / 3);
-        uint32_t v = 0u;
-        if (ntx >= 0 && ntx < L.tiles_x && nty >= 0 && nty < L.tiles_y)
-            v = reinterpret_cast<const uint32_t*>(&hl[nty * L.tiles_x + ntx])[w];
-        s_nb[t][w] = v;
+    // nine headers of 64 bytes: eight lanes x 8 bytes per header, eight headers in the first pass, the ninth in a second one
+    // (round 3: 16 lanes x 4 bytes and three passes with a division by three each)
+    if (tid < 64) {
+#pragma unroll
+        for (int pass = 0; pass < 2; pass++) {
+            const int t = (tid >> 3) + 8 * pass, w2 = tid & 7;
+            if (t < 9) {
+                const int dyt = (t * 11) >> 5, dxt = t - 3 * dyt;            // t / 3, t % 3 for t < 9
+                const int ntx = tx - 1 + dxt, nty = ty - 1 + dyt;
+                uint2 v = make_uint2(0u, 0u);
+                if (ntx >= 0 && ntx < L.tiles_x && nty >= 0 && nty < L.tiles_y)
+                    v = reinterpret_cast<const uint2*>(&hl[nty * L.tiles_x + ntx])[w2];
+                *reinterpret_cast<uint2*>(&s_nb[t][2 * w2]) = v;
+            }
+        }
     }
     // the per-cell maxima include corners beyond the 10 % cap; when the cap is active (pathological frames) a cell
     // maximum is a valid suppressor only if its whole tile lies below the cap
