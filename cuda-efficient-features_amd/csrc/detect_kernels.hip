@@ -1826,28 +1826,33 @@ __global__ __launch_bounds__(64) void emit_kernel(const LevelTable* __restrict__
                                                   uint8_t* __restrict__ kps, size_t kps_pitch, int capacity,
                                                   float4* __restrict__ kp4, int* __restrict__ kp_level)
 {
-    const int gt = blockIdx.x;
-    int l, tx, ty;
-    efx_tile_of(T, gt, l, tx, ty);
+    // TWO tiles per wave, 32 lanes each (round 3): a tile has three survivors on average and the kernel is a chain of
+    // dependent loads per wave (tile word -> header -> survivors), so its time is the number of waves the chip must cycle
+    // through: 25 500 one-tile waves took 3.1 rounds of the chip's 8192 wave slots, 12 750 take 1.6
+    const int lane = threadIdx.x, half = lane >> 5, sub = lane & 31;
+    const int gt = 2 * (int)blockIdx.x + half;
+    const bool tile_ok = gt < T->total_tiles;
+    int l = 0, tx = 0, ty = 0;
+    if (tile_ok) efx_tile_of(T, gt, l, tx, ty);
     const LevelDev& L = T->lv[l];
-    if (!L.active) return;
-    const TileHdr& h = hdr[gt];
-    const int sc = (int)h.surv_count;
-    if (sc == 0 || cnt->sum.overflow) return;
+    const bool act = tile_ok && L.active && !cnt->sum.overflow;
+    const int sc = act ? (int)hdr[gt].surv_count : 0;
+    const int out_off = act ? (int)hdr[gt].out_off : 0;
+    const int sc_max = max(__shfl(sc, 0, 64), __shfl(sc, 32, 64));
+    if (sc_max == 0) return;
     const unsigned long long thresh = cnt->thresh[l];
-    const Corner* q = surv_all + L.surv_base + (size_t)((gt - L.tile_base) & (EFX_NSUB - 1)) * L.surv_sub_cap + h.surv_start;
-    const int lane = threadIdx.x;
+    const Corner* q = surv_all + L.surv_base + (size_t)((gt - L.tile_base) & (EFX_NSUB - 1)) * L.surv_sub_cap + (act ? hdr[gt].surv_start : 0u);
 
     int running = 0;
-    for (int i0 = 0; i0 < sc; i0 += 64) {
-        const int i = i0 + lane;
+    for (int i0 = 0; i0 < sc_max; i0 += 32) {
+        const int i = i0 + sub;
         Corner c; c.xy = 0; c.resp = 0.f;
         bool sel = false;
         if (i < sc) { c = q[i]; sel = efx_select_key(c.xy, c.resp) >= thresh; }
-        const unsigned long long m = __ballot(sel);
-        const int rank = __popcll(m & ((1ull << lane) - 1ull));
-        const int out = (int)h.out_off + running + rank;
-        running += __popcll(m);
+        const unsigned m = (unsigned)(__ballot(sel) >> (32 * half));     // this tile's 32 lanes
+        const int rank = __popc(m & ((1u << sub) - 1u));
+        const int out = out_off + running + rank;
+        running += __popc(m);
         if (sel && out < capacity) {
             const int x = c.xy & 0xffff, y = c.xy >> 16;
             const short sx = (short)(L.scale * (float)x + 0.5f);
@@ -2230,7 +2235,7 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
     hipLaunchKernelGGL(select_kernel, dim3(H.nlevels), dim3(1024), SEL_LDS_BYTES, stream, a.d_table, a.hdr, a.surv, a.counters,
                        a.capacity, a.d_count);
     EFX_TRACE_POINT("select");
-    hipLaunchKernelGGL(emit_kernel, dim3(H.total_tiles), dim3(64), 0, stream, a.d_table, a.hdr, a.surv, a.counters,
+    hipLaunchKernelGGL(emit_kernel, dim3((H.total_tiles + 1) / 2), dim3(64), 0, stream, a.d_table, a.hdr, a.surv, a.counters,
                        a.img0, a.pitch0, a.pyramid, (uint8_t*)a.d_keypoints, a.kps_pitch, a.capacity, a.kp4, a.kp_level);
     EFX_TRACE_POINT("emit");
     if (a.capacity > 0) {
