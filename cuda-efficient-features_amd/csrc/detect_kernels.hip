@@ -1820,17 +1820,21 @@ __device__ __forceinline__ float atan2_deg(int m01, int m10)
 // ================================================================================================
 // (Four tiles per 256-thread workgroup were measured: 10.6 against 9.6 us.  The kernel is a chain of dependent loads --
 // header, threshold, survivors -- per wave, not a workgroup-launch-rate problem.)
+#ifndef EMIT_TPW
+#define EMIT_TPW 4
+#endif
 __global__ __launch_bounds__(64) void emit_kernel(const LevelTable* __restrict__ T, const TileHdr* __restrict__ hdr,
                                                   const Corner* __restrict__ surv_all, const Counters* __restrict__ cnt,
                                                   const uint8_t* __restrict__ img0, int pitch0, const uint8_t* __restrict__ pyramid,
                                                   uint8_t* __restrict__ kps, size_t kps_pitch, int capacity,
                                                   float4* __restrict__ kp4, int* __restrict__ kp_level)
 {
-    // TWO tiles per wave, 32 lanes each (round 3): a tile has three survivors on average and the kernel is a chain of
-    // dependent loads per wave (tile word -> header -> survivors), so its time is the number of waves the chip must cycle
-    // through: 25 500 one-tile waves took 3.1 rounds of the chip's 8192 wave slots, 12 750 take 1.6
-    const int lane = threadIdx.x, half = lane >> 5, sub = lane & 31;
-    const int gt = 2 * (int)blockIdx.x + half;
+    // EMIT_TPW tiles per wave, 64 / EMIT_TPW lanes each (round 3): a tile has three survivors on average and the kernel is a
+    // chain of dependent loads per wave (tile word -> header -> survivors), so its time is the number of waves the chip must
+    // cycle through: 25 500 one-tile waves took 3.1 rounds of the chip's 8192 wave slots
+    constexpr int LPT = 64 / EMIT_TPW;                      // lanes per tile
+    const int lane = threadIdx.x, part = lane / LPT, sub = lane % LPT;
+    const int gt = EMIT_TPW * (int)blockIdx.x + part;
     const bool tile_ok = gt < T->total_tiles;
     int l = 0, tx = 0, ty = 0;
     if (tile_ok) efx_tile_of(T, gt, l, tx, ty);
@@ -1838,18 +1842,20 @@ __global__ __launch_bounds__(64) void emit_kernel(const LevelTable* __restrict__
     const bool act = tile_ok && L.active && !cnt->sum.overflow;
     const int sc = act ? (int)hdr[gt].surv_count : 0;
     const int out_off = act ? (int)hdr[gt].out_off : 0;
-    const int sc_max = max(__shfl(sc, 0, 64), __shfl(sc, 32, 64));
+    int sc_max = sc;
+#pragma unroll
+    for (int d = LPT; d < 64; d <<= 1) sc_max = max(sc_max, __shfl_xor(sc_max, d, 64));
     if (sc_max == 0) return;
     const unsigned long long thresh = cnt->thresh[l];
     const Corner* q = surv_all + L.surv_base + (size_t)((gt - L.tile_base) & (EFX_NSUB - 1)) * L.surv_sub_cap + (act ? hdr[gt].surv_start : 0u);
 
     int running = 0;
-    for (int i0 = 0; i0 < sc_max; i0 += 32) {
+    for (int i0 = 0; i0 < sc_max; i0 += LPT) {
         const int i = i0 + sub;
         Corner c; c.xy = 0; c.resp = 0.f;
         bool sel = false;
         if (i < sc) { c = q[i]; sel = efx_select_key(c.xy, c.resp) >= thresh; }
-        const unsigned m = (unsigned)(__ballot(sel) >> (32 * half));     // this tile's 32 lanes
+        const unsigned m = (unsigned)(__ballot(sel) >> (LPT * part)) & (unsigned)((1ull << LPT) - 1ull);     // this tile's lanes
         const int rank = __popc(m & ((1u << sub) - 1u));
         const int out = out_off + running + rank;
         running += __popc(m);
@@ -2235,7 +2241,7 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
     hipLaunchKernelGGL(select_kernel, dim3(H.nlevels), dim3(1024), SEL_LDS_BYTES, stream, a.d_table, a.hdr, a.surv, a.counters,
                        a.capacity, a.d_count);
     EFX_TRACE_POINT("select");
-    hipLaunchKernelGGL(emit_kernel, dim3((H.total_tiles + 1) / 2), dim3(64), 0, stream, a.d_table, a.hdr, a.surv, a.counters,
+    hipLaunchKernelGGL(emit_kernel, dim3((H.total_tiles + EMIT_TPW - 1) / EMIT_TPW), dim3(64), 0, stream, a.d_table, a.hdr, a.surv, a.counters,
                        a.img0, a.pitch0, a.pyramid, (uint8_t*)a.d_keypoints, a.kps_pitch, a.capacity, a.kp4, a.kp_level);
     EFX_TRACE_POINT("emit");
     if (a.capacity > 0) {
