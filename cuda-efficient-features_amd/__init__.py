@@ -35,7 +35,7 @@ ABI_SYMBOLS = [
     "efx_set_descriptor_type", "efx_get_descriptor_type",
     "efx_descriptor_size", "efx_descriptor_dtype", "efx_default_norm",
     "efx_detect_async", "efx_detect_and_compute_async", "efx_compute_async", "efx_compute_kp4_async",
-    "efx_last_count", "efx_last_level_stats", "efx_overflow_events",
+    "efx_last_count", "efx_last_level_stats", "efx_overflow_events", "efx_tracked_streams",
     "efx_detect", "efx_compute", "efx_detect_and_compute", "efx_convert",
     "efx_bad_create", "efx_hashsift_create", "efx_describer_destroy", "efx_describer_descriptor_size",
     "efx_describer_last_error", "efx_describer_compute_kp4_async", "efx_describer_compute_async",
@@ -111,6 +111,7 @@ def lib():
                                             C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]
         L.efx_last_count.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.efx_overflow_events.restype = C.c_int; L.efx_overflow_events.argtypes = [C.c_void_p]
+        L.efx_tracked_streams.restype = C.c_int; L.efx_tracked_streams.argtypes = [C.c_void_p]
         L.efx_device_bytes.restype = C.c_size_t
         L.efx_trim_memory.restype = C.c_size_t; L.efx_trim_memory.argtypes = []
         L.efx_cached_bytes.restype = C.c_size_t; L.efx_cached_bytes.argtypes = []
@@ -333,8 +334,13 @@ class EfficientFeatures:
         return n.value
 
     def overflowEvents(self):
-        """Frames of this context that were void because they overflowed the density-sized arenas (include/efx.h)."""
+        """Times the context observed its overflow word set: at least one void frame each time (include/efx.h) -- several
+        void frames enqueued back to back count once."""
         return int(lib().efx_overflow_events(self._h))
+
+    def trackedStreams(self):
+        """Diagnostics: streams the context's release waits cover (include/efx.h: efx_tracked_streams)."""
+        return int(lib().efx_tracked_streams(self._h))
 
     def lastLevelStats(self):
         st = (LevelStats * 32)()

@@ -392,9 +392,10 @@ struct efx_context {
     bool arena_full = false;        // corner / survivor arenas sized for the worst case (set after a frame overflowed them)
     bool g_arena_full = false;      // ... as the cached geometry was built
     std::vector<hipStream_t> streams;   // streams this context has launched on since it last waited for them (ctx_quiesce)
+    hipStream_t active_stream = nullptr; bool has_active = false;   // the stream of the call on the stack (QuiesceScope)
     int* h_overflow = nullptr;      // sticky overflow word: pinned host memory the kernels store to (LevelTable::host_overflow)
     int* d_overflow = nullptr;      // ... its device address
-    int overflow_events = 0;        // frames that were void because of it (efx_overflow_events)
+    int overflow_events = 0;        // observations of the word set: >= 1 void frame each (efx_overflow_events)
     DetectLaunch last_launch;       // investigation (efx_debug_rerun): the last frame's launch arguments
     bool has_frame = false;
     const uint8_t* last_img0 = nullptr; int last_pitch0 = 0;
@@ -412,8 +413,25 @@ struct efx_context {
         for (hipStream_t st : c->streams) ok = ok && hipStreamSynchronize(st) == hipSuccess;
         if (!ok) { (void)hipGetLastError(); (void)hipDeviceSynchronize(); }      // e.g. a stream the caller has destroyed meanwhile
         c->streams.clear();
+        // the call that triggered this wait (a regrow inside detect / compute) launches on its stream AFTER the wait: that
+        // stream stays tracked, or the next release (another stream's regrow, the destructor) would not wait for this
+        // call's kernels and hand blocks they still use to the process-wide cache
+        if (c->has_active) c->streams.push_back(c->active_stream);
     }
-    void note_stream(hipStream_t st) { for (hipStream_t q : streams) if (q == st) return; streams.push_back(st); }
+    void note_stream(hipStream_t st)
+    {
+        for (hipStream_t q : streams) if (q == st) return;
+        // a caller that makes a stream per call: forget streams that have drained (or no longer exist) before the list grows
+        if (streams.size() >= 32) {
+            size_t k = 0;
+            for (hipStream_t q : streams) {
+                const hipError_t e = hipStreamQuery(q);
+                if (e == hipErrorNotReady) streams[k++] = q; else if (e != hipSuccess) (void)hipGetLastError();
+            }
+            streams.resize(k);
+        }
+        streams.push_back(st);
+    }
     ~efx_context()
     {
         Quiesce q = { &efx_context::quiesce_cb, this, false };
@@ -434,8 +452,15 @@ namespace {
 // while one of these is alive on the calling thread, blocks released by `c` (regrow, describer rebuild) wait for c's streams
 struct QuiesceScope {
     Quiesce q; Quiesce* prev;
-    explicit QuiesceScope(efx_context* c) : q{ &efx_context::quiesce_cb, c, false }, prev(tl_quiesce) { tl_quiesce = &q; }
-    ~QuiesceScope() { tl_quiesce = prev; }
+    efx_context* ctx; hipStream_t prev_stream; bool prev_has;
+    QuiesceScope(efx_context* c, hipStream_t stream)
+        : q{ &efx_context::quiesce_cb, c, false }, prev(tl_quiesce), ctx(c), prev_stream(c->active_stream), prev_has(c->has_active)
+    {
+        tl_quiesce = &q;
+        c->active_stream = stream; c->has_active = true;
+        c->note_stream(stream);
+    }
+    ~QuiesceScope() { tl_quiesce = prev; ctx->active_stream = prev_stream; ctx->has_active = prev_has; }
 };
 }
 
@@ -660,8 +685,7 @@ int detect_common(efx_context* c, const uint8_t* d_image, int rows, int cols, si
     if (d_desc && desc_pitch < (size_t)efx_descriptor_size(c)) return set_err(c->err, EFX_ERR_BAD_ARG, "desc_pitch smaller than the descriptor");
     int rc = validate_params(c->p, c->err);
     if (rc) return rc;
-    QuiesceScope quiesce(c);
-    c->note_stream(stream);
+    QuiesceScope quiesce(c, stream);
     consume_sticky_overflow(c);
     rc = build_geometry(c, rows, cols);
     if (rc) return rc;
@@ -746,8 +770,7 @@ int compute_provided(efx_context* c, const uint8_t* d_image, int rows, int cols,
     if (!d_desc || desc_pitch < (size_t)efx_descriptor_size(c)) return set_err(c->err, EFX_ERR_BAD_ARG, "bad descriptor buffer");
     int rc = validate_params(c->p, c->err);
     if (rc) return rc;
-    QuiesceScope quiesce(c);
-    c->note_stream(stream);
+    QuiesceScope quiesce(c, stream);
     rc = build_geometry(c, rows, cols);
     if (rc) return rc;
     HIP_TRY(c->err, c->kp4.reserve((size_t)n * sizeof(float4)));
@@ -981,8 +1004,7 @@ int efx_compute_async(efx_context* ctx, const uint8_t* d_image, int rows, int co
                       const void* d_keypoints, size_t kps_pitch, int n, uint8_t* d_descriptors, size_t desc_pitch, void* stream)
 {
     if (!ctx) return EFX_ERR_BAD_ARG;
-    QuiesceScope quiesce(ctx);
-    ctx->note_stream((hipStream_t)stream);
+    QuiesceScope quiesce(ctx, (hipStream_t)stream);
     return describe_5xn(ctx->desc, ctx->err, d_image, rows, cols, pitch, d_keypoints, kps_pitch, n, d_descriptors, desc_pitch, (hipStream_t)stream);
 }
 
@@ -990,8 +1012,7 @@ int efx_compute_kp4_async(efx_context* ctx, const uint8_t* d_image, int rows, in
                           const float* d_kp4, int n, float max_size, uint8_t* d_descriptors, size_t desc_pitch, void* stream)
 {
     if (!ctx) return EFX_ERR_BAD_ARG;
-    QuiesceScope quiesce(ctx);
-    ctx->note_stream((hipStream_t)stream);
+    QuiesceScope quiesce(ctx, (hipStream_t)stream);
     return describe_single(ctx->desc, ctx->err, d_image, rows, cols, pitch, reinterpret_cast<const float4*>(d_kp4), n, max_size,
                            d_descriptors, desc_pitch, nullptr, nullptr, (hipStream_t)stream);
 }
@@ -1123,6 +1144,7 @@ int efx_debug_rerun(efx_context* ctx, int stages, int* surv_totals, int nlevels_
 #endif
 
 int efx_overflow_events(const efx_context* ctx) { return ctx ? ctx->overflow_events : 0; }
+int efx_tracked_streams(const efx_context* ctx) { return ctx ? (int)ctx->streams.size() : 0; }
 
 size_t efx_trim_memory(void) { (void)hipDeviceSynchronize(); return block_cache().trim(); }
 size_t efx_cached_bytes(void) { return block_cache().cached(); }

@@ -137,7 +137,7 @@ int efx_default_norm(const efx_context* ctx);      /* 6 == cv::NORM_HAMMING, .cp
  * whichever entry point -- enlarges the arenas to the worst case before it launches, without a synchronisation; so at most
  * the frames already enqueued when the first dense frame ran are lost, never "every dense frame".  A caller who must not
  * lose a frame polls efx_last_count() after synchronising: it returns EFX_ERR_OVERFLOW for a void frame (repeat the
- * call); efx_overflow_events() counts the void frames seen so far.  The synchronous entry points (efx_detect, ...) rerun
+ * call); efx_overflow_events() says whether (not how often) that happened.  The synchronous entry points (efx_detect, ...) rerun
  * the frame by themselves. */
 int efx_detect_async(efx_context* ctx, const uint8_t* d_image, int rows, int cols, size_t pitch,
                      void* d_keypoints, size_t kps_pitch, int capacity, int* d_count, void* stream);
@@ -165,8 +165,13 @@ int efx_compute_kp4_async(efx_context* ctx, const uint8_t* d_image, int rows, in
 /* N of the last detect / detectAndCompute on this context (valid after the stream was synchronised).  Returns
  * EFX_ERR_OVERFLOW when that frame was void because it overflowed the scratch arenas (contract at efx_detect_async). */
 int efx_last_count(const efx_context* ctx, int* n);
-/* Frames of this context found void by arena overflow so far (host-side count, no device access). */
+/* Times this context has OBSERVED its sticky overflow word set (host-side count, no device access): every observation means
+ * "at least one frame since the last observation was void" -- several void frames enqueued back to back count once, so this
+ * is a did-it-happen counter, not a list of the frames to rerun (poll efx_last_count() per frame for that). */
 int efx_overflow_events(const efx_context* ctx);
+/* Diagnostics: streams the context currently tracks for its release waits (a block a regrow or the destructor hands back
+ * waits for exactly these; the stream of the call that triggered a regrow stays tracked).  No reference counterpart. */
+int efx_tracked_streams(const efx_context* ctx);
 /* Per-level counters of the last detect call (valid after the stream was synchronised). */
 int efx_last_level_stats(const efx_context* ctx, efx_level_stats* stats, int max_levels, int* nlevels);
 

@@ -123,3 +123,41 @@ def test_batch_reports_void_frames(cef):
     assert b.overflowEvents() == n
     assert all(int(c.item()) > 0 for c in cnt) and int(cnt[0].item()) == int(cnt[1].item())
     assert torch.equal(kps[0], kps[1]) and torch.equal(desc[0], desc[1])
+
+
+def test_regrow_keeps_the_calling_stream_tracked(cef, oracle):
+    """a regrow inside a call waits for the context's streams and used to forget ALL of them -- including the
+    stream the call then launches on, so that the next release (another stream's regrow, the destructor) handed blocks
+    still in use to the process-wide cache.  The calling stream must stay tracked, and a regrow on stream B right after
+    an unsynchronised call on stream A must leave A's results intact."""
+    import torch
+    small = torch.from_numpy(synth.synth_frame(300, 400, seed=5)).cuda()
+    big = torch.from_numpy(synth.synth_frame(900, 1200, seed=6)).cuda()
+    huge = torch.from_numpy(synth.synth_frame(1500, 2100, seed=7)).cuda()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    det = cef.EfficientFeatures.create(2000, dtype=cef.EfficientFeatures.BAD_256)
+    with torch.cuda.stream(sa):
+        det.detectAndComputeAsync(small, stream=sa)
+        assert det.trackedStreams() == 1
+        ka, da, ca = det.detectAndComputeAsync(big, stream=sa)        # larger geometry: regrow -> wait -> launch on sa
+    assert det.trackedStreams() == 1                                  # sa is still covered by the next release wait
+    with torch.cuda.stream(sb):
+        kb, db, cb = det.detectAndComputeAsync(huge, stream=sb)       # regrow on another stream, sa never synchronised by us
+    assert det.trackedStreams() >= 1
+    del det                                                           # destructor: waits for what is tracked
+    torch.cuda.synchronize()
+    for img, (k, d, c) in ((big, (ka, da, ca)), (huge, (kb, db, cb))):
+        ref = oracle.detect_and_compute(img.cpu().numpy(), nfeatures=2000, desc_type=oracle.BAD_256)
+        n = int(c.item())
+        assert n == ref["n"]
+        assert np.array_equal(k[:, :n].cpu().numpy().view(np.uint32), ref["kps"].view(np.uint32))
+        assert np.array_equal(d[:n].cpu().numpy(), ref["desc"])
+    # streams made per call do not accumulate without bound
+    det = cef.EfficientFeatures.create(500, dtype=cef.EfficientFeatures.BAD_256)
+    for i in range(80):
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            det.detectAndComputeAsync(small, stream=s)
+        s.synchronize()
+    assert det.trackedStreams() <= 33
