@@ -109,13 +109,18 @@ def dry_run(args, rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    # defaults: 400 steps x 8 frames x ~0.36 ms = a timed region of ~1.2 s (long enough for the driver's
+    # SMI sampler to see the GPU busy, and for the clocks to be what a sustained load gets)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--frames-per-step", type=int, default=8)
     ap.add_argument("--streams", type=int, default=3,
                     help="independent frames in flight per GPU: one context + one HIP stream each (a context is not "
                          "re-entrant, like the reference's EfficientFeaturesImpl; frames are independent)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the `configs` block (BASELINE.json C2 / C3 / C4 and the README rows, tools/bench_configs.py; N = 1 only)")
+    ap.add_argument("--config-iters", type=int, default=30)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for the counters: nccl (= RCCL, the GPU path) or gloo (only with --dry-run)")
     ap.add_argument("--dry-run", action="store_true",
@@ -199,8 +204,10 @@ def main():
         step()
     barrier()
     # HIP event pairs around the kernels of one frame per step on context 0 (each pair costs a few microseconds of
-    # stream idle time, so not on every frame)
-    det.profileEnable(args.steps * 12 + 12, stride=max(1, F // NS))
+    # stream idle time, so not on every frame;
+    # on the first PROF_STEPS steps only: a long run needs no more samples)
+    PROF_STEPS = min(args.steps, 24)
+    det.profileEnable(PROF_STEPS * 12 + 12, stride=max(1, F // NS))
     # one event per step and stream (no host wait): per-step spread, reported next to the mean
     marks = [[torch.cuda.Event(enable_timing=True) for _ in range(NS)] for _ in range(args.steps + 1)]
     barrier()
@@ -285,8 +292,8 @@ def main():
             counters_info["why_null"] = ("no counters file" if not prof_all else "no source stamp in the counters file" if not stamp else
                                          "kernel sources changed since the counters were collected: " +
                                          ", ".join(k for k in here if (stamp or {}).get(k) != here[k]))
-        roof = {"bound": "hbm", "bound_that_binds": "valu (instruction issue; see roofline.valu -- every kernel of the path issues "
-                                                    "more than ~5 lane-operations per byte, DESIGN.md section 9)",
+        roof = {"bound": "hbm", "bound_that_binds": "valu (instruction issue; see roofline.valu, which carries the fraction against the guide's "
+                                                    "2-cycle peak AND against the measured half-rate / own-mix ceilings, DESIGN.md section 9)",
                 "counters": counters_info, "kernel": dom, "achieved": iso[dom]["achieved"] if dom else None, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": iso[dom]["frac"] if dom else None,
                 "traffic": (prof.get("traffic_bytes_per_launch", {}) or {}).get(dom),
@@ -318,25 +325,57 @@ def main():
         # wave-instructions per launch come from the committed SQ counter pass, the issue peak from the committed
         # micro-benchmark (profiles/valu_rate.txt): 1024 SIMDs x clock / cycles per wave-instruction
         if prof.get("valu_wave_instr_per_launch") and prof.get("issue_peak_wave_instr_per_s"):
-            peak = float(prof["issue_peak_wave_instr_per_s"])
+            # three ceilings (profiles/rNN_valu_rate.txt has the per-instruction table they come from):
+            #   guide      1024 SIMDs x 2.4 GHz / 2 cycles (MI355X_MICROARCH.md: wave64 VALU = 2 cycles) -- EVERY instruction full rate
+            #   half_rate  measured: 4.19 cycles -- a kernel made only of half-rate instructions (packed 16-bit, perm, dot, cvt,
+            #              min / max, 3-operand integer, packed fp32 ...: most of what these kernels issue)
+            #   mix        the kernel's own static mix of full- and half-rate instructions (tools/valu_mix.py)
+            clk = float(prof.get("clock_ghz", 2.4)) * 1e9
+            peak_guide = float(prof.get("issue_peak_guide", 1024 * 2.4e9 / 2))
+            peak_half = float(prof.get("issue_peak_half_rate", prof["issue_peak_wave_instr_per_s"]))
+            mixc = prof.get("mix_cycles_per_wave_instr", {}) or {}
+
+            def vrow(name, v, ms_):
+                rate = v / (ms_ * 1e-3)
+                row = {"valu_wave_instr": v, "avg_launch_ms": round(ms_, 5), "achieved": round(rate / 1e9, 1),
+                       "frac_vs_guide_peak": round(rate / peak_guide, 4), "frac_vs_half_rate_ceiling": round(rate / peak_half, 4)}
+                if mixc.get(name):
+                    row["mix_cycles_per_wave_instr"] = mixc[name]
+                    row["frac_vs_mix_ceiling"] = round(rate / (1024 * clk / mixc[name]), 4)
+                row["frac"] = row.get("frac_vs_mix_ceiling", row["frac_vs_half_rate_ceiling"])
+                return row
             vt = {}
             for name, row in iso.items():
                 v = prof["valu_wave_instr_per_launch"].get(name)
                 if v:
-                    rate = v / (row["avg_launch_ms"] * 1e-3)
-                    vt[name] = {"valu_wave_instr": v, "avg_launch_ms": row["avg_launch_ms"], "achieved": round(rate / 1e9, 1), "frac": round(rate / peak, 4)}
+                    vt[name] = vrow(name, v, row["avg_launch_ms"])
             vchain = prof["valu_wave_instr_per_launch"].get("resize_chain")
             if vchain and iso_chain > 0:
-                rate = vchain / (iso_chain * 1e-3)
-                vt["resize_chain"] = {"valu_wave_instr": vchain, "avg_launch_ms": round(iso_chain, 5), "achieved": round(rate / 1e9, 1), "frac": round(rate / peak, 4)}
+                vt["resize_chain"] = vrow("resize_chain", vchain, iso_chain)
             tot = prof.get("valu_wave_instr_per_frame")
-            roof["valu"] = {"bound": "valu", "unit": "G wave-instructions/s", "peak": round(peak / 1e9, 1),
-                            "peak_from": "profiles/valu_rate.txt: %s cycles per wave-instruction, 1024 SIMDs, %s GHz" % (prof.get("cycles_per_wave_instr"), prof.get("clock_ghz")),
+            roof["valu"] = {"bound": "valu", "unit": "G wave-instructions/s",
+                            "peaks": {"guide": round(peak_guide / 1e9, 1), "full_rate_measured": round(float(prof.get("issue_peak_full_rate", 0)) / 1e9, 1),
+                                      "half_rate_measured": round(peak_half / 1e9, 1)},
+                            "peak": round(peak_guide / 1e9, 1),
+                            "peak_from": "guide = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction (MI355X_MICROARCH.md); the measured ceilings "
+                                         "are profiles/%s_valu_rate.txt: %s cycles for the full-rate instructions (32-bit add / sub / logic / right "
+                                         "shift / move, fp32 add / mul / fma), %s cycles for everything else, clock %s GHz measured under load; "
+                                         "`frac` = against the kernel's own static mix of the two (%s)" % (
+                                             os.path.basename(cfiles[-1])[:3], prof.get("cycles_full_rate"), prof.get("cycles_half_rate"),
+                                             prof.get("clock_ghz"), prof.get("mix_from")),
                             "kernels_isolated": vt}
             if tot:
                 rate = tot / (t_max / args.steps / F)
+                # the frame's mix: the kernels' mixes weighted by their instruction counts
+                wsum = sum(prof["valu_wave_instr_per_launch"].get(k, 0) for k in mixc if k in prof["valu_wave_instr_per_launch"] and k != "resize_stream_kernel")
+                fmix = (sum(prof["valu_wave_instr_per_launch"][k] * mixc[k] for k in mixc if k in prof["valu_wave_instr_per_launch"] and k != "resize_stream_kernel") / wsum) if wsum else None
                 roof["valu"]["whole_frame"] = {"valu_wave_instr_per_frame": tot, "ms_per_frame": round(t_max / args.steps / F * 1e3, 4),
-                                               "achieved": round(rate / 1e9, 1), "frac": round(rate / peak, 4)}
+                                               "achieved": round(rate / 1e9, 1), "frac_vs_guide_peak": round(rate / peak_guide, 4),
+                                               "frac_vs_half_rate_ceiling": round(rate / peak_half, 4)}
+                if fmix:
+                    roof["valu"]["whole_frame"]["mix_cycles_per_wave_instr"] = round(fmix, 3)
+                    roof["valu"]["whole_frame"]["frac_vs_mix_ceiling"] = round(rate / (1024 * clk / fmix), 4)
+                roof["valu"]["whole_frame"]["frac"] = roof["valu"]["whole_frame"].get("frac_vs_mix_ceiling", roof["valu"]["whole_frame"]["frac_vs_half_rate_ceiling"])
             if prof.get("lds_cycles_per_launch", {}).get(dom):
                 lc = prof["lds_cycles_per_launch"][dom]
                 roof["lds"] = {"kernel": dom, "lds_array_cycles_per_launch": lc, "cus": 256,
@@ -360,7 +399,7 @@ def main():
         tag = os.path.basename(cfiles[-1])[:3] if cfiles else "rNN"
         roof["profiles"] = {"frac / kernels_isolated (one stream)": "profiles/%s_kernel_stats.csv" % tag,
                             "live (the default command, three frames in flight)": "profiles/%s_kernel_stats_3streams.csv" % tag,
-                            "traffic, valu, lds": "profiles/%s_counters.json <- profiles/%s_pmc_sq.txt, %s_pmc_lds.txt, %s_traffic.json, valu_rate.txt" % (tag, tag, tag, tag)}
+                            "traffic, valu, lds": "profiles/%s_counters.json <- profiles/%s_pmc_sq.txt, %s_pmc_lds.txt, %s_traffic.json, %s_valu_rate.txt, %s_valu_mix.json" % (tag, tag, tag, tag, tag, tag)}
         if not counters_ok:
             roof["valu"] = None; roof["lds"] = None
 
@@ -383,30 +422,45 @@ def main():
             from oracle import pyoracle
             img = frames[0].cpu().numpy()
             pyoracle.set_threads(1)
-            t1 = time.perf_counter()
-            ref = pyoracle.detect_and_compute(img, nfeatures=NFEATURES, desc_type=pyoracle.BAD_512)
-            t_cpu = time.perf_counter() - t1
+            t_runs = []
+            for _ in range(3):                            # three repeats of the single-thread port (~2.4 s each): min and median
+                t1 = time.perf_counter()
+                ref = pyoracle.detect_and_compute(img, nfeatures=NFEATURES, desc_type=pyoracle.BAD_512)
+                t_runs.append(time.perf_counter() - t1)
+            t_cpu = min(t_runs)
             # the same frame with OpenMP over rows / candidates / keypoints on the host's cores (bounded at 64 threads)
             nthr = max(1, min(os.cpu_count() or 1, 64))
             pyoracle.set_threads(nthr)
             pyoracle.detect_and_compute(img[:512, :512].copy(), nfeatures=100, desc_type=pyoracle.BAD_512)   # start the thread pool
-            t1 = time.perf_counter()
-            ref_mt = pyoracle.detect_and_compute(img, nfeatures=NFEATURES, desc_type=pyoracle.BAD_512)
-            t_mt = time.perf_counter() - t1
+            t_mts = []
+            for _ in range(3):
+                t1 = time.perf_counter()
+                ref_mt = pyoracle.detect_and_compute(img, nfeatures=NFEATURES, desc_type=pyoracle.BAD_512)
+                t_mts.append(time.perf_counter() - t1)
+            t_mt = min(t_mts)
             pyoracle.set_threads(1)
             out["cpu_baseline"] = {"value": round(ref["n"] / t_cpu / 1e6, 5), "unit": "Mkeypoints/s", "cores": 1,
                                    "kind": "port", "ms_per_frame": round(t_cpu * 1e3, 1),
+                                   "ms_per_frame_min_median_max": [round(min(t_runs) * 1e3, 1), round(float(np.median(t_runs)) * 1e3, 1), round(max(t_runs) * 1e3, 1)],
+                                   "repeats": len(t_runs),
                                    "sample": "one 8K frame (seed 1000) of the same workload, oracle/efx_oracle.c, "
-                                             f"single thread as the reference CPU module; {ref['n']} keypoints",
+                                             f"single thread as the reference CPU module, best of {len(t_runs)}; {ref['n']} keypoints",
                                    "host_cores_available": os.cpu_count(),
                                    "all_cores": {"value": round(ref_mt["n"] / t_mt / 1e6, 5), "cores": nthr,
                                                  "ms_per_frame": round(t_mt * 1e3, 1),
+                                                 "ms_per_frame_min_median_max": [round(min(t_mts) * 1e3, 1), round(float(np.median(t_mts)) * 1e3, 1), round(max(t_mts) * 1e3, 1)],
                                                  "same_result": bool(np.array_equal(ref_mt["desc"], ref["desc"]))}}
             # the bench frame doubles as a full-size parity check (bit-exact keypoints + BAD512 bytes)
             n0 = int(cnt[0].item())
             same = (n0 == ref["n"] and np.array_equal(kps[0][:, :n0].cpu().numpy().view(np.uint32), ref["kps"].view(np.uint32))
                     and np.array_equal(desc[0][:n0].cpu().numpy(), ref["desc"]))
             out["parity_8k_frame0"] = bool(same)
+        if world == 1 and not args.no_configs:
+            # the other BASELINE.json configurations and the README's rows, reference protocol, in the driver-run line
+            for d_ in dets[1:]:
+                d_.profileEnable(0)
+            from tools import bench_configs
+            out["configs"] = bench_configs.measure(cef, iters=args.config_iters, cpu_baseline=not args.no_cpu_baseline)
         print(json.dumps(out), flush=True)
 
     if dist is not None:

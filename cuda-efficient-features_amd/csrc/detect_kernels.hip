@@ -232,8 +232,9 @@ __device__ __forceinline__ void efx_zero_counters(Counters* __restrict__ c, int 
 
 // Four horizontally adjacent outputs of the bilinear resize (spec S5), the arithmetic all three resize kernels share.
 // ra / rb: the two source rows in LDS, lc[k]: the LDS column of output k's left source pixel (its right neighbour is the
-// next byte), wa / wb: the x weights, wy0 / wy1: the y weights.  Per output the expression of the reference, term by term
-// (unfused multiplies and adds: -ffp-contract=off).
+// next byte), wa / wb: the x weights, wy0 / wy1: the y weights.  Per output the expression of the reference, term by term, as
+// nvcc's default contraction builds it (spec S5, round 4: the weight product is a rounded multiply, pixel x weight is fused
+// into the accumulator -- explicit fmaf, the translation unit itself is compiled with -ffp-contract=off).
 // Measured and dropped (round 3, tools/microbench/bench_ab.sh): two outputs per instruction on packed fp32 lanes
 // (v_pk_mul_f32 / v_pk_add_f32: 42 instead of 64 VALU instructions per four outputs) -- kernel 11.10 vs 10.97 us, bench
 // line 106.6 vs 106.8 Mkeypoints/s; a pixel pair as ONE unaligned 16-bit LDS read -- 40 us instead of 11 (unaligned
@@ -250,10 +251,10 @@ __device__ __forceinline__ uint32_t resize_quad(const uint8_t* ra, const uint8_t
     for (int k = 0; k < 4; k++) {
         const uint8_t* pa = ra + lc[k];
         const uint8_t* pb = rb + lc[k];
-        float out = (float)pa[0] * (wa[k] * wy0);                    // == 0.f + ... exactly
-        out = out + (float)pa[one] * (wb[k] * wy0);
-        out = out + (float)pb[0] * (wa[k] * wy1);
-        out = out + (float)pb[one] * (wb[k] * wy1);
+        float out = (float)pa[0] * (wa[k] * wy0);                    // == fma(p, w, 0.f) exactly
+        out = __builtin_fmaf((float)pa[one], wb[k] * wy0, out);
+        out = __builtin_fmaf((float)pb[0], wa[k] * wy1, out);
+        out = __builtin_fmaf((float)pb[one], wb[k] * wy1, out);
         packed = __builtin_amdgcn_cvt_pk_u8_f32(out, k, packed);     // rint (half even) + saturate + pack
     }
     return packed;
@@ -297,10 +298,10 @@ __device__ __forceinline__ uint32_t resize_quad_win(const uint8_t* ra, const uin
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const uint32_t pa = pr[k >> 1][0] >> (16 * (k & 1)), pb = pr[k >> 1][1] >> (16 * (k & 1));
-        float out = (float)(pa & 0xffu) * (wa[k] * wy0);              // == 0.f + ... exactly
-        out = out + (float)((pa >> 8) & 0xffu) * (wb[k] * wy0);
-        out = out + (float)(pb & 0xffu) * (wa[k] * wy1);
-        out = out + (float)((pb >> 8) & 0xffu) * (wb[k] * wy1);
+        float out = (float)(pa & 0xffu) * (wa[k] * wy0);              // == fma(p, w, 0.f) exactly
+        out = __builtin_fmaf((float)((pa >> 8) & 0xffu), wb[k] * wy0, out);
+        out = __builtin_fmaf((float)(pb & 0xffu), wa[k] * wy1, out);
+        out = __builtin_fmaf((float)((pb >> 8) & 0xffu), wb[k] * wy1, out);
         packed = __builtin_amdgcn_cvt_pk_u8_f32(out, k, packed);     // rint (half even) + saturate + pack
     }
     return packed;

@@ -497,7 +497,8 @@ void efxo_resize_linear(const uint8_t* src, int srows, int scols, int sstride,
 {
     /* Spec S5: cv::cuda::resize(INTER_LINEAR) as in opencv_contrib cudawarping resize_linear:
      * src = dst * (1/f) with f = dsize/ssize (double) cast to float, no half-pixel offset, floor,
-     * +1 neighbour clamped to the last row/col, four float weights, round-to-nearest-even saturate. */
+     * +1 neighbour clamped to the last row/col, four float weights (each a rounded product), accumulated by
+     * fused multiply-adds in (00,01,10,11) order, round-to-nearest-even saturate. */
     const float fx = (float)(1.0 / ((double)dcols / (double)scols));
     const float fy = (float)(1.0 / ((double)drows / (double)srows));
     EFXO_PAR
@@ -513,11 +514,16 @@ void efxo_resize_linear(const uint8_t* src, int srows, int scols, int sstride,
             if (x1 > scols - 1) x1 = scols - 1;
             const int x2 = x1 + 1;
             const int x2r = x2 < scols - 1 ? x2 : scols - 1;
+            /* `out = out + src_reg * (wx * wy)` four times (opencv_contrib cudawarping resize_linear / LinearFilter): under
+             * nvcc's default -fmad each statement is ONE fused multiply-add of the pixel and the ROUNDED weight product into
+             * the accumulator -- the same contraction spec S6 models for the Gaussian (the reference binary is one nvcc build:
+             * both third-party kernels are contracted or neither is).  The first statement adds to 0.f and is the
+             * rounded product either way. */
             float out = 0.f;
-            out = out + (float)src[(size_t)y1 * sstride + x1] * (((float)x2 - sx) * ((float)y2 - sy));
-            out = out + (float)src[(size_t)y1 * sstride + x2r] * ((sx - (float)x1) * ((float)y2 - sy));
-            out = out + (float)src[(size_t)y2r * sstride + x1] * (((float)x2 - sx) * (sy - (float)y1));
-            out = out + (float)src[(size_t)y2r * sstride + x2r] * ((sx - (float)x1) * (sy - (float)y1));
+            out = fmaf((float)src[(size_t)y1 * sstride + x1], ((float)x2 - sx) * ((float)y2 - sy), out);
+            out = fmaf((float)src[(size_t)y1 * sstride + x2r], (sx - (float)x1) * ((float)y2 - sy), out);
+            out = fmaf((float)src[(size_t)y2r * sstride + x1], ((float)x2 - sx) * (sy - (float)y1), out);
+            out = fmaf((float)src[(size_t)y2r * sstride + x2r], (sx - (float)x1) * (sy - (float)y1), out);
             dst[(size_t)dy * dstride + dx] = sat_u8_f(out);
         }
     }

@@ -149,3 +149,46 @@ def test_c5_8k_detect_and_compute_hashsift512(cef, threaded_oracle):
     _same_keypoints(kps, n, ref)
     got = desc[:n].cpu().numpy()
     assert np.count_nonzero(got != ref["desc"]) <= max(1, int(1e-4 * got.size))       # descriptor_test.cpp:72
+
+
+@pytest.mark.parametrize("kind", ["powerlaw", "powerlaw_dense", "blurred_edges"])
+def test_natural_statistics_4k(cef, threaded_oracle, kind):
+    """4K frames with the statistics of photographs (the reference tests on 11 photographs,
+    tests/descriptor_test.cpp:25-36): 1/f texture (beta 1.3, and beta 1.0 where 17 % of the pixels are FAST corners and the
+    10 % cap cuts) and shapes behind Gaussian defocus of four widths.  detectAndCompute BAD512 bit-exact, HashSIFT512 on the
+    same frame inside the stated byte tolerance."""
+    import torch
+    from tools import synth
+    rows, cols = workloads.K4
+    img = {"powerlaw": lambda: synth.powerlaw_frame(rows, cols, seed=2001),
+           "powerlaw_dense": lambda: synth.powerlaw_frame(rows, cols, seed=2002, beta=1.0),
+           "blurred_edges": lambda: synth.blurred_edges_frame(rows, cols, seed=2003)}[kind]()
+    d_img = _dev(img)
+    det = cef.EfficientFeatures.create(workloads.N40K, dtype=cef.EfficientFeatures.BAD_512)
+    kps, desc, cnt = det.detectAndComputeAsync(d_img)
+    torch.cuda.synchronize()
+    if det.overflowEvents() or int(cnt.item()) == 0:           # a frame denser than the density-sized arenas is void once
+        kps, desc, cnt = det.detectAndComputeAsync(d_img)
+        torch.cuda.synchronize()
+    n = int(cnt.item())
+    ref = threaded_oracle.detect_and_compute(img, nfeatures=workloads.N40K, desc_type=threaded_oracle.BAD_512)
+    _same_keypoints(kps, n, ref)
+    assert n > 5000
+    if kind == "powerlaw_dense":
+        assert ref["stats"]["n_candidates"][0] > ref["stats"]["n_after_cap"][0]      # the cap is active on this frame
+    assert np.array_equal(desc[:n].cpu().numpy(), ref["desc"])
+    st = det.lastLevelStats()
+    for l in range(8):
+        assert st[l]["n_candidates"] == ref["stats"]["n_candidates"][l] and st[l]["n_after_nms"] == ref["stats"]["n_after_nms"][l]
+    hs = cef.EfficientFeatures.create(workloads.N40K, dtype=cef.EfficientFeatures.HASH_SIFT_512)
+    kps2, desc2, cnt2 = hs.detectAndComputeAsync(d_img)
+    torch.cuda.synchronize()
+    if int(cnt2.item()) == 0:
+        kps2, desc2, cnt2 = hs.detectAndComputeAsync(d_img)
+        torch.cuda.synchronize()
+    ref2 = threaded_oracle.detect_and_compute(img, nfeatures=workloads.N40K, desc_type=threaded_oracle.HASH_SIFT_512)
+    _same_keypoints(kps2, int(cnt2.item()), ref2)
+    got = desc2[:n].cpu().numpy()
+    nbad = int(np.count_nonzero(got != ref2["desc"]))
+    print(f"\n{kind}: {n} keypoints, FAST corners {sum(ref['stats']['n_candidates'])}, HashSIFT512 bytes differing {nbad} of {got.size} ({nbad / got.size:.2e})")
+    assert nbad <= max(4, int(1e-4 * got.size))

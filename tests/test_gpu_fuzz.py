@@ -1,4 +1,4 @@
-"""Seeded fuzz parity: random frame sizes, image kinds, detector parameters, masks and descriptor types, HIP path vs the
+"""Seeded fuzz parity: random frame sizes, image kinds (shapes, noise, ramps, checkerboards, dots, 1/f texture, defocused edges), detector parameters, masks and descriptor types, HIP path vs the
 oracle through the C-ABI.  Bit-exact keypoints (location, response bits, angle bits, octave, size) and BAD bytes;
 HashSIFT within the byte tolerance of tests/test_golden.py (spec S8).  The cases are small so the oracle stays fast;
 every case prints its parameters on failure, so a failing seed is a ready-made regression test."""
@@ -46,6 +46,19 @@ def _image(rng, rows, cols, kind):
     return img
 
 
+def _natural(seed, rows, cols, img):
+    """Seeds 5 and 6 modulo 7 replace the drawn image by one with natural-image statistics, from a
+    generator of their own, so that every other draw of the case -- and every other seed -- stays what earlier sweeps ran."""
+    if seed % 7 == 5:
+        r2 = np.random.default_rng(seed + 777_000)
+        return synth.powerlaw_frame(rows, cols, seed=seed, beta=float(r2.choice([1.0, 1.3, 1.6])), contrast=float(r2.choice([25.0, 45.0, 70.0])))
+    if seed % 7 == 6:
+        r2 = np.random.default_rng(seed + 777_000)
+        sig = tuple(float(v) for v in r2.choice([0.5, 0.8, 1.2, 2.0, 3.5], size=int(r2.integers(1, 5))))
+        return synth.blurred_edges_frame(rows, cols, seed=seed, density=float(r2.choice([0.6, 1.5, 3.0])), sigmas=sig)
+    return img
+
+
 def _case(seed):
     rng = np.random.default_rng(seed)
     rows, cols = int(rng.integers(33, 420)), int(rng.integers(33, 520))
@@ -57,7 +70,7 @@ def _case(seed):
               first_level=int(rng.choice([0, 0, 0, 0, 1, 2])),
               fast_threshold=int(rng.choice([1, 5, 10, 20, 20, 40, 90])),
               nonmax_radius=int(rng.choice([0, 1, 3, 8, 15, 15, 15, 16, 17, 24, 33])))
-    img = _image(rng, rows, cols, int(rng.integers(0, 5)))
+    img = _natural(seed, rows, cols, _image(rng, rows, cols, int(rng.integers(0, 5))))
     mask = None
     if rng.random() < 0.3:
         mask = (rng.random((rows, cols)) < 0.7).astype(np.uint8) * 255
@@ -73,13 +86,17 @@ def _case(seed):
 # a tree, the CPU serially: section 3) flips the bits whose projection lies within one weight of zero, usually none, now and
 # then three or four bytes of ONE descriptor -- so the per-case bound is the stated fraction plus ONE such event.  (Found by
 # the round-3 sweep: seed 103188, 1935 keypoints x 64 bytes, 13 differing bytes against int(1e-4 x bytes) = 12.)
-_HS_TOTAL = {"bytes": 0, "bad": 0}
+_HS_TOTAL = {"bytes": 0, "bad": 0, "elems": 0, "bad_elems": 0}
 
 
 def _hashsift_check(nbad, nbits, n, info, got=None, want=None):
     nbytes = max(n, 0) * (nbits // 8)
     _HS_TOTAL["bytes"] += nbytes
     _HS_TOTAL["bad"] += nbad
+    # every differing byte counts here: a localised defect -- one bad box or cell pattern repeated across the
+    # keypoints of a case -- would show as far more than one rounding event per thousand bytes, whatever the de-duplication
+    # below makes of it
+    assert nbad <= int(1e-3 * nbytes) + 4, f"{info}: {nbad} of {nbytes} HashSIFT descriptor bytes differ (every byte counted)"
     # A periodic image (checkerboards: kind 3) holds the same patch many times over, and ONE rounding event then shows up in
     # every keypoint that has it (found by the round-3 sweep: seed 705467, 24 keypoints of a checkerboard with the same two
     # bytes, 42 differing bytes against a bound of 21).  Events are counted once per distinct (expected, computed) descriptor;
@@ -89,6 +106,27 @@ def _hashsift_check(nbad, nbits, n, info, got=None, want=None):
         half = want.shape[1]
         nbad = int(np.count_nonzero(pairs[:, :half] != pairs[:, half:]))
     assert nbad <= int(1e-4 * nbytes) + 4, f"{info}: {nbad} of {nbytes} HashSIFT descriptor bytes differ (distinct descriptors)"
+
+
+def _hashsift_vectors_check(cef, oracle, img, kps, scale, info):
+    """The 129-vectors themselves (not only the bytes they flip): the kernel must equal the CPU model of ITS OWN
+    arithmetic bit for bit in every case, and differ from the reference's float arithmetic by at most one event per case
+    (elements off by a few units; the rate over the sweep is asserted in test_zz_hashsift_bytes_over_the_sweep)."""
+    import torch
+    hs = cef.HashSIFT.create(scale, cef.HashSIFT.SIZE_256_BITS)
+    resp, _ = hs.debug(torch.from_numpy(img).cuda(), torch.from_numpy(kps).cuda(), max_size=float(kps[:, 2].max()))
+    torch.cuda.synchronize()
+    resp = resp.cpu().numpy()
+    model = oracle.hashsift_responses_fixedpoint(img, kps, crop_scale=scale)
+    rows_off = np.nonzero((resp != model).any(axis=1))[0]
+    assert rows_off.size == 0, f"{info}: {rows_off.size} vectors differ from the fixed-point model: {rows_off[:6].tolist()}"
+    want = oracle.hashsift_responses(img, kps, crop_scale=scale)
+    d = np.abs(resp - want)
+    nbad = int(np.count_nonzero(d))
+    _HS_TOTAL["elems"] += d.size
+    _HS_TOTAL["bad_elems"] += nbad
+    assert d.max() <= 4.0, f"{info}: a 129-vector element is off by {d.max()}"
+    assert nbad <= int(1e-4 * d.size) + 4, f"{info}: {nbad} of {d.size} 129-vector elements differ from the reference arithmetic"
 
 
 # EFX_FUZZ_CASES / EFX_FUZZ_FIRST widen the sweep from the command line (the committed default keeps the suite fast)
@@ -140,7 +178,7 @@ def test_fuzz_compute(cef, oracle, seed):
     every angle convention (-1 axis aligned, < 0 unrotated, degrees), random scale factors."""
     rng = np.random.default_rng(10_000 + seed)
     rows, cols = int(rng.integers(20, 300)), int(rng.integers(20, 400))
-    img = _image(rng, rows, cols, int(rng.integers(0, 5)))
+    img = _natural(seed, rows, cols, _image(rng, rows, cols, int(rng.integers(0, 5))))
     n = int(rng.integers(1, 300))
     kps = np.zeros((n, 4), np.float32)
     kps[:, 0] = rng.uniform(-20, cols + 20, n)
@@ -167,7 +205,8 @@ def test_fuzz_compute(cef, oracle, seed):
         got = cef.HashSIFT.create(scale, enum).compute(img, kps)
         want = oracle.hashsift_compute(img, kps, nbits, crop_scale=scale)
         nbad = int(np.count_nonzero(got != want))
-        _hashsift_check(nbad, nbits, n, info)
+        _hashsift_check(nbad, nbits, n, info, got, want)
+        _hashsift_vectors_check(cef, oracle, img, kps, scale, info)
 
 
 @pytest.mark.parametrize("seed", range(_FIRST, _FIRST + max(_N // 3, 1)))
@@ -177,7 +216,7 @@ def test_fuzz_provided_keypoints(cef, torch_mod, oracle, seed):
     torch = torch_mod
     rng = np.random.default_rng(20_000 + seed)
     rows, cols = int(rng.integers(40, 400)), int(rng.integers(40, 500))
-    img = _image(rng, rows, cols, int(rng.integers(0, 5)))
+    img = _natural(seed, rows, cols, _image(rng, rows, cols, int(rng.integers(0, 5))))
     nlevels = int(rng.integers(1, 9))
     scale = float(rng.choice([1.2, 1.2, 1.5, 2.0]))
     dt = int(rng.integers(0, 4))
@@ -203,7 +242,7 @@ def test_fuzz_provided_keypoints(cef, torch_mod, oracle, seed):
         assert np.array_equal(got, want), f"{info}: rows {np.nonzero((got != want).any(axis=1))[0][:6].tolist()} differ"
     else:
         nbad = int(np.count_nonzero(got != want))
-        _hashsift_check(nbad, 256 if dt == 2 else 512, n, info)
+        _hashsift_check(nbad, 256 if dt == 2 else 512, n, info, got, want)
 
 
 def test_every_small_frame_size(cef, torch_mod, oracle):
@@ -226,10 +265,15 @@ def test_every_small_frame_size(cef, torch_mod, oracle):
 
 
 def test_zz_hashsift_bytes_over_the_sweep():
-    """The stated HashSIFT tolerance over everything the fuzz tests of this process compared: at most 1e-4 of the
-    descriptor bytes differ from the CPU reference arithmetic (descriptor_test.cpp:72); measured 2e-5."""
+    """The HashSIFT tolerance over everything the fuzz tests of this process compared.  Stated bound: at most 1e-4 of the
+    descriptor bytes differ from the CPU reference arithmetic (descriptor_test.cpp:72).  Asserted: the MEASURED rates with the
+    margin the C4 full-size test uses (3e-5 of the 129-vector elements, 4e-5 of the bytes; measured 1.4e-5 / 2e-5, DESIGN.md
+    section 3), with a floor of two events for sweeps too small to resolve such rates."""
     if _HS_TOTAL["bytes"] == 0:
         pytest.skip("no HashSIFT case ran in this process")
     rate = _HS_TOTAL["bad"] / _HS_TOTAL["bytes"]
-    print(f"\nHashSIFT over the sweep: {_HS_TOTAL['bad']} of {_HS_TOTAL['bytes']} bytes differ ({rate:.2e})")
-    assert _HS_TOTAL["bad"] <= max(4, int(1e-4 * _HS_TOTAL["bytes"]))
+    erate = _HS_TOTAL["bad_elems"] / max(_HS_TOTAL["elems"], 1)
+    print(f"\nHashSIFT over the sweep: {_HS_TOTAL['bad']} of {_HS_TOTAL['bytes']} bytes differ ({rate:.2e}); "
+          f"{_HS_TOTAL['bad_elems']} of {_HS_TOTAL['elems']} 129-vector elements differ ({erate:.2e})")
+    assert _HS_TOTAL["bad"] <= max(8, int(4e-5 * _HS_TOTAL["bytes"]))
+    assert _HS_TOTAL["bad_elems"] <= max(8, int(3e-5 * _HS_TOTAL["elems"]))

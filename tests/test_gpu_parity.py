@@ -632,7 +632,7 @@ def test_descriptor_keypoint_extremes(cef, oracle):
         assert np.array_equal(cef.BAD.create(1.0, enum).compute(img, kps), oracle.bad_compute(img, kps, nbits))
     got = cef.HashSIFT.create(1.0, cef.HashSIFT.SIZE_256_BITS).compute(img, kps)
     want = oracle.hashsift_compute(img, kps, 256)
-    assert np.count_nonzero(got != want) <= 2
+    assert np.array_equal(got, want)          # 10 keypoints: nothing may differ (the rate is 2e-5 of the bytes)
     # a keypoint whose window cannot fit the 160 KB LDS is refused, not silently mis-described
     with pytest.raises(cef.EfxError):
         cef.BAD.create(1.0, cef.BAD.SIZE_256_BITS).compute(img, np.array([[100, 100, 5000, 0]], np.float32))
@@ -705,7 +705,10 @@ def test_quota_sum_exceeds_nfeatures(cef, torch_mod, oracle, desc_type):
     if desc_type < 2:
         assert np.array_equal(desc[:n].cpu().numpy(), ref["desc"])
     else:
-        assert np.mean(desc[:n].cpu().numpy() != ref["desc"]) <= 0.05 and not np.all(desc[3].cpu().numpy() == 0xEE)
+        # four HashSIFT descriptors: at most ONE rounding event (a few bytes of one descriptor; measured rate 2e-5 of the bytes)
+        g = desc[:n].cpu().numpy()
+        rows_off = np.nonzero((g != ref["desc"]).any(axis=1))[0]
+        assert rows_off.size <= 1 and np.count_nonzero(g != ref["desc"]) <= 4 and not np.all(desc[3].cpu().numpy() == 0xEE)
 
 
 def test_detect_and_compute_without_descriptors(cef, torch_mod, oracle):

@@ -9,9 +9,9 @@ tag=${1:-rXX}
 export EFX_GIT_HEAD=${2:-${EFX_GIT_HEAD:-unknown}}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out
-rocprofv3 --kernel-trace --stats -d $O/prof_$tag -o bench -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --streams 1 > $O/bench_$tag.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/prof_$tag -o bench -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-configs --streams 1 > $O/bench_$tag.log 2>&1
 python tools/prof_summary.py $O/prof_$tag/bench_results.db $O/${tag}_kernel_stats.csv > /dev/null; rm -rf $O/prof_$tag
-rocprofv3 --kernel-trace --stats -d $O/prof_${tag}_3s -o bench -- python bench.py --no-cpu-baseline > $O/bench_${tag}_3s.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/prof_${tag}_3s -o bench -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-configs > $O/bench_${tag}_3s.log 2>&1
 python tools/prof_summary.py $O/prof_${tag}_3s/bench_results.db $O/${tag}_kernel_stats_3streams.csv > /dev/null; rm -rf $O/prof_${tag}_3s
 tools/pmc_run.sh sq SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_LDS > /dev/null
 python tools/pmc_summary.py $O/pmc_sq/pmc_results.db > $O/${tag}_pmc_sq.txt; rm -rf $O/pmc_sq
@@ -20,9 +20,9 @@ python tools/pmc_summary.py $O/pmc_lds/pmc_results.db > $O/${tag}_pmc_lds.txt; r
 tools/pmc_run.sh fetch FETCH_SIZE > /dev/null
 tools/pmc_run.sh write WRITE_SIZE > /dev/null
 python tools/traffic_json.py $O/pmc_fetch/pmc_results.db $O/pmc_write/pmc_results.db $O/${tag}_traffic.json > /dev/null; rm -rf $O/pmc_fetch $O/pmc_write
-tools/microbench/valu_rate > $O/valu_rate.txt 2>&1
+tools/microbench/valu_rate > $O/${tag}_valu_rate.txt 2>&1
 tools/microbench/wg_rate > $O/wg_rate.txt 2>&1
-python tools/counters_json.py $O/${tag}_pmc_sq.txt $O/${tag}_pmc_lds.txt $O/${tag}_traffic.json $O/valu_rate.txt $O/${tag}_counters.json
+python tools/counters_json.py $O/${tag}_pmc_sq.txt $O/${tag}_pmc_lds.txt $O/${tag}_traffic.json $O/${tag}_valu_rate.txt $O/${tag}_counters.json profiles/${tag}_valu_mix.json
 if [ -n "$FULL" ]; then
   python tools/bench_configs.py --out $O/${tag}_configs.json > /dev/null
   rocprofv3 --kernel-trace --stats -d $O/prof_hs -o hs -- python tools/microbench/hs_stage.py > $O/prof_hs.log 2>&1

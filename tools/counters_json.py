@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """Builds profiles/<tag>_counters.json, the file bench.py's `roofline.valu / lds / traffic` figures are computed from.
 
-usage: tools/counters_json.py <pmc_sq.txt> <pmc_lds.txt> <traffic.json> <valu_rate.txt> <out.json>
+usage: tools/counters_json.py <pmc_sq.txt> <pmc_lds.txt> <traffic.json> <valu_rate.txt> <out.json> [<valu_mix.json>]
   pmc_sq.txt / pmc_lds.txt   tools/pmc_summary.py output of separate rocprofv3 --pmc passes over a short bench.py run
                              (SQ_INSTS_VALU ...; SQ_LDS_IDX_ACTIVE, SQ_LDS_BANK_CONFLICT)
   traffic.json               tools/traffic_json.py (FETCH_SIZE / WRITE_SIZE passes)
-  valu_rate.txt              stdout of tools/microbench/valu_rate (cycles per wave-instruction per SIMD)
+  valu_rate.txt              stdout of tools/microbench/valu_rate (cycles per wave-instruction per SIMD, by instruction)
+  valu_mix.json              tools/valu_mix.py (static instruction mix of the kernels by rate class; built in the build container)
 Per-launch figures are totals / dispatches; per-frame figures use fast_kernel's dispatch count (one per frame)."""
 import hashlib
 import json
@@ -43,7 +44,7 @@ def parse_pmc(path):
     return d
 
 
-def main(sq_path, lds_path, traffic_path, valu_path, out_path):
+def main(sq_path, lds_path, traffic_path, valu_path, out_path, mix_path=None):
     sq, lds = parse_pmc(sq_path), parse_pmc(lds_path)
     frames = sq["fast_kernel"]["n"]
     valu_launch, valu_frame = {}, 0.0
@@ -59,16 +60,37 @@ def main(sq_path, lds_path, traffic_path, valu_path, out_path):
     conf_launch = {k: round(v["SQ_LDS_BANK_CONFLICT"] / v["n"]) for k, v in lds.items()
                    if "SQ_LDS_BANK_CONFLICT" in v and not k.startswith("at::") and not k.startswith("__amd")}
     traffic = {k.split("<")[0]: v["bytes_per_launch"] for k, v in json.load(open(traffic_path)).get("per_kernel", {}).items()}
+    # issue rates (tools/microbench/valu_rate, round-4 format): a wave64 VALU instruction occupies its SIMD for 2 cycles
+    # ("full rate": 32-bit add / sub / logic / right shifts / moves, fp32 add / mul / fma) or 4 ("half rate": everything else the
+    # kernels are made of) -- cycles from s_memtime, the clock measured during the run
+    from tools import valu_mix
     txt = open(valu_path).read()
-    clock = float(re.search(r"clock ([\d.]+) GHz", txt).group(1))
-    cyc = {m.group(1): float(m.group(2)) for m in re.finditer(r"^(k_\w+)\s+[\d.]+ us\s+->\s+([\d.]+) cycles", txt, re.M)}
-    # the single-rate 32-bit / packed-16 integer instructions the detector kernels are made of (not v_pk_fma_f32, not v_mul_lo)
-    # (nor the round-3 probes: k_cndmask reads a never-written VCC, the k_cmp_* pairs are two instructions per slot)
-    ref = statistics.median(v for k, v in cyc.items() if k not in ("k_pk_fma_f32", "k_mullo", "k_cndmask", "k_cmp_cnd", "k_cmp_addc"))
+    rates = valu_mix.parse_rates(valu_path)
+    full = statistics.median(v for v in rates.values() if v < 3.0)
+    half = statistics.median(v for v in rates.values() if 3.0 <= v < 6.0)
+    sus = [float(x) for x in re.findall(r"\[\s*\d+\]\s+(\d+) MHz", txt)]
+    clock = round(statistics.median(sus) * 1e-3, 3) if sus else float(re.search(r"attribute clock ([\d.]+) GHz", txt).group(1))
+    mix = {}
+    if mix_path and os.path.exists(mix_path):
+        mk = json.load(open(mix_path))["kernels"]
+        for name, inst in (("fast_kernel", "fast_kernel"), ("harris_kernel", "harris_kernel<1>"), ("nms_kernel", "nms_kernel<1>"),
+                           ("bad_det_kernel", "bad_det_kernel"), ("resize_chain", "resize_stream_kernel"), ("resize_stream_kernel", "resize_stream_kernel"),
+                           ("select_kernel", "select_kernel"), ("emit_kernel", "emit_kernel"), ("angle_kernel", "angle_kernel<false>"),
+                           ("angle_tail_kernel", "angle_tail_kernel")):
+            if inst in mk:
+                mix[name] = mk[inst]["mix_cycles_per_wave_instr"]
     res = {"note": __doc__.split("\n")[0], "git_head": os.environ.get("EFX_GIT_HEAD", "unknown (set EFX_GIT_HEAD)"),
            "source_sha256": source_digests(), "frames_profiled": frames, "clock_ghz": clock,
-           "cycles_per_wave_instr": round(ref, 3), "cycles_per_wave_instr_by_instruction": cyc,
-           "issue_peak_wave_instr_per_s": 1024 * clock * 1e9 / ref,
+           "clock_from": "s_memtime / s_memrealtime during ~1 s of dense VALU work (valu_rate's sustained leg)" if sus else "device attribute",
+           "cycles_full_rate": round(full, 3), "cycles_half_rate": round(half, 3),
+           "cycles_per_wave_instr": round(half, 3), "cycles_per_wave_instr_by_instruction": rates,
+           # three ceilings, in wave-instructions per second over the chip's 1024 SIMDs:
+           "issue_peak_guide": 1024 * 2.4e9 / 2.0,            # MI355X_MICROARCH.md: wave64 VALU = 2 cycles at 2.4 GHz (every instruction full rate)
+           "issue_peak_full_rate": 1024 * clock * 1e9 / full,   # measured, a kernel made of full-rate instructions only
+           "issue_peak_half_rate": 1024 * clock * 1e9 / half,   # measured, a kernel made of half-rate instructions only
+           "issue_peak_wave_instr_per_s": 1024 * clock * 1e9 / half,
+           "mix_cycles_per_wave_instr": mix,
+           "mix_from": (os.path.relpath(mix_path, ROOT) + " (tools/valu_mix.py: STATIC instruction mix of the compiled kernels by rate class)") if mix else None,
            "valu_wave_instr_per_launch": valu_launch, "valu_wave_instr_per_frame": round(valu_frame),
            "lds_cycles_per_launch": lds_launch, "lds_bank_conflict_cycles_per_launch": conf_launch,
            "traffic_bytes_per_launch": traffic}
@@ -77,4 +99,5 @@ def main(sq_path, lds_path, traffic_path, valu_path, out_path):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:6])
+    sys.path.insert(0, ROOT)
+    main(*sys.argv[1:7])

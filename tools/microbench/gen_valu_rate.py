@@ -176,7 +176,7 @@ struct Entry { const char* name; const char* group; int per_body; kern_t clean, 
     "v_mov_b32 v32, 0\n v_mov_b32 v33, 0\n v_mov_b32 v34, 0\n v_mov_b32 v35, 0\n v_mov_b32 v36, 0\n v_mov_b32 v37, 0\n" \
     "v_mov_b32 v38, 0\n v_mov_b32 v39, 0\n v_mov_b32 v40, 0\n v_mov_b32 v41, 0\n v_mov_b32 v42, 0\n v_mov_b32 v43, 0\n" \
     "v_mov_b32 v44, 0\n v_mov_b32 v45, 0\n v_mov_b32 v46, 0\n v_mov_b32 v47, 0\n" \
-    "s_mov_b64 s[42:43], 0x55555555\n s_mov_b32 s47, 7\n" \
+    "s_mov_b64 s[42:43], 0x55555555\n s_mov_b32 s47, 7\n s_mov_b64 vcc, 0x33333333\n" \
     "s_mov_b32 s48, %[it]\n" \
     "s_getreg_b32 %[hw], hwreg(HW_REG_HW_ID)\n s_getreg_b32 %[xc], hwreg(HW_REG_XCC_ID)\n" \
     "s_barrier\n" \
@@ -246,6 +246,7 @@ static const char* rate_class(double c) {
 }
 int main(int argc, char** argv) {
     const char* only = argc > 1 ? argv[1] : nullptr;
+    const bool calib = only && !strcmp(only, "--calib");
     Rec* d_rec; (void)hipMalloc(&d_rec, sizeof(Rec) * 256 * 8 * 4);
     int khz = 0; (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeClockRate, 0);
     (void)hipDeviceGetAttribute(&g_wall_khz, hipDeviceAttributeWallClockRate, 0);
@@ -258,6 +259,25 @@ int main(int argc, char** argv) {
     printf("%-26s %-22s | %7s %7s %7s %7s | %7s | %7s | %7s %9s %-10s %s\n", "instruction", "group", "W=1", "W=2", "W=4", "W=8", "same W8", "dep W1", "sclkMHz", "event W8", "placement", "rate");
     std::vector<Rec> h;
     const int iters = 1200;
+    if (calib) {
+        // counter calibration (run under rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE ...): kernels whose
+        // VALU pipe is saturated by construction (8 waves per SIMD, nothing but one instruction class), two launches each
+        const char* names[] = {"v_add_u32", "v_fma_f32", "v_perm_b32", "v_pk_mad_u16", "v_pk_fma_f32", "v_cvt_f32_ubyte0", "v_rcp_f32"};
+        int idx = 0;
+        for (const Entry& e : entries) {
+            bool take = false;
+            for (const char* n : names) take = take || !strcmp(n, e.name);
+            if (take) {
+                const int lds = 20 * 1024, it = 4800;
+                (void)hipFuncSetAttribute((const void*)e.clean, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                for (int l = 0; l < 2; l++) hipLaunchKernelGGL(e.clean, dim3(256 * 8), dim3(256), lds, 0, d_rec, it);
+                (void)hipDeviceSynchronize();
+                printf("calib k%d_clean = %s: %d wave-instructions per wave, 8 waves per SIMD\n", idx, e.name, it * 32 * e.per_body);
+            }
+            idx++;
+        }
+        return 0;
+    }
     for (const Entry& e : entries) {
         if (only && !strstr(e.name, only)) continue;
         const int per_iter = 32 * e.per_body;

@@ -69,3 +69,68 @@ def random_keypoints(rows, cols, n, seed=3, size=31.0, border=0.0, special=True)
         k[3::16, 0] = rng.uniform(0, 20, size=k[3::16].shape[0])              # left border
         k[4::16, 1] = rng.uniform(rows - 21, rows - 1, size=k[4::16].shape[0])  # bottom border
     return k
+
+
+def _bilinear_up(g, rows, cols, cell):
+    """Bilinear interpolation of a coarse grid (float64, elementwise IEEE operations only: the same frame on every host)."""
+    y = np.arange(rows, dtype=np.float64) / cell
+    x = np.arange(cols, dtype=np.float64) / cell
+    y0 = np.floor(y).astype(np.int64); x0 = np.floor(x).astype(np.int64)
+    ty = (y - y0)[:, None]; tx = (x - x0)[None, :]
+    a = g[np.ix_(y0, x0)]; b = g[np.ix_(y0, x0 + 1)]; c = g[np.ix_(y0 + 1, x0)]; d = g[np.ix_(y0 + 1, x0 + 1)]
+    return (a * (1 - tx) + b * tx) * (1 - ty) + (c * (1 - tx) + d * tx) * ty
+
+
+def powerlaw_frame(rows, cols, seed=1000, beta=1.3, contrast=45.0):
+    """1/f-textured frame: the amplitude spectrum of natural photographs falls off as 1/f^beta.  Built as
+    octaves of bilinearly interpolated Gaussian noise, cell size c weighted c^(beta - 1) (beta = 1: the same variance in every
+    octave, which is what a 1/f amplitude spectrum means in two dimensions), down to single pixels -- texture at every
+    scale, soft gradients, no flat areas: the regime of FAST threshold ties, Harris near-ties and HashSIFT projections close
+    to zero that rectangles-and-noise frames do not reach.  beta 1.3 (photographs: 1.0 .. 1.5) gives ~3 % FAST corners at
+    threshold 20, beta 1.0 ~17 % (the 10 % cap becomes active)."""
+    rng = np.random.default_rng(seed)
+    acc = np.zeros((rows, cols), np.float64)
+    c = 1
+    while c <= max(8, min(rows, cols) // 2):
+        g = rng.standard_normal((rows // c + 2, cols // c + 2))
+        acc += (float(c) ** (beta - 1.0)) * (_bilinear_up(g, rows, cols, c) if c > 1 else g[:rows, :cols])
+        c *= 2
+    acc -= acc.mean()
+    s = acc.std()
+    acc = 128.0 + acc * (contrast / s if s > 0 else 0.0)
+    return np.clip(np.rint(acc), 0, 255).astype(np.uint8)
+
+
+def _gauss_blur(img, sigma):
+    r = max(1, int(np.ceil(3 * sigma)))
+    k = np.exp(-0.5 * (np.arange(-r, r + 1, dtype=np.float64) / sigma) ** 2)
+    k /= k.sum()
+    p = np.pad(img, ((0, 0), (r, r)), mode="edge")
+    t = np.zeros(img.shape, np.float64)
+    for j in range(2 * r + 1):
+        t += k[j] * p[:, j:j + img.shape[1]]
+    p = np.pad(t, ((r, r), (0, 0)), mode="edge")
+    o = np.zeros(img.shape, np.float64)
+    for j in range(2 * r + 1):
+        o += k[j] * p[j:j + img.shape[0], :]
+    return o
+
+
+def blurred_edges_frame(rows, cols, seed=1000, density=0.6, sigmas=(0.6, 1.2, 2.5, 5.0)):
+    """The shapes of synth_frame seen through defocus: vertical bands of the frame are blurred with
+    Gaussians of several widths (band k with sigmas[k]), then sensor noise is added -- edges a few pixels wide, corners whose
+    FAST arcs sit at the threshold, the gradient statistics of photographs of man-made scenes."""
+    base = synth_frame(rows, cols, seed=seed, density=density, noise=0).astype(np.float64)
+    out = np.empty_like(base)
+    nb = len(sigmas)
+    edges = [cols * k // nb for k in range(nb + 1)]
+    for k, s in enumerate(sigmas):
+        x0, x1 = edges[k], edges[k + 1]
+        if x1 <= x0:
+            continue
+        m = int(np.ceil(3 * s)) + 1
+        a, b = max(0, x0 - m), min(cols, x1 + m)
+        out[:, x0:x1] = _gauss_blur(base[:, a:b], s)[:, x0 - a:x0 - a + (x1 - x0)]
+    rng = np.random.default_rng(seed + 99991)
+    out += rng.integers(-2, 3, size=out.shape)
+    return np.clip(np.rint(out), 0, 255).astype(np.uint8)
