@@ -623,6 +623,225 @@ void efx_gaussian_taps_host(float taps[7])
     for (int i = 0; i < 7; i++) taps[i] = (float)(e[i] / sum);
 }
 
+// ================================================================================================
+// Whole-level Gaussian for detectAndCompute (round 4; spec S6, cuda_efficient_features.cpp:193,302-306: the reference blurs
+// every level before it describes on it).  Until round 3 every keypoint blurred its own 54 x 54 window inside bad_det_kernel
+// (no blurred copy of the pyramid): 18.7 lane-instructions per blurred pixel -- aprons, idle lanes of the item shapes, one
+// workgroup per keypoint -- against the 17.5 of a streaming blur whose instructions are the CHEAP ones: profiles/
+// r04_valu_rate.txt shows v_fma_f32 / v_mul_f32 at 2.2 cycles per wave64 instruction and v_pk_fma_f32 / conversions at 4.2.
+// So the levels are blurred once, as images, and a wave describes a keypoint on the blurred level (bad_raw_kernel) instead
+// of a workgroup (bad_det_kernel: 1550 wave-instructions per keypoint, bad_raw_kernel: 630).
+//
+// One WAVE owns a strip of 256 columns (a lane: 4 adjacent pixels = one dword) and BLV_ROWS output rows, and walks down:
+//   load    the lane's dword of the next input row and its two neighbours (px -4 .. 7; the same 128-byte lines as the
+//           neighbouring lanes': L1 hits), through a buffer resource (range check, no predicates)
+//   rows    10 x v_cvt_f32_ubyteN straight from the three dwords, 4 outputs x 7 taps: acc = fma(v_j, tap_j, acc), j = 0 .. 6,
+//           from tap_0 * v_0 (spec S6: one rounding per tap), plain v_fma_f32 (full rate; the packed form is no faster per
+//           FMA and would need the pixels in register pairs)
+//   ring    the row-pass results of the last 7 rows stay in registers (28 floats, the loop is unrolled by 7: static names)
+//   columns output row y from rows y - 3 .. y + 3 of the ring, same FMA order, v_cvt_pk_u8_f32 (round half even, saturate),
+//           one dword store
+// No LDS, no barrier; BORDER_REFLECT_101: the row index is reflected (scalar), strips that touch the left / right edge
+// of the level -- and levels whose base or pitch is not 4-byte aligned (a caller's level 0) -- fetch their 10 input pixels
+// as bytes at reflected columns (wave-uniform branch).  Bit-exact with efx_blur_window_lds (same expression per pixel).
+// ================================================================================================
+#define BLV_GROUPS 9                     // a task of the dword path: 9 groups of 7 output rows (the ring's period)
+#define BLV_ROWS (7 * BLV_GROUPS)
+#define BLV_ROWS_BYTES 16                // ... of the byte path (narrow or unaligned levels): short tasks, its loads are not prefetched
+// Strips of a level on the dword path (cols >= 512): `n_reg` regular strips at x = 256 s, then ONE strip anchored at the
+// level's right edge, x = xs + 4 lane with xs = ((cols - 1) & ~3) - 252: its last lane's dword holds the level's last pixel, so
+// the BORDER_REFLECT_101 pixels of the right edge are a fixed pattern of register moves in lanes 62 / 63 (by r = number of
+// valid pixels in that dword), as the left edge's are in lane 0 of strip 0.  Regular strips do not store columns >= xs
+// (the anchored strip owns them), so none of the columns they do store needs a pixel beyond the level.
+struct BlurLevel { const uint8_t* src; uint8_t* dst; int spitch, dpitch, rows, cols, bytes, n_reg, nstrips, xs, task_end; };
+struct BlurLevelsArgs { int nlevels, total; BlurLevel lv[EFX_MAX_LEVELS]; };
+
+// the generic form: 10 input pixels per lane as byte loads at reflected columns (any alignment, any size)
+__device__ __forceinline__ void blur_task_bytes(const BlurLevel& L, int strip, int chunk, int lane, const float (&tp)[7])
+{
+    constexpr int NR = BLV_ROWS_BYTES;
+    const int rows = L.rows, cols = L.cols, spitch = L.spitch, dpitch = L.dpitch;
+    const int x = strip * 256 + lane * 4;
+    const int y0 = chunk * NR;
+    const int nout = min(NR, rows - y0);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(L.src), 0, (rows - 1) * spitch + cols, 0x00020000);
+    int cidx[10];
+#pragma unroll
+    for (int k = 0; k < 10; k++) cidx[k] = efx_reflect101(x - 3 + k, cols);
+    auto rowpass = [&](int yy, float (&o)[4]) {
+        const int rbase = efx_reflect101(yy, rows) * spitch;
+        float v[10];
+#pragma unroll
+        for (int k = 0; k < 10; k++) v[k] = (float)__builtin_amdgcn_raw_buffer_load_b8(rsrc, rbase + cidx[k], 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float acc = v[i] * tp[0];
+#pragma unroll
+            for (int jt = 1; jt < 7; jt++) acc = __builtin_fmaf(v[i + jt], tp[jt], acc);
+            o[i] = acc;
+        }
+    };
+    float R[7][4];
+#pragma unroll
+    for (int i = 0; i < 6; i++) rowpass(y0 - 3 + i, R[i]);
+    uint8_t* drow = L.dst + (size_t)y0 * dpitch + x;
+    for (int base = 0; base < nout; base += 7) {
+#pragma unroll
+        for (int u = 0; u < 7; u++) {
+            if (base + u < nout) {                          // wave-uniform
+                rowpass(y0 + base + u + 3, R[(u + 6) % 7]);
+                uint32_t pk = 0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    float acc = R[u % 7][i] * tp[0];
+#pragma unroll
+                    for (int jt = 1; jt < 7; jt++) acc = __builtin_fmaf(R[(u + jt) % 7][i], tp[jt], acc);
+                    pk = __builtin_amdgcn_cvt_pk_u8_f32(acc, i, pk);
+                }
+                // destination rows are padded to 256 bytes: the dword of a row's last pixels is inside the row
+                if (x < cols) *reinterpret_cast<uint32_t*>(drow + (size_t)(base + u) * dpitch) = pk;
+            }
+        }
+    }
+}
+
+// the dword path: straight-line rows (no branch but the loop's), loads two rows ahead, stores through a range-checked resource
+__device__ __forceinline__ void blur_task_dwords(const BlurLevel& L, int strip, int chunk, int lane, const float (&tp)[7])
+{
+    const int rows = L.rows, cols = L.cols, spitch = L.spitch, dpitch = L.dpitch;
+    const bool anchored = strip == L.n_reg;                // wave-uniform
+    const bool leftmost = strip == 0;
+    const int x = (anchored ? L.xs : strip * 256) + lane * 4;
+    const int y0 = chunk * BLV_ROWS;
+    const int nout = min(BLV_ROWS, rows - y0);
+    // a row's dwords up to roundup4(cols) are memory we may read (own levels: padded rows; a caller's aligned level 0: its pitch
+    // is a multiple of 4); beyond that -- and left of the level, where the offset wraps -- the range check returns 0
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(L.src), 0, (rows - 1) * spitch + ((cols + 3) & ~3), 0x00020000);
+    // rows of this task only, and (regular strips) columns left of the anchored strip only: everything else is an offset the
+    // range check drops.  Destination rows are padded to 256 bytes: the dword of a row's last pixels is inside the row
+    const __amdgpu_buffer_rsrc_t dsrc = __builtin_amdgcn_make_buffer_rsrc(L.dst, 0, (y0 + nout) * dpitch, 0x00020000);
+    const int dx = (anchored || x < L.xs) ? x : 0x40000000;
+    const int r = cols - ((cols - 1) & ~3);                // valid pixels in the level's last dword: 1 .. 4
+    struct Raw { uint32_t a, b, c; };
+    auto fetch = [&](int yy) {
+        int ry = yy < 0 ? -yy : (yy > rows - 1 ? 2 * (rows - 1) - yy : yy);      // REFLECT_101, rows >= 16; wave-uniform
+        ry = max(min(ry, rows - 1), 0);                     // rows fetched ahead of a level's last ones: any valid row
+        const int goff = ry * spitch + x - 4;
+        Raw q;
+        q.a = __builtin_amdgcn_raw_buffer_load_b32(rsrc, goff, 0, 0);
+        q.b = __builtin_amdgcn_raw_buffer_load_b32(rsrc, goff + 4, 0, 0);
+        q.c = __builtin_amdgcn_raw_buffer_load_b32(rsrc, goff + 8, 0, 0);
+        return q;
+    };
+    auto rowpass = [&](const Raw& q, float (&o)[4]) {
+        float v[10];
+        v[0] = (float)((q.a >> 8) & 0xffu); v[1] = (float)((q.a >> 16) & 0xffu); v[2] = (float)(q.a >> 24);
+        v[3] = (float)(q.b & 0xffu); v[4] = (float)((q.b >> 8) & 0xffu); v[5] = (float)((q.b >> 16) & 0xffu); v[6] = (float)(q.b >> 24);
+        v[7] = (float)(q.c & 0xffu); v[8] = (float)((q.c >> 8) & 0xffu); v[9] = (float)((q.c >> 16) & 0xffu);
+        if (leftmost) {                                     // px -3, -2, -1 = px 3, 2, 1
+            const bool l0 = lane == 0;
+            v[0] = l0 ? v[6] : v[0]; v[1] = l0 ? v[5] : v[1]; v[2] = l0 ? v[4] : v[2];
+        }
+        if (anchored) {
+            // lane 63 holds the level's last pixel at input index kmax = r + 2, lane 62 at r + 6: input k in (kmax, kmax + 3] is
+            // the mirror image 2 kmax - k (outputs beyond the level are not stored and need nothing)
+            const bool l63 = lane == 63, l62 = lane == 62;
+            if (r == 1) { v[4] = l63 ? v[2] : v[4]; v[5] = l63 ? v[1] : v[5]; v[6] = l63 ? v[0] : v[6]; v[8] = l62 ? v[6] : v[8]; v[9] = l62 ? v[5] : v[9]; }
+            else if (r == 2) { v[5] = l63 ? v[3] : v[5]; v[6] = l63 ? v[2] : v[6]; v[7] = l63 ? v[1] : v[7]; v[9] = l62 ? v[7] : v[9]; }
+            else if (r == 3) { v[6] = l63 ? v[4] : v[6]; v[7] = l63 ? v[3] : v[7]; v[8] = l63 ? v[2] : v[8]; }
+            else { v[7] = l63 ? v[5] : v[7]; v[8] = l63 ? v[4] : v[8]; v[9] = l63 ? v[3] : v[9]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float acc = v[i] * tp[0];                      // == fma(tp[0], v, 0) exactly
+#pragma unroll
+            for (int jt = 1; jt < 7; jt++) acc = __builtin_fmaf(v[i + jt], tp[jt], acc);
+            o[i] = acc;
+        }
+    };
+    float R[7][4];
+    Raw p1 = fetch(y0 - 3), p2 = fetch(y0 - 2);
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        const Raw cur = p1;
+        p1 = p2;
+        p2 = fetch(y0 - 3 + i + 2);
+        rowpass(cur, R[i]);
+    }
+    int doff = y0 * dpitch + dx;
+    for (int base = 0; base < nout; base += 7) {
+#pragma unroll
+        for (int u = 0; u < 7; u++) {
+            const Raw cur = p1;
+            p1 = p2;
+            p2 = fetch(y0 + base + u + 5);
+            rowpass(cur, R[(u + 6) % 7]);
+            uint32_t pk = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                float acc = R[u % 7][i] * tp[0];
+#pragma unroll
+                for (int jt = 1; jt < 7; jt++) acc = __builtin_fmaf(R[(u + jt) % 7][i], tp[jt], acc);
+                pk = __builtin_amdgcn_cvt_pk_u8_f32(acc, i, pk);
+            }
+            __builtin_amdgcn_raw_buffer_store_b32(pk, dsrc, doff, 0, 0);
+            doff += dpitch;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 7) void blur_levels_kernel(const BlurLevelsArgs A, float tp0, float tp1, float tp2, float tp3)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int task = xcd_chunked(blockIdx.x, gridDim.x) * 4 + wave;
+    if (task >= A.total) return;
+    int l = 0;
+    while (l + 1 < A.nlevels && task >= A.lv[l].task_end) l++;
+    const BlurLevel& L = A.lv[l];
+    const int t = task - (l ? A.lv[l - 1].task_end : 0);
+    const int chunk = t / L.nstrips, strip = t - chunk * L.nstrips;
+    const float tp[7] = { tp0, tp1, tp2, tp3, tp2, tp1, tp0 };
+    if (L.bytes) blur_task_bytes(L, strip, chunk, lane, tp);
+    else blur_task_dwords(L, strip, chunk, lane, tp);
+}
+
+hipError_t efx_launch_blur_levels(const LevelTable& H, const uint8_t* img0, int pitch0, const uint8_t* pyramid, uint8_t* blurred,
+                                  int blur0_pitch, size_t blur_levels_off, const ProfRec& prof_rec, hipStream_t stream)
+{
+    BlurLevelsArgs A = {};
+    for (int l = 0; l < H.nlevels; l++) {
+        const LevelDev& L = H.lv[l];
+        if (!L.active || L.rows <= 0 || L.cols <= 0) continue;
+        BlurLevel& B = A.lv[A.nlevels++];
+        B.src = l == 0 ? img0 : pyramid + L.img_off;
+        B.spitch = l == 0 ? pitch0 : L.pitch;
+        B.dst = l == 0 ? blurred : blurred + blur_levels_off + L.img_off;
+        B.dpitch = l == 0 ? blur0_pitch : L.pitch;
+        B.rows = L.rows; B.cols = L.cols;
+        const bool aligned = ((((uintptr_t)B.src) | (uintptr_t)B.spitch) & 3u) == 0;
+        B.bytes = !(aligned && L.cols >= 512 && L.rows >= 16);
+        if (B.bytes) {
+            B.nstrips = (L.cols + 255) / 256;
+            A.total += B.nstrips * ((L.rows + BLV_ROWS_BYTES - 1) / BLV_ROWS_BYTES);
+        } else {
+            B.xs = ((L.cols - 1) & ~3) - 252;
+            B.n_reg = (B.xs + 255) / 256;                   // regular strips cover [0, xs)
+            B.nstrips = B.n_reg + 1;
+            A.total += B.nstrips * ((L.rows + BLV_ROWS - 1) / BLV_ROWS);
+        }
+        B.task_end = A.total;
+    }
+    if (A.total == 0) return hipSuccess;
+    float t[7];
+    efx_gaussian_taps_host(t);
+    const bool prof = prof_rec.begin(11, stream);
+    const int nblk = ((A.total + 3) / 4 + EFX_NXCD - 1) / EFX_NXCD * EFX_NXCD;     // xcd_chunked wants whole rounds
+    hipLaunchKernelGGL(blur_levels_kernel, dim3(nblk), dim3(256), 0, stream, A, t[0], t[1], t[2], t[3]);
+    prof_rec.end(prof, 11, stream);
+    return hipGetLastError();
+}
+
 hipError_t efx_launch_bad(const DescribeLaunch& a, const BadParamsDev* d_params, float reach, hipStream_t stream)
 {
     if (a.n <= 0) return hipSuccess;
@@ -644,6 +863,17 @@ hipError_t efx_launch_bad(const DescribeLaunch& a, const BadParamsDev* d_params,
     if (!a.affine_ready)         // detectAndCompute: angle_kernel has left the records (DetectLaunch::bad_affine)
         hipLaunchKernelGGL(bad_affine_kernel, dim3((a.n + 255) / 256), dim3(256), 0, stream, a.kp4, a.kps5, a.kps5_pitch, a.kp_level, a.d_table, a.img0, a.pitch0, a.pyramid, a.rows0, a.cols0,
                            a.d_count, a.n, a.scale_factor, reach, S, sfixed, aff);
+    if (a.blur && a.level_blurred) {
+        // the records point at BLURRED level images (efx_launch_blur_levels ran on this stream): a wave per keypoint, no blur
+        // of its own.  detect_common sets level_blurred only under bad_raw_kernel's conditions (S == 48, box edges <= 16)
+        if (a.nbits == 256)
+            hipLaunchKernelGGL(bad_raw_kernel<4>, dim3((a.n + 3) / 4), dim3(256), 4 * BAD_RAW_WAVE_LDS, stream, a.d_count, a.n, d_params, aff,
+                               a.desc, a.desc_pitch);
+        else
+            hipLaunchKernelGGL(bad_raw_kernel<8>, dim3((a.n + 3) / 4), dim3(256), 4 * BAD_RAW_WAVE_LDS, stream, a.d_count, a.n, d_params, aff,
+                               a.desc, a.desc_pitch);
+        return hipGetLastError();
+    }
     if (a.blur) {
         if (S == 48 && a.uniform_size && max_size == (float)EFX_PATCH_SIZE && a.kp_level && a.bad_det_tables == 2) {
             // detector keypoints: the per-pair table of BadParamsDev was built for exactly this s; LDS: raw | pix | hb / I

@@ -1889,7 +1889,8 @@ __global__ __launch_bounds__(ANGLE_KP * 32) void angle_kernel(const LevelTable* 
                                                     const uint8_t* __restrict__ img0, int pitch0, const uint8_t* __restrict__ pyramid,
                                                     float4* __restrict__ kp4, const int* __restrict__ kp_level,
                                                     uint8_t* __restrict__ kps, size_t kps_pitch,
-                                                    Affine* __restrict__ aff, float bad_scale, float bad_reach, int bad_smax, int bad_sfixed)
+                                                    Affine* __restrict__ aff, float bad_scale, float bad_reach, int bad_smax, int bad_sfixed,
+                                                    const uint8_t* __restrict__ rec_img0, int rec_pitch0, const uint8_t* __restrict__ rec_levels)
 {
     // The intensity-centroid moments m01, m10 of every keypoint's patch; two keypoints per wave (31 of each 32 lanes hold
     // one patch column), ANGLE_KP per workgroup.  The moments are left in the .z / .w words of the keypoint's kp4 entry
@@ -1953,7 +1954,7 @@ __global__ __launch_bounds__(ANGLE_KP * 32) void angle_kernel(const LevelTable* 
             float4 kq = kp4[k8]; kq.w = angle;
             const int lv = kp_level[k8];
             const LevelDev& L = T->lv[lv];
-            aff[k8] = efx_bad_affine(kq, lv == 0 ? img0 : pyramid + L.img_off, lv == 0 ? pitch0 : L.pitch, L.rows, L.cols, lv,
+            aff[k8] = efx_bad_affine(kq, lv == 0 ? rec_img0 : rec_levels + L.img_off, lv == 0 ? rec_pitch0 : L.pitch, L.rows, L.cols, lv,
                                      bad_scale, bad_reach, bad_smax, bad_sfixed);
         }
     }
@@ -1966,7 +1967,8 @@ __global__ __launch_bounds__(64) void angle_tail_kernel(const LevelTable* __rest
                                                         const uint8_t* __restrict__ img0, int pitch0, const uint8_t* __restrict__ pyramid,
                                                         float4* __restrict__ kp4, const int* __restrict__ kp_level,
                                                         uint8_t* __restrict__ kps, size_t kps_pitch,
-                                                        Affine* __restrict__ aff, float bad_scale, float bad_reach, int bad_smax, int bad_sfixed)
+                                                        Affine* __restrict__ aff, float bad_scale, float bad_reach, int bad_smax, int bad_sfixed,
+                                                        const uint8_t* __restrict__ rec_img0, int rec_pitch0, const uint8_t* __restrict__ rec_levels)
 {
     const int count = min(*d_count, capacity);
     const int k = (int)blockIdx.x * 64 + (int)threadIdx.x;
@@ -1979,7 +1981,7 @@ __global__ __launch_bounds__(64) void angle_tail_kernel(const LevelTable* __rest
     if (aff) {
         const int lv = kp_level[k];
         const LevelDev& L = T->lv[lv];
-        aff[k] = efx_bad_affine(kq, lv == 0 ? img0 : pyramid + L.img_off, lv == 0 ? pitch0 : L.pitch, L.rows, L.cols, lv,
+        aff[k] = efx_bad_affine(kq, lv == 0 ? rec_img0 : rec_levels + L.img_off, lv == 0 ? rec_pitch0 : L.pitch, L.rows, L.cols, lv,
                                 bad_scale, bad_reach, bad_smax, bad_sfixed);
     }
 }
@@ -2187,6 +2189,13 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
         EFX_TRACE_POINT("tower");
     }
     if (a.pyramid_only) return hipGetLastError();
+    if (a.blurred) {
+        // BAD behind detectAndCompute: every active level blurred once, as an image (bad_kernel.hip); the describer's records
+        // (angle kernels below) point at the copies.  Right behind the pyramid: the levels are still in the caches
+        e = efx_launch_blur_levels(H, a.img0, a.pitch0, a.pyramid, a.blurred, a.blur0_pitch, a.blur_levels_off, a.prof, stream);
+        if (e != hipSuccess) return e;
+        EFX_TRACE_POINT("blur");
+    }
 #ifdef EFX_DEBUG_BUILD
     if (g_trace) {          // poison the corner arenas, so that entries fast_kernel never stores show up in the digest
         size_t ncand = 0;
@@ -2246,6 +2255,10 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
                        a.img0, a.pitch0, a.pyramid, (uint8_t*)a.d_keypoints, a.kps_pitch, a.capacity, a.kp4, a.kp_level);
     EFX_TRACE_POINT("emit");
     if (a.capacity > 0) {
+        // the image the describer's records refer to: the raw levels, or their blurred copies (blur_levels_kernel above)
+        const uint8_t* rec_img0 = a.blurred ? a.blurred : a.img0;
+        const int rec_pitch0 = a.blurred ? a.blur0_pitch : a.pitch0;
+        const uint8_t* rec_levels = a.blurred ? a.blurred + a.blur_levels_off : a.pyramid;
         int nmax = 0;
         for (int s = 0; s < H.nlevels; s++) if (H.lv[s].active) nmax += H.lv[s].quota;
         if (nmax > a.capacity) nmax = a.capacity;
@@ -2253,13 +2266,13 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
             // small frames (the ones whose pyramid is one tower launch): angles and records in the same launch
             hipLaunchKernelGGL(angle_kernel<true>, dim3((nmax + ANGLE_KP - 1) / ANGLE_KP), dim3(ANGLE_KP * 32), 0, stream, a.d_table, a.d_count, a.capacity,
                                a.img0, a.pitch0, a.pyramid, a.kp4, a.kp_level, (uint8_t*)a.d_keypoints, a.kps_pitch,
-                               static_cast<Affine*>(a.bad_affine), a.bad_scale, a.bad_reach, a.bad_smax, a.bad_sfixed);
+                               static_cast<Affine*>(a.bad_affine), a.bad_scale, a.bad_reach, a.bad_smax, a.bad_sfixed, rec_img0, rec_pitch0, rec_levels);
         } else if (nmax > 0) {
             hipLaunchKernelGGL(angle_kernel<false>, dim3((nmax + ANGLE_KP - 1) / ANGLE_KP), dim3(ANGLE_KP * 32), 0, stream, a.d_table, a.d_count, a.capacity,
-                               a.img0, a.pitch0, a.pyramid, a.kp4, a.kp_level, nullptr, 0, nullptr, 0.f, 0.f, 0, 0);
+                               a.img0, a.pitch0, a.pyramid, a.kp4, a.kp_level, nullptr, 0, nullptr, 0.f, 0.f, 0, 0, nullptr, 0, nullptr);
             hipLaunchKernelGGL(angle_tail_kernel, dim3((nmax + 63) / 64), dim3(64), 0, stream, a.d_table, a.d_count, a.capacity,
                                a.img0, a.pitch0, a.pyramid, a.kp4, a.kp_level, (uint8_t*)a.d_keypoints, a.kps_pitch,
-                               static_cast<Affine*>(a.bad_affine), a.bad_scale, a.bad_reach, a.bad_smax, a.bad_sfixed);
+                               static_cast<Affine*>(a.bad_affine), a.bad_scale, a.bad_reach, a.bad_smax, a.bad_sfixed, rec_img0, rec_pitch0, rec_levels);
         }
     }
     a.prof.end(prof, 3, stream);

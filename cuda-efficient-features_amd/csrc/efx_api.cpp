@@ -341,9 +341,10 @@ int describer_run(Describer& d, std::string& err, DescribeLaunch a, float* dbg_r
 
 EfxKnobs efx_read_knobs()
 {
-    EfxKnobs k = { 0, 0, 0, 0 };
+    EfxKnobs k = { 0, 0, 0, 0, 0 };
     k.no_tower = getenv("EFX_NO_TOWER") != nullptr;
     k.no_resize_stream = getenv("EFX_NO_RESIZE_STREAM") != nullptr;
+    k.no_level_blur = getenv("EFX_NO_LEVEL_BLUR") != nullptr;      // BAD behind detectAndCompute: every keypoint blurs its own window (A/B, parity tests)
     const char* d = getenv("EFX_DEBUG");
     const char* h = getenv("EFX_DEBUG_HS");
 #ifdef EFX_DEBUG_BUILD
@@ -386,6 +387,7 @@ struct efx_context {
     LevelTable h_table;
     DevBuf d_table, pyramid, hdr, cand, cmax, surv, counters, kp4, kp_level, img, kps, descout, count, maskbuf;
     DevBuf rplan; ResizePlanLevel rplan_lv[EFX_MAX_LEVELS];        // resize plan (tables of resize_stream_kernel)
+    DevBuf blurred;                 // blurred copies of the pyramid levels for the BAD describer (blur_levels_kernel), on first use
     size_t cand_slots = 0;          // records in `cand`; the coordinate-only array of the same length follows them
     Summary* h_mirror = nullptr;    // host copy of the last frame's summary, filled on demand by fetch_summary()
     int n_out_max = 0;              // sum of the active levels' quotas
@@ -438,6 +440,7 @@ struct efx_context {
         Quiesce* prev = tl_quiesce;
         tl_quiesce = &q;
         desc.release_all();                                // the describer's blocks are this context's: same wait
+        blurred.release();
         rplan.release(); d_table.release(); pyramid.release(); hdr.release(); cand.release(); cmax.release(); surv.release(); counters.release();
         kp4.release(); kp_level.release(); img.release(); kps.release(); descout.release(); count.release(); maskbuf.release();
         delete h_mirror;
@@ -721,13 +724,26 @@ int detect_common(efx_context* c, const uint8_t* d_image, int rows, int cols, si
     }
     // BAD behind detectAndCompute: angle_kernel writes the describer's per-keypoint records (no bad_affine_kernel launch)
     const int n_desc = capacity < c->n_out_max ? capacity : c->n_out_max;     // the bound angle_kernel uses: sum of the active quotas
-    bool affine_ready = false;
+    bool affine_ready = false, level_blurred = false;
     if (d_desc && capacity > 0 && c->desc.kind == 0 && n_desc > 0) {
         HIP_TRY(c->err, c->desc.responses.reserve((size_t)n_desc * sizeof(Affine)));
         const int S = efx_bad_smax_for((float)EFX_PATCH_SIZE, c->desc.scale, c->desc.reach);
         a.bad_affine = c->desc.responses.p; a.bad_scale = c->desc.scale; a.bad_reach = c->desc.reach;
         a.bad_smax = S; a.bad_sfixed = S == 48 ? 48 : 0;
         affine_ready = true;
+        // the levels blurred as images, a wave per keypoint on them (bad_kernel.hip: blur_levels_kernel + bad_raw_kernel) -- under
+        // bad_raw_kernel's conditions: the 48-pixel window, no box edge above 16 (integral modulo 2^16)
+        if (S == 48 && c->desc.ubox_max_side <= 16 && !c->desc.no_raw && !c->knobs.no_level_blur) {
+            const LevelTable& H = c->h_table;
+            size_t lv_bytes = 0;
+            for (int l = 1; l < H.nlevels; l++)
+                if (H.lv[l].rows > 0) lv_bytes = std::max(lv_bytes, (size_t)H.lv[l].img_off + (size_t)H.lv[l].pitch * H.lv[l].rows);
+            const int p0 = (int)align_up((size_t)cols, 256);
+            const size_t l0_bytes = H.lv[0].active ? (size_t)p0 * rows : 0;
+            HIP_TRY(c->err, c->blurred.reserve(l0_bytes + lv_bytes + 256));
+            a.blurred = static_cast<uint8_t*>(c->blurred.p); a.blur0_pitch = p0; a.blur_levels_off = l0_bytes;
+            level_blurred = true;
+        }
     }
 #ifdef EFX_DEBUG_BUILD
     efx_trace_hook = trace_digest;
@@ -748,6 +764,7 @@ int detect_common(efx_context* c, const uint8_t* d_image, int rows, int cols, si
         dl.kp4 = a.kp4; dl.kp_level = a.kp_level; dl.d_count = a.d_count;
         dl.n = n_desc;
         dl.affine_ready = affine_ready ? 1 : 0;
+        dl.level_blurred = level_blurred ? 1 : 0;
         dl.blur = 1;
         dl.max_size = (float)EFX_PATCH_SIZE;
         dl.uniform_size = 1;
@@ -1152,7 +1169,7 @@ size_t efx_cached_bytes(void) { return block_cache().cached(); }
 size_t efx_device_bytes(const efx_context* ctx)
 {
     if (!ctx) return 0;
-    const DevBuf* b[] = { &ctx->rplan, &ctx->d_table, &ctx->pyramid, &ctx->hdr, &ctx->cand, &ctx->cmax, &ctx->surv, &ctx->counters, &ctx->kp4,
+    const DevBuf* b[] = { &ctx->blurred, &ctx->rplan, &ctx->d_table, &ctx->pyramid, &ctx->hdr, &ctx->cand, &ctx->cmax, &ctx->surv, &ctx->counters, &ctx->kp4,
                           &ctx->kp_level, &ctx->img, &ctx->kps, &ctx->descout, &ctx->count, &ctx->maskbuf, &ctx->desc.params,
                           &ctx->desc.responses, &ctx->desc.kp4, &ctx->desc.img, &ctx->desc.desc };
     size_t t = 0;

@@ -171,7 +171,7 @@ __device__ __forceinline__ int efx_wave_incl_scan(int v)
 #else
 #define EFX_DBG(v) 0
 #endif
-struct EfxKnobs { int dbg, dbg_hs, no_tower, no_resize_stream; };
+struct EfxKnobs { int dbg, dbg_hs, no_tower, no_resize_stream, no_level_blur; };
 EfxKnobs efx_read_knobs();      // efx_api.cpp
 
 // ---- launchers (host side, defined in the .hip files) ----
@@ -207,7 +207,7 @@ struct ProfRec {
     hipEvent_t* start; hipEvent_t* stop; int* code; int* count; int capacity;
     unsigned skip;              // bit g set: launches of group g are not timed (0 fast, 1 harris, 2 nms, 3 select+emit+angle,
                                 // 4 describe, 5 pyramid) -- every event pair costs a few microseconds of stream idle time
-    static int group_of(int c) { return c >= 100 ? 5 : (c == 10 ? 4 : c); }
+    static int group_of(int c) { return c >= 100 ? 5 : (c == 10 || c == 11 ? 4 : c); }     // 10 describe, 11 blur_levels_kernel
     bool begin(int c, hipStream_t st) const
     {
         if (!count || *count >= capacity || ((skip >> group_of(c)) & 1u)) return false;
@@ -254,6 +254,10 @@ struct DetectLaunch {
     float4* kp4; int* kp_level;
     // BAD describer behind this detect call: angle_kernel also writes the per-keypoint Affine records (bad_affine.h)
     void* bad_affine; float bad_scale, bad_reach; int bad_smax, bad_sfixed;
+    // ... on BLURRED copies of the levels (round 4, bad_kernel.hip: blur_levels_kernel): level 0 at `blurred` with pitch
+    // blur0_pitch, level l >= 1 at blurred + blur_levels_off + its pyramid offset with the level's pitch; null: the describers
+    // blur per keypoint.  The records' image pointers then refer to the blurred levels
+    uint8_t* blurred; int blur0_pitch; size_t blur_levels_off;
     ProfRec prof;                                          // optional HIP-event pairs around the launches
 };
 
@@ -279,11 +283,14 @@ struct DescribeLaunch {
     int bad_no_raw;                                        // EFX_BAD_NO_RAW (variant knob, read when the describer is created; parity tests):
                                                            // computeAsync through the generic one-workgroup-per-keypoint kernel
     int affine_ready;                                      // bad_affine already holds this call's records (written by angle_kernel)
+    int level_blurred;                                     // ... and they point at blurred level images: describe without a blur (bad_raw_kernel)
     int dbg_hs;                                            // EFX_DEBUG_HS (EFX_DEBUG_BUILD builds only)
     ProfRec prof;
 };
 
 hipError_t efx_launch_bad(const DescribeLaunch& a, const BadParamsDev* d_params, float reach, hipStream_t stream);
+hipError_t efx_launch_blur_levels(const LevelTable& H, const uint8_t* img0, int pitch0, const uint8_t* pyramid, uint8_t* blurred,
+                                  int blur0_pitch, size_t blur_levels_off, const ProfRec& prof_rec, hipStream_t stream);
 
 #define EFX_HS_REC_BYTES 64
 struct HashSiftDev {
