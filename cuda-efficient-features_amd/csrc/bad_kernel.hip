@@ -645,7 +645,18 @@ void efx_gaussian_taps_host(float taps[7])
 // of the level -- and levels whose base or pitch is not 4-byte aligned (a caller's level 0) -- fetch their 10 input pixels
 // as bytes at reflected columns (wave-uniform branch).  Bit-exact with efx_blur_window_lds (same expression per pixel).
 // ================================================================================================
+#ifndef BLV_GROUPS
 #define BLV_GROUPS 9                     // a task of the dword path: 9 groups of 7 output rows (the ring's period)
+#endif
+#ifndef BLV_WAVES
+#define BLV_WAVES 7                      // waves per SIMD the kernel is compiled for (72 VGPRs)
+#endif
+#ifndef BLV_TAPS
+#define BLV_TAPS 7                       // INVESTIGATION builds: fewer taps in the row pass = fewer VALU instructions, same memory traffic
+#endif
+#ifndef BLV_PF
+#define BLV_PF 2                         // rows the loads run ahead of the arithmetic
+#endif
 #define BLV_ROWS (7 * BLV_GROUPS)
 #define BLV_ROWS_BYTES 16                // ... of the byte path (narrow or unaligned levels): short tasks, its loads are not prefetched
 // Strips of a level on the dword path (cols >= 512): `n_reg` regular strips at x = 256 s, then ONE strip anchored at the
@@ -728,9 +739,13 @@ __device__ __forceinline__ void blur_task_dwords(const BlurLevel& L, int strip, 
         ry = max(min(ry, rows - 1), 0);                     // rows fetched ahead of a level's last ones: any valid row
         const int goff = ry * spitch + x - 4;
         Raw q;
+#ifdef BLV_NOLOAD                                            // INVESTIGATION builds (tools/microbench/blur_sweep.sh): results invalid
+        q.a = (uint32_t)goff; q.b = (uint32_t)goff * 3u; q.c = (uint32_t)goff * 5u;
+#else
         q.a = __builtin_amdgcn_raw_buffer_load_b32(rsrc, goff, 0, 0);
         q.b = __builtin_amdgcn_raw_buffer_load_b32(rsrc, goff + 4, 0, 0);
         q.c = __builtin_amdgcn_raw_buffer_load_b32(rsrc, goff + 8, 0, 0);
+#endif
         return q;
     };
     auto rowpass = [&](const Raw& q, float (&o)[4]) {
@@ -738,11 +753,11 @@ __device__ __forceinline__ void blur_task_dwords(const BlurLevel& L, int strip, 
         v[0] = (float)((q.a >> 8) & 0xffu); v[1] = (float)((q.a >> 16) & 0xffu); v[2] = (float)(q.a >> 24);
         v[3] = (float)(q.b & 0xffu); v[4] = (float)((q.b >> 8) & 0xffu); v[5] = (float)((q.b >> 16) & 0xffu); v[6] = (float)(q.b >> 24);
         v[7] = (float)(q.c & 0xffu); v[8] = (float)((q.c >> 8) & 0xffu); v[9] = (float)((q.c >> 16) & 0xffu);
-        if (leftmost) {                                     // px -3, -2, -1 = px 3, 2, 1
+        if (__builtin_expect(leftmost, 0)) {                // px -3, -2, -1 = px 3, 2, 1 (wave-uniform branch)
             const bool l0 = lane == 0;
             v[0] = l0 ? v[6] : v[0]; v[1] = l0 ? v[5] : v[1]; v[2] = l0 ? v[4] : v[2];
         }
-        if (anchored) {
+        if (__builtin_expect(anchored, 0)) {
             // lane 63 holds the level's last pixel at input index kmax = r + 2, lane 62 at r + 6: input k in (kmax, kmax + 3] is
             // the mirror image 2 kmax - k (outputs beyond the level are not stored and need nothing)
             const bool l63 = lane == 63, l62 = lane == 62;
@@ -755,27 +770,32 @@ __device__ __forceinline__ void blur_task_dwords(const BlurLevel& L, int strip, 
         for (int i = 0; i < 4; i++) {
             float acc = v[i] * tp[0];                      // == fma(tp[0], v, 0) exactly
 #pragma unroll
-            for (int jt = 1; jt < 7; jt++) acc = __builtin_fmaf(v[i + jt], tp[jt], acc);
+            for (int jt = 1; jt < (BLV_TAPS); jt++) acc = __builtin_fmaf(v[i + jt], tp[jt], acc);
             o[i] = acc;
         }
     };
     float R[7][4];
-    Raw p1 = fetch(y0 - 3), p2 = fetch(y0 - 2);
+    Raw pf[BLV_PF];
+#pragma unroll
+    for (int k = 0; k < BLV_PF; k++) pf[k] = fetch(y0 - 3 + k);
 #pragma unroll
     for (int i = 0; i < 6; i++) {
-        const Raw cur = p1;
-        p1 = p2;
-        p2 = fetch(y0 - 3 + i + 2);
+        const Raw cur = pf[0];
+#pragma unroll
+        for (int k = 0; k + 1 < BLV_PF; k++) pf[k] = pf[k + 1];
+        pf[BLV_PF - 1] = fetch(y0 - 3 + i + BLV_PF);
         rowpass(cur, R[i]);
     }
     int doff = y0 * dpitch + dx;
     for (int base = 0; base < nout; base += 7) {
 #pragma unroll
         for (int u = 0; u < 7; u++) {
-            const Raw cur = p1;
-            p1 = p2;
-            p2 = fetch(y0 + base + u + 5);
+            const Raw cur = pf[0];
+#pragma unroll
+            for (int k = 0; k + 1 < BLV_PF; k++) pf[k] = pf[k + 1];
+            pf[BLV_PF - 1] = fetch(y0 + base + u + 3 + BLV_PF);
             rowpass(cur, R[(u + 6) % 7]);
+            __builtin_amdgcn_sched_barrier(0);              // row pass, then column pass: interleaved by the scheduler they need 72 VGPRs
             uint32_t pk = 0;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
@@ -784,13 +804,18 @@ __device__ __forceinline__ void blur_task_dwords(const BlurLevel& L, int strip, 
                 for (int jt = 1; jt < 7; jt++) acc = __builtin_fmaf(R[(u + jt) % 7][i], tp[jt], acc);
                 pk = __builtin_amdgcn_cvt_pk_u8_f32(acc, i, pk);
             }
+#ifdef BLV_NOSTORE
+            if (pk == 0x12345679u) __builtin_amdgcn_raw_buffer_store_b32(pk, dsrc, doff, 0, 0);
+#else
             __builtin_amdgcn_raw_buffer_store_b32(pk, dsrc, doff, 0, 0);
+#endif
             doff += dpitch;
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
 
-__global__ __launch_bounds__(256, 7) void blur_levels_kernel(const BlurLevelsArgs A, float tp0, float tp1, float tp2, float tp3)
+__global__ __launch_bounds__(256, BLV_WAVES) void blur_levels_kernel(const BlurLevelsArgs A, float tp0, float tp1, float tp2, float tp3)
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -801,6 +826,10 @@ __global__ __launch_bounds__(256, 7) void blur_levels_kernel(const BlurLevelsArg
     const BlurLevel& L = A.lv[l];
     const int t = task - (l ? A.lv[l - 1].task_end : 0);
     const int chunk = t / L.nstrips, strip = t - chunk * L.nstrips;
+    // the taps live in VECTOR registers: a full-rate VALU instruction (v_fmac_f32: 2 cycles per wave64) with a scalar-register
+    // source runs at HALF rate (4.1 cycles; profiles/r04_valu_rate.txt "(sgpr)" rows) -- left to the compiler the 64 FMAs of a
+    // row read the taps from SGPRs and the kernel took 68 instead of 41 us
+    asm volatile("" : "+v"(tp0), "+v"(tp1), "+v"(tp2), "+v"(tp3));
     const float tp[7] = { tp0, tp1, tp2, tp3, tp2, tp1, tp0 };
     if (L.bytes) blur_task_bytes(L, strip, chunk, lane, tp);
     else blur_task_dwords(L, strip, chunk, lane, tp);

@@ -721,3 +721,35 @@ def test_detect_and_compute_without_descriptors(cef, torch_mod, oracle):
     n = int(cnt.item())
     assert desc is None and n == ref["n"]
     assert np.array_equal(kps[:, :n].cpu().numpy().view(np.uint32), ref["kps"].view(np.uint32))
+
+
+# ---- whole-level blur (round 4): blur_levels_kernel + a wave per keypoint, against the per-window blur and the oracle ----
+@pytest.mark.parametrize("cols", [1040, 1041, 1042, 1043, 700])
+def test_level_blur_paths_equal_oracle(cef, torch_mod, oracle, cols, monkeypatch):
+    """detectAndCompute BAD behind the whole-level Gaussian: levels of 512 columns and more take the dword path of
+    blur_levels_kernel, whose right-edge strip patches the BORDER_REFLECT_101 pixels by r = cols - ((cols - 1) & ~3) (1 .. 4:
+    every residue of cols modulo 4, here and again on the upper levels), narrower levels the byte path; an image whose base is
+    not 4-byte aligned sends level 0 through the byte path as well.  All of them, and the per-window blur (EFX_NO_LEVEL_BLUR),
+    must give the oracle's keypoints and descriptor bytes."""
+    torch = torch_mod
+    rows = 560
+    img = synth.synth_frame(rows, cols, seed=900 + cols, density=1.5)
+    ref = oracle.detect_and_compute(img, nfeatures=6000, nonmax_radius=7, desc_type=oracle.BAD_512)
+    big = torch.zeros((rows, cols + 61), dtype=torch.uint8, device="cuda")
+    for off in (0, 1):                                      # aligned base, then base + 1 with an odd pitch
+        view = big[:, off:off + cols]
+        view.copy_(torch.from_numpy(img).cuda())
+        for knob in (False, True):
+            if knob:
+                monkeypatch.setenv("EFX_NO_LEVEL_BLUR", "1")
+            else:
+                monkeypatch.delenv("EFX_NO_LEVEL_BLUR", raising=False)
+            det = cef.EfficientFeatures.create(6000, 1.2, 8, 0, 20, 7, cef.EfficientFeatures.BAD_512)     # knobs are read here
+            kps, desc, cnt = det.detectAndComputeAsync(view)
+            torch.cuda.synchronize()
+            n = int(cnt.item())
+            assert n == ref["n"] and n > 1500, (off, knob, n)
+            assert np.array_equal(kps[:, :n].cpu().numpy().view(np.uint32), ref["kps"].view(np.uint32)), (off, knob)
+            bad = np.nonzero((desc[:n].cpu().numpy() != ref["desc"]).any(axis=1))[0]
+            assert bad.size == 0, f"offset {off}, EFX_NO_LEVEL_BLUR {knob}: {bad.size} descriptors differ, first at keypoints {bad[:6]}"
+    monkeypatch.delenv("EFX_NO_LEVEL_BLUR", raising=False)

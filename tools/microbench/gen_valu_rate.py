@@ -108,6 +108,12 @@ CLASSES = [
     ("v_accvgpr_write", "v_accvgpr_write_b32 a{i}, {a}", "move"),
     ("v_accvgpr_read", "v_accvgpr_read_b32 {d}, a{i}", "move"),
     ("v_fmac_f32", "v_fmac_f32 {d}, {a}, {b}", "fp32"),
+    ("v_fmac_f32 (sgpr)", "v_fmac_f32 {d}, s47, {b}", "fp32"),
+    ("v_fmac_f32 (body of 1024)", "v_fmac_f32 {d}, {a}, {b}", "instruction fetch"),
+    ("v_fmac_f32 (sgpr, body 1024)", "v_fmac_f32 {d}, s47, {b}", "instruction fetch"),
+    ("v_fma_f32 (body of 1024)", "v_fma_f32 {d}, {a}, {b}, {d}", "instruction fetch"),
+    ("v_add_u32 (body of 1024)", "v_add_u32 {d}, {a}, {d}", "instruction fetch"),
+    ("v_pk_mad_u16 (body of 1024)", "v_pk_mad_u16 {d}, {a}, {b}, {d}", "instruction fetch"),
     ("v_mad_f32_like(mul+add)", "v_mul_f32 {c}, {a}, {b}\\n v_add_f32 {d}, {c}, {d}", "fp32 (two instructions)"),
     ("v_pk_fma_f32", "v_pk_fma_f32 {D}, {A}, {B}, {D}", "packed fp32"),
     ("v_pk_mul_f32", "v_pk_mul_f32 {D}, {A}, {D}", "packed fp32"),
@@ -142,9 +148,13 @@ MODES = ["clean", "same", "dep"]
 UNROLL = 4
 
 
-def body(tmpl, mode):
+BIG = {"v_fmac_f32 (body of 1024)": 128, "v_fma_f32 (body of 1024)": 128, "v_add_u32 (body of 1024)": 128, "v_pk_mad_u16 (body of 1024)": 128,
+       "v_fmac_f32 (sgpr, body 1024)": 128}
+
+
+def body(tmpl, mode, unroll=UNROLL):
     lines = []
-    for _ in range(UNROLL):
+    for _ in range(unroll):
         for i in range(8):
             r = regs(i, mode)
             lines.append(tmpl.format(**r))
@@ -168,8 +178,8 @@ struct Rec { unsigned long long t0, t1, r0, r1; unsigned hwid, xcc; unsigned pad
 typedef void (*kern_t)(Rec*, int);
 struct Entry { const char* name; const char* group; int per_body; kern_t clean, same, dep; };
 #define PROLOGUE \
-    "v_mov_b32 v4, 1.0\n v_mov_b32 v5, 1.0\n v_mov_b32 v6, 1.0\n v_mov_b32 v7, 1.0\n" \
-    "v_mov_b32 v8, 0\n v_mov_b32 v9, 0\n v_mov_b32 v10, 0\n v_mov_b32 v11, 0\n" \
+    "v_mov_b32 v4, %[x0]\n v_mov_b32 v5, %[x1]\n v_mov_b32 v6, %[x2]\n v_mov_b32 v7, %[x3]\n" \
+    "v_mov_b32 v8, %[y0]\n v_mov_b32 v9, %[y1]\n v_mov_b32 v10, %[y2]\n v_mov_b32 v11, %[y3]\n" \
     "v_mov_b32 v12, 0\n v_mov_b32 v13, 0\n v_mov_b32 v14, 0\n v_mov_b32 v15, 0\n" \
     "v_mov_b32 v16, 1.0\n v_mov_b32 v17, 1.0\n v_mov_b32 v18, 1.0\n v_mov_b32 v19, 1.0\n" \
     "v_mov_b32 v20, 1.0\n v_mov_b32 v21, 1.0\n v_mov_b32 v22, 1.0\n v_mov_b32 v23, 1.0\n" \
@@ -193,8 +203,22 @@ struct Entry { const char* name; const char* group; int per_body; kern_t clean, 
 #define KERNEL(NAME, BODY) \
 __global__ __launch_bounds__(256) void NAME(Rec* rec, int iters) { \
     unsigned long long t0, t1, r0, r1; unsigned hw, xc; \
+    /* iters < 0: lane-dependent operands with random mantissas (x in [0.5, 1), y in [0, 2^-20)) instead of the constants 1.0 and 0 */ \
+    const bool rnd = iters < 0; const int it_ = rnd ? -iters : iters; \
+    unsigned h = (threadIdx.x + 1u) * 2654435761u + blockIdx.x * 40503u; \
+    float x0 = 1.f, x1 = 1.f, x2 = 1.f, x3 = 1.f, y0 = 0.f, y1 = 0.f, y2 = 0.f, y3 = 0.f; \
+    if (rnd) { \
+        x0 = __uint_as_float(0x3f000000u | (h & 0x7fffffu)); h = h * 1664525u + 1013904223u; \
+        x1 = __uint_as_float(0x3f000000u | (h & 0x7fffffu)); h = h * 1664525u + 1013904223u; \
+        x2 = __uint_as_float(0x3f000000u | (h & 0x7fffffu)); h = h * 1664525u + 1013904223u; \
+        x3 = __uint_as_float(0x3f000000u | (h & 0x7fffffu)); h = h * 1664525u + 1013904223u; \
+        y0 = __uint_as_float(0x35000000u | (h & 0x7fffffu)); h = h * 1664525u + 1013904223u; \
+        y1 = __uint_as_float(0x35000000u | (h & 0x7fffffu)); h = h * 1664525u + 1013904223u; \
+        y2 = __uint_as_float(0x35000000u | (h & 0x7fffffu)); h = h * 1664525u + 1013904223u; \
+        y3 = __uint_as_float(0x35000000u | (h & 0x7fffffu)); } \
     asm volatile(PROLOGUE BODY EPILOGUE \
-        : [t0] "=&s"(t0), [t1] "=&s"(t1), [r0] "=&s"(r0), [r1] "=&s"(r1), [hw] "=&s"(hw), [xc] "=&s"(xc) : [it] "s"(iters) : CLOBBERS); \
+        : [t0] "=&s"(t0), [t1] "=&s"(t1), [r0] "=&s"(r0), [r1] "=&s"(r1), [hw] "=&s"(hw), [xc] "=&s"(xc) \
+        : [it] "s"(it_), [x0] "v"(x0), [x1] "v"(x1), [x2] "v"(x2), [x3] "v"(x3), [y0] "v"(y0), [y1] "v"(y1), [y2] "v"(y2), [y3] "v"(y3) : CLOBBERS); \
     if ((threadIdx.x & 63) == 0) { Rec r; r.t0 = t0; r.t1 = t1; r.r0 = r0; r.r1 = r1; r.hwid = hw; r.xcc = xc; r.pad[0] = r.pad[1] = 0; \
         rec[blockIdx.x * 4 + (threadIdx.x >> 6)] = r; } }
 '''
@@ -291,6 +315,27 @@ int main(int argc, char** argv) {
                r8.sclk_mhz, r8.cyc_event, place, rate_class(c[3]));
         fflush(stdout);
     }
+    // data dependence: the same kernels with lane-dependent random mantissas in the operands (the table above uses the constants
+    // 1.0 and 0: the least switching activity there is).  If the rate or the clock moves, the ceiling is a power figure
+    if (!only) {
+        printf("# random operands (x in [0.5, 1), y tiny, per lane): cycles per wave-instruction at W = 8, clock during the run; 200 launches back to back, last one read\n");
+        for (const Entry& e : entries) {
+            if (strcmp(e.name, "v_add_u32") && strcmp(e.name, "v_fma_f32") && strcmp(e.name, "v_fmac_f32") && strcmp(e.name, "v_mul_f32") && strcmp(e.name, "v_pk_fma_f32") &&
+                strcmp(e.name, "v_pk_mad_u16") && strcmp(e.name, "v_perm_b32") && strcmp(e.name, "v_cvt_f32_ubyte1") && strcmp(e.name, "v_dot2c_i32_i16")) continue;
+            for (int rnd = 0; rnd < 2; rnd++) {
+                const int W = 8, lds = 20 * 1024, nblk = 256 * W, it = 2400; const double n = (double)it * 32 * e.per_body;
+                (void)hipFuncSetAttribute((const void*)e.clean, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                for (int l = 0; l < 200; l++) hipLaunchKernelGGL(e.clean, dim3(nblk), dim3(256), lds, 0, d_rec, rnd ? -it : it);
+                (void)hipDeviceSynchronize(); h.resize((size_t)nblk * 4); (void)hipMemcpy(h.data(), d_rec, h.size() * sizeof(Rec), hipMemcpyDeviceToHost);
+                std::map<unsigned long long, std::vector<const Rec*>> simd; std::vector<double> clk, per;
+                for (const Rec& r : h) { simd[((unsigned long long)(r.xcc & 0xf) << 32) | (r.hwid & 0xff30u)].push_back(&r); clk.push_back((double)(r.t1 - r.t0) / (double)(r.r1 - r.r0) * g_wall_khz * 1e-3); }
+                for (auto& kv : simd) { unsigned long long lo = ~0ull, hi = 0; for (const Rec* r : kv.second) { lo = std::min(lo, r->t0); hi = std::max(hi, r->t1); } per.push_back((double)(hi - lo) / (n * kv.second.size())); }
+                std::sort(clk.begin(), clk.end()); std::sort(per.begin(), per.end());
+                printf("%-22s %-8s %6.2f cycles  %5.0f MHz  -> %6.1f G wave-instr/s per chip\n", e.name, rnd ? "random" : "constant", per[per.size() / 2], clk[clk.size() / 2],
+                       1024.0 * clk[clk.size() / 2] * 1e-3 / per[per.size() / 2]);
+            }
+        }
+    }
     // sustained leg: what the clock does under ~1 s of dense VALU work (the bench's timed region is that long)
     if (!only) {
         printf("# sustained: 400 back-to-back launches at W = 8 (about 1 s); shader clock during launches 0, 100, 200, 399\n");
@@ -321,9 +366,10 @@ def main():
     out = [HEADER]
     ents = []
     for idx, (name, tmpl, group) in enumerate(CLASSES):
-        per_body = tmpl.count("\\n") + 1
+        unroll = BIG.get(name, UNROLL)
+        per_body = (tmpl.count("\\n") + 1) * unroll // UNROLL
         for mode in MODES:
-            out.append(f'KERNEL({kname(idx, mode)}, "{body(tmpl, mode)}")')
+            out.append(f'KERNEL({kname(idx, mode)}, "{body(tmpl, mode, unroll)}")')
         ents.append(f'    {{"{name}", "{group}", {per_body}, {kname(idx, "clean")}, {kname(idx, "same")}, {kname(idx, "dep")}}},')
     out.append("static const Entry entries[] = {")
     out.extend(ents)

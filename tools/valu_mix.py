@@ -6,7 +6,8 @@
 Why: on gfx950 a wave64 VALU instruction takes 2 cycles of its SIMD ("full rate": v_mov / v_add / v_sub / v_and / v_or / v_xor /
 v_not / v_lshrrev / v_ashrrev _b32, v_add / v_sub / v_mul / v_fma / v_fmac _f32, v_add_f16, v_accvgpr_*) or 4 cycles ("half
 rate": everything else the kernels use -- min / max, v_lshlrev, all three-operand integer forms, packed 16-bit, dot, perm,
-conversions, packed fp32, fp64, SDWA / DPP forms, compares, v_cndmask, lane moves) or 8 (transcendentals); measured by
+conversions, packed fp32, fp64, SDWA / DPP forms, compares, v_cndmask, lane moves -- AND any full-rate opcode with a scalar-register
+source operand) or 8 (transcendentals); measured by
 tools/microbench/valu_rate (profiles/rNN_valu_rate.txt).  The SQ counters do not tell the classes apart (SQ_ACTIVE_INST_VALU ==
 SQ_INSTS_VALU for both, profiles/r04_valu_calib.txt), so the issue ceiling of a kernel's MIX is estimated from its ISA: every
 VALU instruction of the compiled kernel is looked up in the measured table, and the kernel's mean cycles per wave-instruction
@@ -41,8 +42,12 @@ def base(mnemonic):
     return re.sub(r"_(e32|e64|sdwa|dpp|e64_dpp)$", "", mnemonic)
 
 
-def classify(mnemonic, rates, full, half, quarter):
-    """cycles for one static VALU instruction: its measured row when there is one, else the class of its kind."""
+def classify(mnemonic, rates, full, half, quarter, sgpr=False):
+    """cycles for one static VALU instruction: its measured row when there is one, else the class of its kind.  A full-rate
+    instruction with a scalar-register source runs at half rate (measured: the "(sgpr)" rows of the table)."""
+    if sgpr:
+        c, k = classify(mnemonic, rates, full, half, quarter)
+        return (half, "half (full-rate opcode with an SGPR source)") if k == "full" else (c, k)
     b = base(mnemonic)
     if mnemonic.endswith(("_sdwa", "_dpp")):
         return half, "half"                                  # measured: v_add_u32_sdwa / _dpp run at half rate
@@ -71,7 +76,12 @@ def kernel_bodies(asm):
             continue
         if t.startswith(".") or t.startswith(";") or not t:
             continue
-        out[cur].append(t.split()[0])
+        # mnemonic, and whether a SOURCE operand is a scalar register (s12, s[4:5], vcc, ttmp...; not the destination of a compare)
+        parts = t.split(None, 1)
+        ops = parts[1].split(";")[0] if len(parts) > 1 else ""
+        srcs = ops.split(",")[1:]
+        sgpr = any(re.match(r"\s*-?\|?(s\d+|s\[|vcc|exec|m0|ttmp)", o) for o in srcs)
+        out[cur].append((parts[0], sgpr))
     return out
 
 
@@ -93,23 +103,26 @@ def main(rate_path, out_path):
         bodies = kernel_bodies(asm)
         names = list(bodies)
         for mangled, pretty in zip(names, demangle(names)):
-            ins = [i for i in bodies[mangled] if i.startswith("v_") and not i.startswith(NOT_VALU)]
+            ins = [(i, sg) for i, sg in bodies[mangled] if i.startswith("v_") and not i.startswith(NOT_VALU)]
             if len(ins) < 16:
                 continue
-            cyc, cls, unknown = 0.0, {"full": 0, "half": 0, "quarter": 0}, {}
-            for i in ins:
-                c, k = classify(i, rates, full, half, quarter)
+            cyc, cls, unknown, demoted = 0.0, {"full": 0, "half": 0, "quarter": 0}, {}, {}
+            for i, sg in ins:
+                c, k = classify(i, rates, full, half, quarter, sg)
                 cyc += c
                 cls[k.split(" ")[0]] += 1
                 if "not in the table" in k:
                     unknown[base(i)] = unknown.get(base(i), 0) + 1
+                if "SGPR source" in k:
+                    demoted[base(i)] = demoted.get(base(i), 0) + 1
             res["kernels"][pretty] = {"valu_static": len(ins), "full_rate_share": round(cls["full"] / len(ins), 3),
                                       "half_rate_share": round(cls["half"] / len(ins), 3), "quarter_rate_share": round(cls["quarter"] / len(ins), 3),
                                       "mix_cycles_per_wave_instr": round(cyc / len(ins), 3),
+                                      "full_rate_opcodes_with_sgpr_source": dict(sorted(demoted.items(), key=lambda kv: -kv[1])[:8]),
                                       "not_in_table": dict(sorted(unknown.items(), key=lambda kv: -kv[1])[:8])}
     json.dump(res, open(out_path, "w"), indent=1)
     for k, v in res["kernels"].items():
-        print(f"{k:48s} {v['valu_static']:6d} VALU  full {v['full_rate_share']:.2f}  mix {v['mix_cycles_per_wave_instr']:.2f} cycles")
+        print(f"{k:48s} {v['valu_static']:6d} VALU  full {v['full_rate_share']:.2f}  mix {v['mix_cycles_per_wave_instr']:.2f} cycles  sgpr-demoted {sum(v['full_rate_opcodes_with_sgpr_source'].values())}")
 
 
 if __name__ == "__main__":
