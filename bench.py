@@ -240,14 +240,18 @@ def main():
         #   fast_kernel    every pyramid level read once (sum_s P_s = 3.096 B per input pixel) + 4 B per corner out
         #   harris_kernel  9x9 footprints lie inside the levels (read once more) + 4 B in / 4 B out per corner
         #   nms_kernel     8 B per corner in, 8 B per survivor out (per-cell maxima are cache traffic)
-        #   bad_det_kernel the (blur-extended) windows lie inside the levels: sum_s P_s + 80 B record in + 64 B out per keypoint
+        #   bad_det_kernel (EFX_NO_LEVEL_BLUR) the (blur-extended) windows lie inside the levels: sum_s P_s + 80 B record in + 64 B out per keypoint
         #                  (the reference design -- per-level blur + global integral images, SURVEY 8d -- moves
         #                  2 F P + 5 sum P_s + gathers ~ 1.06 GB for the same stage; reported as survey_design_bytes)
         #   resize chain   level s read + level s+1 written, s = 0..6: (2 F - 2) P + P_0 - P_7 ... = sum_s P_s + sum_{s>=1} P_s - P_7
         sumP = float(sum(px))
         chain_bytes = float(sum(px[:-1]) + sum(px[1:]))
+        #   blur_levels_kernel (round 4) every level read once, its blurred copy written once: 2 sum_s P_s; the keypoints are then
+        #                  described a wave each on the blurred levels (bad_raw_kernel: windows inside the levels + record + descriptor)
+        level_blur = bool((lvl == 11).any())
         kinfo = {0: ("fast_kernel", sumP + 4 * n_corners), 1: ("harris_kernel", sumP + 8 * n_corners),
-                 2: ("nms_kernel", 8 * n_corners + 8 * n_surv), 10: ("bad_det_kernel", sumP + 144 * n_kp)}
+                 2: ("nms_kernel", 8 * n_corners + 8 * n_surv),
+                 10: ("bad_raw_kernel" if level_blur else "bad_det_kernel", sumP + 144 * n_kp), 11: ("blur_levels_kernel", 2 * sumP)}
 
         def table(ms_, lvl_):
             t = {}
@@ -261,7 +265,7 @@ def main():
 
         def chain_ms_per_frame(ms_, lvl_):
             nl = max(1, int((lvl_ == 0).sum()))
-            return float(ms_[lvl_ >= 100].sum()) / nl
+            return float(ms_[lvl_ >= 100].sum()) / nl            # codes 100 + s: the resize launches
 
         live = table(ms, lvl)
         live_chain = chain_ms_per_frame(ms, lvl)

@@ -665,7 +665,7 @@ void efx_gaussian_taps_host(float taps[7])
 // valid pixels in that dword), as the left edge's are in lane 0 of strip 0.  Regular strips do not store columns >= xs
 // (the anchored strip owns them), so none of the columns they do store needs a pixel beyond the level.
 struct BlurLevel { const uint8_t* src; uint8_t* dst; int spitch, dpitch, rows, cols, bytes, n_reg, nstrips, xs, task_end; };
-struct BlurLevelsArgs { int nlevels, total; BlurLevel lv[EFX_MAX_LEVELS]; };
+struct BlurLevelsArgs { int nlevels, total, nr; BlurLevel lv[EFX_MAX_LEVELS]; };     // nr: output rows of a dword-path task (7 .. BLV_ROWS)
 
 // the generic form: 10 input pixels per lane as byte loads at reflected columns (any alignment, any size)
 __device__ __forceinline__ void blur_task_bytes(const BlurLevel& L, int strip, int chunk, int lane, const float (&tp)[7])
@@ -717,14 +717,14 @@ __device__ __forceinline__ void blur_task_bytes(const BlurLevel& L, int strip, i
 }
 
 // the dword path: straight-line rows (no branch but the loop's), loads two rows ahead, stores through a range-checked resource
-__device__ __forceinline__ void blur_task_dwords(const BlurLevel& L, int strip, int chunk, int lane, const float (&tp)[7])
+__device__ __forceinline__ void blur_task_dwords(const BlurLevel& L, int strip, int chunk, int lane, const float (&tp)[7], int nr)
 {
     const int rows = L.rows, cols = L.cols, spitch = L.spitch, dpitch = L.dpitch;
     const bool anchored = strip == L.n_reg;                // wave-uniform
     const bool leftmost = strip == 0;
     const int x = (anchored ? L.xs : strip * 256) + lane * 4;
-    const int y0 = chunk * BLV_ROWS;
-    const int nout = min(BLV_ROWS, rows - y0);
+    const int y0 = chunk * nr;
+    const int nout = min(nr, rows - y0);
     // a row's dwords up to roundup4(cols) are memory we may read (own levels: padded rows; a caller's aligned level 0: its pitch
     // is a multiple of 4); beyond that -- and left of the level, where the offset wraps -- the range check returns 0
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(L.src), 0, (rows - 1) * spitch + ((cols + 3) & ~3), 0x00020000);
@@ -832,34 +832,42 @@ __global__ __launch_bounds__(256, BLV_WAVES) void blur_levels_kernel(const BlurL
     asm volatile("" : "+v"(tp0), "+v"(tp1), "+v"(tp2), "+v"(tp3));
     const float tp[7] = { tp0, tp1, tp2, tp3, tp2, tp1, tp0 };
     if (L.bytes) blur_task_bytes(L, strip, chunk, lane, tp);
-    else blur_task_dwords(L, strip, chunk, lane, tp);
+    else blur_task_dwords(L, strip, chunk, lane, tp, A.nr);
 }
 
 hipError_t efx_launch_blur_levels(const LevelTable& H, const uint8_t* img0, int pitch0, const uint8_t* pyramid, uint8_t* blurred,
                                   int blur0_pitch, size_t blur_levels_off, const ProfRec& prof_rec, hipStream_t stream)
 {
+    // Rows per task of the dword path: 63 on large pyramids (a task recomputes 6 rows of the row pass: 10 %), fewer on small ones
+    // -- an FHD pyramid has 400 tasks of 63 rows for 1024 SIMDs, and a lone wave issues one VALU instruction per 4 cycles: the
+    // kernel then took 25 us of a 110 us call.  The smallest multiple of 7 that still leaves ~3000 tasks, but not below 14
     BlurLevelsArgs A = {};
-    for (int l = 0; l < H.nlevels; l++) {
-        const LevelDev& L = H.lv[l];
-        if (!L.active || L.rows <= 0 || L.cols <= 0) continue;
-        BlurLevel& B = A.lv[A.nlevels++];
-        B.src = l == 0 ? img0 : pyramid + L.img_off;
-        B.spitch = l == 0 ? pitch0 : L.pitch;
-        B.dst = l == 0 ? blurred : blurred + blur_levels_off + L.img_off;
-        B.dpitch = l == 0 ? blur0_pitch : L.pitch;
-        B.rows = L.rows; B.cols = L.cols;
-        const bool aligned = ((((uintptr_t)B.src) | (uintptr_t)B.spitch) & 3u) == 0;
-        B.bytes = !(aligned && L.cols >= 512 && L.rows >= 16);
-        if (B.bytes) {
-            B.nstrips = (L.cols + 255) / 256;
-            A.total += B.nstrips * ((L.rows + BLV_ROWS_BYTES - 1) / BLV_ROWS_BYTES);
-        } else {
-            B.xs = ((L.cols - 1) & ~3) - 252;
-            B.n_reg = (B.xs + 255) / 256;                   // regular strips cover [0, xs)
-            B.nstrips = B.n_reg + 1;
-            A.total += B.nstrips * ((L.rows + BLV_ROWS - 1) / BLV_ROWS);
+    for (int nr = BLV_ROWS; nr >= 14; nr -= 7) {
+        A = BlurLevelsArgs{};
+        A.nr = nr;
+        for (int l = 0; l < H.nlevels; l++) {
+            const LevelDev& L = H.lv[l];
+            if (!L.active || L.rows <= 0 || L.cols <= 0) continue;
+            BlurLevel& B = A.lv[A.nlevels++];
+            B.src = l == 0 ? img0 : pyramid + L.img_off;
+            B.spitch = l == 0 ? pitch0 : L.pitch;
+            B.dst = l == 0 ? blurred : blurred + blur_levels_off + L.img_off;
+            B.dpitch = l == 0 ? blur0_pitch : L.pitch;
+            B.rows = L.rows; B.cols = L.cols;
+            const bool aligned = ((((uintptr_t)B.src) | (uintptr_t)B.spitch) & 3u) == 0;
+            B.bytes = !(aligned && L.cols >= 512 && L.rows >= 16);
+            if (B.bytes) {
+                B.nstrips = (L.cols + 255) / 256;
+                A.total += B.nstrips * ((L.rows + BLV_ROWS_BYTES - 1) / BLV_ROWS_BYTES);
+            } else {
+                B.xs = ((L.cols - 1) & ~3) - 252;
+                B.n_reg = (B.xs + 255) / 256;                   // regular strips cover [0, xs)
+                B.nstrips = B.n_reg + 1;
+                A.total += B.nstrips * ((L.rows + nr - 1) / nr);
+            }
+            B.task_end = A.total;
         }
-        B.task_end = A.total;
+        if (A.total >= 3072) break;
     }
     if (A.total == 0) return hipSuccess;
     float t[7];
