@@ -2189,13 +2189,29 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
         EFX_TRACE_POINT("tower");
     }
     if (a.pyramid_only) return hipGetLastError();
-    if (a.blurred) {
-        // BAD behind detectAndCompute: every active level blurred once, as an image (bad_kernel.hip); the describer's records
-        // (angle kernels below) point at the copies.  Right behind the pyramid: the levels are still in the caches
-        e = efx_launch_blur_levels(H, a.img0, a.pitch0, a.pyramid, a.blurred, a.blur0_pitch, a.blur_levels_off, a.prof, stream);
-        if (e != hipSuccess) return e;
+    // BAD behind detectAndCompute: every active level blurred once, as an image (bad_kernel.hip: blur_levels_kernel); the
+    // describer's records (angle kernels below) point at the copies.  The blur needs the pyramid only: on the call's stream right
+    // here, or on the context's side stream beside the detector kernels (fork point: DetectLaunch::blur_fork)
+    bool blur_pending = a.blurred != nullptr, forked = false;
+    const int fork_point = (a.side && a.ev_fork && a.ev_join && a.blur_fork >= 1 && a.blur_fork <= 3) ? a.blur_fork : 0;
+    auto launch_blur = [&](int point) -> hipError_t {
+        if (!blur_pending || point != fork_point) return hipSuccess;
+        blur_pending = false;
+        hipStream_t st = stream;
+        if (point > 0) {
+            hipError_t e2 = hipEventRecord(a.ev_fork, stream);
+            if (e2 == hipSuccess) e2 = hipStreamWaitEvent(a.side, a.ev_fork, 0);
+            if (e2 != hipSuccess) return e2;
+            st = a.side; forked = true;
+        }
+        hipError_t e2 = efx_launch_blur_levels(H, a.img0, a.pitch0, a.pyramid, a.blurred, a.blur0_pitch, a.blur_levels_off, a.prof, st);
+        if (e2 == hipSuccess && forked) e2 = hipEventRecord(a.ev_join, a.side);
         EFX_TRACE_POINT("blur");
-    }
+        return e2;
+    };
+    e = launch_blur(0);
+    if (e == hipSuccess) e = launch_blur(1);
+    if (e != hipSuccess) return e;
 #ifdef EFX_DEBUG_BUILD
     if (g_trace) {          // poison the corner arenas, so that entries fast_kernel never stores show up in the digest
         size_t ncand = 0;
@@ -2224,6 +2240,8 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
                                a.cand_xy, a.cand, a.cmax, a.hdr, a.counters, a.knobs.dbg & 15);
         a.prof.end(prof, 1, stream);
         EFX_TRACE_POINT("harris");
+        e = launch_blur(2);
+        if (e != hipSuccess) return e;
     }
     bool prof = a.prof.begin(2, stream);
     // several waves per tile when the tiles alone do not fill the chip (256 CUs x 32 waves)
@@ -2238,6 +2256,8 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
                            a.counters, a.nonmax_radius, a.knobs.dbg >> 4);
     a.prof.end(prof, 2, stream);
     EFX_TRACE_POINT("nms");
+    e = launch_blur(3);
+    if (e != hipSuccess) return e;
     prof = a.prof.begin(3, stream);
     {
         static bool attr_set[64] = { false };  // 128 KB of dynamic LDS: above the default limit of a launch; set once per device
@@ -2277,6 +2297,10 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
     }
     a.prof.end(prof, 3, stream);
     EFX_TRACE_POINT("angle");
+    if (forked) {                       // the describer (next on this stream) reads the blurred levels
+        e = hipStreamWaitEvent(stream, a.ev_join, 0);
+        if (e != hipSuccess) return e;
+    }
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     return e;        // the host reads the summary (N, per-level counts) on demand: fetch_summary(), efx_api.cpp

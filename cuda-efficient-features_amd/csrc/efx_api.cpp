@@ -339,12 +339,18 @@ int describer_run(Describer& d, std::string& err, DescribeLaunch a, float* dbg_r
 
 } // namespace
 
+#ifndef EFX_BLUR_FORK_DEFAULT
+#define EFX_BLUR_FORK_DEFAULT 0
+#endif
+
 EfxKnobs efx_read_knobs()
 {
-    EfxKnobs k = { 0, 0, 0, 0, 0 };
+    EfxKnobs k = { 0, 0, 0, 0, 0, 0 };
     k.no_tower = getenv("EFX_NO_TOWER") != nullptr;
     k.no_resize_stream = getenv("EFX_NO_RESIZE_STREAM") != nullptr;
-    k.no_level_blur = getenv("EFX_NO_LEVEL_BLUR") != nullptr;      // BAD behind detectAndCompute: every keypoint blurs its own window (A/B, parity tests)
+    k.no_level_blur = getenv("EFX_NO_LEVEL_BLUR") != nullptr;
+    { const char* f = getenv("EFX_BLUR_FORK"); k.blur_fork = f ? atoi(f) : EFX_BLUR_FORK_DEFAULT; }   // DetectLaunch::blur_fork
+    // BAD behind detectAndCompute: every keypoint blurs its own window (A/B, parity tests)
     const char* d = getenv("EFX_DEBUG");
     const char* h = getenv("EFX_DEBUG_HS");
 #ifdef EFX_DEBUG_BUILD
@@ -388,6 +394,8 @@ struct efx_context {
     DevBuf d_table, pyramid, hdr, cand, cmax, surv, counters, kp4, kp_level, img, kps, descout, count, maskbuf;
     DevBuf rplan; ResizePlanLevel rplan_lv[EFX_MAX_LEVELS];        // resize plan (tables of resize_stream_kernel)
     DevBuf blurred;                 // blurred copies of the pyramid levels for the BAD describer (blur_levels_kernel), on first use
+    hipStream_t side = nullptr;     // side stream + fork / join events of the level blur (DetectLaunch::blur_fork), on first use
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     size_t cand_slots = 0;          // records in `cand`; the coordinate-only array of the same length follows them
     Summary* h_mirror = nullptr;    // host copy of the last frame's summary, filled on demand by fetch_summary()
     int n_out_max = 0;              // sum of the active levels' quotas
@@ -440,6 +448,9 @@ struct efx_context {
         Quiesce* prev = tl_quiesce;
         tl_quiesce = &q;
         desc.release_all();                                // the describer's blocks are this context's: same wait
+        if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
         blurred.release();
         rplan.release(); d_table.release(); pyramid.release(); hdr.release(); cand.release(); cmax.release(); surv.release(); counters.release();
         kp4.release(); kp_level.release(); img.release(); kps.release(); descout.release(); count.release(); maskbuf.release();
@@ -743,6 +754,17 @@ int detect_common(efx_context* c, const uint8_t* d_image, int rows, int cols, si
             HIP_TRY(c->err, c->blurred.reserve(l0_bytes + lv_bytes + 256));
             a.blurred = static_cast<uint8_t*>(c->blurred.p); a.blur0_pitch = p0; a.blur_levels_off = l0_bytes;
             level_blurred = true;
+            a.blur_fork = c->knobs.blur_fork;
+            if (a.blur_fork >= 1 && a.blur_fork <= 3) {
+                // the side stream joins the call's stream before the describer runs, so whoever waits for the call's stream has
+                // waited for it too (release waits, the caller's own synchronisation)
+                if (!c->side) {
+                    HIP_TRY(c->err, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+                    HIP_TRY(c->err, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+                    HIP_TRY(c->err, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+                }
+                a.side = c->side; a.ev_fork = c->ev_fork; a.ev_join = c->ev_join;
+            }
         }
     }
 #ifdef EFX_DEBUG_BUILD

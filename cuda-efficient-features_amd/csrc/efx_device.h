@@ -171,7 +171,7 @@ __device__ __forceinline__ int efx_wave_incl_scan(int v)
 #else
 #define EFX_DBG(v) 0
 #endif
-struct EfxKnobs { int dbg, dbg_hs, no_tower, no_resize_stream, no_level_blur; };
+struct EfxKnobs { int dbg, dbg_hs, no_tower, no_resize_stream, no_level_blur, blur_fork; };
 EfxKnobs efx_read_knobs();      // efx_api.cpp
 
 // ---- launchers (host side, defined in the .hip files) ----
@@ -258,6 +258,10 @@ struct DetectLaunch {
     // blur0_pitch, level l >= 1 at blurred + blur_levels_off + its pyramid offset with the level's pitch; null: the describers
     // blur per keypoint.  The records' image pointers then refer to the blurred levels
     uint8_t* blurred; int blur0_pitch; size_t blur_levels_off;
+    // where the level blur runs: 0 on the call's stream right behind the pyramid; 1 / 2 / 3 on the context's side stream, forked
+    // behind the pyramid / harris_kernel / nms_kernel and joined at the end of the detect launches (it needs the pyramid only,
+    // and select / emit / angle leave most of the chip idle)
+    int blur_fork; hipStream_t side; hipEvent_t ev_fork, ev_join;
     ProfRec prof;                                          // optional HIP-event pairs around the launches
 };
 
