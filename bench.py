@@ -109,9 +109,9 @@ def dry_run(args, rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # defaults: 400 steps x 8 frames x ~0.36 ms = a timed region of ~1.2 s (long enough for the driver's
+    # defaults: 1000 steps x 8 frames x ~0.33 ms = a timed region of ~2.7 s (long enough for the driver's
     # SMI sampler to see the GPU busy, and for the clocks to be what a sustained load gets)
-    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--frames-per-step", type=int, default=8)
     ap.add_argument("--streams", type=int, default=3,

@@ -84,7 +84,8 @@ __device__ __forceinline__ void efx_blur_window_lds(const uint8_t* __restrict__ 
             // predicates (rows / dwords past the window are inside the image or range-checked to zero, and not stored), and
             // -- unlike loads through the generic pointer -- counted in issue order, so that the overlap() work waits for
             // ITS operands only, not for these loads
-            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(img), 0, rows * pitch, 0x00020000);
+            // (the last row counts up to roundup4(cols) only: a caller's allocation may end there -- ADVICE r3; bad_raw_kernel uses the same bound)
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(img), 0, (rows - 1) * pitch + ((cols + 3) & ~3), 0x00020000);
             int goff = (wy0 - 3 + r0) * pitch + ((wx0 - 3) & ~3) + 4 * j;
             uint32_t v[4];
 #pragma unroll

@@ -12,6 +12,7 @@
 //
 // Compile with -ffp-contract=off: the float expressions below must not be fused.
 
+#include <atomic>
 #include "efx_device.h"
 #include "bad_affine.h"
 #include <algorithm>
@@ -2159,11 +2160,13 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
         const ResizePlanLevel* R = a.rplan_lv ? &a.rplan_lv[s + 1] : nullptr;
         if (aligned && R && R->W != 0 && a.rplan && !no_stream) {
             // streamed variant: a grid the chip holds at once (8 workgroups of 256 threads per CU), a multiple of the 8 XCDs
-            static int s_slots = 0;
+            static std::atomic<int> s_slots_a{0};
+            int s_slots = s_slots_a.load(std::memory_order_relaxed);
             if (s_slots == 0) {
                 int dev = 0, cus = 0;
                 if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
                 s_slots = cus * 8;
+                s_slots_a.store(s_slots, std::memory_order_relaxed);
             }
             const int per_xcd = std::min(s_slots / EFX_NXCD, (ntiles + EFX_NXCD - 1) / EFX_NXCD);
             hipLaunchKernelGGL(resize_stream_kernel, dim3(per_xcd * EFX_NXCD), dim3(256), RS_YTAB + EFX_TILE * 16, stream, src, spitch, L.rows, L.cols,
@@ -2260,13 +2263,20 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
     if (e != hipSuccess) return e;
     prof = a.prof.begin(3, stream);
     {
-        static bool attr_set[64] = { false };  // 128 KB of dynamic LDS: above the default limit of a launch; set once per device
+        // 128 KB of dynamic LDS: above the default limit of a launch; raised once per device (atomics: contexts launch from several
+        // threads), and a refusal -- a device with less LDS -- is reported as such instead of as an opaque launch failure
+        static std::atomic<int> attr_state[64];             // 0 not tried, 1 ok, 2 refused
         int dev = 0;
         (void)hipGetDevice(&dev);
-        if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SEL_LDS_BYTES);
-            if (dev >= 0 && dev < 64) attr_set[dev] = true;
+        const bool slot = dev >= 0 && dev < 64;
+        int st = slot ? attr_state[dev].load(std::memory_order_acquire) : 0;
+        if (st == 0) {
+            const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SEL_LDS_BYTES);
+            st = ea == hipSuccess ? 1 : 2;
+            if (ea != hipSuccess) (void)hipGetLastError();
+            if (slot) attr_state[dev].store(st, std::memory_order_release);
         }
+        if (st == 2) return hipErrorInvalidConfiguration;   // efx_api.cpp: EFX_ERR_UNSUPPORTED, "select_kernel needs 128 KB of LDS"
     }
     hipLaunchKernelGGL(select_kernel, dim3(H.nlevels), dim3(1024), SEL_LDS_BYTES, stream, a.d_table, a.hdr, a.surv, a.counters,
                        a.capacity, a.d_count);

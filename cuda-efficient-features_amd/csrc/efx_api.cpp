@@ -771,6 +771,8 @@ int detect_common(efx_context* c, const uint8_t* d_image, int rows, int cols, si
     efx_trace_hook = trace_digest;
 #endif
     hipError_t e = efx_launch_detect(a, stream);
+    if (e == hipErrorInvalidConfiguration)
+        return set_err(c->err, EFX_ERR_UNSUPPORTED, "this device refuses the 128 KB of dynamic LDS select_kernel needs (MI355X has 160 KB per CU)");
     if (e != hipSuccess) return set_err(c->err, EFX_ERR_HIP, "detect launch failed: %s", hipGetErrorString(e));
     c->has_frame = true; c->last_img0 = d_image; c->last_pitch0 = (int)pitch;
 #ifdef EFX_DEBUG_BUILD
