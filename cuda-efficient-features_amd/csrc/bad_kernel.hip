@@ -655,7 +655,7 @@ void efx_gaussian_taps_host(float taps[7])
 #define BLV_TAPS 7                       // INVESTIGATION builds: fewer taps in the row pass = fewer VALU instructions, same memory traffic
 #endif
 #ifndef BLV_PF
-#define BLV_PF 2                         // rows the loads run ahead of the arithmetic
+#define BLV_PF 1                         // rows the loads run ahead of the arithmetic (2: same speed, 7 more VGPRs -> spills at 72)
 #endif
 #define BLV_ROWS (7 * BLV_GROUPS)
 #define BLV_ROWS_BYTES 16                // ... of the byte path (narrow or unaligned levels): short tasks, its loads are not prefetched
@@ -815,7 +815,11 @@ __device__ __forceinline__ void blur_task_dwords(const BlurLevel& L, int strip, 
     }
 }
 
-__global__ __launch_bounds__(256, BLV_WAVES) void blur_levels_kernel(const BlurLevelsArgs A, float tp0, float tp1, float tp2, float tp3)
+// Two kernels, one per path: in ONE kernel the register allocation is the larger path's plus a few, and the dword path then
+// spills at seven waves per SIMD -- a kernel with scratch costs ~25 us of dispatch stall per launch on this runtime (round 4: the
+// HIP-event pair around the launch read 88 us where the kernel itself ran 57)
+template <bool BYTES>
+__global__ __launch_bounds__(256, BYTES ? 7 : BLV_WAVES) void blur_levels_kernel(const BlurLevelsArgs A, float tp0, float tp1, float tp2, float tp3)
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -828,10 +832,10 @@ __global__ __launch_bounds__(256, BLV_WAVES) void blur_levels_kernel(const BlurL
     const int chunk = t / L.nstrips, strip = t - chunk * L.nstrips;
     // the taps live in VECTOR registers: a full-rate VALU instruction (v_fmac_f32: 2 cycles per wave64) with a scalar-register
     // source runs at HALF rate (4.1 cycles; profiles/r04_valu_rate.txt "(sgpr)" rows) -- left to the compiler the 64 FMAs of a
-    // row read the taps from SGPRs and the kernel took 68 instead of 41 us
+    // row read the taps from SGPRs and the kernel took 68 instead of 57 us
     asm volatile("" : "+v"(tp0), "+v"(tp1), "+v"(tp2), "+v"(tp3));
     const float tp[7] = { tp0, tp1, tp2, tp3, tp2, tp1, tp0 };
-    if (L.bytes) blur_task_bytes(L, strip, chunk, lane, tp);
+    if (BYTES) blur_task_bytes(L, strip, chunk, lane, tp);
     else blur_task_dwords(L, strip, chunk, lane, tp, A.nr);
 }
 
@@ -841,40 +845,47 @@ hipError_t efx_launch_blur_levels(const LevelTable& H, const uint8_t* img0, int 
     // Rows per task of the dword path: 63 on large pyramids (a task recomputes 6 rows of the row pass: 10 %), fewer on small ones
     // -- an FHD pyramid has 400 tasks of 63 rows for 1024 SIMDs, and a lone wave issues one VALU instruction per 4 cycles: the
     // kernel then took 25 us of a 110 us call.  The smallest multiple of 7 that still leaves ~3000 tasks, but not below 14
-    BlurLevelsArgs A = {};
+    BlurLevelsArgs A[2] = {};            // [0] the dword path, [1] the byte path (narrow or unaligned levels)
     for (int nr = BLV_ROWS; nr >= 14; nr -= 7) {
-        A = BlurLevelsArgs{};
-        A.nr = nr;
+        A[0] = BlurLevelsArgs{}; A[1] = BlurLevelsArgs{};
+        A[0].nr = A[1].nr = nr;
         for (int l = 0; l < H.nlevels; l++) {
             const LevelDev& L = H.lv[l];
             if (!L.active || L.rows <= 0 || L.cols <= 0) continue;
-            BlurLevel& B = A.lv[A.nlevels++];
-            B.src = l == 0 ? img0 : pyramid + L.img_off;
-            B.spitch = l == 0 ? pitch0 : L.pitch;
+            const uint8_t* src = l == 0 ? img0 : pyramid + L.img_off;
+            const int spitch = l == 0 ? pitch0 : L.pitch;
+            const bool aligned = ((((uintptr_t)src) | (uintptr_t)spitch) & 3u) == 0;
+            const bool bytes = !(aligned && L.cols >= 512 && L.rows >= 16);
+            BlurLevelsArgs& T = A[bytes ? 1 : 0];
+            BlurLevel& B = T.lv[T.nlevels++];
+            B.src = src; B.spitch = spitch;
             B.dst = l == 0 ? blurred : blurred + blur_levels_off + L.img_off;
             B.dpitch = l == 0 ? blur0_pitch : L.pitch;
             B.rows = L.rows; B.cols = L.cols;
-            const bool aligned = ((((uintptr_t)B.src) | (uintptr_t)B.spitch) & 3u) == 0;
-            B.bytes = !(aligned && L.cols >= 512 && L.rows >= 16);
-            if (B.bytes) {
+            B.bytes = bytes ? 1 : 0;
+            if (bytes) {
                 B.nstrips = (L.cols + 255) / 256;
-                A.total += B.nstrips * ((L.rows + BLV_ROWS_BYTES - 1) / BLV_ROWS_BYTES);
+                T.total += B.nstrips * ((L.rows + BLV_ROWS_BYTES - 1) / BLV_ROWS_BYTES);
             } else {
                 B.xs = ((L.cols - 1) & ~3) - 252;
                 B.n_reg = (B.xs + 255) / 256;                   // regular strips cover [0, xs)
                 B.nstrips = B.n_reg + 1;
-                A.total += B.nstrips * ((L.rows + nr - 1) / nr);
+                T.total += B.nstrips * ((L.rows + nr - 1) / nr);
             }
-            B.task_end = A.total;
+            B.task_end = T.total;
         }
-        if (A.total >= 3072) break;
+        if (A[0].total + A[1].total >= 3072) break;
     }
-    if (A.total == 0) return hipSuccess;
+    if (A[0].total + A[1].total == 0) return hipSuccess;
     float t[7];
     efx_gaussian_taps_host(t);
     const bool prof = prof_rec.begin(11, stream);
-    const int nblk = ((A.total + 3) / 4 + EFX_NXCD - 1) / EFX_NXCD * EFX_NXCD;     // xcd_chunked wants whole rounds
-    hipLaunchKernelGGL(blur_levels_kernel, dim3(nblk), dim3(256), 0, stream, A, t[0], t[1], t[2], t[3]);
+    for (int k = 0; k < 2; k++) {
+        if (A[k].total == 0) continue;
+        const int nblk = ((A[k].total + 3) / 4 + EFX_NXCD - 1) / EFX_NXCD * EFX_NXCD;     // xcd_chunked wants whole rounds
+        if (k == 0) hipLaunchKernelGGL(blur_levels_kernel<false>, dim3(nblk), dim3(256), 0, stream, A[k], t[0], t[1], t[2], t[3]);
+        else hipLaunchKernelGGL(blur_levels_kernel<true>, dim3(nblk), dim3(256), 0, stream, A[k], t[0], t[1], t[2], t[3]);
+    }
     prof_rec.end(prof, 11, stream);
     return hipGetLastError();
 }
