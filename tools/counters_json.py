@@ -74,7 +74,7 @@ def main(sq_path, lds_path, traffic_path, valu_path, out_path, mix_path=None):
     if mix_path and os.path.exists(mix_path):
         mk = json.load(open(mix_path))["kernels"]
         for name, inst in (("fast_kernel", "fast_kernel"), ("harris_kernel", "harris_kernel<1>"), ("nms_kernel", "nms_kernel<1>"),
-                           ("bad_det_kernel", "bad_det_kernel"), ("bad_raw_kernel", "bad_raw_kernel<8>"), ("blur_levels_kernel", "blur_levels_kernel"),
+                           ("bad_det_kernel", "bad_det_kernel"), ("bad_raw_kernel", "bad_raw_kernel<8>"), ("blur_levels_kernel", "blur_levels_kernel<false>"),
                            ("resize_chain", "resize_stream_kernel"), ("resize_stream_kernel", "resize_stream_kernel"),
                            ("select_kernel", "select_kernel"), ("emit_kernel", "emit_kernel"), ("angle_kernel", "angle_kernel<false>"),
                            ("angle_tail_kernel", "angle_tail_kernel")):
