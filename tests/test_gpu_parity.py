@@ -724,11 +724,12 @@ def test_detect_and_compute_without_descriptors(cef, torch_mod, oracle):
 
 
 # ---- whole-level blur (round 4): blur_levels_kernel + a wave per keypoint, against the per-window blur and the oracle ----
-@pytest.mark.parametrize("cols", [1040, 1041, 1042, 1043, 700])
+@pytest.mark.parametrize("cols", [1040, 1041, 1042, 1043, 700, 509, 512, 513, 768, 769])
 def test_level_blur_paths_equal_oracle(cef, torch_mod, oracle, cols, monkeypatch):
     """detectAndCompute BAD behind the whole-level Gaussian: levels of 512 columns and more take the dword path of
     blur_levels_kernel, whose right-edge strip patches the BORDER_REFLECT_101 pixels by r = cols - ((cols - 1) & ~3) (1 .. 4:
-    every residue of cols modulo 4, here and again on the upper levels), narrower levels the byte path; an image whose base is
+    every residue of cols modulo 4, here and again on the upper levels; 509 .. 513 and 768 / 769: the anchored strip starting exactly on
+    / next to a regular strip's boundary), narrower levels the byte path; an image whose base is
     not 4-byte aligned sends level 0 through the byte path as well.  All of them, and the per-window blur (EFX_NO_LEVEL_BLUR),
     must give the oracle's keypoints and descriptor bytes."""
     torch = torch_mod
