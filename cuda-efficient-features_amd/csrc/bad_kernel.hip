@@ -12,6 +12,7 @@
 // global one; the float expressions are evaluated exactly as in bad.cpp (compile with -ffp-contract=off).
 
 #include "efx_device.h"
+#include <algorithm>
 #include "blur_window.h"
 #include "bad_affine.h"
 #include <stdlib.h>
@@ -97,6 +98,18 @@ __device__ __forceinline__ bool bad_taps_bit(const BadTaps& t, uint32_t thr_bits
 __device__ __forceinline__ bool bad_ubox_bit(const Affine& A, uint4 q, const unsigned char* Jb, int wbase)
 {
     return bad_taps_bit(bad_ubox_taps(A, q, wbase), q.w, Jb);
+}
+// The same with the integral's LDS byte address folded into the taps' base, held in a VECTOR register (vbase = LDS address of
+// the plane + wbase): per box pair the wave-uniform base would otherwise be added from a scalar register nine times, and a
+// scalar source halves the rate of v_add_u32 (profiles/r04_valu_rate.txt; 98 of bad_raw_kernel<8>'s 1762 VALU instructions)
+__device__ __forceinline__ bool bad_ubox_bit_v(const Affine& A, uint4 q, int vbase)
+{
+    const BadTaps t = bad_ubox_taps(A, q, vbase);
+    typedef __attribute__((address_space(3))) const uint16_t lds_u16;
+    auto at = [&](int o) -> int { return (int)*reinterpret_cast<lds_u16*>((uintptr_t)(uint32_t)o); };
+    const int sa = (at(t.a_tl) + at(t.a_tl + t.side2 + t.sideJ2) - at(t.a_tl + t.side2) - at(t.a_tl + t.sideJ2)) & 0xffff;
+    const int sb = (at(t.b_tl) + at(t.b_tl + t.side2 + t.sideJ2) - at(t.b_tl + t.side2) - at(t.b_tl + t.sideJ2)) & 0xffff;
+    return (float)(sa - sb) <= __uint_as_float(q.w);
 }
 
 // rectifyBoxes etc. for keypoint lists that do not come from the detector (bad_affine.h)
@@ -581,6 +594,8 @@ __global__ __launch_bounds__(256) void bad_raw_kernel(
     const bool border = (A.border & 1) != 0;
     const int fw = cols + 1, fh = rows + 1;
     const int wbase = -(wy0 * JP + wx0) * 2;
+    int vbase = (int)(uint32_t)(uintptr_t)wbuf + wbase;     // LDS byte address of the plane (low half of the generic address) + wbase
+    asm volatile("" : "+v"(vbase));
     uint32_t mlo = 0u, mhi = 0u;
 #pragma unroll
     for (int it = 0; it < NIT; it++) {
@@ -591,7 +606,7 @@ __global__ __launch_bounds__(256) void bad_raw_kernel(
                 bit = bad_border_bit<uint16_t>(A, P->box[b], J, JP, S, wx0, wy0, fw, fh);
             } else {
                 // integer fast path, bad.cpp:365-393; the window holds every tap (bad_det_kernel has the argument)
-                bit = bad_ubox_bit(A, q[it], wbuf, wbase);
+                bit = bad_ubox_bit_v(A, q[it], vbase);
             }
         }
         const unsigned long long m = __ballot(bit);
