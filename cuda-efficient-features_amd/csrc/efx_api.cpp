@@ -376,6 +376,7 @@ struct efx_describer { Describer d; };
 
 struct efx_matcher {
     bool no_mfma = getenv("EFX_MATCH_NO_MFMA") != nullptr;        // variant knob (tests: force the popcount kernel), read when the matcher is created
+    bool no_fp4 = getenv("EFX_MATCH_NO_FP4") != nullptr;          // ... the int8 matrix-core kernel instead of the FP4 one
     DevBuf scratch, expanded, a_idx, a_dist, b_idx, b_dist;
     std::string err;
     ~efx_matcher() { scratch.release(); expanded.release(); a_idx.release(); a_dist.release(); b_idx.release(); b_dist.release(); }
@@ -1693,15 +1694,19 @@ static int knn2_run(efx_matcher* m, const uint8_t* q, size_t qp, int nq, const u
 {
     if (nq == 0) return EFX_OK;
     if (nq >= 128 && nt >= 64 && !m->no_mfma) {
-        // large sets: the distance matrix as an int8 GEMM on the matrix cores (match_kernels.hip)
-        int nchunks = 1024 / ((nq + 255) / 256);
+        // large sets: the distance matrix as a GEMM on the matrix cores (match_kernels.hip): FP4 (MX) operands, int8 with EFX_MATCH_NO_FP4
+        // (query block, train chunk) pairs: one round of the chip's 512 resident 512-thread workgroups (two per CU) -- fewer chunks
+        // mean fewer best-two updates per wave (a wave's updates fall off as 1 / trains seen); 40 000 x 40 000 x 512 bit:
+        // 3 / 6 / 13 chunks 0.473 / 0.499 / 0.524 ms
+        int nchunks = 512 / ((nq + 255) / 256);
+        { static const int env = [] { const char* v = getenv("EFX_MATCH_CHUNKS"); return v ? atoi(v) : 0; }(); if (env > 0) nchunks = env; }   // INVESTIGATION knob
         if (nchunks < 1) nchunks = 1;
         if (nchunks > 64) nchunks = 64;
         const int ntiles = (nt + 31) / 32;
         if (nchunks > ntiles) nchunks = ntiles;
         HIP_TRY(m->err, m->scratch.reserve((size_t)nchunks * nq * 16));
         HIP_TRY(m->err, m->expanded.reserve(efx_knn2_mfma_scratch(nq, nt, db)));
-        hipError_t e = efx_launch_knn2_mfma(q, qp, nq, t, tp, nt, db, m->expanded.p, m->scratch.p, nchunks, idx, dist, stream);
+        hipError_t e = efx_launch_knn2_mfma(q, qp, nq, t, tp, nt, db, m->expanded.p, m->scratch.p, nchunks, idx, dist, stream, m->no_fp4 ? 0 : 1);
         if (e != hipSuccess) return set_err(m->err, EFX_ERR_HIP, "knn launch failed: %s", hipGetErrorString(e));
         return EFX_OK;
     }

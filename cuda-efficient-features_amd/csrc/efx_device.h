@@ -331,7 +331,7 @@ hipError_t efx_launch_cvt_gray(const uint8_t* src, size_t spitch, int rows, int 
 // int8 matrix-core variant for large sets: scratch_x = efx_knn2_mfma_scratch() bytes (the +-1 expansions of both sets)
 size_t efx_knn2_mfma_scratch(int nq, int nt, int desc_bytes);
 hipError_t efx_launch_knn2_mfma(const uint8_t* query, size_t q_pitch, int nq, const uint8_t* train, size_t t_pitch, int nt,
-                                int desc_bytes, void* scratch_x, void* scratch, int nchunks, int* idx, int* dist, hipStream_t stream);
+                                int desc_bytes, void* scratch_x, void* scratch, int nchunks, int* idx, int* dist, hipStream_t stream, int fp4);
 hipError_t efx_launch_knn2(const uint8_t* query, size_t q_pitch, int nq, const uint8_t* train, size_t t_pitch, int nt,
                            int desc_bytes, void* scratch, int nchunks, int* idx, int* dist, hipStream_t stream);
 hipError_t efx_launch_crosscheck(const int* q2t, const int* t2q, int nq, int* match, hipStream_t stream);

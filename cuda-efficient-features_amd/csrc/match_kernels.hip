@@ -12,6 +12,7 @@
 
 #include "efx_device.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -97,20 +98,58 @@ __global__ void expand_pm1_kernel(const uint8_t* __restrict__ src, size_t pitch,
     *reinterpret_cast<uint4*>(dst + ((size_t)row * groups + g) * 16) = out;
 }
 
-// (dot product, train index) a better than b: larger dot (smaller distance), then lower index
-__device__ __forceinline__ bool knn_better(int da, int ia, int db, int ib) { return da > db || (da == db && (unsigned)ia < (unsigned)ib); }
+// bits -> FP4 (E2M1) nibbles of +1.0 (0x2) / -1.0 (0xA), two per byte (round 4: the MX matrix-core path below); bit j of a
+// descriptor -> nibble j, the same order for queries and trains; rows [n, n_pad) are zero nibbles (0.0)
+__global__ void expand_fp4_kernel(const uint8_t* __restrict__ src, size_t pitch, int n, int n_pad, int nbytes, uint8_t* __restrict__ dst)
+{
+    const int groups = nbytes >> 1;                        // 16 bits -> 8 bytes per thread
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)n_pad * groups) return;
+    const int row = (int)(i / groups), g = (int)(i - (size_t)row * groups);
+    uint2 out = make_uint2(0u, 0u);
+    if (row < n) {
+        const uint8_t* p = src + (size_t)row * pitch + 2 * g;
+        uint32_t w[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            uint32_t x = p[k];                              // bit j -> bit 4 j
+            x = (x | (x << 12)) & 0x000f000fu;
+            x = (x | (x << 6)) & 0x03030303u;
+            x = (x | (x << 3)) & 0x11111111u;
+            w[k] = 0x22222222u | ((~x & 0x11111111u) << 3);  // 1 -> 0x2 (+1.0), 0 -> 0xA (-1.0)
+        }
+        out = make_uint2(w[0], w[1]);
+    }
+    *reinterpret_cast<uint2*>(dst + ((size_t)row * groups + g) * 8) = out;
+}
 
-// NB: bytes of an expanded descriptor = bits (256 or 512); CB: 32-query column blocks per wave (the A fragment a wave
-// reads from LDS serves CB MFMAs: the kernel is bound by those reads); NW waves per workgroup: NW * CB * 32 = 256 queries
-template <int NB, int CB, int NW>
+// (dot product, train index) a better than b: larger dot (smaller distance), then lower index
+template <class T> __device__ __forceinline__ bool knn_better(T da, int ia, T db, int ib) { return da > db || (da == db && (unsigned)ia < (unsigned)ib); }
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// NBITS: descriptor bits (256 or 512); NB: bytes of an expanded descriptor = NBITS (int8) or NBITS / 2 (FP4); CB: 32-query column
+// blocks per wave (the A fragment a wave reads from LDS serves CB MFMAs: the kernel is bound by those reads); NW waves per
+// workgroup: NW * CB * 32 = 256 queries.
+// FP4 (round 4): the same GEMM on the MX matrix cores -- v_mfma_f32_32x32x64_f8f6f4 with both operands FP4 (E2M1 holds +-1.0
+// exactly; no block scales: the unscaled form), 64 terms of K per instruction at the int8 instruction's issue cost (32 cycles)
+// and 16 bytes per lane and operand: half the MFMAs AND half the LDS bytes per descriptor pair.  The fp32 accumulator is exact
+// (|dot| <= 512).  The lane layout of the operands is the int8 form's with two elements per byte (row = lane & 31, K range by
+// lane >> 5), the C layout is the shape's; which K index a nibble stands for does not matter as long as queries and trains agree.
+template <int NBITS, int CB, int NW, bool FP4>
 __global__ __launch_bounds__(NW * 64) void knn2_mfma_kernel(const uint8_t* __restrict__ xq, int nq, const uint8_t* __restrict__ xt, int nt,
                                                             int tiles_per_chunk, Best2* __restrict__ partial)
 {
     constexpr int NT = NW * 64;
-    constexpr int KS = NB / 32;                            // K steps of the 32x32x32 MFMA
+    constexpr int NB = FP4 ? NBITS / 2 : NBITS;
+    constexpr int KS = NB / 32;                            // K steps: 32 bytes of a row per MFMA (32 int8 or 64 FP4 terms)
     constexpr int LP = NB + 16;                            // LDS row pitch: rows 4 banks apart
-    constexpr int NPF = 32 * NB / 16 / NT;                 // 16-byte loads per thread that stage a 32-row tile
-    static_assert(NW * CB == 8 && NPF >= 1, "256 queries per workgroup");
+    constexpr int NPIECE = 32 * NB / 16;                   // 16-byte pieces of a 32-row tile
+    constexpr int NPF = (NPIECE + NT - 1) / NT;            // ... per thread
+    static_assert(NW * CB == 8, "256 queries per workgroup");
+    typedef typename std::conditional<FP4, float, int>::type acc_t;
+    typedef typename std::conditional<FP4, f32x16, i32x16>::type accv_t;
+    const acc_t LOWEST = FP4 ? (acc_t)-1.0e30f : (acc_t)-0x7fffffff;
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[32 * LP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -124,30 +163,32 @@ __global__ __launch_bounds__(NW * 64) void knn2_mfma_kernel(const uint8_t* __res
     }
     const int ntiles = (nt + 31) >> 5;
     const int tile0 = blockIdx.y * tiles_per_chunk, tile1 = min(tile0 + tiles_per_chunk, ntiles);
-    int bd0[CB], bi0[CB], bd1[CB], bi1[CB];
+    acc_t bd0[CB], bd1[CB];
+    int bi0[CB], bi1[CB];
 #pragma unroll
-    for (int c = 0; c < CB; c++) { bd0[c] = bd1[c] = -0x7fffffff; bi0[c] = bi1[c] = -1; }
+    for (int c = 0; c < CB; c++) { bd0[c] = bd1[c] = LOWEST; bi0[c] = bi1[c] = -1; }
 
     // a tile is 32 x NB bytes = 32 * NB / 16 sixteen-byte pieces, NPF per thread, rows contiguous in memory
     uint4 pf[NPF];
     auto fetch = [&](int tile) {
         const uint4* src = reinterpret_cast<const uint4*>(xt + (size_t)tile * 32 * NB);
 #pragma unroll
-        for (int j = 0; j < NPF; j++) pf[j] = src[tid + NT * j];
+        for (int j = 0; j < NPF; j++) if (NPIECE % NT == 0 || tid + NT * j < NPIECE) pf[j] = src[tid + NT * j];
     };
     if (tile0 < tile1) fetch(tile0);
     for (int tile = tile0; tile < tile1; tile++) {
 #pragma unroll
         for (int j = 0; j < NPF; j++) {
             const int piece = tid + NT * j, row = piece / (NB / 16), col = piece - row * (NB / 16);
-            *reinterpret_cast<uint4*>(s_tile + row * LP + 16 * col) = pf[j];
+            if (NPIECE % NT == 0 || piece < NPIECE) *reinterpret_cast<uint4*>(s_tile + row * LP + 16 * col) = pf[j];
         }
         __syncthreads();
         if (tile + 1 < tile1) fetch(tile + 1);             // in flight while this tile is multiplied
-        const i32x16 zero = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-        i32x16 acc[CB];
+        accv_t acc[CB];
 #pragma unroll
-        for (int c = 0; c < CB; c++) acc[c] = zero;
+        for (int c = 0; c < CB; c++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[c][r] = (acc_t)0;
         const uint8_t* arow = s_tile + li * LP + 16 * lh;
         // one A fragment ahead; the scheduling barrier keeps the compiler from hoisting all KS fragments (4 VGPRs each)
         i32x4 a = *reinterpret_cast<const i32x4*>(arow);
@@ -155,7 +196,15 @@ __global__ __launch_bounds__(NW * 64) void knn2_mfma_kernel(const uint8_t* __res
         for (int ks = 0; ks < KS; ks++) {
             const i32x4 an = *reinterpret_cast<const i32x4*>(arow + 32 * (ks + 1 < KS ? ks + 1 : ks));
 #pragma unroll
-            for (int c = 0; c < CB; c++) acc[c] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[c][ks], acc[c], 0, 0, 0);
+            for (int c = 0; c < CB; c++) {
+                if constexpr (FP4) {
+                    const i32x8 a8 = { a[0], a[1], a[2], a[3], 0, 0, 0, 0 };
+                    const i32x8 b8 = { bq[c][ks][0], bq[c][ks][1], bq[c][ks][2], bq[c][ks][3], 0, 0, 0, 0 };
+                    acc[c] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[c], 4, 4, 0, 0, 0, 0);   // cbsz / blgp 4: FP4 E2M1; scales 0: the unscaled form
+                } else {
+                    acc[c] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[c][ks], acc[c], 0, 0, 0);
+                }
+            }
             a = an;
             if (CB > 1) __builtin_amdgcn_sched_barrier(0);
         }
@@ -166,15 +215,14 @@ __global__ __launch_bounds__(NW * 64) void knn2_mfma_kernel(const uint8_t* __res
         for (int c = 0; c < CB; c++) {
             if (partial_tile) {
 #pragma unroll
-                for (int r = 0; r < 16; r++) if (t0 + (r & 3) + 8 * (r >> 2) >= nt) acc[c][r] = -0x7fffffff;
+                for (int r = 0; r < 16; r++) if (t0 + (r & 3) + 8 * (r >> 2) >= nt) acc[c][r] = LOWEST;
             }
-            int m = -0x7fffffff;
-#pragma unroll
-            for (int r = 0; r < 16; r++) m = max(m, acc[c][r]);
-            if (__ballot(m > bd1[c]) == 0ull) continue;    // nobody's second best is beaten: the usual case after the first tiles
+            // a register (one train per lane) is looked at only if it beats some lane's second best (knn2_fp4_kernel has the reason)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int d = acc[c][r], ti = t0 + (r & 3) + 8 * (r >> 2);
+                const acc_t d = acc[c][r];
+                if (__ballot(d > bd1[c]) == 0ull) continue;
+                const int ti = t0 + (r & 3) + 8 * (r >> 2);
                 // trains arrive in increasing index order, so a strict > keeps the lower index on ties
                 if (d > bd0[c]) { bd1[c] = bd0[c]; bi1[c] = bi0[c]; bd0[c] = d; bi0[c] = ti; }
                 else if (d > bd1[c]) { bd1[c] = d; bi1[c] = ti; }
@@ -185,10 +233,11 @@ __global__ __launch_bounds__(NW * 64) void knn2_mfma_kernel(const uint8_t* __res
     // the two row-halves of a query (lanes l and l + 32) merge their best two; dot -> Hamming distance
 #pragma unroll
     for (int c = 0; c < CB; c++) {
-        const int od0 = __shfl_xor(bd0[c], 32, 64), oi0 = __shfl_xor(bi0[c], 32, 64);
-        const int od1 = __shfl_xor(bd1[c], 32, 64), oi1 = __shfl_xor(bi1[c], 32, 64);
-        int d0 = bd0[c], i0 = bi0[c], d1 = bd1[c], i1 = bi1[c];
-        const int cd[2] = { od0, od1 }, ci[2] = { oi0, oi1 };
+        const acc_t od0 = __shfl_xor(bd0[c], 32, 64), od1 = __shfl_xor(bd1[c], 32, 64);
+        const int oi0 = __shfl_xor(bi0[c], 32, 64), oi1 = __shfl_xor(bi1[c], 32, 64);
+        acc_t d0 = bd0[c], d1 = bd1[c];
+        int i0 = bi0[c], i1 = bi1[c];
+        const acc_t cd[2] = { od0, od1 }; const int ci[2] = { oi0, oi1 };
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             if (ci[j] < 0) continue;
@@ -198,8 +247,116 @@ __global__ __launch_bounds__(NW * 64) void knn2_mfma_kernel(const uint8_t* __res
         const int q = q0 + 32 * c + li;
         if (lh == 0 && q < nq) {
             Best2 b;
-            b.d0 = i0 >= 0 ? (NB - d0) >> 1 : 0x7fffffff; b.i0 = i0;
-            b.d1 = i1 >= 0 ? (NB - d1) >> 1 : 0x7fffffff; b.i1 = i1;
+            b.d0 = i0 >= 0 ? (NBITS - (int)d0) >> 1 : 0x7fffffff; b.i0 = i0;      // dot = bits - 2 * distance (exact in either accumulator)
+            b.d1 = i1 >= 0 ? (NBITS - (int)d1) >> 1 : 0x7fffffff; b.i1 = i1;
+            partial[(size_t)blockIdx.y * nq + q] = b;
+        }
+    }
+}
+
+// The FP4 kernel with TT train tiles (TT x 32 trains) per step: the MX instruction halved the matrix time of a tile (8 MFMAs of
+// 32 cycles for 512 bits), and what was left -- staging, two barriers, the best-two bookkeeping of a tile -- then took three
+// quarters of a step.  TT tiles share one staging pass and one pair of barriers, and their TT accumulators are independent
+// MFMA chains (a wave's eight MFMAs on ONE accumulator wait for each other).  Eight waves x 32 queries, CB = 1.
+template <int NBITS, int TT>
+__global__ __launch_bounds__(512) void knn2_fp4_kernel(const uint8_t* __restrict__ xq, int nq, const uint8_t* __restrict__ xt, int nt,
+                                                       int tiles_per_chunk, Best2* __restrict__ partial)
+{
+    constexpr int NT = 512;
+    constexpr int NB = NBITS / 2;
+    constexpr int KS = NB / 32;
+    constexpr int LP = NB + 16;
+    constexpr int NPIECE = TT * 32 * NB / 16;              // 16-byte pieces of a step's TT tiles (rows contiguous in memory)
+    constexpr int NPF = (NPIECE + NT - 1) / NT;
+    const float LOWEST = -1.0e30f;
+    __shared__ __attribute__((aligned(16))) uint8_t s_tile[TT * 32 * LP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int q0 = blockIdx.x * 256 + wave * 32;
+    i32x4 bq[KS];
+    {
+        const i32x4* p = reinterpret_cast<const i32x4*>(xq + (size_t)(q0 + li) * NB + 16 * lh);
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) bq[ks] = p[2 * ks];
+    }
+    const int ntiles = (nt + 31) >> 5;                     // tiles that hold trains; the buffer is padded to whole steps
+    const int tile0 = blockIdx.y * tiles_per_chunk, tile1 = min(tile0 + tiles_per_chunk, ntiles);
+    float bd0 = LOWEST, bd1 = LOWEST;
+    int bi0 = -1, bi1 = -1;
+    uint4 pf[NPF];
+    auto fetch = [&](int tile) {
+        const uint4* src = reinterpret_cast<const uint4*>(xt + (size_t)tile * 32 * NB);
+#pragma unroll
+        for (int j = 0; j < NPF; j++) if (NPIECE % NT == 0 || tid + NT * j < NPIECE) pf[j] = src[tid + NT * j];
+    };
+    if (tile0 < tile1) fetch(tile0);
+    for (int tile = tile0; tile < tile1; tile += TT) {
+#pragma unroll
+        for (int j = 0; j < NPF; j++) {
+            const int piece = tid + NT * j, row = piece / (NB / 16), col = piece - row * (NB / 16);
+            if (NPIECE % NT == 0 || piece < NPIECE) *reinterpret_cast<uint4*>(s_tile + row * LP + 16 * col) = pf[j];
+        }
+        __syncthreads();
+        if (tile + TT < tile1) fetch(tile + TT);           // in flight while these tiles are multiplied
+        f32x16 acc[TT];
+#pragma unroll
+        for (int tt = 0; tt < TT; tt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[tt][r] = 0.f;
+        const uint8_t* arow = s_tile + li * LP + 16 * lh;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            const i32x8 b8 = { bq[ks][0], bq[ks][1], bq[ks][2], bq[ks][3], 0, 0, 0, 0 };
+#pragma unroll
+            for (int tt = 0; tt < TT; tt++) {
+                const i32x4 a = *reinterpret_cast<const i32x4*>(arow + tt * 32 * LP + 32 * ks);
+                const i32x8 a8 = { a[0], a[1], a[2], a[3], 0, 0, 0, 0 };
+                acc[tt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[tt], 4, 4, 0, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int tt = 0; tt < TT; tt++) {                   // increasing train index: a strict > keeps the lower index on ties
+            const int tb = (tile + tt) * 32;
+            if (tb >= nt) break;                            // a padding tile of the last step (wave-uniform)
+            const int t0 = tb + 4 * lh;
+            if (tb + 32 > nt) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) if (t0 + (r & 3) + 8 * (r >> 2) >= nt) acc[tt][r] = LOWEST;
+            }
+            // A register holds one train per lane (64 pairs).  It is looked at only if it beats SOME lane's second best: one
+            // compare + a scalar branch per register.  (Until round 4 the tile's maximum was tested once and all 16 registers
+            // then went through the update -- with the trains split into chunks for occupancy a wave sees few thousand of them,
+            // two thirds of its tiles held a new best-two for one of its 64 queries, and the update sequence was half of the
+            // kernel's time: 252 M VALU instructions for 40 000 x 40 000 descriptors.)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const float d = acc[tt][r];
+                if (__ballot(d > bd1) == 0ull) continue;
+                const int ti = t0 + (r & 3) + 8 * (r >> 2);
+                if (d > bd0) { bd1 = bd0; bi1 = bi0; bd0 = d; bi0 = ti; }
+                else if (d > bd1) { bd1 = d; bi1 = ti; }
+            }
+        }
+        __syncthreads();                                   // every wave is done with the tiles before they are overwritten
+    }
+    // the two row-halves of a query (lanes l and l + 32) merge their best two; dot -> Hamming distance
+    {
+        const float od0 = __shfl_xor(bd0, 32, 64), od1 = __shfl_xor(bd1, 32, 64);
+        const int oi0 = __shfl_xor(bi0, 32, 64), oi1 = __shfl_xor(bi1, 32, 64);
+        float d0 = bd0, d1 = bd1;
+        int i0 = bi0, i1 = bi1;
+        const float cd[2] = { od0, od1 }; const int ci[2] = { oi0, oi1 };
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            if (ci[j] < 0) continue;
+            if (i0 < 0 || knn_better(cd[j], ci[j], d0, i0)) { d1 = d0; i1 = i0; d0 = cd[j]; i0 = ci[j]; }
+            else if (i1 < 0 || knn_better(cd[j], ci[j], d1, i1)) { d1 = cd[j]; i1 = ci[j]; }
+        }
+        const int q = q0 + li;
+        if (lh == 0 && q < nq) {
+            Best2 b;
+            b.d0 = i0 >= 0 ? (NBITS - (int)d0) >> 1 : 0x7fffffff; b.i0 = i0;
+            b.d1 = i1 >= 0 ? (NBITS - (int)d1) >> 1 : 0x7fffffff; b.i1 = i1;
             partial[(size_t)blockIdx.y * nq + q] = b;
         }
     }
@@ -220,27 +377,48 @@ __global__ void crosscheck_kernel(const int* __restrict__ q2t, const int* __rest
 size_t efx_knn2_mfma_scratch(int nq, int nt, int desc_bytes)
 {
     const size_t nb = (size_t)desc_bytes * 8;
-    return ((size_t)((nq + 255) & ~255) + (size_t)((nt + 31) & ~31)) * nb;
+    return ((size_t)((nq + 255) & ~255) + (size_t)((nt + 127) & ~127)) * nb;      // trains padded to whole steps of up to four 32-row tiles
 }
 
 hipError_t efx_launch_knn2_mfma(const uint8_t* query, size_t q_pitch, int nq, const uint8_t* train, size_t t_pitch, int nt,
-                                int desc_bytes, void* scratch_x, void* scratch, int nchunks, int* idx, int* dist, hipStream_t stream)
+                                int desc_bytes, void* scratch_x, void* scratch, int nchunks, int* idx, int* dist, hipStream_t stream, int fp4)
 {
     if (nq <= 0) return hipSuccess;
-    const int nb = desc_bytes * 8, nq_pad = (nq + 255) & ~255, nt_pad = (nt + 31) & ~31;
+    const int nb = fp4 ? desc_bytes * 4 : desc_bytes * 8, nq_pad = (nq + 255) & ~255, nt_pad = (nt + 127) & ~127;
     uint8_t* xq = static_cast<uint8_t*>(scratch_x);
     uint8_t* xt = xq + (size_t)nq_pad * nb;
     const size_t gq = (size_t)nq_pad * (desc_bytes / 2), gt = (size_t)nt_pad * (desc_bytes / 2);
-    hipLaunchKernelGGL(expand_pm1_kernel, dim3((unsigned)((gq + 255) / 256)), dim3(256), 0, stream, query, q_pitch, nq, nq_pad, desc_bytes, xq);
-    hipLaunchKernelGGL(expand_pm1_kernel, dim3((unsigned)((gt + 255) / 256)), dim3(256), 0, stream, train, t_pitch, nt, nt_pad, desc_bytes, xt);
-    const int ntiles = nt_pad / 32, tpc = (ntiles + nchunks - 1) / nchunks;
+    if (fp4) {
+        hipLaunchKernelGGL(expand_fp4_kernel, dim3((unsigned)((gq + 255) / 256)), dim3(256), 0, stream, query, q_pitch, nq, nq_pad, desc_bytes, xq);
+        hipLaunchKernelGGL(expand_fp4_kernel, dim3((unsigned)((gt + 255) / 256)), dim3(256), 0, stream, train, t_pitch, nt, nt_pad, desc_bytes, xt);
+    } else {
+        hipLaunchKernelGGL(expand_pm1_kernel, dim3((unsigned)((gq + 255) / 256)), dim3(256), 0, stream, query, q_pitch, nq, nq_pad, desc_bytes, xq);
+        hipLaunchKernelGGL(expand_pm1_kernel, dim3((unsigned)((gt + 255) / 256)), dim3(256), 0, stream, train, t_pitch, nt, nt_pad, desc_bytes, xt);
+    }
+    const int ntiles = (nt + 31) / 32;
+    int tpc = (ntiles + nchunks - 1) / nchunks;
+    tpc = (tpc + 3) & ~3;                                   // whole steps of the FP4 kernel (up to four tiles)
     const int chunks = (ntiles + tpc - 1) / tpc;
     Best2* partial = static_cast<Best2*>(scratch);
     const dim3 grid(nq_pad / 256, chunks);
     // eight waves of 32 queries each (two column blocks per wave read half as much LDS per MFMA but run at half the
     // occupancy: 1.6 against 1.0 ms; a double-buffered tile with one barrier per step: 1.3 ms)
-    if (desc_bytes == 32) hipLaunchKernelGGL((knn2_mfma_kernel<256, 1, 8>), grid, dim3(512), 0, stream, xq, nq, xt, nt, tpc, partial);
-    else hipLaunchKernelGGL((knn2_mfma_kernel<512, 1, 8>), grid, dim3(512), 0, stream, xq, nq, xt, nt, tpc, partial);
+    if (fp4) {
+        // tiles per step: measured (40 000 x 40 000): 512 bit 0.509 ms with one tile, 0.533 with two (1.32 with four: spills);
+        // 256 bit 0.363 / 0.348 / 0.552 -- a 256-bit tile is four MFMAs, two tiles amortise its barriers
+        static const int tt_env = [] { const char* v = getenv("EFX_MATCH_TT"); return v ? atoi(v) : 0; }();     // INVESTIGATION knob
+        const int tt = tt_env ? tt_env : (desc_bytes == 32 ? 2 : 1);
+        if (tt == 2) {
+            if (desc_bytes == 32) hipLaunchKernelGGL((knn2_fp4_kernel<256, 2>), grid, dim3(512), 0, stream, xq, nq, xt, nt, tpc, partial);
+            else hipLaunchKernelGGL((knn2_fp4_kernel<512, 2>), grid, dim3(512), 0, stream, xq, nq, xt, nt, tpc, partial);
+        } else {
+            if (desc_bytes == 32) hipLaunchKernelGGL((knn2_mfma_kernel<256, 1, 8, true>), grid, dim3(512), 0, stream, xq, nq, xt, nt, tpc, partial);
+            else hipLaunchKernelGGL((knn2_mfma_kernel<512, 1, 8, true>), grid, dim3(512), 0, stream, xq, nq, xt, nt, tpc, partial);
+        }
+    } else {
+        if (desc_bytes == 32) hipLaunchKernelGGL((knn2_mfma_kernel<256, 1, 8, false>), grid, dim3(512), 0, stream, xq, nq, xt, nt, tpc, partial);
+        else hipLaunchKernelGGL((knn2_mfma_kernel<512, 1, 8, false>), grid, dim3(512), 0, stream, xq, nq, xt, nt, tpc, partial);
+    }
     hipLaunchKernelGGL(knn2_merge_kernel, dim3((nq + 255) / 256), dim3(256), 0, stream, partial, nq, chunks, idx, dist);
     return hipGetLastError();
 }

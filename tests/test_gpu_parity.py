@@ -434,15 +434,27 @@ def test_matcher_paths_agree(cef, torch_mod, monkeypatch):
     q = rng.integers(0, 256, size=(3000, 64), dtype=np.uint8)
     t = np.concatenate([q[::3], q[::5], rng.integers(0, 256, size=(700, 64), dtype=np.uint8)])     # duplicates: ties everywhere
     monkeypatch.delenv("EFX_MATCH_NO_MFMA", raising=False)
-    m_mfma = cef.BFMatcher.create(cef.BFMatcher.NORM_HAMMING)
+    monkeypatch.delenv("EFX_MATCH_NO_FP4", raising=False)
+    m_mfma = cef.BFMatcher.create(cef.BFMatcher.NORM_HAMMING)          # the FP4 (MX) matrix-core kernel: round 4
+    monkeypatch.setenv("EFX_MATCH_NO_FP4", "1")
+    m_i8 = cef.BFMatcher.create(cef.BFMatcher.NORM_HAMMING)            # the int8 matrix-core kernel
+    monkeypatch.delenv("EFX_MATCH_NO_FP4")
     monkeypatch.setenv("EFX_MATCH_NO_MFMA", "1")
     m_pop = cef.BFMatcher.create(cef.BFMatcher.NORM_HAMMING)
     monkeypatch.delenv("EFX_MATCH_NO_MFMA")
     dq, dt = _dev(torch_mod, q), _dev(torch_mod, t)
     idx, dist = m_mfma.knnMatch(dq, dt, 2)
     idx2, dist2 = m_pop.knnMatch(dq, dt, 2)
+    idx3, dist3 = m_i8.knnMatch(dq, dt, 2)
     torch_mod.cuda.synchronize()
     assert torch_mod.equal(idx, idx2) and torch_mod.equal(dist, dist2)
+    assert torch_mod.equal(idx, idx3) and torch_mod.equal(dist, dist3)
+    # 256-bit descriptors through all three kernels as well
+    q32, t32 = np.ascontiguousarray(q[:, :32]), np.ascontiguousarray(t[:, :32])
+    d32q, d32t = _dev(torch_mod, q32), _dev(torch_mod, t32)
+    ra, rb, rc = m_mfma.knnMatch(d32q, d32t, 2), m_pop.knnMatch(d32q, d32t, 2), m_i8.knnMatch(d32q, d32t, 2)
+    torch_mod.cuda.synchronize()
+    assert torch_mod.equal(ra[0], rb[0]) and torch_mod.equal(ra[1], rb[1]) and torch_mod.equal(ra[0], rc[0]) and torch_mod.equal(ra[1], rc[1])
     from oracle import matcher_oracle as MO
     widx, wdist = MO.knn2(q, t)
     assert np.array_equal(dist.cpu().numpy(), wdist) and np.array_equal(idx.cpu().numpy(), widx)

@@ -1,5 +1,6 @@
 """Brute-force Hamming matcher: 40 000 x 40 000 descriptors, knnMatch(k = 2), ms per call (512 and 256 bit)."""
 import sys; sys.path.insert(0, '.')
+import os
 import numpy as np, torch, cef_loader
 cef = cef_loader.load()
 rng = np.random.default_rng(1)
