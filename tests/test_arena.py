@@ -30,6 +30,9 @@ def test_8k_context_is_below_400_mb(cef):
     held = det.deviceBytes()
     assert held <= 400e6, held          # 289 MB of pyramid, arenas and lists + 103 MB of blurred levels (round 4: blur_levels_kernel)
     # a destroyed context's blocks go to the process-wide cache, and the next context of the same geometry runs on them
+    import os
+    if os.environ.get("EFX_NO_BLOCK_CACHE"):
+        return                       # the knob under which the suite is also run returns blocks to the driver at once
     del det
     assert cef.cachedBytes() >= held
     det2 = cef.EfficientFeatures.create(40000, dtype=cef.EfficientFeatures.BAD_512)
