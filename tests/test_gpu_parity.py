@@ -766,3 +766,36 @@ def test_level_blur_paths_equal_oracle(cef, torch_mod, oracle, cols, monkeypatch
             bad = np.nonzero((desc[:n].cpu().numpy() != ref["desc"]).any(axis=1))[0]
             assert bad.size == 0, f"offset {off}, EFX_NO_LEVEL_BLUR {knob}: {bad.size} descriptors differ, first at keypoints {bad[:6]}"
     monkeypatch.delenv("EFX_NO_LEVEL_BLUR", raising=False)
+
+
+def test_detect_and_compute_is_graph_capturable(cef, torch_mod, oracle):
+    """The whole detectAndCompute launch sequence (17 kernels, no host synchronisation, no allocation once the context has seen
+    the geometry) can be captured into a HIP graph and replayed: same keypoints and descriptors as the direct call and as the
+    oracle, also for a DIFFERENT image written into the captured input buffer.  (Replay does not shorten a call -- the
+    ~4.5 us between dependent kernels is the GPU's, tools/microbench/graph_latency.py -- but it takes the 55 us of host
+    enqueue work off the caller's thread.)"""
+    torch = torch_mod
+    a = synth.synth_frame(480, 640, seed=61)
+    b = synth.synth_frame(480, 640, seed=62, density=1.0)
+    img = torch.from_numpy(a).cuda()
+    det = cef.EfficientFeatures.create(3000, dtype=cef.EfficientFeatures.BAD_256)
+    kps = torch.zeros((5, 3000), dtype=torch.float32, device="cuda"); cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    desc = torch.zeros((3000, 32), dtype=torch.uint8, device="cuda")
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        det.detectAndComputeAsync(img, kps, desc, cnt, stream=s)          # geometry, arenas, side buffers: allocated here
+        s.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        det.detectAndComputeAsync(img, kps, desc, cnt, stream=s)
+    for frame in (a, b, a):
+        img.copy_(torch.from_numpy(frame).cuda())
+        kps.zero_(); desc.zero_(); cnt.zero_()
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        ref = oracle.detect_and_compute(frame, nfeatures=3000, desc_type=oracle.BAD_256)
+        n = int(cnt.item())
+        assert n == ref["n"]
+        assert np.array_equal(kps[:, :n].cpu().numpy().view(np.uint32), ref["kps"].view(np.uint32))
+        assert np.array_equal(desc[:n].cpu().numpy(), ref["desc"])
