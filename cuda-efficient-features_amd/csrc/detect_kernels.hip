@@ -191,7 +191,8 @@ __device__ __forceinline__ float harris_rows(const uint8_t* p0, int P)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             // H = 2 * O + (E[j] + E[j+1]) as one v_pk_mad_u16 (the compiler turns the doubling into a separate shift)
-            const u16x2 e = E[j] + E[j + 1];
+            // two sums of bytes per register, neither above 510: ONE 32-bit add (full rate) does both (v_pk_add_u16: half rate)
+            const u16x2 e = __builtin_bit_cast(u16x2, __builtin_bit_cast(uint32_t, E[j]) + __builtin_bit_cast(uint32_t, E[j + 1]));
             asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(H[j]) : "v"(O[j]), "v"(two2), "v"(e));
             D[j] = E[j + 1] - E[j];                               // the high half of D[3] is p7 - p7 = 0: ix = 7 does not exist
         }
