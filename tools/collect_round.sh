@@ -4,6 +4,9 @@
 # one stream and the default three), SQ / LDS counters and HBM traffic (separate --pmc passes), the issue-rate and
 # workgroup-rate micro-benchmarks, <tag>_counters.json (what bench.py's roofline.valu / lds / traffic read), the bench.py
 # line, the BASELINE.json configurations, HashSIFT / matcher kernel stats.  Copy the files into profiles/ afterwards.
+# BEFORE the GPU call, in the build container: python tools/valu_mix.py profiles/<tag>_valu_rate.txt profiles/<tag>_valu_mix.json (static
+# instruction mix of the compiled kernels; counters_json.py folds it in).  AFTER it: copy gpurun_out/<tag>_* into profiles/ and rerun
+# tools/counters_json.py there if the mix file changed.
 # usage: tools/collect_round.sh <tag> [git commit of the tree]   (the box has no .git: pass `git rev-parse HEAD` from the build container)
 tag=${1:-rXX}
 export EFX_GIT_HEAD=${2:-${EFX_GIT_HEAD:-unknown}}
