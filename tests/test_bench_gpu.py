@@ -34,6 +34,10 @@ def test_contract_fields(line):
     assert j["value"] > 20.0 and j["value"] == pytest.approx(8 * j["config"]["keypoints_per_frame"] / (j["ms_per_step"] * 1e-3) / 1e6, rel=1e-3)
     assert j["vs_baseline"] == pytest.approx(j["value"] / (40000 / 8.2e-3 / 1e6), rel=1e-2)
     assert j["parity_8k_frame0"] is True                          # the timed path == the oracle on the bench frame
+    # 6 steps are over in 16 ms: the same steps run again for --sustain-seconds (default 2 s) and are reported beside `value`
+    s = j["sustained"]
+    assert s["seconds"] >= 1.7 and s["steps"] > 100 and s["value"] == pytest.approx(s["steps"] * 8 * j["config"]["keypoints_per_frame"] / s["seconds"] / 1e6, rel=1e-3)
+    assert 0.5 * j["value"] < s["value"] < 1.5 * j["value"]
 
 
 def test_roofline_and_cpu_baseline(line):

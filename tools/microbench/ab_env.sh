@@ -5,7 +5,7 @@ var=$1; reps=${2:-3}
 for i in $(seq $reps); do
   for v in 1 0; do
     if [ $v = 1 ]; then export $var=1; else unset $var; fi
-    python bench.py --no-cpu-baseline --no-configs --steps ${STEPS:-200} --warmup 5 2>/dev/null | tail -1 | python -c "
+    python bench.py --no-cpu-baseline --no-configs --sustain-seconds 0 --steps ${STEPS:-200} --warmup 5 2>/dev/null | tail -1 | python -c "
 import json,sys,os; d=json.loads(sys.stdin.read()); r=d['roofline']; print('$var', os.environ.get('$var'), d['value'], d['ms_per_frame'], d['latency']['ms_per_frame'], {k:v['avg_launch_ms'] for k,v in r['kernels_isolated'].items()})"
   done
 done

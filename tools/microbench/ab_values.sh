@@ -4,7 +4,7 @@
 var=$1; shift
 for rep in 1 2; do
   for v in "$@"; do
-    env $var=$v python bench.py --no-cpu-baseline --no-configs --steps ${STEPS:-200} --warmup 5 2>/dev/null | tail -1 | python -c "
+    env $var=$v python bench.py --no-cpu-baseline --no-configs --sustain-seconds 0 --steps ${STEPS:-200} --warmup 5 2>/dev/null | tail -1 | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); print('$var=$v', d['value'], d['ms_per_frame'], 'lat', d['latency']['ms_per_frame'])"
   done
 done

@@ -6,7 +6,7 @@ for n in 0 1 2 3 4 full; do
   fl=""; [ $n != full ] && fl="-DBAD_DET_STOP=$n"
   (cd cuda-efficient-features_amd/csrc && rm -f bad_kernel.o hashsift_kernels.o && make -s EXTRA="$fl" 2>&1 | grep -E " error" | head -3)
   rm -rf gpurun_out/pmc_bp
-  timeout 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU --kernel-trace -d gpurun_out/pmc_bp -o pmc -- python bench.py --steps 1 --warmup 1 --frames-per-step 2 --no-cpu-baseline --no-configs --streams 1 > gpurun_out/pmc_bp.log 2>&1 < /dev/null
+  timeout 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU --kernel-trace -d gpurun_out/pmc_bp -o pmc -- python bench.py --steps 1 --warmup 1 --frames-per-step 2 --no-cpu-baseline --no-configs --sustain-seconds 0 --streams 1 > gpurun_out/pmc_bp.log 2>&1 < /dev/null
   echo "== stop after phase $n: $(python tools/pmc_summary.py gpurun_out/pmc_bp/pmc_results.db bad_det | grep -E 'SQ_INSTS' | awk '{printf "%s %.2f M  ", $1, $NF/1e6}')"
   python - <<'P'
 import sqlite3

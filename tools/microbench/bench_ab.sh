@@ -12,7 +12,7 @@ for rep in $(seq 1 ${REPS:-4}); do
   i=0
   for fl in "$@"; do
     cp $O/ab/lib$i.so cuda-efficient-features_amd/libefx_hip.so
-    v=$(python bench.py --no-cpu-baseline --no-configs --steps ${STEPS:-20} --warmup 3 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_frame'])")
+    v=$(python bench.py --no-cpu-baseline --no-configs --sustain-seconds 0 --steps ${STEPS:-20} --warmup 3 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_frame'])")
     echo "rep $rep flags '$fl': $v"
     i=$((i+1))
   done

@@ -2,7 +2,7 @@
 # INVESTIGATION (GPU box): how the three streams of the bench loop share the GPU -- from a kernel trace of `python bench.py`:
 # wall time, time with 0 / 1 / 2 / 3+ kernels running, per-stream busy time.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-rm -rf gpurun_out/ovl; timeout 200 rocprofv3 --kernel-trace -d gpurun_out/ovl -o t -- python bench.py --no-cpu-baseline --no-configs --steps 10 --warmup 2 > gpurun_out/ovl.log 2>&1 < /dev/null
+rm -rf gpurun_out/ovl; timeout 200 rocprofv3 --kernel-trace -d gpurun_out/ovl -o t -- python bench.py --no-cpu-baseline --no-configs --sustain-seconds 0 --steps 10 --warmup 2 > gpurun_out/ovl.log 2>&1 < /dev/null
 tail -1 gpurun_out/ovl.log | cut -c1-120
 python - <<'P'
 import sqlite3

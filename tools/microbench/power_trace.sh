@@ -4,7 +4,7 @@
 O=gpurun_out; mkdir -p $O
 ( while true; do echo "t $(date +%s.%N) $(rocm-smi --showclocks --showpower --showtemp 2>/dev/null | grep -E 'sclk|Socket Graphics|Temperature \(Sensor junction\)' | sed -E 's/.*: //' | tr '\n' ' ')"; sleep 0.25; done ) > $O/power_trace.txt &
 S=$!
-python bench.py --no-cpu-baseline --no-configs "$@" > $O/power_bench.json 2>/dev/null
+python bench.py --no-cpu-baseline --no-configs --sustain-seconds 0 "$@" > $O/power_bench.json 2>/dev/null
 kill $S
 python - <<'PY'
 import re

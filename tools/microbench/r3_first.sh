@@ -12,4 +12,4 @@ done
 EFX_BAD_NO_RAW=1 rocprofv3 --kernel-trace --stats -d $O/prof_c3 -o c3 -- python tools/microbench/c3_run.py --nbits 512 > $O/c3_generic_512.log 2>&1
 tail -1 $O/c3_generic_512.log
 python tools/prof_summary.py $O/prof_c3/c3_results.db $O/r03_c3_bad512_generic_kernel_stats.csv | head -8 | cut -c1-110; rm -rf $O/prof_c3
-python bench.py --no-cpu-baseline --no-configs --steps 12 --warmup 3 | tail -1 | cut -c1-400
+python bench.py --no-cpu-baseline --no-configs --sustain-seconds 0 --steps 12 --warmup 3 | tail -1 | cut -c1-400

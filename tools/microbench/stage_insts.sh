@@ -6,7 +6,7 @@ cd "$GRAFT_REPO_ROOT/cuda-efficient-features_amd/csrc" && rm -f detect_kernels.o
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for k in "$@"; do
   rm -rf gpurun_out/pmc_st
-  EFX_DEBUG=$k timeout 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --kernel-trace -d gpurun_out/pmc_st -o pmc -- python bench.py --steps 1 --warmup 1 --frames-per-step 2 --no-cpu-baseline --no-configs --streams 1 > gpurun_out/pmc_st.log 2>&1 < /dev/null
+  EFX_DEBUG=$k timeout 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --kernel-trace -d gpurun_out/pmc_st -o pmc -- python bench.py --steps 1 --warmup 1 --frames-per-step 2 --no-cpu-baseline --no-configs --sustain-seconds 0 --streams 1 > gpurun_out/pmc_st.log 2>&1 < /dev/null
   echo "== EFX_DEBUG=$k"
   python tools/pmc_summary.py gpurun_out/pmc_st/pmc_results.db | python -c "
 import sys
