@@ -1695,10 +1695,11 @@ static int knn2_run(efx_matcher* m, const uint8_t* q, size_t qp, int nq, const u
     if (nq == 0) return EFX_OK;
     if (nq >= 128 && nt >= 64 && !m->no_mfma) {
         // large sets: the distance matrix as a GEMM on the matrix cores (match_kernels.hip): FP4 (MX) operands, int8 with EFX_MATCH_NO_FP4
-        // (query block, train chunk) pairs: one round of the chip's 512 resident 512-thread workgroups (two per CU) -- fewer chunks
-        // mean fewer best-two updates per wave (a wave's updates fall off as 1 / trains seen); 40 000 x 40 000 x 512 bit:
-        // 3 / 6 / 13 chunks 0.473 / 0.499 / 0.524 ms
-        int nchunks = 512 / ((nq + 255) / 256);
+        // (query block, train chunk) pairs: ONE round of the workgroups the chip holds of the kernel that will run (two 512-thread
+        // workgroups per CU for 512 bits, three for 256) -- fewer chunks mean fewer best-two updates per wave (a wave's updates
+        // fall off as 1 / trains seen), a second, partly filled round costs as much as the first; 40 000 x 40 000: 512 bit
+        // 2 / 3 / 4 / 6 chunks 0.576 / 0.436 / 0.436 / 0.469 ms, 256 bit 0.376 / 0.295 / 0.277 / 0.323
+        int nchunks = efx_knn2_mfma_resident_workgroups(db, m->no_fp4 ? 0 : 1) / ((nq + 255) / 256);
         { static const int env = [] { const char* v = getenv("EFX_MATCH_CHUNKS"); return v ? atoi(v) : 0; }(); if (env > 0) nchunks = env; }   // INVESTIGATION knob
         if (nchunks < 1) nchunks = 1;
         if (nchunks > 64) nchunks = 64;

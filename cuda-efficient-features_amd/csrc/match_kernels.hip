@@ -124,6 +124,20 @@ __global__ void expand_fp4_kernel(const uint8_t* __restrict__ src, size_t pitch,
 }
 
 // (dot product, train index) a better than b: larger dot (smaller distance), then lower index
+// maximum of four accumulator values: two instructions (fmaxf would add a canonicalising v_max_f32 x, x per operand; the values
+// are exact small integers, never NaN)
+__device__ __forceinline__ float knn_max4(float a, float b, float c, float d)
+{
+    float m;
+    asm("v_max3_f32 %0, %1, %2, %3\n\tv_max_f32 %0, %0, %4" : "=&v"(m) : "v"(a), "v"(b), "v"(c), "v"(d));
+    return m;
+}
+__device__ __forceinline__ int knn_max4(int a, int b, int c, int d)
+{
+    int m;
+    asm("v_max3_i32 %0, %1, %2, %3\n\tv_max_i32 %0, %0, %4" : "=&v"(m) : "v"(a), "v"(b), "v"(c), "v"(d));
+    return m;
+}
 template <class T> __device__ __forceinline__ bool knn_better(T da, int ia, T db, int ib) { return da > db || (da == db && (unsigned)ia < (unsigned)ib); }
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -217,15 +231,21 @@ __global__ __launch_bounds__(NW * 64) void knn2_mfma_kernel(const uint8_t* __res
 #pragma unroll
                 for (int r = 0; r < 16; r++) if (t0 + (r & 3) + 8 * (r >> 2) >= nt) acc[c][r] = LOWEST;
             }
-            // a register (one train per lane) is looked at only if it beats some lane's second best (knn2_fp4_kernel has the reason)
+            // four registers (four trains per lane) are looked at only if their maximum beats some lane's second best, and then
+            // a register only if it does (knn2_fp4_kernel has the reason)
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const acc_t d = acc[c][r];
-                if (__ballot(d > bd1[c]) == 0ull) continue;
-                const int ti = t0 + (r & 3) + 8 * (r >> 2);
-                // trains arrive in increasing index order, so a strict > keeps the lower index on ties
-                if (d > bd0[c]) { bd1[c] = bd0[c]; bi1[c] = bi0[c]; bd0[c] = d; bi0[c] = ti; }
-                else if (d > bd1[c]) { bd1[c] = d; bi1[c] = ti; }
+            for (int g = 0; g < 4; g++) {
+                const acc_t m = knn_max4(acc[c][4 * g], acc[c][4 * g + 1], acc[c][4 * g + 2], acc[c][4 * g + 3]);
+                if (__builtin_expect(__ballot(m > bd1[c]) == 0ull, 1)) continue;
+#pragma unroll
+                for (int r = 4 * g; r < 4 * g + 4; r++) {
+                    const acc_t d = acc[c][r];
+                    if (__ballot(d > bd1[c]) == 0ull) continue;
+                    const int ti = t0 + (r & 3) + 8 * (r >> 2);
+                    // trains arrive in increasing index order, so a strict > keeps the lower index on ties
+                    if (d > bd0[c]) { bd1[c] = bd0[c]; bi1[c] = bi0[c]; bd0[c] = d; bi0[c] = ti; }
+                    else if (d > bd1[c]) { bd1[c] = d; bi1[c] = ti; }
+                }
             }
         }
         __syncthreads();                                   // every wave is done with the tile before it is overwritten
@@ -323,18 +343,25 @@ __global__ __launch_bounds__(512) void knn2_fp4_kernel(const uint8_t* __restrict
 #pragma unroll
                 for (int r = 0; r < 16; r++) if (t0 + (r & 3) + 8 * (r >> 2) >= nt) acc[tt][r] = LOWEST;
             }
-            // A register holds one train per lane (64 pairs).  It is looked at only if it beats SOME lane's second best: one
-            // compare + a scalar branch per register.  (Until round 4 the tile's maximum was tested once and all 16 registers
-            // then went through the update -- with the trains split into chunks for occupancy a wave sees few thousand of them,
-            // two thirds of its tiles held a new best-two for one of its 64 queries, and the update sequence was half of the
-            // kernel's time: 252 M VALU instructions for 40 000 x 40 000 descriptors.)
+            // A register holds one train per lane (64 pairs).  It is looked at only if it beats SOME lane's second best.  (Until
+            // round 4 the tile's maximum was tested once and all 16 registers then went through the update -- with the trains
+            // split into chunks for occupancy a wave sees few thousand of them, two thirds of its tiles held a new best-two for
+            // one of its 64 queries, and the update sequence was half of the kernel's time: 252 M VALU instructions for
+            // 40 000 x 40 000 descriptors.  Then one compare + scalar branch per register -- whose common case, "nothing
+            // here", was a TAKEN branch, 16 per tile.)  Now two levels: the maximum of four registers (v_max3_f32 + v_max_f32)
+            // against the second bests, falling through when nothing beats them; the four registers one by one only otherwise.
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const float d = acc[tt][r];
-                if (__ballot(d > bd1) == 0ull) continue;
-                const int ti = t0 + (r & 3) + 8 * (r >> 2);
-                if (d > bd0) { bd1 = bd0; bi1 = bi0; bd0 = d; bi0 = ti; }
-                else if (d > bd1) { bd1 = d; bi1 = ti; }
+            for (int g = 0; g < 4; g++) {
+                const float m = knn_max4(acc[tt][4 * g], acc[tt][4 * g + 1], acc[tt][4 * g + 2], acc[tt][4 * g + 3]);
+                if (__builtin_expect(__ballot(m > bd1) == 0ull, 1)) continue;
+#pragma unroll
+                for (int r = 4 * g; r < 4 * g + 4; r++) {
+                    const float d = acc[tt][r];
+                    if (__ballot(d > bd1) == 0ull) continue;
+                    const int ti = t0 + (r & 3) + 8 * (r >> 2);
+                    if (d > bd0) { bd1 = bd0; bi1 = bi0; bd0 = d; bi0 = ti; }
+                    else if (d > bd1) { bd1 = d; bi1 = ti; }
+                }
             }
         }
         __syncthreads();                                   // every wave is done with the tiles before they are overwritten
@@ -380,6 +407,33 @@ size_t efx_knn2_mfma_scratch(int nq, int nt, int desc_bytes)
     return ((size_t)((nq + 255) & ~255) + (size_t)((nt + 127) & ~127)) * nb;      // trains padded to whole steps of up to four 32-row tiles
 }
 
+// tiles per step of the FP4 kernel: measured (40 000 x 40 000): a 256-bit tile is four MFMAs, two tiles amortise its barriers;
+// a 512-bit step of two tiles is slower than two steps of one (0.467 against 0.436 ms)
+static int knn2_fp4_tt(int desc_bytes)
+{
+    static const int tt_env = [] { const char* v = getenv("EFX_MATCH_TT"); return v ? atoi(v) : 0; }();     // INVESTIGATION knob
+    return tt_env ? tt_env : (desc_bytes == 32 ? 2 : 1);
+}
+
+// Workgroups of the matrix-core kernel the chip holds at once (CUs x resident workgroups per CU, from the runtime's occupancy
+// calculation for the variant efx_launch_knn2_mfma will launch): the host cuts the trains into as many chunks as fill ONE such
+// round with (query block, chunk) pairs
+int efx_knn2_mfma_resident_workgroups(int desc_bytes, int fp4)
+{
+    static int cache[2][2][3] = {};
+    const int tt = fp4 ? knn2_fp4_tt(desc_bytes) : 0, b = desc_bytes == 32 ? 0 : 1;
+    int& c = cache[b][fp4 ? 1 : 0][tt > 2 ? 0 : tt];
+    if (c > 0) return c;
+    const void* f;
+    if (!fp4) f = desc_bytes == 32 ? reinterpret_cast<const void*>(&knn2_mfma_kernel<256, 1, 8, false>) : reinterpret_cast<const void*>(&knn2_mfma_kernel<512, 1, 8, false>);
+    else if (tt == 2) f = desc_bytes == 32 ? reinterpret_cast<const void*>(&knn2_fp4_kernel<256, 2>) : reinterpret_cast<const void*>(&knn2_fp4_kernel<512, 2>);
+    else f = desc_bytes == 32 ? reinterpret_cast<const void*>(&knn2_mfma_kernel<256, 1, 8, true>) : reinterpret_cast<const void*>(&knn2_mfma_kernel<512, 1, 8, true>);
+    int per_cu = 0, dev = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, f, 512, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    return c = per_cu * cus;
+}
+
 hipError_t efx_launch_knn2_mfma(const uint8_t* query, size_t q_pitch, int nq, const uint8_t* train, size_t t_pitch, int nt,
                                 int desc_bytes, void* scratch_x, void* scratch, int nchunks, int* idx, int* dist, hipStream_t stream, int fp4)
 {
@@ -404,10 +458,7 @@ hipError_t efx_launch_knn2_mfma(const uint8_t* query, size_t q_pitch, int nq, co
     // eight waves of 32 queries each (two column blocks per wave read half as much LDS per MFMA but run at half the
     // occupancy: 1.6 against 1.0 ms; a double-buffered tile with one barrier per step: 1.3 ms)
     if (fp4) {
-        // tiles per step: measured (40 000 x 40 000): 512 bit 0.509 ms with one tile, 0.533 with two (1.32 with four: spills);
-        // 256 bit 0.363 / 0.348 / 0.552 -- a 256-bit tile is four MFMAs, two tiles amortise its barriers
-        static const int tt_env = [] { const char* v = getenv("EFX_MATCH_TT"); return v ? atoi(v) : 0; }();     // INVESTIGATION knob
-        const int tt = tt_env ? tt_env : (desc_bytes == 32 ? 2 : 1);
+        const int tt = knn2_fp4_tt(desc_bytes);
         if (tt == 2) {
             if (desc_bytes == 32) hipLaunchKernelGGL((knn2_fp4_kernel<256, 2>), grid, dim3(512), 0, stream, xq, nq, xt, nt, tpc, partial);
             else hipLaunchKernelGGL((knn2_fp4_kernel<512, 2>), grid, dim3(512), 0, stream, xq, nq, xt, nt, tpc, partial);
