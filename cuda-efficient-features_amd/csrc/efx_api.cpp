@@ -1689,6 +1689,8 @@ static int match_args_ok(efx_matcher* m, const uint8_t* q, size_t qp, int nq, co
     return EFX_OK;
 }
 
+int efx_knn2_mfma_resident_workgroups(int desc_bytes, int fp4);     // match_kernels.hip (declared here: efx_device.h is one of the headline kernels' stamped sources)
+
 static int knn2_run(efx_matcher* m, const uint8_t* q, size_t qp, int nq, const uint8_t* t, size_t tp, int nt, int db,
                     int* idx, int* dist, hipStream_t stream)
 {

@@ -329,7 +329,6 @@ hipError_t efx_launch_cvt_gray(const uint8_t* src, size_t spitch, int rows, int 
 
 // brute-force Hamming matcher (match_kernels.hip); scratch: nchunks * nq * 16 bytes
 // int8 matrix-core variant for large sets: scratch_x = efx_knn2_mfma_scratch() bytes (the +-1 expansions of both sets)
-int efx_knn2_mfma_resident_workgroups(int desc_bytes, int fp4);
 size_t efx_knn2_mfma_scratch(int nq, int nt, int desc_bytes);
 hipError_t efx_launch_knn2_mfma(const uint8_t* query, size_t q_pitch, int nq, const uint8_t* train, size_t t_pitch, int nt,
                                 int desc_bytes, void* scratch_x, void* scratch, int nchunks, int* idx, int* dist, hipStream_t stream, int fp4);
