@@ -8,6 +8,9 @@
 #include "efx_device.h"
 #include "bad_affine.h"
 
+// match_kernels.hip (declared here, not in efx_device.h: that header is one of the headline kernels' stamped sources, profiles/rNN_counters.json)
+int efx_knn2_mfma_resident_workgroups(int desc_bytes, int fp4);
+
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -1688,8 +1691,6 @@ static int match_args_ok(efx_matcher* m, const uint8_t* q, size_t qp, int nq, co
         return set_err(m->err, EFX_ERR_BAD_ARG, "descriptor rows must be 4-byte aligned and at least desc_bytes apart");
     return EFX_OK;
 }
-
-int efx_knn2_mfma_resident_workgroups(int desc_bytes, int fp4);     // match_kernels.hip (declared here: efx_device.h is one of the headline kernels' stamped sources)
 
 static int knn2_run(efx_matcher* m, const uint8_t* q, size_t qp, int nq, const uint8_t* t, size_t tp, int nt, int db,
                     int* idx, int* dist, hipStream_t stream)
