@@ -342,8 +342,12 @@ int describer_run(Describer& d, std::string& err, DescribeLaunch a, float* dbg_r
 
 } // namespace
 
+// where the level blur runs when EFX_BLUR_FORK does not say: -1 = decided per call (detect_common): on the side stream behind
+// nms_kernel (3) when the call's stream has nothing pending -- a caller that waits for every frame, whose chip is mostly idle
+// under select / emit / angle: 8K one-call latency 0.447 -> 0.426 ms -- and inline (0) otherwise: with frames in flight the side
+// stream's two event edges and the slots the blur takes from the next frame's kernels cost 2.5 % of the throughput
 #ifndef EFX_BLUR_FORK_DEFAULT
-#define EFX_BLUR_FORK_DEFAULT 0
+#define EFX_BLUR_FORK_DEFAULT (-1)
 #endif
 
 EfxKnobs efx_read_knobs()
@@ -400,6 +404,7 @@ struct efx_context {
     DevBuf blurred;                 // blurred copies of the pyramid levels for the BAD describer (blur_levels_kernel), on first use
     hipStream_t side = nullptr;     // side stream + fork / join events of the level blur (DetectLaunch::blur_fork), on first use
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int idle_streak = 0;            // consecutive calls that found their stream idle (where the level blur runs: detect_common)
     size_t cand_slots = 0;          // records in `cand`; the coordinate-only array of the same length follows them
     Summary* h_mirror = nullptr;    // host copy of the last frame's summary, filled on demand by fetch_summary()
     int n_out_max = 0;              // sum of the active levels' quotas
@@ -425,6 +430,9 @@ struct efx_context {
         efx_context* c = static_cast<efx_context*>(p);
         bool ok = true;
         for (hipStream_t st : c->streams) ok = ok && hipStreamSynchronize(st) == hipSuccess;
+        // the context's own side stream is joined into the call's stream by every call that uses it -- unless that call failed
+        // between its fork and its join: wait for it by name
+        if (c->side) ok = ok && hipStreamSynchronize(c->side) == hipSuccess;
         if (!ok) { (void)hipGetLastError(); (void)hipDeviceSynchronize(); }      // e.g. a stream the caller has destroyed meanwhile
         c->streams.clear();
         // the call that triggered this wait (a regrow inside detect / compute) launches on its stream AFTER the wait: that
@@ -759,16 +767,31 @@ int detect_common(efx_context* c, const uint8_t* d_image, int rows, int cols, si
             a.blurred = static_cast<uint8_t*>(c->blurred.p); a.blur0_pitch = p0; a.blur_levels_off = l0_bytes;
             level_blurred = true;
             a.blur_fork = c->knobs.blur_fork;
-            if (a.blur_fork >= 1 && a.blur_fork <= 3) {
-                // the side stream joins the call's stream before the describer runs, so whoever waits for the call's stream has
-                // waited for it too (release waits, the caller's own synchronisation)
-                if (!c->side) {
-                    HIP_TRY(c->err, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-                    HIP_TRY(c->err, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-                    HIP_TRY(c->err, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+            if (a.blur_fork < 0) {
+                // per call: the side stream only for an idle stream; never inside a stream capture (a query would invalidate it)
+                // and not in a profiled call (its event pairs time the kernels of ONE stream)
+                a.blur_fork = 0;
+                hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+                if (!a.prof.start) {
+                    if (hipStreamIsCapturing(stream, &cs) != hipSuccess) (void)hipGetLastError();
+                    else if (cs == hipStreamCaptureStatusNone) {
+                        const hipError_t q = hipStreamQuery(stream);
+                        // ... and only for a caller that found it idle twice in a row: a throughput loop whose queue runs dry
+                        // now and then stays inline
+                        if (q == hipSuccess) { if (++c->idle_streak >= 2) a.blur_fork = 3; }
+                        else { c->idle_streak = 0; if (q != hipErrorNotReady) (void)hipGetLastError(); }
+                    }
                 }
-                a.side = c->side; a.ev_fork = c->ev_fork; a.ev_join = c->ev_join;
             }
+            // the side stream and its two events exist from the context's first describing call on (creating them costs ~0.2 ms: not
+            // inside the first call that forks); it joins the call's stream before the describer runs, so whoever waits for the
+            // call's stream has waited for it too (release waits, the caller's own synchronisation)
+            if (!c->side && (c->knobs.blur_fork != 0)) {
+                HIP_TRY(c->err, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+                HIP_TRY(c->err, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+                HIP_TRY(c->err, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+            }
+            if (a.blur_fork >= 1 && a.blur_fork <= 3) { a.side = c->side; a.ev_fork = c->ev_fork; a.ev_join = c->ev_join; }
         }
     }
 #ifdef EFX_DEBUG_BUILD
