@@ -799,3 +799,51 @@ def test_detect_and_compute_is_graph_capturable(cef, torch_mod, oracle):
         assert n == ref["n"]
         assert np.array_equal(kps[:, :n].cpu().numpy().view(np.uint32), ref["kps"].view(np.uint32))
         assert np.array_equal(desc[:n].cpu().numpy(), ref["desc"])
+
+
+def test_level_blur_side_stream_is_chosen_per_call(cef, torch_mod, oracle, monkeypatch):
+    """Where the level blur of detectAndCompute (BAD) runs is decided per call (efx_api.cpp, detect_common): on the context's
+    side stream when the call's stream had nothing pending at this call and at the one before -- a caller that waits for
+    every frame -- and on the call's stream otherwise.  Same keypoints and descriptors either way, also when the two kinds of call
+    alternate on one context, on two user streams, and for different frames in the same buffers."""
+    torch = torch_mod
+    monkeypatch.delenv("EFX_BLUR_FORK", raising=False)
+    EF = cef.EfficientFeatures
+    frames = [synth.synth_frame(600, 800, seed=71 + i, density=0.5 + 0.25 * i) for i in range(3)]
+    refs = [oracle.detect_and_compute(f, nfeatures=4000, desc_type=oracle.BAD_512) for f in frames]
+    det = EF.create(4000, dtype=EF.BAD_512)
+    img = torch.zeros((600, 800), dtype=torch.uint8, device="cuda")
+    kps = torch.zeros((5, 4000), dtype=torch.float32, device="cuda"); cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    desc = torch.zeros((4000, 64), dtype=torch.uint8, device="cuda")
+
+    def check(i):
+        n = int(cnt.item())
+        assert n == refs[i]["n"]
+        assert np.array_equal(kps[:, :n].cpu().numpy().view(np.uint32), refs[i]["kps"].view(np.uint32))
+        assert np.array_equal(desc[:n].cpu().numpy(), refs[i]["desc"])
+
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    # call, wait, call, wait ...: from the second call on the blur runs on the side stream
+    for rep in range(6):
+        i = rep % 3
+        with torch.cuda.stream(s1):
+            img.copy_(torch.from_numpy(frames[i]).cuda(), non_blocking=False)
+            s1.synchronize()
+            det.detectAndComputeAsync(img, kps, desc, cnt, stream=s1)
+        s1.synchronize()
+        check(i)
+    # back to back without waiting (the stream is busy: inline), then waiting again, on another stream
+    outs = [(torch.zeros_like(kps), torch.zeros_like(desc), torch.zeros_like(cnt)) for _ in range(6)]
+    imgs = [torch.from_numpy(frames[j % 3]).cuda() for j in range(6)]
+    torch.cuda.synchronize()
+    for j in range(6):
+        det.detectAndComputeAsync(imgs[j], outs[j][0], outs[j][1], outs[j][2], stream=s2)
+    s2.synchronize()
+    for j in range(6):
+        kps, desc, cnt = outs[j]
+        check(j % 3)
+    for j in range(4):
+        det.detectAndComputeAsync(imgs[j], outs[j][0], outs[j][1], outs[j][2], stream=s2 if j % 2 else s1)
+        torch.cuda.synchronize()
+        kps, desc, cnt = outs[j]
+        check(j % 3)
