@@ -136,6 +136,20 @@ def test_c5_8k_detect_and_compute_bad512(cef, threaded_oracle, k):
     _same_keypoints(kps, n, ref)
     assert n == workloads.N40K
     assert np.array_equal(desc[:n].cpu().numpy(), ref["desc"])
+    if k == 0 and "EFX_BLUR_FORK" not in os.environ:
+        # a caller that waits for every frame: from the second such call on, a frame of this size has its level blur on the
+        # context's side stream beside select / emit / angle (efx_api.cpp, detect_common) -- same result, call after call,
+        # and again inline when the calls come back to back
+        dimg = _dev(img)
+        for rep in range(4):
+            if rep != 3:
+                kps.zero_(); desc.zero_(); cnt.zero_()
+                torch.cuda.synchronize()
+            det.detectAndComputeAsync(dimg, kps, desc, cnt)
+            if rep == 2: continue                             # the fourth call finds the stream busy
+            torch.cuda.synchronize()
+            _same_keypoints(kps, int(cnt.item()), ref)
+            assert np.array_equal(desc[:n].cpu().numpy(), ref["desc"])
 
 
 def test_c5_8k_detect_and_compute_hashsift512(cef, threaded_oracle):
