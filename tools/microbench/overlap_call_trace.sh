@@ -1,6 +1,7 @@
 #!/bin/bash
-# INVESTIGATION (GPU box): the kernel timeline of ONE 8K detectAndCompute call, call-then-wait protocol, with EFX_OVERLAP=$1
-# (0 inline, 1 the pyramid chain beside level 0's detector kernels): start / end of every kernel relative to the call's first
+# INVESTIGATION (GPU box): the kernel timeline of ONE detectAndCompute BAD512 call (8K; TRACE_ROWS / TRACE_COLS for other sizes),
+# call-then-wait protocol: start / end of every kernel relative to the call's first.  ($1: value of EFX_OVERLAP for a build
+# with tools/experiments/overlap_chain_level0.patch applied; ignored by the shipped library)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/oct
 cat > /tmp/oct.py <<'P'
@@ -8,7 +9,9 @@ import sys; sys.path.insert(0, '.')
 import torch, cef_loader
 from tools import synth
 cef = cef_loader.load(); EF = cef.EfficientFeatures
-img = torch.from_numpy(synth.synth_frame(4320, 7680, seed=1000)).cuda()
+import os
+R, C = int(os.environ.get('TRACE_ROWS', 4320)), int(os.environ.get('TRACE_COLS', 7680))
+img = torch.from_numpy(synth.synth_frame(R, C, seed=1000)).cuda()
 d = EF.create(40000, dtype=EF.BAD_512)
 k, desc, cnt = d.detectAndComputeAsync(img); torch.cuda.synchronize()
 for _ in range(6):
