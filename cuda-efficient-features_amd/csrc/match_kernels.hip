@@ -124,19 +124,20 @@ __global__ void expand_fp4_kernel(const uint8_t* __restrict__ src, size_t pitch,
 }
 
 // (dot product, train index) a better than b: larger dot (smaller distance), then lower index
-// maximum of four accumulator values: two instructions (fmaxf would add a canonicalising v_max_f32 x, x per operand; the values
-// are exact small integers, never NaN)
-__device__ __forceinline__ float knn_max4(float a, float b, float c, float d)
-{
-    float m;
-    asm("v_max3_f32 %0, %1, %2, %3\n\tv_max_f32 %0, %0, %4" : "=&v"(m) : "v"(a), "v"(b), "v"(c), "v"(d));
-    return m;
-}
+// The best-two bookkeeping compares INTEGER keys.  The int8 kernel's accumulators are integers already; the FP4 kernel's fp32
+// accumulators start at KNN_FP4_BIAS instead of 0, so that every value is a positive float (a dot product is within +-512, and
+// exact), and positive floats order like their bit patterns.  Integer max / compare have no NaN cases to canonicalise
+// (fmaxf costs a v_max_f32 x, x per operand), and -- unlike an inline-asm v_max3_f32, round 4's first form of the group
+// filter -- they are instructions the compiler knows read the MFMA's result registers: it places the wait states behind the
+// last MFMA itself (the asm form read stale accumulators and lost ~1 in 300 best-two updates on tie-heavy sets:
+// tools/microbench/match_fuzz.py found it, the parity tests' random sets had not).
+#define KNN_FP4_BIAS 1024.f
+__device__ __forceinline__ int knn_key(float v) { return __builtin_bit_cast(int, v); }
+__device__ __forceinline__ int knn_key(int v) { return v; }
 __device__ __forceinline__ int knn_max4(int a, int b, int c, int d)
 {
-    int m;
-    asm("v_max3_i32 %0, %1, %2, %3\n\tv_max_i32 %0, %0, %4" : "=&v"(m) : "v"(a), "v"(b), "v"(c), "v"(d));
-    return m;
+    const int ab = a > b ? a : b, cd = c > d ? c : d;
+    return ab > cd ? ab : cd;
 }
 template <class T> __device__ __forceinline__ bool knn_better(T da, int ia, T db, int ib) { return da > db || (da == db && (unsigned)ia < (unsigned)ib); }
 typedef int i32x8 __attribute__((ext_vector_type(8)));
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(NW * 64) void knn2_mfma_kernel(const uint8_t* __res
     static_assert(NW * CB == 8, "256 queries per workgroup");
     typedef typename std::conditional<FP4, float, int>::type acc_t;
     typedef typename std::conditional<FP4, f32x16, i32x16>::type accv_t;
-    const acc_t LOWEST = FP4 ? (acc_t)-1.0e30f : (acc_t)-0x7fffffff;
+    const int LOWEST = FP4 ? 0 : -0x7fffffff;             // key below every real one (FP4: +0.0f)
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[32 * LP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(NW * 64) void knn2_mfma_kernel(const uint8_t* __res
     }
     const int ntiles = (nt + 31) >> 5;
     const int tile0 = blockIdx.y * tiles_per_chunk, tile1 = min(tile0 + tiles_per_chunk, ntiles);
-    acc_t bd0[CB], bd1[CB];
+    int bd0[CB], bd1[CB];                                  // keys (knn_key) of the best two
     int bi0[CB], bi1[CB];
 #pragma unroll
     for (int c = 0; c < CB; c++) { bd0[c] = bd1[c] = LOWEST; bi0[c] = bi1[c] = -1; }
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(NW * 64) void knn2_mfma_kernel(const uint8_t* __res
 #pragma unroll
         for (int c = 0; c < CB; c++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[c][r] = (acc_t)0;
+            for (int r = 0; r < 16; r++) acc[c][r] = FP4 ? (acc_t)KNN_FP4_BIAS : (acc_t)0;
         const uint8_t* arow = s_tile + li * LP + 16 * lh;
         // one A fragment ahead; the scheduling barrier keeps the compiler from hoisting all KS fragments (4 VGPRs each)
         i32x4 a = *reinterpret_cast<const i32x4*>(arow);
@@ -227,19 +228,22 @@ __global__ __launch_bounds__(NW * 64) void knn2_mfma_kernel(const uint8_t* __res
         const bool partial_tile = tile * 32 + 32 > nt;     // padded trains must not compete
 #pragma unroll
         for (int c = 0; c < CB; c++) {
+            int key[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) key[r] = knn_key(acc[c][r]);
             if (partial_tile) {
 #pragma unroll
-                for (int r = 0; r < 16; r++) if (t0 + (r & 3) + 8 * (r >> 2) >= nt) acc[c][r] = LOWEST;
+                for (int r = 0; r < 16; r++) if (t0 + (r & 3) + 8 * (r >> 2) >= nt) key[r] = LOWEST;
             }
             // four registers (four trains per lane) are looked at only if their maximum beats some lane's second best, and then
             // a register only if it does (knn2_fp4_kernel has the reason)
 #pragma unroll
             for (int g = 0; g < 4; g++) {
-                const acc_t m = knn_max4(acc[c][4 * g], acc[c][4 * g + 1], acc[c][4 * g + 2], acc[c][4 * g + 3]);
+                const int m = knn_max4(key[4 * g], key[4 * g + 1], key[4 * g + 2], key[4 * g + 3]);
                 if (__builtin_expect(__ballot(m > bd1[c]) == 0ull, 1)) continue;
 #pragma unroll
                 for (int r = 4 * g; r < 4 * g + 4; r++) {
-                    const acc_t d = acc[c][r];
+                    const int d = key[r];
                     if (__ballot(d > bd1[c]) == 0ull) continue;
                     const int ti = t0 + (r & 3) + 8 * (r >> 2);
                     // trains arrive in increasing index order, so a strict > keeps the lower index on ties
@@ -253,11 +257,11 @@ __global__ __launch_bounds__(NW * 64) void knn2_mfma_kernel(const uint8_t* __res
     // the two row-halves of a query (lanes l and l + 32) merge their best two; dot -> Hamming distance
 #pragma unroll
     for (int c = 0; c < CB; c++) {
-        const acc_t od0 = __shfl_xor(bd0[c], 32, 64), od1 = __shfl_xor(bd1[c], 32, 64);
+        const int od0 = __shfl_xor(bd0[c], 32, 64), od1 = __shfl_xor(bd1[c], 32, 64);
         const int oi0 = __shfl_xor(bi0[c], 32, 64), oi1 = __shfl_xor(bi1[c], 32, 64);
-        acc_t d0 = bd0[c], d1 = bd1[c];
+        int d0 = bd0[c], d1 = bd1[c];
         int i0 = bi0[c], i1 = bi1[c];
-        const acc_t cd[2] = { od0, od1 }; const int ci[2] = { oi0, oi1 };
+        const int cd[2] = { od0, od1 }; const int ci[2] = { oi0, oi1 };
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             if (ci[j] < 0) continue;
@@ -267,8 +271,10 @@ __global__ __launch_bounds__(NW * 64) void knn2_mfma_kernel(const uint8_t* __res
         const int q = q0 + 32 * c + li;
         if (lh == 0 && q < nq) {
             Best2 b;
-            b.d0 = i0 >= 0 ? (NBITS - (int)d0) >> 1 : 0x7fffffff; b.i0 = i0;      // dot = bits - 2 * distance (exact in either accumulator)
-            b.d1 = i1 >= 0 ? (NBITS - (int)d1) >> 1 : 0x7fffffff; b.i1 = i1;
+            // key -> dot -> distance: dot = bits - 2 * distance (exact in either accumulator)
+            auto dot_of = [](int key) -> int { return FP4 ? (int)(__builtin_bit_cast(float, key) - KNN_FP4_BIAS) : key; };
+            b.d0 = i0 >= 0 ? (NBITS - dot_of(d0)) >> 1 : 0x7fffffff; b.i0 = i0;
+            b.d1 = i1 >= 0 ? (NBITS - dot_of(d1)) >> 1 : 0x7fffffff; b.i1 = i1;
             partial[(size_t)blockIdx.y * nq + q] = b;
         }
     }
@@ -288,7 +294,7 @@ __global__ __launch_bounds__(512) void knn2_fp4_kernel(const uint8_t* __restrict
     constexpr int LP = NB + 16;
     constexpr int NPIECE = TT * 32 * NB / 16;              // 16-byte pieces of a step's TT tiles (rows contiguous in memory)
     constexpr int NPF = (NPIECE + NT - 1) / NT;
-    const float LOWEST = -1.0e30f;
+    const int LOWEST = 0;                                  // key (knn_key: the bits of a positive float) below every real one
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[TT * 32 * LP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -301,7 +307,7 @@ __global__ __launch_bounds__(512) void knn2_fp4_kernel(const uint8_t* __restrict
     }
     const int ntiles = (nt + 31) >> 5;                     // tiles that hold trains; the buffer is padded to whole steps
     const int tile0 = blockIdx.y * tiles_per_chunk, tile1 = min(tile0 + tiles_per_chunk, ntiles);
-    float bd0 = LOWEST, bd1 = LOWEST;
+    int bd0 = LOWEST, bd1 = LOWEST;
     int bi0 = -1, bi1 = -1;
     uint4 pf[NPF];
     auto fetch = [&](int tile) {
@@ -322,7 +328,7 @@ __global__ __launch_bounds__(512) void knn2_fp4_kernel(const uint8_t* __restrict
 #pragma unroll
         for (int tt = 0; tt < TT; tt++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[tt][r] = 0.f;
+            for (int r = 0; r < 16; r++) acc[tt][r] = KNN_FP4_BIAS;
         const uint8_t* arow = s_tile + li * LP + 16 * lh;
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) {
@@ -339,9 +345,12 @@ __global__ __launch_bounds__(512) void knn2_fp4_kernel(const uint8_t* __restrict
             const int tb = (tile + tt) * 32;
             if (tb >= nt) break;                            // a padding tile of the last step (wave-uniform)
             const int t0 = tb + 4 * lh;
+            int key[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) key[r] = knn_key(acc[tt][r]);
             if (tb + 32 > nt) {
 #pragma unroll
-                for (int r = 0; r < 16; r++) if (t0 + (r & 3) + 8 * (r >> 2) >= nt) acc[tt][r] = LOWEST;
+                for (int r = 0; r < 16; r++) if (t0 + (r & 3) + 8 * (r >> 2) >= nt) key[r] = LOWEST;
             }
             // A register holds one train per lane (64 pairs).  It is looked at only if it beats SOME lane's second best.  (Until
             // round 4 the tile's maximum was tested once and all 16 registers then went through the update -- with the trains
@@ -352,11 +361,11 @@ __global__ __launch_bounds__(512) void knn2_fp4_kernel(const uint8_t* __restrict
             // against the second bests, falling through when nothing beats them; the four registers one by one only otherwise.
 #pragma unroll
             for (int g = 0; g < 4; g++) {
-                const float m = knn_max4(acc[tt][4 * g], acc[tt][4 * g + 1], acc[tt][4 * g + 2], acc[tt][4 * g + 3]);
+                const int m = knn_max4(key[4 * g], key[4 * g + 1], key[4 * g + 2], key[4 * g + 3]);
                 if (__builtin_expect(__ballot(m > bd1) == 0ull, 1)) continue;
 #pragma unroll
                 for (int r = 4 * g; r < 4 * g + 4; r++) {
-                    const float d = acc[tt][r];
+                    const int d = key[r];
                     if (__ballot(d > bd1) == 0ull) continue;
                     const int ti = t0 + (r & 3) + 8 * (r >> 2);
                     if (d > bd0) { bd1 = bd0; bi1 = bi0; bd0 = d; bi0 = ti; }
@@ -368,11 +377,11 @@ __global__ __launch_bounds__(512) void knn2_fp4_kernel(const uint8_t* __restrict
     }
     // the two row-halves of a query (lanes l and l + 32) merge their best two; dot -> Hamming distance
     {
-        const float od0 = __shfl_xor(bd0, 32, 64), od1 = __shfl_xor(bd1, 32, 64);
+        const int od0 = __shfl_xor(bd0, 32, 64), od1 = __shfl_xor(bd1, 32, 64);
         const int oi0 = __shfl_xor(bi0, 32, 64), oi1 = __shfl_xor(bi1, 32, 64);
-        float d0 = bd0, d1 = bd1;
+        int d0 = bd0, d1 = bd1;
         int i0 = bi0, i1 = bi1;
-        const float cd[2] = { od0, od1 }; const int ci[2] = { oi0, oi1 };
+        const int cd[2] = { od0, od1 }; const int ci[2] = { oi0, oi1 };
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             if (ci[j] < 0) continue;
@@ -382,8 +391,8 @@ __global__ __launch_bounds__(512) void knn2_fp4_kernel(const uint8_t* __restrict
         const int q = q0 + li;
         if (lh == 0 && q < nq) {
             Best2 b;
-            b.d0 = i0 >= 0 ? (NBITS - (int)d0) >> 1 : 0x7fffffff; b.i0 = i0;
-            b.d1 = i1 >= 0 ? (NBITS - (int)d1) >> 1 : 0x7fffffff; b.i1 = i1;
+            b.d0 = i0 >= 0 ? (NBITS - (int)(__builtin_bit_cast(float, d0) - KNN_FP4_BIAS)) >> 1 : 0x7fffffff; b.i0 = i0;
+            b.d1 = i1 >= 0 ? (NBITS - (int)(__builtin_bit_cast(float, d1) - KNN_FP4_BIAS)) >> 1 : 0x7fffffff; b.i1 = i1;
             partial[(size_t)blockIdx.y * nq + q] = b;
         }
     }

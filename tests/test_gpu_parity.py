@@ -847,3 +847,48 @@ def test_level_blur_side_stream_is_chosen_per_call(cef, torch_mod, oracle, monke
         torch.cuda.synchronize()
         kps, desc, cnt = outs[j]
         check(j % 3)
+
+
+def test_matcher_kernels_agree_on_tie_heavy_random_sets(cef, torch_mod, monkeypatch):
+    """The three Hamming kernels (FP4 matrix cores, int8 matrix cores, popcount) on random set sizes and descriptors that
+    produce ties everywhere: exact duplicates from a small pool, descriptors with few set bits (a handful of distinct
+    distances), noisy copies.  Such sets make EVERY best-two update matter: round 4's first group filter (an inline-asm
+    v_max3_f32 the compiler could not see reading the MFMA's result registers) lost about one update in 300 on them while every
+    uniformly random set of this module still passed.  tools/microbench/match_fuzz.py is the long form."""
+    torch = torch_mod
+    from oracle import matcher_oracle as MO
+    for k in ("EFX_MATCH_NO_MFMA", "EFX_MATCH_NO_FP4"):
+        monkeypatch.delenv(k, raising=False)
+    m_fp4 = cef.BFMatcher.create(cef.BFMatcher.NORM_HAMMING)
+    monkeypatch.setenv("EFX_MATCH_NO_FP4", "1")
+    m_i8 = cef.BFMatcher.create(cef.BFMatcher.NORM_HAMMING)
+    monkeypatch.delenv("EFX_MATCH_NO_FP4")
+    monkeypatch.setenv("EFX_MATCH_NO_MFMA", "1")
+    m_pop = cef.BFMatcher.create(cef.BFMatcher.NORM_HAMMING)
+    monkeypatch.delenv("EFX_MATCH_NO_MFMA")
+    rng = np.random.default_rng(2024)
+    for case in range(48):
+        nb = int(rng.choice([32, 64]))
+        nq, nt = int(rng.integers(128, 2500)), int(rng.integers(64, 4000))
+        kind = case % 4
+        if kind == 0:
+            q = rng.integers(0, 256, size=(nq, nb), dtype=np.uint8); t = rng.integers(0, 256, size=(nt, nb), dtype=np.uint8)
+        elif kind == 1:
+            pool = rng.integers(0, 256, size=(int(rng.integers(2, 40)), nb), dtype=np.uint8)
+            q = pool[rng.integers(0, len(pool), nq)]; t = pool[rng.integers(0, len(pool), nt)]
+        elif kind == 2:
+            q = (rng.random((nq, nb)) < 0.03).astype(np.uint8) * np.uint8(1 << int(rng.integers(0, 8)))
+            t = (rng.random((nt, nb)) < 0.03).astype(np.uint8) * np.uint8(1 << int(rng.integers(0, 8)))
+        else:
+            q = rng.integers(0, 256, size=(nq, nb), dtype=np.uint8)
+            t = q[rng.integers(0, nq, nt)] ^ ((rng.random((nt, nb)) < 0.02).astype(np.uint8) * np.uint8(16))
+        q, t = np.ascontiguousarray(q), np.ascontiguousarray(t)
+        dq, dt = _dev(torch, q), _dev(torch, t)
+        a, b, d = m_fp4.knnMatch(dq, dt, 2), m_i8.knnMatch(dq, dt, 2), m_pop.knnMatch(dq, dt, 2)
+        torch.cuda.synchronize()
+        info = (case, kind, nb, nq, nt)
+        assert torch.equal(a[0], d[0]) and torch.equal(a[1], d[1]), ("fp4 vs popcount", info)
+        assert torch.equal(b[0], d[0]) and torch.equal(b[1], d[1]), ("int8 vs popcount", info)
+        if nq * nt <= 3_000_000:
+            widx, wdist = MO.knn2(q, t)
+            assert np.array_equal(d[0].cpu().numpy(), widx) and np.array_equal(d[1].cpu().numpy(), wdist), ("popcount vs oracle", info)
