@@ -529,6 +529,218 @@ __global__ __launch_bounds__(256) void resize_stream_kernel(
 }
 
 // ================================================================================================
+// Kernel R-rows (round 5): TWO pyramid levels per launch for large frames, by waves that walk DOWN the image.
+// The tiled kernels above are bound by neither VALU issue (46 % of its ceiling) nor HBM (0.30): a workgroup stages a footprint,
+// meets at barriers, runs four short row iterations and starts over, and every level is a launch with its own ramp and tail
+// (7 x 10 us at 8K for 170 MB of traffic and ~30 us of issue time).  Here a WAVE owns a strip of RW_OWN = 248 columns of level
+// s + 1 (a lane: four adjacent outputs = one dword of the destination; lanes 62 / 63 compute eight halo columns) and a chunk of
+// rows, and visits the source rows of level s it needs ONE BY ONE, top to bottom:
+//   * source row r arrives by LDS-DMA (buffer_load ... lds: lane j's dword j of the footprint straight into one of the wave's
+//     RW_D LDS slots, RW_D rows ahead, no registers, no workgroup barrier anywhere); every lane takes the two 8-byte windows
+//     that hold the source pixel pairs of its four outputs (the byte gather of resize_quad_win) and converts them to float
+//     ONCE -- a source row serves two destination rows five times out of six at scale 1.2;
+//   * when r is the lower source row of a destination row (a bit mask from the host says so) that row is made: 16 rounded
+//     weight products + the 4-term FMA chain of spec S5 per lane on full-rate fp32 instructions with VECTOR operands,
+//     v_cvt_pk_u8_f32, one range-checked dword store;
+//   * NLEV == 2: that row of level s + 1 also goes to an LDS row of its own, and the same two steps produce level s + 2 from it
+//     (lanes 0 .. ~52: a strip owns the level-(s+2) column groups whose first source column it owns, so every store is a whole
+//     dword and the levels are partitioned exactly; one halo row of level s + 1 per chunk is computed and not stored).
+// Level s + 1 is never re-read from memory, the chain is 4 launches instead of 7 (8K: 0 -> 1, 2; 2 -> 3, 4; 4 -> 5, 6; 6 -> 7).
+// Per pixel the arithmetic is resize_quad_win's, term by term: bit-identical levels (tests: the chain_rows mode).
+// What the first version taught: the CU's ONE scalar unit is the bound of a loop like this -- with ~60 scalar instructions per
+// source row (row / slot bookkeeping, per-row "is a destination row due" compares on v_readlane values, M0 save / restore
+// around every LDS-DMA) the first launch took 21 us with loads, stores AND arithmetic compiled out, and neither the
+// prefetch depth nor the number of waves changed that.  Hence: everything that can be decided ahead is a table
+// (RowsPlanLaunch, efx_api.cpp, spec S5's float expressions): which source rows complete a destination row (two 64-bit masks
+// per chunk), column / row weights, strips; rows beyond the chunk fall outside the buffer resource (no compares); the loop is
+// unrolled by the slot count, so slots and the upper / lower roles of the two converted source rows are static.  The host
+// also checks what the kernel relies on (footprint <= 128 dwords, windows valid, <= 64 source rows per chunk, no clamped +1
+// neighbours: a geometry that fails goes through the tiled kernels).
+// ================================================================================================
+#ifndef RW_DBG
+#define RW_DBG 0                                            // investigation builds: 1 no stores, 2 no arithmetic, 4 no loads in the loop, 8 no conversion of source rows, 16 no level s + 2
+#endif
+#define RW_LDS_A 528                                        // 128 dwords + the reach of a window read
+#define RW_LDS_B 272                                        // 64 dwords + the same
+#define RW_LDS (RW_D * RW_LDS_A + RW_LDS_B)
+typedef __attribute__((address_space(3))) unsigned char efx_lds_uchar;
+
+struct RowsArgs {
+    const uint8_t* src; int spitch, srows, scols;
+    uint8_t* dstB; int bpitch, brows, bcols;
+    uint8_t* dstC; int cpitch, crows, ccols;
+    const int* xB; const int4* yB; const int* xC; const int4* yC; const int4* strips; const int4* chunks;
+    int WB, WC, nstrips, ntasks;
+};
+
+// One dword per lane from a buffer straight into LDS (LDS-DMA: no VGPR destination, so nothing the compiler could copy or
+// wait for): lane i's dword lands at lds_dst + 4 i (+ 256 for the second load, whose immediate offset counts on both sides).
+// The compiler does not count these loads -- the kernel waits for them itself (rows_wait_vm).  M0 is written in the statement
+// that reads it and not restored: nothing else in this kernel uses it (checked in the ISA: tools/isa_dump.sh).
+__device__ __forceinline__ void rows_dma2(const __amdgpu_buffer_rsrc_t rsrc, int voff0, int voff1, uint32_t lds_dst)
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %0, %3, 0 offen lds\n\tbuffer_load_dword %1, %3, 0 offen offset:256 lds"
+                 : : "v"(voff0), "v"(voff1), "s"(lds_dst), "s"(rsrc) : "memory");
+}
+template <int N> __device__ __forceinline__ void rows_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" : : "i"((RW_DBG & 4) ? 0 : N) : "memory"); }
+
+// the source pixel pairs of a lane's four outputs from an LDS row: [left, right] x 4 as floats
+__device__ __forceinline__ void rows_conv(const unsigned char* row, const ResizeWin& w, float (&f)[8])
+{
+    const uint32_t* qa = reinterpret_cast<const uint32_t*>(row + w.offA);
+    const uint32_t* qb = reinterpret_cast<const uint32_t*>(row + w.offB);
+    const uint32_t a0 = qa[0], a1 = qa[1], b0 = qb[0], b1 = qb[1];
+    const uint32_t pa = __builtin_amdgcn_perm(a1, a0, w.selA), pb = __builtin_amdgcn_perm(b1, b0, w.selB);
+    f[0] = (float)(pa & 0xffu); f[1] = (float)((pa >> 8) & 0xffu); f[2] = (float)((pa >> 16) & 0xffu); f[3] = (float)(pa >> 24);
+    f[4] = (float)(pb & 0xffu); f[5] = (float)((pb >> 8) & 0xffu); f[6] = (float)((pb >> 16) & 0xffu); f[7] = (float)(pb >> 24);
+    // the row's pixels are in registers at this point (the conversions cannot sink below it): its LDS bytes may be overwritten
+    asm volatile("" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]));
+}
+
+// four outputs from the converted pairs of the upper (fa) and lower (fb) source row: resize_quad_win's expression (spec S5)
+__device__ __forceinline__ uint32_t rows_quad(const float (&fa)[8], const float (&fb)[8], const float (&wa)[4], const float (&wb)[4],
+                                              float wy0, float wy1)
+{
+    if (RW_DBG & 2) return __float_as_uint(fa[0] + fb[7] + wy0 + wy1);
+    uint32_t packed = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        float out = fa[2 * k] * (wa[k] * wy0);                       // == fma(p, w, 0.f) exactly
+        out = __builtin_fmaf(fa[2 * k + 1], wb[k] * wy0, out);
+        out = __builtin_fmaf(fb[2 * k], wa[k] * wy1, out);
+        out = __builtin_fmaf(fb[2 * k + 1], wb[k] * wy1, out);
+        packed = __builtin_amdgcn_cvt_pk_u8_f32(out, k, packed);     // rint (half even) + saturate + pack
+    }
+    return packed;
+}
+
+__device__ __forceinline__ void rows_lds_order()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int NLEV>
+__global__ __launch_bounds__(256) void resize_rows_kernel(const RowsArgs A, Counters* __restrict__ zero, int zero_levels)
+{
+    static_assert((RW_LDS & 15) == 0 && (RW_D & 1) == 0, "LDS rows: 16-byte aligned; an even number of slots");
+    __shared__ __attribute__((aligned(16))) unsigned char s_rows[4 * RW_LDS];
+    if (zero && blockIdx.x == 0) efx_zero_counters(zero, zero_levels, threadIdx.x, 256);
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int task = xcd_chunked(blockIdx.x, gridDim.x) * 4 + wave;
+    if (task >= A.ntasks) return;
+    const int chunk = task / A.nstrips, strip = task - chunk * A.nstrips;
+    const int4 st = A.strips[strip];
+    const int4 k0 = A.chunks[3 * chunk], k1 = A.chunks[3 * chunk + 1], k2 = A.chunks[3 * chunk + 2];
+    const int ax0 = st.x, nd = st.y;
+    const int a_first = k0.x, a_last = k0.y, b_first = k0.z, b_end = k0.w, c_first = k1.x, c_end = k1.y, na_pad = k1.z;
+    // bit i: source row a_first + i is the lower source row of a row of level s + 1 / that row in turn of one of level s + 2
+    unsigned long long mask_b = ((unsigned long long)(uint32_t)k2.y << 32) | (uint32_t)k2.x;
+    unsigned long long mask_c = ((unsigned long long)(uint32_t)k2.w << 32) | (uint32_t)k2.z;
+    unsigned char* rowA = s_rows + wave * RW_LDS;            // RW_D slots of one source row each
+    unsigned char* rowB = rowA + RW_D * RW_LDS_A;
+
+    // ---- level s + 1: this lane's four columns ----
+    const int bx0 = strip * RW_OWN, bxq = bx0 + 4 * lane;
+    float wa[4], wb[4];
+    ResizeWin win;
+    {
+        const int4 x1 = *reinterpret_cast<const int4*>(A.xB + bxq);
+        const float4 w0 = *reinterpret_cast<const float4*>(A.xB + A.WB + bxq);
+        const float4 w1 = *reinterpret_cast<const float4*>(A.xB + 2 * A.WB + bxq);
+        const int lc[4] = { x1.x - ax0, x1.y - ax0, x1.z - ax0, x1.w - ax0 };
+        win = resize_windows(lc);
+        wa[0] = w0.x; wa[1] = w0.y; wa[2] = w0.z; wa[3] = w0.w;
+        wb[0] = w1.x; wb[1] = w1.y; wb[2] = w1.z; wb[3] = w1.w;
+    }
+    const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(A.dstB, 0, b_end * A.bpitch, 0x00020000);
+    // lanes that own no column of the level (halo lanes, lanes beyond the last column): an offset the range check drops
+    int boff = (lane < RW_OWN / 4 && bxq < A.bcols) ? b_first * A.bpitch + bxq : 0x7ffffff0;
+    const int4 ytb = A.yB[b_first + lane];                           // row table of this chunk, one row per lane (v_readlane)
+
+    // ---- level s + 2: this lane's column group ----
+    float wc[4], wd[4];
+    ResizeWin winC;
+    __amdgpu_buffer_rsrc_t rsrcC = rsrcB;
+    int coff = 0x7ffffff0;
+    int4 ytc = make_int4(0, 0, 0, 0);
+    if (NLEV == 2) {
+        const bool act = lane < st.w;
+        const int cxq = 4 * (st.z + lane);
+        const int4 x1 = *reinterpret_cast<const int4*>(A.xC + cxq);
+        const float4 w0 = *reinterpret_cast<const float4*>(A.xC + A.WC + cxq);
+        const float4 w1 = *reinterpret_cast<const float4*>(A.xC + 2 * A.WC + cxq);
+        const int lc[4] = { act ? x1.x - bx0 : 0, act ? x1.y - bx0 : 0, act ? x1.z - bx0 : 0, act ? x1.w - bx0 : 0 };
+        winC = resize_windows(lc);
+        wc[0] = w0.x; wc[1] = w0.y; wc[2] = w0.z; wc[3] = w0.w;
+        wd[0] = w1.x; wd[1] = w1.y; wd[2] = w1.z; wd[3] = w1.w;
+        rsrcC = __builtin_amdgcn_make_buffer_rsrc(A.dstC, 0, c_end * A.cpitch, 0x00020000);
+        if (act && cxq < A.ccols) coff = c_first * A.cpitch + cxq;
+        ytc = A.yC[c_first + lane];
+    }
+
+    // ---- source rows: dword j of the footprint by lane j (and j + 64), RW_D rows ahead, straight into the wave's LDS slots ----
+    // Branch-free: the resource ends with the chunk's last source row, lanes beyond the footprint carry an offset beyond
+    // every resource -- the hardware range check drops those loads (no traffic, zeros land) -- so the number of loads in flight
+    // is the same at every row and the wait below is a constant.
+    const __amdgpu_buffer_rsrc_t rsrcA =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(A.src), 0, a_last * A.spitch + ((A.scols + 3) & ~3), 0x00020000);
+    int vo0 = a_first * A.spitch + ax0 + 4 * lane;
+    int vo1 = lane + 64 < nd ? vo0 : 0x7ffffff0;            // (the second load's + 256 is its immediate offset)
+    const uint32_t ldsA = (uint32_t)(uintptr_t)(efx_lds_uchar*)s_rows + (uint32_t)wave * RW_LDS;
+#pragma unroll
+    for (int u = 0; u < RW_D; u++) { rows_dma2(rsrcA, vo0, vo1, ldsA + u * RW_LDS_A); vo0 += A.spitch; vo1 += A.spitch; }
+
+    float f0[8], f1[8], ga[8], gb[8];                        // converted source rows: even / odd slots; level s + 1: upper / lower
+#pragma unroll
+    for (int i = 0; i < 8; i++) { f0[i] = 0.f; f1[i] = 0.f; ga[i] = 0.f; gb[i] = 0.f; }
+    int ib = 0, ic = 0;                                      // rows of level s + 1 / s + 2 made so far
+
+    for (int i0 = 0; i0 < na_pad; i0 += RW_D) {
+#pragma unroll
+        for (int u = 0; u < RW_D; u++) {
+            float (&fcur)[8] = (u & 1) ? f1 : f0;
+            float (&fprev)[8] = (u & 1) ? f0 : f1;
+            // source row i0 + u has landed in slot u when at most the loads of the RW_D - 1 rows behind it are in flight (stores
+            // issued since count as well: the wait is conservative by the rows they stand for)
+            rows_wait_vm<2 * (RW_D - 1)>();
+            if (!(RW_DBG & 8)) rows_conv(rowA + u * RW_LDS_A, win, fcur);
+            if (!(RW_DBG & 4)) rows_dma2(rsrcA, vo0, vo1, ldsA + u * RW_LDS_A);            // the slot's next row (beyond the chunk: dropped)
+            vo0 += A.spitch; vo1 += A.spitch;
+            const bool due_b = (mask_b & 1ull) != 0;
+            const bool due_c = (mask_c & 1ull) != 0;
+            mask_b >>= 1; mask_c >>= 1;
+            if (due_b) {
+                float wy0 = __int_as_float(__builtin_amdgcn_readlane(ytb.z, ib)), wy1 = __int_as_float(__builtin_amdgcn_readlane(ytb.w, ib));
+                asm volatile("" : "+v"(wy0), "+v"(wy1));    // vector registers: a scalar source halves the rate of v_mul / v_fma
+                ib++;
+                const uint32_t packed = rows_quad(fprev, fcur, wa, wb, wy0, wy1);
+                if (!(RW_DBG & 1) || packed == 0x12345678u)
+                    __builtin_amdgcn_raw_buffer_store_b32(packed, rsrcB, boff, 0, 0);      // rows from b_end on: dropped by the range check
+                boff += A.bpitch;
+                if (NLEV == 2 && !(RW_DBG & 16)) {
+                    // ---- the row just made is the next source row of level s + 2 ----
+                    *reinterpret_cast<uint32_t*>(rowB + 4 * lane) = packed;
+                    rows_lds_order();
+#pragma unroll
+                    for (int q = 0; q < 8; q++) ga[q] = gb[q];
+                    rows_conv(rowB, winC, gb);
+                    if (due_c) {
+                        float vy0 = __int_as_float(__builtin_amdgcn_readlane(ytc.z, ic)), vy1 = __int_as_float(__builtin_amdgcn_readlane(ytc.w, ic));
+                        asm volatile("" : "+v"(vy0), "+v"(vy1));
+                        ic++;
+                        const uint32_t pc = rows_quad(ga, gb, wc, wd, vy0, vy1);
+                        if (!(RW_DBG & 1) || pc == 0x12345678u) __builtin_amdgcn_raw_buffer_store_b32(pc, rsrcC, coff, 0, 0);
+                        coff += A.cpitch;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ================================================================================================
 // Kernel R2: a whole small pyramid in one launch ("tower"; frames up to EFX_TOWER_MAX_PX pixels, see plan_tower).  The
 // per-level kernel above is launch- and latency-bound once the levels are small (7 dependent launches cost a third of
 // an FHD frame's detectAndCompute).  Here a workgroup owns one
@@ -2150,6 +2362,30 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
         // dword staging reads up to roundup4(cols) bytes of a row: always inside our own (padded) pyramid levels, inside a
         // caller's image only when its width is a multiple of 4 (otherwise the byte path)
         const int aligned = (((uintptr_t)src | (uintptr_t)spitch) & 3u) == 0 && (s > 0 || (L.cols & 3) == 0);
+        // round 5: two levels per launch by waves walking down strips (resize_rows_kernel); EFX_NO_RESIZE_ROWS: the tiled kernels
+        const RowsPlanLaunch* RP = (a.rows_plan && a.rplan && !a.knobs.no_resize_rows) ? &a.rows_plan[s] : nullptr;
+        if (RP && RP->nlev > 0 && aligned && s + RP->nlev <= chain_end) {
+            const LevelDev& C = H.lv[s + RP->nlev];
+            RowsArgs ra;
+            ra.src = src; ra.spitch = spitch; ra.srows = L.rows; ra.scols = L.cols;
+            ra.dstB = a.pyramid + N.img_off; ra.bpitch = N.pitch; ra.brows = N.rows; ra.bcols = N.cols;
+            ra.dstC = a.pyramid + C.img_off; ra.cpitch = C.pitch; ra.crows = C.rows; ra.ccols = C.cols;
+            ra.xB = reinterpret_cast<const int*>(a.rplan + RP->xB_off); ra.yB = reinterpret_cast<const int4*>(a.rplan + RP->yB_off);
+            ra.xC = reinterpret_cast<const int*>(a.rplan + RP->xC_off); ra.yC = reinterpret_cast<const int4*>(a.rplan + RP->yC_off);
+            ra.strips = reinterpret_cast<const int4*>(a.rplan + RP->strip_off); ra.chunks = reinterpret_cast<const int4*>(a.rplan + RP->chunk_off);
+            ra.WB = RP->WB; ra.WC = RP->WC; ra.nstrips = RP->nstrips; ra.ntasks = RP->nstrips * RP->nchunks;
+            const int nblk = (ra.ntasks + 3) / 4;
+            const bool prof = a.prof.begin(100 + s, stream);
+            if (RP->nlev == 2)
+                hipLaunchKernelGGL(resize_rows_kernel<2>, dim3(nblk), dim3(256), 0, stream, ra, zeroed ? nullptr : a.counters, H.nlevels);
+            else
+                hipLaunchKernelGGL(resize_rows_kernel<1>, dim3(nblk), dim3(256), 0, stream, ra, zeroed ? nullptr : a.counters, H.nlevels);
+            zeroed = true;
+            a.prof.end(prof, 100 + s, stream);
+            EFX_TRACE_POINT("resize_rows");
+            s += RP->nlev - 1;
+            continue;
+        }
         const int sw = (int)ceilf((float)(EFX_TILE - 1) * N.fx) + 8, sh = (int)ceilf((float)(EFX_TILE - 1) * N.fy) + 3;
         const int lpitch = (sw + 3) & ~3;
         const int ytab_off = ((lpitch * sh) + 15) & ~15;          // per-row table behind the tile

@@ -352,9 +352,10 @@ int describer_run(Describer& d, std::string& err, DescribeLaunch a, float* dbg_r
 
 EfxKnobs efx_read_knobs()
 {
-    EfxKnobs k = { 0, 0, 0, 0, 0, 0 };
+    EfxKnobs k = { 0, 0, 0, 0, 0, 0, 0 };
     k.no_tower = getenv("EFX_NO_TOWER") != nullptr;
     k.no_resize_stream = getenv("EFX_NO_RESIZE_STREAM") != nullptr;
+    k.no_resize_rows = getenv("EFX_NO_RESIZE_ROWS") != nullptr;     // the tiled per-level kernels instead of resize_rows_kernel
     k.no_level_blur = getenv("EFX_NO_LEVEL_BLUR") != nullptr;
     { const char* f = getenv("EFX_BLUR_FORK"); k.blur_fork = f ? atoi(f) : EFX_BLUR_FORK_DEFAULT; }   // DetectLaunch::blur_fork
     // BAD behind detectAndCompute: every keypoint blurs its own window (A/B, parity tests)
@@ -401,6 +402,7 @@ struct efx_context {
     LevelTable h_table;
     DevBuf d_table, pyramid, hdr, cand, cmax, surv, counters, kp4, kp_level, img, kps, descout, count, maskbuf;
     DevBuf rplan; ResizePlanLevel rplan_lv[EFX_MAX_LEVELS];        // resize plan (tables of resize_stream_kernel)
+    RowsPlanLaunch rows_plan[EFX_MAX_LEVELS];                       // ... and of resize_rows_kernel, by source level
     DevBuf blurred;                 // blurred copies of the pyramid levels for the BAD describer (blur_levels_kernel), on first use
     hipStream_t side = nullptr;     // side stream + fork / join events of the level blur (DetectLaunch::blur_fork), on first use
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -502,6 +504,168 @@ int validate_params(const efx_params& p, std::string& err)
     if (p.nonmax_radius < 0 || p.nonmax_radius > 1024) return set_err(err, EFX_ERR_BAD_ARG, "nonmax_radius must be in [0, 1024]");
     if (p.descriptor_type < EFX_BAD_256 || p.descriptor_type > EFX_HASH_SIFT_512) return set_err(err, EFX_ERR_BAD_ARG, "unknown descriptor type %d", p.descriptor_type);
     return EFX_OK;
+}
+
+// Tables of resize_rows_kernel (detect_kernels.hip): for every even source level s a launch that makes level s + 1 and, when it
+// exists, s + 2.  Everything the kernel relies on is checked here; a launch whose geometry does not fit gets nlev = 0 and its
+// levels go through the tiled per-level kernels.  The float expressions are spec S5's (the ones of the plan above).
+void build_rows_plan(const LevelTable& T, int nlevels, std::vector<int>& blob, RowsPlanLaunch* out)
+{
+    auto fbits = [](float f) { int i; memcpy(&i, &f, 4); return i; };
+    memset(out, 0, sizeof(RowsPlanLaunch) * EFX_MAX_LEVELS);
+    static const int wave_target = getenv("EFX_ROWS_WAVES") ? atoi(getenv("EFX_ROWS_WAVES")) : 3072;      // investigation: waves per launch aimed at
+    for (int s = 0; s + 1 < nlevels; s += (getenv("EFX_ROWS_ONE_LEVEL") ? 1 : 2)) {
+        const LevelDev& A = T.lv[s];
+        const LevelDev& B = T.lv[s + 1];
+        if (A.rows < 2 || A.cols < 8 || B.rows < 1 || B.cols < 4) continue;
+        int nlev = (s + 2 < nlevels && T.lv[s + 2].rows >= 1 && T.lv[s + 2].cols >= 4) ? 2 : 1;
+        static const bool one_level = getenv("EFX_ROWS_ONE_LEVEL") != nullptr;      // investigation: one level per launch
+        if (one_level) nlev = 1;
+        const LevelDev& C = T.lv[s + (nlev == 2 ? 2 : 1)];       // (nlev == 1: unused alias)
+        if (!(B.fx >= 1.f && B.fx <= 1.9f && B.fy >= 1.f && B.fy <= 1.9f)) continue;
+        if (nlev == 2 && !(C.fx >= 1.f && C.fx <= 1.9f && C.fy >= 1.f && C.fy <= 1.9f)) nlev = 1;
+        const size_t mark = blob.size();
+        RowsPlanLaunch R;
+        memset(&R, 0, sizeof(R));
+        bool ok = true;
+        R.nstrips = (B.cols + RW_OWN - 1) / RW_OWN;
+        // column tables
+        auto xtable = [&](const LevelDev& D, const LevelDev& S, int W) -> unsigned {
+            const unsigned off = (unsigned)(blob.size() * 4);
+            blob.resize(blob.size() + 3 * (size_t)W);
+            int* xt = blob.data() + off / 4;
+            for (int i = 0; i < W; i++) {
+                const int ox = i < D.cols - 1 ? i : D.cols - 1;
+                const float sx = (float)ox * D.fx;
+                int x1 = (int)floorf(sx);
+                if (x1 > S.cols - 1) x1 = S.cols - 1;
+                const int x2 = x1 + 1;
+                xt[i] = x1; xt[W + i] = fbits((float)x2 - sx); xt[2 * W + i] = fbits(sx - (float)x1);
+            }
+            return off;
+        };
+        auto ytable = [&](const LevelDev& D, const LevelDev& S) -> unsigned {
+            while (blob.size() & 3) blob.push_back(0);                      // int4 loads
+            const unsigned off = (unsigned)(blob.size() * 4);
+            const int Hh = D.rows + 64;
+            blob.resize(blob.size() + 4 * (size_t)Hh);
+            int* yt = blob.data() + off / 4;
+            for (int i = 0; i < Hh; i++) {
+                const int oy = i < D.rows - 1 ? i : D.rows - 1;
+                const float sy = (float)oy * D.fy;
+                int y1 = (int)floorf(sy);
+                if (y1 > S.rows - 1) y1 = S.rows - 1;
+                const int y2 = y1 + 1;
+                const int y2r = y2 < S.rows - 1 ? y2 : S.rows - 1;
+                yt[4 * i] = y1; yt[4 * i + 1] = y2r; yt[4 * i + 2] = fbits((float)y2 - sy); yt[4 * i + 3] = fbits(sy - (float)y1);
+            }
+            return off;
+        };
+        while (blob.size() & 3) blob.push_back(0);
+        R.WB = (RW_OWN * R.nstrips + 8 + 3) & ~3;
+        R.xB_off = xtable(B, A, R.WB);
+        R.yB_off = ytable(B, A);
+        if (nlev == 2) {
+            while (blob.size() & 3) blob.push_back(0);
+            R.WC = ((C.cols + 3) & ~3) + 256 + 8;
+            R.xC_off = xtable(C, B, R.WC);
+            R.yC_off = ytable(C, B);
+        }
+        const int* xb = blob.data() + R.xB_off / 4;
+        const int* yb = blob.data() + R.yB_off / 4;
+        const int* xc = nlev == 2 ? blob.data() + R.xC_off / 4 : nullptr;
+        const int* yc = nlev == 2 ? blob.data() + R.yC_off / 4 : nullptr;
+        // strips
+        while (blob.size() & 3) blob.push_back(0);
+        R.strip_off = (unsigned)(blob.size() * 4);
+        {
+            std::vector<int> stv(4 * (size_t)R.nstrips);
+            int g = 0;                                                      // next unowned column group of level s + 2
+            const int ngroups = nlev == 2 ? (C.cols + 3) / 4 : 0;
+            for (int j = 0; j < R.nstrips && ok; j++) {
+                const int bx0 = j * RW_OWN;
+                const int ax0 = xb[bx0] & ~3;
+                const int lastx1 = xb[bx0 + 255 < R.WB ? bx0 + 255 : R.WB - 1];
+                const int lastcol = std::min(lastx1 + 1, A.cols - 1);
+                const int nd = ((lastcol - ax0) >> 2) + 1;
+                if (nd > 128) ok = false;
+                if (lastx1 >= A.cols - 1) ok = false;                     // a clamped +1 neighbour (fx == 1): the tiled kernels
+                // every lane's windows (resize_windows: both pixel pairs of an output pair within 8 bytes of an aligned dword)
+                for (int l = 0; l < 64 && ok; l++) {
+                    const int* q = xb + bx0 + 4 * l;
+                    const int oA = (q[0] - ax0) & ~3, oB = (q[2] - ax0) & ~3;
+                    if (q[1] < q[0] || q[1] - ax0 - oA + 1 > 7 || q[3] < q[2] || q[3] - ax0 - oB + 1 > 7 || q[0] < ax0 || q[3] + 1 - ax0 >= 512 + 8) ok = false;
+                }
+                int cnt = 0;
+                const int g0 = g;
+                if (nlev == 2) {
+                    const int own_end = j == R.nstrips - 1 ? 0x7fffffff : bx0 + RW_OWN;
+                    while (g < ngroups && xc[4 * g] < own_end) {
+                        const int* q = xc + 4 * g;
+                        // the group's source columns lie in the 256 columns of level s + 1 this strip computes
+                        if (q[0] < bx0 || q[3] + 1 - bx0 > 255 || q[3] >= B.cols - 1) ok = false;
+                        const int oA = (q[0] - bx0) & ~3, oB = (q[2] - bx0) & ~3;
+                        if (q[1] < q[0] || q[1] - bx0 - oA + 1 > 7 || q[3] < q[2] || q[3] - bx0 - oB + 1 > 7) ok = false;
+                        g++; cnt++;
+                    }
+                    if (cnt > 64) ok = false;
+                }
+                stv[4 * j] = ax0; stv[4 * j + 1] = nd; stv[4 * j + 2] = g0; stv[4 * j + 3] = cnt;
+            }
+            if (nlev == 2 && g != ngroups) ok = false;
+            blob.insert(blob.end(), stv.begin(), stv.end());
+        }
+        // chunks of rows: of level s + 2 when it is made, else of level s + 1; as many as give ~wave_target waves; at most 64 source
+        // rows (the masks) and 64 rows of either level (row tables: one row per lane) per chunk
+        {
+            const LevelDev& Top = nlev == 2 ? C : B;
+            const int want = std::max(1, (wave_target + R.nstrips - 1) / R.nstrips);
+            int rc = (Top.rows + want - 1) / want;
+            const float ftot = nlev == 2 ? C.fy * B.fy : B.fy;
+            const int rc_max = std::max(1, (int)((64 - RW_D - 3) / ftot) - 2);
+            rc = std::max(std::min(8, rc_max), std::min(rc_max, rc));
+            R.nchunks = (Top.rows + rc - 1) / rc;
+            while (blob.size() & 3) blob.push_back(0);
+            R.chunk_off = (unsigned)(blob.size() * 4);
+            std::vector<int> cv(12 * (size_t)R.nchunks, 0);
+            for (int k = 0; k < R.nchunks && ok; k++) {
+                const bool lastk = k == R.nchunks - 1;
+                int b_first, b_end, b_last, c_first = 0, c_end = 0;
+                if (nlev == 2) {
+                    c_first = k * rc; c_end = std::min(c_first + rc, C.rows);
+                    b_first = yc[4 * c_first];                              // y1 of the chunk's first row (0 for k == 0)
+                    b_end = lastk ? B.rows : yc[4 * c_end];
+                    b_last = lastk ? B.rows - 1 : b_end;                    // one halo row: the lower source row of the chunk's last row
+                    if (yc[4 * (c_end - 1) + 1] > b_last) ok = false;
+                    if (c_end - c_first > 64) ok = false;
+                } else {
+                    b_first = k * rc; b_end = std::min(b_first + rc, B.rows); b_last = b_end - 1;
+                }
+                if (b_last - b_first + 1 > 64 || b_last < b_first) { ok = false; break; }
+                const int a_first = yb[4 * b_first], a_last = yb[4 * b_last + 1];
+                const int na = a_last - a_first + 1, na_pad = (na + RW_D - 1) / RW_D * RW_D;
+                if (na_pad > 64) { ok = false; break; }
+                unsigned long long mb = 0, mc = 0;
+                for (int b = b_first; b <= b_last; b++) {
+                    if (yb[4 * b + 1] != yb[4 * b] + 1) ok = false;         // clamped bottom (fy == 1): the tiled kernels
+                    mb |= 1ull << (yb[4 * b + 1] - a_first);
+                }
+                for (int cc = c_first; cc < c_end; cc++) {
+                    if (yc[4 * cc + 1] != yc[4 * cc] + 1) ok = false;
+                    const int bq = yc[4 * cc + 1];                          // the row of level s + 1 that completes it ...
+                    if (bq < b_first || bq > b_last) { ok = false; break; }
+                    mc |= 1ull << (yb[4 * bq + 1] - a_first);               // ... is made at this source row
+                }
+                int* q = cv.data() + 12 * k;
+                q[0] = a_first; q[1] = a_last; q[2] = b_first; q[3] = b_end; q[4] = c_first; q[5] = c_end; q[6] = na_pad;
+                q[8] = (int)(uint32_t)mb; q[9] = (int)(uint32_t)(mb >> 32); q[10] = (int)(uint32_t)mc; q[11] = (int)(uint32_t)(mc >> 32);
+            }
+            blob.insert(blob.end(), cv.begin(), cv.end());
+        }
+        if (!ok) { blob.resize(mark); continue; }
+        R.nlev = nlev;
+        out[s] = R;
+    }
 }
 
 // pyramid geometry, quotas, caps (calcImagePyramid .cpp:136-157, calcNumFeaturesPerLevel :159-174, :252)
@@ -676,6 +840,7 @@ int build_geometry(efx_context* c, int rows, int cols)
                     if (ndw > 32 || nrow > 80) R.W = 0;          // footprint beyond what the streamed kernel stages: no plan
                 }
         }
+        build_rows_plan(T, p.nlevels, blob, c->rows_plan);
         if (!blob.empty()) {
             HIP_TRY(c->err, c->rplan.reserve(blob.size() * 4));
             HIP_TRY(c->err, hipMemcpy(c->rplan.p, blob.data(), blob.size() * 4, hipMemcpyHostToDevice));
@@ -726,7 +891,7 @@ int detect_common(efx_context* c, const uint8_t* d_image, int rows, int cols, si
     a.d_table = static_cast<const LevelTable*>(c->d_table.p);
     a.h_table = &c->h_table;
     a.hdr = static_cast<TileHdr*>(c->hdr.p);
-    a.rplan = static_cast<const unsigned char*>(c->rplan.p); a.rplan_lv = c->rplan_lv;
+    a.rplan = static_cast<const unsigned char*>(c->rplan.p); a.rplan_lv = c->rplan_lv; a.rows_plan = c->rows_plan;
     a.cand = static_cast<Corner*>(c->cand.p);
     a.cand_xy = reinterpret_cast<uint32_t*>(a.cand + c->cand_slots);
     a.surv = static_cast<Corner*>(c->surv.p);

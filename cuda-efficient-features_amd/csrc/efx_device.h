@@ -171,7 +171,7 @@ __device__ __forceinline__ int efx_wave_incl_scan(int v)
 #else
 #define EFX_DBG(v) 0
 #endif
-struct EfxKnobs { int dbg, dbg_hs, no_tower, no_resize_stream, no_level_blur, blur_fork; };
+struct EfxKnobs { int dbg, dbg_hs, no_tower, no_resize_stream, no_level_blur, blur_fork, no_resize_rows; };
 EfxKnobs efx_read_knobs();      // efx_api.cpp
 
 // ---- launchers (host side, defined in the .hip files) ----
@@ -230,8 +230,28 @@ struct ProfRec {
 //   tile table  int4 per tile: sy0 | ax0 | ndw + (nrow << 8) + (touches the last source column << 16) | tx + (ty << 16)
 struct ResizePlanLevel { unsigned x_off, y_off, t_off; int W; };      // byte offsets into DetectLaunch::rplan; W == 0: no plan
 
+// Plan of one launch of resize_rows_kernel (round 5, detect_kernels.hip): level s -> s + 1 (-> s + 2 when nlev == 2) by waves that
+// walk down strips of RW_OWN destination columns.  Offsets are bytes into DetectLaunch::rplan.
+//   xB / xC   3 x W words: source column x1 | weight of x1 | weight of x1 + 1 per destination column (clamped beyond the last one)
+//   yB / yC   int4 per destination row, padded by 64 rows: y1, min(y1 + 1, rows - 1) | the two weights as float bits
+//   strips    int4 per strip: first source column staged (4-aligned) | dwords of a source row it needs | first group of four
+//             level-(s+2) columns it owns | how many
+//   chunks    3 x int4 per chunk of rows: first / last source row | first row of level s + 1, end of the rows it stores || first / end
+//             row of level s + 2 | source rows padded to the kernel's slot count || two 64-bit masks, bit i: source row i of the chunk
+//             completes a row of level s + 1 / that row completes one of level s + 2
+#define RW_OWN 248
+#ifndef RW_D
+#define RW_D 6                  // source rows in flight per wave = LDS slots = the unroll of the kernel's row loop (even); chunks are padded to it
+#endif
+struct RowsPlanLaunch {
+    int nlev;                   // 0: no plan for this source level
+    int nstrips, nchunks, WB, WC;
+    unsigned xB_off, yB_off, xC_off, yC_off, strip_off, chunk_off;
+};
+
 struct DetectLaunch {
     const unsigned char* rplan; const ResizePlanLevel* rplan_lv;      // device blob, host index by destination level
+    const RowsPlanLaunch* rows_plan;                                  // host array indexed by SOURCE level (null: none)
     const uint8_t* img0;        // level 0 (caller's image)
     int pitch0;
     uint8_t* pyramid;           // levels >= 1

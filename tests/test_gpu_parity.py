@@ -662,13 +662,17 @@ def test_equal_responses_suppress_each_other(cef, torch_mod, oracle, period, rad
     assert np.array_equal(got["desc"], ref["desc"])
 
 
-@pytest.mark.parametrize("mode", ["tower", "chain_streamed", "chain_plain"])
-@pytest.mark.parametrize("shape,scale", [((480, 640), 1.2), ((501, 703), 1.2), ((333, 1111), 1.1), ((700, 900), 1.5), ((600, 800), 2.0)])
+@pytest.mark.parametrize("mode", ["tower", "chain_rows", "chain_streamed", "chain_plain"])
+@pytest.mark.parametrize("shape,scale", [((480, 640), 1.2), ((501, 703), 1.2), ((333, 1111), 1.1), ((700, 900), 1.5), ((600, 800), 2.0),
+                                         ((1201, 2504), 1.2), ((997, 1500), 1.7), ((64, 3000), 1.2), ((2100, 300), 1.25)])
 def test_pyramid_kernel_variants_bit_exact(cef, torch_mod, oracle, monkeypatch, mode, shape, scale):
-    """The three ways a pyramid is produced -- one tower launch (small frames), the streamed per-level kernel and the
-    one-tile-per-workgroup per-level kernel (large frames / other scale factors) -- give the same levels, bit for bit."""
+    """The four ways a pyramid is produced -- one tower launch (small frames), two levels per launch by waves walking down
+    strips (large frames, round 5: resize_rows_kernel), the streamed per-level kernel and the one-tile-per-workgroup
+    per-level kernel (other scale factors, unaligned sources) -- give the same levels, bit for bit."""
     if mode != "tower":
         monkeypatch.setenv("EFX_NO_TOWER", "1")
+    if mode in ("chain_streamed", "chain_plain"):
+        monkeypatch.setenv("EFX_NO_RESIZE_ROWS", "1")
     if mode == "chain_plain":
         monkeypatch.setenv("EFX_NO_RESIZE_STREAM", "1")
     img = synth.synth_frame(shape[0], shape[1], seed=21)
