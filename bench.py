@@ -92,15 +92,21 @@ def dry_run(args, rank, world):
     else:
         seen, d = 1, None
         gathered = [sharding.frames_for_rank(F, rank, world)]
+    cpus = None if args.no_affinity else sharding.pin_to_rank_cpus(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     dt = 1e-3 * args.steps * (1.0 + 0.01 * rank)
     t_max, kp_step, nfr = sharding.reduce_counters(d, "cpu", dt, NFEATURES * F, F)
+    per_rank_s = sharding.gather_per_rank(d, "cpu", dt)
+    ncpu = sharding.gather_per_rank(d, "cpu", len(cpus) if cpus else 0)
     if rank == 0:
         frames = sorted(sum(gathered, []))
         print(json.dumps({"metric": "Mkeypoints/s detectAndCompute (8K, 40k kp, BAD512)", "dry_run": True,
                           "value": round(kp_step * args.steps / t_max / 1e6, 3), "unit": "Mkeypoints/s",
                           "n_gpus": world, "rccl_world": seen, "backend": args.backend, "steps": args.steps,
                           "warmup": args.warmup, "frames_per_step": int(nfr),
-                          "frames_each_once": frames == list(range(F * world)), "scaling": "weak"}), flush=True)
+                          "frames_each_once": frames == list(range(F * world)), "scaling": "weak",
+                          "per_rank": {"ms_per_frame": [round(t / args.steps / F * 1e3, 4) for t in per_rank_s],
+                                       "value": [round(NFEATURES * F * args.steps / t / 1e6, 3) for t in per_rank_s],
+                                       "cpus_pinned": [int(n) for n in ncpu]}}), flush=True)
     if d is not None:
         d.barrier()
         d.destroy_process_group()
@@ -127,6 +133,8 @@ def main():
                          "load that lasts); 0 = off")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for the counters: nccl (= RCCL, the GPU path) or gloo (only with --dry-run)")
+    ap.add_argument("--no-affinity", action="store_true",
+                    help="do not pin each rank to its slice of the node's CPUs (sharding.pin_to_rank_cpus; N > 1 only)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: run the launcher, the rendezvous, the frame sharding and the counter reductions with "
                          "stand-in per-frame numbers (CPU test of the N > 1 plumbing, tests/test_bench_launcher.py)")
@@ -158,6 +166,11 @@ def main():
     if torch.cuda.device_count() < world or local_rank >= torch.cuda.device_count():
         raise SystemExit(f"bench.py: --gpus {world} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
+    sharding = cef_loader.load_submodule("sharding")
+    cpus = None
+    if world > 1 and not args.no_affinity:
+        # one process per GPU: each rank keeps its host threads on its own slice of the node's cores
+        cpus = sharding.pin_to_rank_cpus(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     dist = None
     rccl_world = 1
     if world > 1:
@@ -169,10 +182,15 @@ def main():
             raise SystemExit(f"bench.py: RCCL all-reduce saw {rccl_world} ranks, expected {world}")
 
     F = args.frames_per_step
-    # per-rank frames: global frame k = rank * F + i uses seed 1000 + k
-    sharding = cef_loader.load_submodule("sharding")
+    # per-rank frames: global frame k = rank * F + i uses seed 1000 + k.  Generated here, on the host, BEFORE the first barrier of the
+    # measurement (8 ranks x 8 frames of 33 MB take the host a few seconds and differ between ranks: nothing of it may sit
+    # inside a timed or barrier-bounded region -- `setup_seconds` below is where it shows)
+    t_setup = time.perf_counter()
     my_frames = sharding.frames_for_rank(F, rank, world)
     frames = [torch.from_numpy(synth.synth_frame(ROWS, COLS, seed=1000 + k)).cuda() for k in my_frames]
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t_setup
+    timed_region_open = [False]                       # guard: no frame is generated or uploaded while it is True
     all_frames = [my_frames]
     if dist is not None:
         all_frames = [None] * world
@@ -217,6 +235,8 @@ def main():
     barrier()
     for s_, ev in zip(streams, marks[0]):
         ev.record(s_)
+    n_frames_before = len(frames)
+    timed_region_open[0] = True
     t0 = time.perf_counter()
     for k in range(args.steps):
         step()
@@ -224,6 +244,8 @@ def main():
             ev.record(s_)
     barrier()
     dt = time.perf_counter() - t0
+    timed_region_open[0] = False
+    assert len(frames) == n_frames_before, "frames were generated inside the timed region"
     ms, lvl = det.profileRead()
     # a step is over when its last stream is: time of step k = latest end of step k - latest end of step k-1
     ends = np.array([[marks[0][0].elapsed_time(marks[k][s_]) for s_ in range(NS)] for k in range(args.steps + 1)]).max(axis=1)
@@ -233,6 +255,12 @@ def main():
     # RCCL over xGMI only for the counters: MAX of the time, SUM of the keypoints
     t_max, kp_step, _ = sharding.reduce_counters(dist, "cuda", dt, nkp, F)
     kp_total = kp_step * args.steps                  # keypoints all ranks processed in the timed region
+    # every rank's own time / keypoints / set-up (all-gathers of one double: counters, like the reductions): which GPU the
+    # max-over-ranks time comes from, and how far the ranks are apart
+    per_rank_s = sharding.gather_per_rank(dist, "cuda", dt)
+    per_rank_kp = sharding.gather_per_rank(dist, "cuda", nkp)
+    per_rank_setup = sharding.gather_per_rank(dist, "cuda", t_setup)
+    per_rank_cpus = sharding.gather_per_rank(dist, "cuda", len(cpus) if cpus else 0)
 
     # the same steps again for --sustain-seconds when the K timed steps were over sooner (every rank; `value` stays the K steps)
     sustained = None
@@ -421,6 +449,13 @@ def main():
                           "frames_each_once": sorted(sum(all_frames, [])) == list(range(F * world)), "streams_per_gpu": NS,
                           "keypoints_per_frame": round(nkp / F, 1), "parallelism": f"frames sharded over {world} GPU(s)"},
                "sustained": sustained if sustained else {"note": "the timed region itself lasted %.2f s" % t_max},
+               "per_rank": {"ms_per_frame": [round(t / args.steps / F * 1e3, 4) for t in per_rank_s],
+                            "value": [round(k * args.steps / t / 1e6, 3) for k, t in zip(per_rank_kp, per_rank_s)],
+                            "slowest_over_fastest": round(max(per_rank_s) / min(per_rank_s), 4),
+                            "setup_seconds": [round(t, 2) for t in per_rank_setup],
+                            "cpus_pinned": [int(n) for n in per_rank_cpus],
+                            "note": "rank r = GPU r; `value` (top level) = all ranks' keypoints / the slowest rank's time; the set-up "
+                                    "(synthetic frames generated and uploaded) lies before the first barrier"},
                "roofline": roof}
         tag = os.path.basename(cfiles[-1])[:3] if cfiles else "rNN"
         roof["profiles"] = {"frac / kernels_isolated (one stream)": "profiles/%s_kernel_stats.csv" % tag,

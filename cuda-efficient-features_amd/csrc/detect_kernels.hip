@@ -369,7 +369,7 @@ __global__ __launch_bounds__(NT) void resize_kernel(
             if (y1 > rows - 1) y1 = rows - 1;
             const int y2 = y1 + 1;
             const int y2r = y2 < rows - 1 ? y2 : rows - 1;
-            ytab[tid] = make_int4((y1 - sy0) * lpitch, (y2r - sy0) * lpitch, __float_as_int((float)y2 - sy), __float_as_int(sy - (float)y1));
+            ytab[tid] = make_int4((y1 - sy0) * lpitch, (y2r - sy0) * lpitch, __float_as_int(efx_s5_w_hi(oy, fy, sy, y2)), __float_as_int(efx_s5_w_lo(oy, fy, sy, y1)));
         }
     }
     __syncthreads();
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(NT) void resize_kernel(
         int x1 = (int)floorf(sx);
         if (x1 > cols - 1) x1 = cols - 1;
         const int x2 = x1 + 1;
-        wx0[k] = (float)x2 - sx; wx1[k] = sx - (float)x1;
+        wx0[k] = efx_s5_w_hi(ox, fx, sx, x2); wx1[k] = efx_s5_w_lo(ox, fx, sx, x1);
         lc[k] = x1 - ax0;                                   // the clamped +1 neighbour is the next LDS byte
     }
     const bool full4 = oxq + 4 <= ox1 && ((((uintptr_t)dst) | (uintptr_t)dpitch) & 3u) == 0;
@@ -633,8 +633,10 @@ __global__ __launch_bounds__(256) void resize_rows_kernel(const RowsArgs A, Coun
     const int chunk = task / A.nstrips, strip = task - chunk * A.nstrips;
     const int4 st = A.strips[strip];
     const int4 k0 = A.chunks[3 * chunk], k1 = A.chunks[3 * chunk + 1], k2 = A.chunks[3 * chunk + 2];
-    const int ax0 = st.x, nd = st.y;
-    const int a_first = k0.x, a_last = k0.y, b_first = k0.z, b_end = k0.w, c_first = k1.x, c_end = k1.y, na_pad = k1.z;
+    // (wave-uniform by construction; said so explicitly: the LDS-DMA statements need their descriptor and M0 in scalar registers)
+    auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+    const int ax0 = uni(st.x), nd = uni(st.y);
+    const int a_first = uni(k0.x), a_last = uni(k0.y), b_first = uni(k0.z), b_end = uni(k0.w), c_first = uni(k1.x), c_end = uni(k1.y), na_pad = uni(k1.z);
     // bit i: source row a_first + i is the lower source row of a row of level s + 1 / that row in turn of one of level s + 2
     unsigned long long mask_b = ((unsigned long long)(uint32_t)k2.y << 32) | (uint32_t)k2.x;
     unsigned long long mask_c = ((unsigned long long)(uint32_t)k2.w << 32) | (uint32_t)k2.z;
@@ -820,7 +822,7 @@ __global__ __launch_bounds__(NT) void pyramid_tower_kernel(const LevelTable* __r
             if (y1 > S.rows - 1) y1 = S.rows - 1;
             const int y2 = y1 + 1;
             const int y2r = y2 < S.rows - 1 ? y2 : S.rows - 1;
-            yt[i] = make_int4((y1 - loy0) * spitch_l, (y2r - loy0) * spitch_l, __float_as_int((float)y2 - sy), __float_as_int(sy - (float)y1));
+            yt[i] = make_int4((y1 - loy0) * spitch_l, (y2r - loy0) * spitch_l, __float_as_int(efx_s5_w_hi(oy, D.fy, sy, y2)), __float_as_int(efx_s5_w_lo(oy, D.fy, sy, y1)));
         }
     };
     // LDS row pitch of a level's region: its columns plus the replicated +1 neighbour of the last one, in dwords
@@ -890,7 +892,7 @@ __global__ __launch_bounds__(NT) void pyramid_tower_kernel(const LevelTable* __r
                 int x1 = (int)floorf(sx);
                 if (x1 > S.cols - 1) x1 = S.cols - 1;
                 const int x2 = x1 + 1;
-                wx0[k] = (float)x2 - sx; wx1[k] = sx - (float)x1;
+                wx0[k] = efx_s5_w_hi(ox, D.fx, sx, x2); wx1[k] = efx_s5_w_lo(ox, D.fx, sx, x1);
                 lc[k] = x1 - lox0;
             }
             const bool colfull = oxq >= ownlox && oxq + 4 <= ownhix;
@@ -2334,7 +2336,19 @@ static bool plan_tower(const LevelTable& H, int last, const uint8_t* img0, int p
     return true;
 }
 
+static hipError_t efx_launch_detect_impl(const DetectLaunch& a, hipStream_t stream, bool* forked_out);
+
 hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
+{
+    bool forked = false;
+    const hipError_t e = efx_launch_detect_impl(a, stream, &forked);
+    // A failure between the fork and the join would leave the side stream's blur unjoined: a later inline blur of the same
+    // context could then write `blurred` concurrently.  Wait for it here, on the failure path only.
+    if (e != hipSuccess && forked && a.side) { (void)hipStreamSynchronize(a.side); (void)hipGetLastError(); }
+    return e;
+}
+
+static hipError_t efx_launch_detect_impl(const DetectLaunch& a, hipStream_t stream, bool* forked_out)
 {
     const LevelTable& H = *a.h_table;
     hipError_t e = hipSuccess;
@@ -2442,7 +2456,7 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
             hipError_t e2 = hipEventRecord(a.ev_fork, stream);
             if (e2 == hipSuccess) e2 = hipStreamWaitEvent(a.side, a.ev_fork, 0);
             if (e2 != hipSuccess) return e2;
-            st = a.side; forked = true;
+            st = a.side; forked = true; *forked_out = true;
         }
         hipError_t e2 = efx_launch_blur_levels(H, a.img0, a.pitch0, a.pyramid, a.blurred, a.blur0_pitch, a.blur_levels_off, a.prof, st);
         if (e2 == hipSuccess && forked) e2 = hipEventRecord(a.ev_join, a.side);
@@ -2547,6 +2561,7 @@ hipError_t efx_launch_detect(const DetectLaunch& a, hipStream_t stream)
     if (forked) {                       // the describer (next on this stream) reads the blurred levels
         e = hipStreamWaitEvent(stream, a.ev_join, 0);
         if (e != hipSuccess) return e;
+        *forked_out = false;            // joined
     }
     e = hipGetLastError();
     if (e != hipSuccess) return e;

@@ -540,7 +540,7 @@ void build_rows_plan(const LevelTable& T, int nlevels, std::vector<int>& blob, R
                 int x1 = (int)floorf(sx);
                 if (x1 > S.cols - 1) x1 = S.cols - 1;
                 const int x2 = x1 + 1;
-                xt[i] = x1; xt[W + i] = fbits((float)x2 - sx); xt[2 * W + i] = fbits(sx - (float)x1);
+                xt[i] = x1; xt[W + i] = fbits(efx_s5_w_hi(ox, D.fx, sx, x2)); xt[2 * W + i] = fbits(efx_s5_w_lo(ox, D.fx, sx, x1));
             }
             return off;
         };
@@ -557,7 +557,7 @@ void build_rows_plan(const LevelTable& T, int nlevels, std::vector<int>& blob, R
                 if (y1 > S.rows - 1) y1 = S.rows - 1;
                 const int y2 = y1 + 1;
                 const int y2r = y2 < S.rows - 1 ? y2 : S.rows - 1;
-                yt[4 * i] = y1; yt[4 * i + 1] = y2r; yt[4 * i + 2] = fbits((float)y2 - sy); yt[4 * i + 3] = fbits(sy - (float)y1);
+                yt[4 * i] = y1; yt[4 * i + 1] = y2r; yt[4 * i + 2] = fbits(efx_s5_w_hi(oy, D.fy, sy, y2)); yt[4 * i + 3] = fbits(efx_s5_w_lo(oy, D.fy, sy, y1));
             }
             return off;
         };
@@ -808,7 +808,7 @@ int build_geometry(efx_context* c, int rows, int cols)
                 int x1 = (int)floorf(sx);
                 if (x1 > P.cols - 1) x1 = P.cols - 1;
                 const int x2 = x1 + 1;
-                xt[i] = x1; xt[W + i] = fbits((float)x2 - sx); xt[2 * W + i] = fbits(sx - (float)x1);
+                xt[i] = x1; xt[W + i] = fbits(efx_s5_w_hi(ox, N.fx, sx, x2)); xt[2 * W + i] = fbits(efx_s5_w_lo(ox, N.fx, sx, x1));
             }
             R.y_off = (unsigned)(blob.size() * 4);
             blob.resize(blob.size() + 4 * (size_t)Hh);
@@ -820,7 +820,7 @@ int build_geometry(efx_context* c, int rows, int cols)
                 if (y1 > P.rows - 1) y1 = P.rows - 1;
                 const int y2 = y1 + 1;
                 const int y2r = y2 < P.rows - 1 ? y2 : P.rows - 1;
-                yt[4 * i] = y1; yt[4 * i + 1] = y2r; yt[4 * i + 2] = fbits((float)y2 - sy); yt[4 * i + 3] = fbits(sy - (float)y1);
+                yt[4 * i] = y1; yt[4 * i + 1] = y2r; yt[4 * i + 2] = fbits(efx_s5_w_hi(oy, N.fy, sy, y2)); yt[4 * i + 3] = fbits(efx_s5_w_lo(oy, N.fy, sy, y1));
             }
             R.t_off = (unsigned)(blob.size() * 4);
             blob.resize(blob.size() + 4 * (size_t)N.tiles_x * N.tiles_y);
@@ -941,7 +941,9 @@ int detect_common(efx_context* c, const uint8_t* d_image, int rows, int cols, si
                 // reference's call-then-wait protocol, 8K (103 M level pixels) 0.430 -> 0.408 ms, 4K (26 M) 0.195 -> 0.199, FHD 0.115 -> 0.122
                 size_t level_px = 0;
                 for (int l = 0; l < H.nlevels; l++) level_px += (size_t)H.lv[l].rows * H.lv[l].cols;
-                if (!a.prof.start && level_px >= (size_t)50 * 1000 * 1000) {
+                // (EFX_BLUR_FORK_MIN_PX: the gate, for tests that exercise the per-call decision on small frames)
+                static const size_t min_px = getenv("EFX_BLUR_FORK_MIN_PX") ? (size_t)atoll(getenv("EFX_BLUR_FORK_MIN_PX")) : (size_t)50 * 1000 * 1000;
+                if (!a.prof.start && level_px >= min_px) {
                     if (hipStreamIsCapturing(stream, &cs) != hipSuccess) (void)hipGetLastError();
                     else if (cs == hipStreamCaptureStatusNone) {
                         const hipError_t q = hipStreamQuery(stream);
@@ -1181,7 +1183,17 @@ int efx_set_descriptor_type(efx_context* ctx, int v)
     if (rc) return rc;
     if (v == ctx->p.descriptor_type) return EFX_OK;
     ctx->p = q;
-    return ctx_rebuild_describer(ctx);
+    rc = ctx_rebuild_describer(ctx);
+    // the blurred copies of the levels (+103 MB at 8K) serve BAD describers only: a context switched to HashSIFT gives them back
+    // (ADVICE r4); its streams are waited for first, like any regrow (Quiesce)
+    if (rc == EFX_OK && ctx->desc.kind != 0 && ctx->blurred.p) {
+        Quiesce q2 = { &efx_context::quiesce_cb, ctx, false };
+        Quiesce* prev = tl_quiesce;
+        tl_quiesce = &q2;
+        ctx->blurred.release();
+        tl_quiesce = prev;
+    }
+    return rc;
 }
 int efx_get_descriptor_type(const efx_context* ctx) { return ctx ? ctx->p.descriptor_type : -1; }
 

@@ -223,6 +223,30 @@ struct ProfRec {
     }
 };
 
+// Spec S5 weights of destination index o (source position s = (float)o * f, rounded): of the upper neighbour i2 = i1 + 1 and of
+// the lower one i1.  Default: separate subtractions of the rounded product.  -DEFX_S5_FUSED_WEIGHTS=1 (library AND oracle): the
+// other thing nvcc's contraction could have made of opencv_contrib's `x2 - src_x` / `src_x - x1` (undecidable in
+// this image: no CUDA build, no cv::cuda::resize dump) -- every pyramid kernel and plan takes its weights from here.
+#ifndef EFX_S5_FUSED_WEIGHTS
+#define EFX_S5_FUSED_WEIGHTS 0
+#endif
+__host__ __device__ inline float efx_s5_w_hi(int o, float f, float s, int i2)
+{
+#if EFX_S5_FUSED_WEIGHTS
+    return __builtin_fmaf(-(float)o, f, (float)i2);
+#else
+    (void)o; (void)f; return (float)i2 - s;
+#endif
+}
+__host__ __device__ inline float efx_s5_w_lo(int o, float f, float s, int i1)
+{
+#if EFX_S5_FUSED_WEIGHTS
+    return __builtin_fmaf((float)o, f, -(float)i1);
+#else
+    (void)o; (void)f; return s - (float)i1;
+#endif
+}
+
 // Resize plan of one destination level (resize_stream_kernel): everything about a tile / column / row that does not
 // depend on the pixels, computed once per geometry on the host with the kernel's own float expressions (spec S5).
 //   x table  3 x W words (W = tiles_x * 64): source column x1 | weight of x1 | weight of x1 + 1, per destination column

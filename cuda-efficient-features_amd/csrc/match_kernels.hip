@@ -10,6 +10,7 @@
 // 32-bit word costs one v_xor + one v_bcnt_u32 (popcount with accumulate).  The train set is split into chunks
 // along grid.y for occupancy; a second kernel merges the per-chunk best-2 lists.
 
+#include <atomic>
 #include "efx_device.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -421,7 +422,7 @@ size_t efx_knn2_mfma_scratch(int nq, int nt, int desc_bytes)
 static int knn2_fp4_tt(int desc_bytes)
 {
     static const int tt_env = [] { const char* v = getenv("EFX_MATCH_TT"); return v ? atoi(v) : 0; }();     // INVESTIGATION knob
-    return tt_env ? tt_env : (desc_bytes == 32 ? 2 : 1);
+    return (tt_env == 1 || tt_env == 2) ? tt_env : (desc_bytes == 32 ? 2 : 1);      // anything else: the default
 }
 
 // Workgroups of the matrix-core kernel the chip holds at once (CUs x resident workgroups per CU, from the runtime's occupancy
@@ -429,10 +430,13 @@ static int knn2_fp4_tt(int desc_bytes)
 // round with (query block, chunk) pairs
 int efx_knn2_mfma_resident_workgroups(int desc_bytes, int fp4)
 {
-    static int cache[2][2][3] = {};
+    // per device (CU count and occupancy differ between devices), written by whichever thread asks first: atomics
+    static std::atomic<int> cache[16][2][2][3];
     const int tt = fp4 ? knn2_fp4_tt(desc_bytes) : 0, b = desc_bytes == 32 ? 0 : 1;
-    int& c = cache[b][fp4 ? 1 : 0][tt > 2 ? 0 : tt];
-    if (c > 0) return c;
+    int dev0 = 0;
+    if (hipGetDevice(&dev0) != hipSuccess) { (void)hipGetLastError(); dev0 = 0; }
+    std::atomic<int>* slot = (dev0 >= 0 && dev0 < 16) ? &cache[dev0][b][fp4 ? 1 : 0][tt] : nullptr;
+    if (slot) { const int c = slot->load(std::memory_order_relaxed); if (c > 0) return c; }
     const void* f;
     if (!fp4) f = desc_bytes == 32 ? reinterpret_cast<const void*>(&knn2_mfma_kernel<256, 1, 8, false>) : reinterpret_cast<const void*>(&knn2_mfma_kernel<512, 1, 8, false>);
     else if (tt == 2) f = desc_bytes == 32 ? reinterpret_cast<const void*>(&knn2_fp4_kernel<256, 2>) : reinterpret_cast<const void*>(&knn2_fp4_kernel<512, 2>);
@@ -440,7 +444,8 @@ int efx_knn2_mfma_resident_workgroups(int desc_bytes, int fp4)
     int per_cu = 0, dev = 0, cus = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, f, 512, 0) != hipSuccess || per_cu < 1) per_cu = 2;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-    return c = per_cu * cus;
+    if (slot) slot->store(per_cu * cus, std::memory_order_relaxed);
+    return per_cu * cus;
 }
 
 hipError_t efx_launch_knn2_mfma(const uint8_t* query, size_t q_pitch, int nq, const uint8_t* train, size_t t_pitch, int nt,

@@ -492,6 +492,19 @@ void efxo_level_quotas(int total, float scale_factor, int nlevels, int* q)
     q[nlevels - 1] = total - sum > 0 ? total - sum : 0;
 }
 
+/* Spec S5 weight of the upper (i2 = i1 + 1) / lower (i1) neighbour of destination index o, s = (float)o * f rounded */
+#ifndef EFX_S5_FUSED_WEIGHTS
+#define EFX_S5_FUSED_WEIGHTS 0
+#endif
+#if EFX_S5_FUSED_WEIGHTS
+#define EFXO_S5_W_HI(o, f, s, i2) fmaf(-(float)(o), (f), (float)(i2))
+#define EFXO_S5_W_LO(o, f, s, i1) fmaf((float)(o), (f), -(float)(i1))
+#else
+#define EFXO_S5_W_HI(o, f, s, i2) ((float)(i2) - (s))
+#define EFXO_S5_W_LO(o, f, s, i1) ((s) - (float)(i1))
+#endif
+int efxo_s5_fused_weights(void) { return EFX_S5_FUSED_WEIGHTS; }
+
 void efxo_resize_linear(const uint8_t* src, int srows, int scols, int sstride,
                         uint8_t* dst, int drows, int dcols, int dstride)
 {
@@ -519,11 +532,20 @@ void efxo_resize_linear(const uint8_t* src, int srows, int scols, int sstride,
              * the accumulator -- the same contraction spec S6 models for the Gaussian (the reference binary is one nvcc build:
              * both third-party kernels are contracted or neither is).  The first statement adds to 0.f and is the
              * rounded product either way. */
+            /* The four weights `(x2 - src_x)`, `(src_x - x1)`, ... are kept as SEPARATE subtractions of the rounded product
+             * src_x = dst_x * fx: nvcc's contraction could also turn them into fma(-dst_x, fx, x2) / fma(dst_x, fx, -x1),
+             * whose result differs in the last bit whenever dst_x * fx is inexact.  Nothing in this image can decide it (no CUDA
+             * build, no dump of cv::cuda::resize); the other reading is one switch away, in the oracle and in the HIP library
+             * alike: build both with -DEFX_S5_FUSED_WEIGHTS=1 (tests/test_oracle_detector.py::test_s5_weight_switch keeps the
+             * two readings alive and distinct).  Default: separate -- the weights are then exactly the CPU cv::resize-style
+             * fractions, and every pyramid fixture of this tree was made that way. */
+            const float wx0 = EFXO_S5_W_HI(dx, fx, sx, x2), wx1 = EFXO_S5_W_LO(dx, fx, sx, x1);
+            const float wy0 = EFXO_S5_W_HI(dy, fy, sy, y2), wy1 = EFXO_S5_W_LO(dy, fy, sy, y1);
             float out = 0.f;
-            out = fmaf((float)src[(size_t)y1 * sstride + x1], ((float)x2 - sx) * ((float)y2 - sy), out);
-            out = fmaf((float)src[(size_t)y1 * sstride + x2r], (sx - (float)x1) * ((float)y2 - sy), out);
-            out = fmaf((float)src[(size_t)y2r * sstride + x1], ((float)x2 - sx) * (sy - (float)y1), out);
-            out = fmaf((float)src[(size_t)y2r * sstride + x2r], (sx - (float)x1) * (sy - (float)y1), out);
+            out = fmaf((float)src[(size_t)y1 * sstride + x1], wx0 * wy0, out);
+            out = fmaf((float)src[(size_t)y1 * sstride + x2r], wx1 * wy0, out);
+            out = fmaf((float)src[(size_t)y2r * sstride + x1], wx0 * wy1, out);
+            out = fmaf((float)src[(size_t)y2r * sstride + x2r], wx1 * wy1, out);
             dst[(size_t)dy * dstride + dx] = sat_u8_f(out);
         }
     }

@@ -74,6 +74,7 @@ void efxo_pyramid_geometry(int rows, int cols, float scale_factor, int nlevels,
 void efxo_level_quotas(int total, float scale_factor, int nlevels, int* quotas);
 
 /* cv::cuda::resize INTER_LINEAR as specified in DESIGN.md S5 (call site cuda_efficient_features.cpp:154). */
+int efxo_s5_fused_weights(void);      /* 1: built with -DEFX_S5_FUSED_WEIGHTS=1 (the other reading of spec S5's weights) */
 void efxo_resize_linear(const uint8_t* src, int srows, int scols, int sstride,
                         uint8_t* dst, int drows, int dcols, int dstride);
 

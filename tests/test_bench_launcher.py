@@ -35,6 +35,35 @@ def test_gpus_2_spawns_two_ranks_gloo_dry_run():
     assert j["value"] == pytest.approx(2 * 8 * 40000 * 3 / (3e-3 * 1.01) / 1e6, rel=1e-3)
 
 
+def test_gpus_8_dry_run_gloo_the_size_the_driver_scales_to():
+    """N = 8 (BASELINE.json configs[4]: 64 frames over 8 GPUs): eight ranks, every frame once, per-rank rows in rank order, and
+    every rank pinned to its own non-empty slice of the node's CPUs (no 8-GPU box was ever reachable: this
+    is the whole N = 8 path but the kernels)."""
+    r = _run(["--gpus", "8", "--steps", "2", "--warmup", "0", "--backend", "gloo", "--dry-run"], timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout
+    j = lines[0]
+    assert j["n_gpus"] == 8 and j["rccl_world"] == 8 and j["frames_each_once"] is True and j["frames_per_step"] == 64
+    pr = j["per_rank"]
+    assert len(pr["ms_per_frame"]) == 8 and len(pr["value"]) == 8
+    assert pr["ms_per_frame"] == sorted(pr["ms_per_frame"])              # the stand-in makes rank r 1 % slower per rank
+    assert all(n >= 1 for n in pr["cpus_pinned"])
+    assert j["value"] == pytest.approx(8 * 8 * 40000 * 2 / (2e-3 * 1.07) / 1e6, rel=1e-3)
+
+
+def test_cpu_slices_partition_the_allowed_set():
+    import cef_loader
+    sh = cef_loader.load_submodule("sharding")
+    allowed = list(range(3, 3 + 21))
+    parts = [sh.cpus_for_rank(allowed, r, 8) for r in range(8)]
+    assert sorted(sum(parts, [])) == allowed and all(parts) and max(map(len, parts)) - min(map(len, parts)) <= 1
+    assert all(p == list(range(p[0], p[0] + len(p))) for p in parts)      # contiguous blocks
+    assert [sh.cpus_for_rank([5, 9], r, 8) for r in range(4)] == [[5], [9], [5], [9]]      # fewer CPUs than ranks: shared
+    with pytest.raises(ValueError):
+        sh.cpus_for_rank([], 0, 1)
+
+
 def test_driver_style_launch_matches():
     """The way the driver launches N > 1: torch.distributed.run around bench.py --gpus N."""
     import socket

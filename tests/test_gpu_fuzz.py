@@ -102,7 +102,10 @@ def _hashsift_check(nbad, nbits, n, info, got=None, want=None):
     rep = 1.0
     if want is not None and nbad and len(want):
         rep = len(want) / max(1, len(np.unique(want, axis=0)))
-    assert nbad <= (int(1e-3 * nbytes) + 4) * rep, f"{info}: {nbad} of {nbytes} HashSIFT descriptor bytes differ (every byte counted, repetition {rep:.1f})"
+    # NOT the spec tolerance (1e-4 of the bytes, asserted below per distinct descriptor and sweep-wide at 4e-5): a sanity cap,
+    # ten times looser on purpose, that catches localised defects before the de-duplication can hide them
+    assert nbad <= (int(1e-3 * nbytes) + 4) * rep, (f"{info}: {nbad} of {nbytes} HashSIFT descriptor bytes differ (every byte counted, repetition {rep:.1f}; "
+                                                     "sanity cap at 10x the tolerance, the tolerance itself is asserted below)")
     # A periodic image (checkerboards: kind 3) holds the same patch many times over, and ONE rounding event then shows up in
     # every keypoint that has it (found by the round-3 sweep: seed 705467, 24 keypoints of a checkerboard with the same two
     # bytes, 42 differing bytes against a bound of 21).  Events are counted once per distinct (expected, computed) descriptor;

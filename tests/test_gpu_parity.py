@@ -9,6 +9,10 @@ from tools import synth
 
 pytestmark = pytest.mark.gpu
 
+import os
+# the per-call fork decision of the level blur has a pixel gate read once per process (test_level_blur_side_stream_is_chosen_per_call)
+os.environ.setdefault("EFX_BLUR_FORK_MIN_PX", "400000")
+
 
 @pytest.fixture(scope="module")
 def cef():
@@ -805,13 +809,21 @@ def test_detect_and_compute_is_graph_capturable(cef, torch_mod, oracle):
         assert np.array_equal(desc[:n].cpu().numpy(), ref["desc"])
 
 
-def test_level_blur_side_stream_is_chosen_per_call(cef, torch_mod, oracle, monkeypatch):
+@pytest.mark.parametrize("fork", ["auto", "1", "2", "3"])
+def test_level_blur_side_stream_is_chosen_per_call(cef, torch_mod, oracle, monkeypatch, fork):
     """Where the level blur of detectAndCompute (BAD) runs is decided per call (efx_api.cpp, detect_common): on the context's
     side stream when the call's stream had nothing pending at this call and at the one before -- a caller that waits for
     every frame -- and on the call's stream otherwise.  Same keypoints and descriptors either way, also when the two kinds of call
-    alternate on one context, on two user streams, and for different frames in the same buffers."""
+    alternate on one context, on two user streams, and for different frames in the same buffers.
+    The per-call decision only applies to pyramids of >= 50 M pixels; EFX_BLUR_FORK_MIN_PX (read once per process, so set for the
+    whole module by the fixture below) lowers the gate so that these 600 x 800 frames take it ("auto"), and EFX_BLUR_FORK = 1 / 2 /
+    3 (read when a context is created) forces the fork behind the pyramid / harris_kernel / nms_kernel on every call: fork / join
+    events reused across streams, the side stream shared by consecutive calls."""
     torch = torch_mod
-    monkeypatch.delenv("EFX_BLUR_FORK", raising=False)
+    if fork == "auto":
+        monkeypatch.delenv("EFX_BLUR_FORK", raising=False)
+    else:
+        monkeypatch.setenv("EFX_BLUR_FORK", fork)
     EF = cef.EfficientFeatures
     frames = [synth.synth_frame(600, 800, seed=71 + i, density=0.5 + 0.25 * i) for i in range(3)]
     refs = [oracle.detect_and_compute(f, nfeatures=4000, desc_type=oracle.BAD_512) for f in frames]

@@ -67,8 +67,9 @@ def test_integral_equals_cumsum(oracle):
     assert np.array_equal(got.astype(np.int64), want)
 
 
-def numpy_resize(src, drows, dcols):
-    """Spec S5 in numpy: float32 weights, fused multiply-adds, same operation order."""
+def numpy_resize(src, drows, dcols, fused_weights=False):
+    """Spec S5 in numpy: float32 weights, fused multiply-adds, same operation order.  fused_weights: the other reading of
+    the four weights (EFX_S5_FUSED_WEIGHTS: fma(-o, f, i2) / fma(o, f, -i1) instead of subtracting the rounded o * f)."""
     srows, scols = src.shape
     fx = np.float32(1.0 / (dcols / scols))
     fy = np.float32(1.0 / (drows / srows))
@@ -79,10 +80,18 @@ def numpy_resize(src, drows, dcols):
     x2, y2 = x1 + 1, y1 + 1
     x2r, y2r = np.minimum(x2, scols - 1), np.minimum(y2, srows - 1)
     S = src.astype(np.float32)
-    wx0 = (x2.astype(np.float32) - sx)[None, :]
-    wx1 = (sx - x1.astype(np.float32))[None, :]
-    wy0 = (y2.astype(np.float32) - sy)[:, None]
-    wy1 = (sy - y1.astype(np.float32))[:, None]
+    if fused_weights:
+        # o * f is exact in double (24-bit x 24-bit), and so is its difference with a small integer: one rounding, like fmaf
+        ox, oy = np.arange(dcols, dtype=np.float64), np.arange(drows, dtype=np.float64)
+        wx0 = (x2 - ox * np.float64(fx)).astype(np.float32)[None, :]
+        wx1 = (ox * np.float64(fx) - x1).astype(np.float32)[None, :]
+        wy0 = (y2 - oy * np.float64(fy)).astype(np.float32)[:, None]
+        wy1 = (oy * np.float64(fy) - y1).astype(np.float32)[:, None]
+    else:
+        wx0 = (x2.astype(np.float32) - sx)[None, :]
+        wx1 = (sx - x1.astype(np.float32))[None, :]
+        wy0 = (y2.astype(np.float32) - sy)[:, None]
+        wy1 = (sy - y1.astype(np.float32))[:, None]
     # fma(pixel, rounded weight product, out): the product of an 8-bit and a 24-bit number is exact in double, and so is
     # its sum with the accumulator unless a weight is below 2^-20 of the other terms (then the double rounding could matter
     # in principle; it does not on these inputs)
@@ -104,6 +113,36 @@ def test_resize_equals_numpy_spec(oracle):
     l1 = numpy_resize(img, lr[1], lc[1])
     l2 = numpy_resize(l1, lr[2], lc[2])
     assert np.array_equal(oracle.pyramid_level(img, 2), l2)
+
+
+def test_s5_weight_switch(tmp_path):
+    """whether nvcc also contracts the weight subtractions of opencv_contrib's resize_linear cannot be decided in
+    this image, so the other reading is a build switch of the oracle and of the HIP library (-DEFX_S5_FUSED_WEIGHTS=1, one
+    shared pair of helpers: efx_s5_w_hi / efx_s5_w_lo).  Both builds of the oracle equal the numpy restatement of their
+    reading, the default build is the separate-subtraction one, and the two readings really differ (in weights by one ulp,
+    in a few pixels of a level) -- so a maintainer with a CUDA box can tell them apart from one cv::cuda::resize dump."""
+    import ctypes
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "oracle", "efx_oracle.c")
+    libs = {}
+    for flag in (0, 1):
+        so = str(tmp_path / f"oracle_s5_{flag}.so")
+        subprocess.check_call(["gcc", "-std=c99", "-O2", "-fPIC", "-mfma", "-ffp-contract=off", "-fno-fast-math", "-fopenmp",
+                               f"-DEFX_S5_FUSED_WEIGHTS={flag}", "-shared", "-o", so, src, "-lm"])
+        libs[flag] = ctypes.CDLL(so)
+        assert libs[flag].efxo_s5_fused_weights() == flag
+    img = synth.powerlaw_frame(480, 640, seed=3)
+    outs = {}
+    for flag, lib in libs.items():
+        dr, dc = 400, 533
+        dst = np.zeros((dr, dc), np.uint8)
+        lib.efxo_resize_linear(img.ctypes.data_as(ctypes.c_void_p), 480, 640, 640, dst.ctypes.data_as(ctypes.c_void_p), dr, dc, dc)
+        assert np.array_equal(dst, numpy_resize(img, dr, dc, fused_weights=bool(flag))), f"EFX_S5_FUSED_WEIGHTS={flag}"
+        outs[flag] = dst
+    ndiff = int(np.count_nonzero(outs[0] != outs[1]))
+    assert 0 < ndiff < outs[0].size // 100, ndiff          # distinguishable, and only in rounding ties
 
 
 def test_gaussian_equals_numpy_spec(oracle):

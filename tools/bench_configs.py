@@ -75,7 +75,7 @@ def detect_bytes(det, rows, cols, stats):
     return survey, design, sum(P)
 
 
-def measure(cef, iters=30, cpu_baseline=True, sizes=("fhd", "4k", "8k"), log=lambda s: None):
+def measure(cef, iters=30, cpu_baseline=True, sizes=("fhd", "4k", "8k"), log=lambda s: None, data_rows=True):
     import torch
     EF = cef.EfficientFeatures
     types = (("BAD256", EF.BAD_256, 32), ("BAD512", EF.BAD_512, 64), ("HashSIFT256", EF.HASH_SIFT_256, 32), ("HashSIFT512", EF.HASH_SIFT_512, 64))
@@ -188,6 +188,34 @@ def measure(cef, iters=30, cpu_baseline=True, sizes=("fhd", "4k", "8k"), log=lam
                 bs2, bd2, _ = detect_bytes(d, r_, c_, st)
                 row["detectAndCompute"]["roofline"] = roof(bs2 + 7 * sumP + 46 * 46 * 4 * n + n * nbytes, bd2 + sumP + (80 + nbytes) * n, tdc["ms"])
             res["rows"].append(row)
+            del d
+    # ---- data dependence of the headline: the same call on frames with the statistics of photographs.  The
+    # headline's rectangle frames have 2.8 M FAST corners per 8K frame (1 pixel in 37); a 1/f^1.3 texture has ~3 % corners, a 1/f^1.0
+    # one ~17 % -- the reference's 10 % candidate cap (.cpp:252, spec S2) is active and the density-sized corner arenas overflow once
+    # (the context then switches to worst-case arenas: the rows are timed after that)
+    if "8k" in sizes and data_rows:
+        r_, c_ = synth.SIZES["8k"]
+        log("natural-statistics frames")
+        betas = (1.3, 1.0)
+        for beta, f in zip(betas, synth.powerlaw_frames_tiled(r_, c_, seed=1000, betas=betas)):
+            img = torch.from_numpy(f).cuda()
+            d = EF.create(workloads.N40K, dtype=EF.BAD_512)
+            desc = torch.zeros((workloads.N40K, 64), dtype=torch.uint8, device="cuda")
+            for _ in range(3):                               # arena growth (beta 1.0) happens here, not in the timed calls
+                d.detectAndComputeAsync(img, kps, desc, cnt); torch.cuda.synchronize(); d.lastCount()
+            t = perf(torch, lambda: d.detectAndComputeAsync(img, kps, desc, cnt), iters)
+            n = int(cnt.item())
+            st = d.lastLevelStats()
+            C = sum(x["n_candidates"] for x in st); S = sum(x["n_after_nms"] for x in st)
+            bs2, bd2, sumP = detect_bytes(d, r_, c_, st)
+            res["rows"].append(dict(config="data", mode="detectAndCompute", size="8k", descriptor="BAD512",
+                                    frame="1/f^%.1f octave noise (tools/synth.py powerlaw_frames_tiled, seed 1000)" % beta,
+                                    fast_corners=int(C), fast_corners_frac_of_pixels=round(C / sumP, 4), nms_survivors=int(S), keypoints=n,
+                                    cap_active=bool(any(x["n_candidates"] >= 0.1 * x2 for x, x2 in zip(st, [d.levelGeometry(r_, c_, l)[0] * d.levelGeometry(r_, c_, l)[1] for l in range(8)]))),
+                                    overflow_events=int(d.overflowEvents()) if hasattr(d, "overflowEvents") else None,
+                                    device_MB=round(d.deviceBytes() / 1e6, 1) if hasattr(d, "deviceBytes") else None,
+                                    **t, Mkeypoints_per_s=round(n / t["ms"] / 1e3, 2),
+                                    roofline=roof(bs2 + 7 * sumP + 46 * 46 * 4 * n + n * 64, bd2 + sumP + (80 + 64) * n, t["ms"])))
             del d
     if oracle:
         oracle.set_threads(1)

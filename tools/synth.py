@@ -101,6 +101,32 @@ def powerlaw_frame(rows, cols, seed=1000, beta=1.3, contrast=45.0):
     return np.clip(np.rint(acc), 0, 255).astype(np.uint8)
 
 
+def powerlaw_frames_tiled(rows, cols, seed=1000, betas=(1.3, 1.0), contrast=45.0, tile_div=2):
+    """Frames with the statistics of powerlaw_frame for the bench line's data-dependence rows: the octave fields are generated
+    ONCE at (rows / tile_div, cols / tile_div) for all `betas` (the interpolation of the octaves is what costs: 34 s per 8K frame
+    otherwise) and mirrored into the full frame (continuous across the seams: no artificial edges).  Not bit-identical to
+    powerlaw_frame -- nothing is compared against these frames but the oracle run on the very same array."""
+    r, c_ = rows // tile_div, cols // tile_div
+    rng = np.random.default_rng(seed)
+    accs = [np.zeros((r, c_), np.float64) for _ in betas]
+    c = 1
+    while c <= max(8, min(r, c_) // 2):
+        g = rng.standard_normal((r // c + 2, c_ // c + 2))
+        f = _bilinear_up(g, r, c_, c) if c > 1 else g[:r, :c_]
+        for a, b in zip(accs, betas):
+            a += (float(c) ** (b - 1.0)) * f
+        c *= 2
+    out = []
+    for a in accs:
+        a -= a.mean()
+        sd = a.std()
+        t = np.clip(np.rint(128.0 + a * (contrast / sd if sd > 0 else 0.0)), 0, 255).astype(np.uint8)
+        row = np.concatenate([t if k % 2 == 0 else t[:, ::-1] for k in range(tile_div)], axis=1)
+        full = np.concatenate([row if k % 2 == 0 else row[::-1, :] for k in range(tile_div)], axis=0)
+        out.append(np.ascontiguousarray(full[:rows, :cols]))
+    return out
+
+
 def _gauss_blur(img, sigma):
     r = max(1, int(np.ceil(3 * sigma)))
     k = np.exp(-0.5 * (np.arange(-r, r + 1, dtype=np.float64) / sigma) ** 2)
