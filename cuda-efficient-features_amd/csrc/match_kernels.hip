@@ -152,7 +152,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // and 16 bytes per lane and operand: half the MFMAs AND half the LDS bytes per descriptor pair.  The fp32 accumulator is exact
 // (|dot| <= 512).  The lane layout of the operands is the int8 form's with two elements per byte (row = lane & 31, K range by
 // lane >> 5), the C layout is the shape's; which K index a nibble stands for does not matter as long as queries and trains agree.
-template <int NBITS, int CB, int NW, bool FP4>
+// DB (round 5): two LDS copies of the train tile, taking turns -- a step then has ONE barrier (behind its staging stores): when a
+// wave passes the barrier of step t + 1 every wave has finished multiplying step t, so step t + 2 may overwrite that copy.
+template <int NBITS, int CB, int NW, bool FP4, bool DB = false>
 __global__ __launch_bounds__(NW * 64) void knn2_mfma_kernel(const uint8_t* __restrict__ xq, int nq, const uint8_t* __restrict__ xt, int nt,
                                                             int tiles_per_chunk, Best2* __restrict__ partial)
 {
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(NW * 64) void knn2_mfma_kernel(const uint8_t* __res
     typedef typename std::conditional<FP4, float, int>::type acc_t;
     typedef typename std::conditional<FP4, f32x16, i32x16>::type accv_t;
     const int LOWEST = FP4 ? 0 : -0x7fffffff;             // key below every real one (FP4: +0.0f)
-    __shared__ __attribute__((aligned(16))) uint8_t s_tile[32 * LP];
+    __shared__ __attribute__((aligned(16))) uint8_t s_tiles[(DB ? 2 : 1) * 32 * LP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int q0 = blockIdx.x * 256 + wave * (32 * CB);    // this wave's queries: CB column blocks of 32
@@ -193,6 +195,7 @@ __global__ __launch_bounds__(NW * 64) void knn2_mfma_kernel(const uint8_t* __res
     };
     if (tile0 < tile1) fetch(tile0);
     for (int tile = tile0; tile < tile1; tile++) {
+        uint8_t* s_tile = s_tiles + (DB ? ((tile - tile0) & 1) * 32 * LP : 0);
 #pragma unroll
         for (int j = 0; j < NPF; j++) {
             const int piece = tid + NT * j, row = piece / (NB / 16), col = piece - row * (NB / 16);
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(NW * 64) void knn2_mfma_kernel(const uint8_t* __res
                 }
             }
         }
-        __syncthreads();                                   // every wave is done with the tile before it is overwritten
+        if (!DB) __syncthreads();                          // every wave is done with the tile before it is overwritten
     }
     // the two row-halves of a query (lanes l and l + 32) merge their best two; dot -> Hamming distance
 #pragma unroll
@@ -477,7 +480,9 @@ hipError_t efx_launch_knn2_mfma(const uint8_t* query, size_t q_pitch, int nq, co
             if (desc_bytes == 32) hipLaunchKernelGGL((knn2_fp4_kernel<256, 2>), grid, dim3(512), 0, stream, xq, nq, xt, nt, tpc, partial);
             else hipLaunchKernelGGL((knn2_fp4_kernel<512, 2>), grid, dim3(512), 0, stream, xq, nq, xt, nt, tpc, partial);
         } else {
+            static const bool db = getenv("EFX_MATCH_DB") != nullptr;      // INVESTIGATION: the double-buffered, one-barrier form
             if (desc_bytes == 32) hipLaunchKernelGGL((knn2_mfma_kernel<256, 1, 8, true>), grid, dim3(512), 0, stream, xq, nq, xt, nt, tpc, partial);
+            else if (db) hipLaunchKernelGGL((knn2_mfma_kernel<512, 1, 8, true, true>), grid, dim3(512), 0, stream, xq, nq, xt, nt, tpc, partial);
             else hipLaunchKernelGGL((knn2_mfma_kernel<512, 1, 8, true>), grid, dim3(512), 0, stream, xq, nq, xt, nt, tpc, partial);
         }
     } else {

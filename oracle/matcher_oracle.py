@@ -44,3 +44,23 @@ def crosscheck(query, train):
         if t2q[q2t[i]] == i:
             m[i] = q2t[i]
     return m, dd
+
+
+def knn2_c(query, train):
+    """knn2 at full size: oracle/matcher_oracle.c (OpenMP, 64-bit popcounts), same tie rule; desc bytes a multiple of 8."""
+    import ctypes
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    so = os.path.join(here, "libefx_matcher_oracle.so")
+    if not os.path.exists(so):
+        import subprocess
+        subprocess.check_call(["make", "-s", "-C", here, "libefx_matcher_oracle.so"])
+    lib = ctypes.CDLL(so)
+    q = np.ascontiguousarray(query, dtype=np.uint8)
+    t = np.ascontiguousarray(train, dtype=np.uint8)
+    assert q.shape[1] == t.shape[1] and q.shape[1] % 8 == 0 and q.shape[1] <= 128
+    idx = np.full((q.shape[0], 2), -1, np.int32)
+    dist = np.full((q.shape[0], 2), -1, np.int32)
+    lib.efxo_knn2_hamming(q.ctypes.data_as(ctypes.c_void_p), q.shape[0], t.ctypes.data_as(ctypes.c_void_p), t.shape[0], q.shape[1],
+                          idx.ctypes.data_as(ctypes.c_void_p), dist.ctypes.data_as(ctypes.c_void_p))
+    return idx, dist

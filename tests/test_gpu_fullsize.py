@@ -206,3 +206,47 @@ def test_natural_statistics_4k(cef, threaded_oracle, kind):
     nbad = int(np.count_nonzero(got != ref2["desc"]))
     print(f"\n{kind}: {n} keypoints, FAST corners {sum(ref['stats']['n_candidates'])}, HashSIFT512 bytes differing {nbad} of {got.size} ({nbad / got.size:.2e})")
     assert nbad <= max(4, int(1e-4 * got.size))
+
+
+@pytest.mark.parametrize("nbytes", [32, 64])
+@pytest.mark.parametrize("kind", ["random", "ties"])
+def test_matcher_40k_by_40k_all_three_kernels(cef, monkeypatch, nbytes, kind):
+    """The quoted matcher workload at its FULL size: knnMatch(k = 2) of 40 000 x 40 000 descriptors of 256 and
+    512 bit through the FP4 (MX) matrix-core kernel, the int8 matrix-core kernel and the popcount kernel -- at this size the
+    matrix-core kernels cut the train set into occupancy-sized chunks and merge the per-chunk best-twos (knn2_merge_kernel), a
+    chunk count no smaller case reaches -- against oracle/matcher_oracle.c (OpenMP popcounts; sample_image_sequence.cpp:114-144).
+    `ties`: descriptors drawn from a pool of 300 with noisy copies, so that most queries have several trains at their best and
+    second-best distance and the lower train index must win across chunk boundaries."""
+    import torch
+    from oracle import matcher_oracle as MO
+    n = 40000
+    rng = np.random.default_rng(4000 + nbytes + (7 if kind == "ties" else 0))
+    if kind == "random":
+        q = rng.integers(0, 256, size=(n, nbytes), dtype=np.uint8)
+        t = rng.integers(0, 256, size=(n, nbytes), dtype=np.uint8)
+        sel = rng.permutation(n)[: n // 2]
+        t[sel] = q[rng.permutation(n)[: n // 2]]                        # exact matches at random train positions
+        near = rng.permutation(n)[: n // 8]
+        t[near] = q[near] ^ (rng.random((len(near), nbytes)) < 0.05).astype(np.uint8) * np.uint8(4)
+    else:
+        pool = rng.integers(0, 256, size=(300, nbytes), dtype=np.uint8)
+        q = pool[rng.integers(0, 300, n)] ^ ((rng.random((n, nbytes)) < 0.01).astype(np.uint8) * np.uint8(1))
+        t = pool[rng.integers(0, 300, n)] ^ ((rng.random((n, nbytes)) < 0.01).astype(np.uint8) * np.uint8(1))
+    q, t = np.ascontiguousarray(q), np.ascontiguousarray(t)
+    widx, wdist = MO.knn2_c(q, t)
+    if kind == "ties":
+        assert (np.diff(wdist, axis=1) == 0).mean() > 0.2                  # many queries with best == second best
+    for k in ("EFX_MATCH_NO_MFMA", "EFX_MATCH_NO_FP4"):
+        monkeypatch.delenv(k, raising=False)
+    dq, dt = _dev(q), _dev(t)
+    for name, env in (("fp4", None), ("int8", "EFX_MATCH_NO_FP4"), ("popcount", "EFX_MATCH_NO_MFMA")):
+        if env:
+            monkeypatch.setenv(env, "1")
+        m = cef.BFMatcher.create(cef.BFMatcher.NORM_HAMMING)               # the knobs are read when a matcher is created
+        if env:
+            monkeypatch.delenv(env)
+        idx, dist = m.knnMatch(dq, dt, 2)
+        torch.cuda.synchronize()
+        gd, gi = dist.cpu().numpy(), idx.cpu().numpy()
+        bad = np.flatnonzero((gd != wdist).any(axis=1) | (gi != widx).any(axis=1))
+        assert bad.size == 0, f"{name} kernel, {8 * nbytes} bit, {kind}: {bad.size} queries differ, first {bad[:5]}: got {gi[bad[:3]].tolist()} / {gd[bad[:3]].tolist()} want {widx[bad[:3]].tolist()} / {wdist[bad[:3]].tolist()}"
