@@ -443,7 +443,7 @@ int efx_knn2_mfma_resident_workgroups(int desc_bytes, int fp4)
     const void* f;
     if (!fp4) f = desc_bytes == 32 ? reinterpret_cast<const void*>(&knn2_mfma_kernel<256, 1, 8, false>) : reinterpret_cast<const void*>(&knn2_mfma_kernel<512, 1, 8, false>);
     else if (tt == 2) f = desc_bytes == 32 ? reinterpret_cast<const void*>(&knn2_fp4_kernel<256, 2>) : reinterpret_cast<const void*>(&knn2_fp4_kernel<512, 2>);
-    else f = desc_bytes == 32 ? reinterpret_cast<const void*>(&knn2_mfma_kernel<256, 1, 8, true>) : reinterpret_cast<const void*>(&knn2_mfma_kernel<512, 1, 8, true>);
+    else f = desc_bytes == 32 ? reinterpret_cast<const void*>(&knn2_mfma_kernel<256, 1, 8, true>) : reinterpret_cast<const void*>(&knn2_mfma_kernel<512, 1, 8, true, true>);
     int per_cu = 0, dev = 0, cus = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, f, 512, 0) != hipSuccess || per_cu < 1) per_cu = 2;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
@@ -480,9 +480,12 @@ hipError_t efx_launch_knn2_mfma(const uint8_t* query, size_t q_pitch, int nq, co
             if (desc_bytes == 32) hipLaunchKernelGGL((knn2_fp4_kernel<256, 2>), grid, dim3(512), 0, stream, xq, nq, xt, nt, tpc, partial);
             else hipLaunchKernelGGL((knn2_fp4_kernel<512, 2>), grid, dim3(512), 0, stream, xq, nq, xt, nt, tpc, partial);
         } else {
-            static const bool db = getenv("EFX_MATCH_DB") != nullptr;      // INVESTIGATION: the double-buffered, one-barrier form
+            // 512 bit: the double-buffered form (one barrier per step; round 5: 0.433 -> 0.414 ms per 40 000 x 40 000 call on one box;
+            // EFX_MATCH_NO_DB: the two-barrier form, A/B).  Measured and dropped on the way: two query blocks per wave (half the LDS
+            // fragment reads per MFMA, but 180 VGPRs with spills: 0.70 ms)
+            static const bool no_db = getenv("EFX_MATCH_NO_DB") != nullptr;
             if (desc_bytes == 32) hipLaunchKernelGGL((knn2_mfma_kernel<256, 1, 8, true>), grid, dim3(512), 0, stream, xq, nq, xt, nt, tpc, partial);
-            else if (db) hipLaunchKernelGGL((knn2_mfma_kernel<512, 1, 8, true, true>), grid, dim3(512), 0, stream, xq, nq, xt, nt, tpc, partial);
+            else if (!no_db) hipLaunchKernelGGL((knn2_mfma_kernel<512, 1, 8, true, true>), grid, dim3(512), 0, stream, xq, nq, xt, nt, tpc, partial);
             else hipLaunchKernelGGL((knn2_mfma_kernel<512, 1, 8, true>), grid, dim3(512), 0, stream, xq, nq, xt, nt, tpc, partial);
         }
     } else {
