@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 // INVESTIGATION (EFX_DEBUG_BUILD builds only): EFX_TRACE=1 names every launch on stderr, waits for it
 // and calls a digest hook (efx_api.cpp) -- how the "16 processes share the GPU" discrepancy was traced to stores of one XCD
 // missing from memory after fast_kernel's first run on freshly allocated buffers
@@ -529,12 +530,12 @@ __global__ __launch_bounds__(256) void resize_stream_kernel(
 }
 
 // ================================================================================================
-// Kernel R-rows (round 5): TWO pyramid levels per launch for large frames, by waves that walk DOWN the image.
+// Kernel R-rows (round 5): SEVERAL pyramid levels per launch for large frames, by waves that walk DOWN the image.
 // The tiled kernels above are bound by neither VALU issue (46 % of its ceiling) nor HBM (0.30): a workgroup stages a footprint,
 // meets at barriers, runs four short row iterations and starts over, and every level is a launch with its own ramp and tail
-// (7 x 10 us at 8K for 170 MB of traffic and ~30 us of issue time).  Here a WAVE owns a strip of RW_OWN = 248 columns of level
-// s + 1 (a lane: four adjacent outputs = one dword of the destination; lanes 62 / 63 compute eight halo columns) and a chunk of
-// rows, and visits the source rows of level s it needs ONE BY ONE, top to bottom:
+// (7 x 10 us at 8K for 170 MB of traffic and ~30 us of issue time).  Here a WAVE owns a strip of `own` columns of level s + 1
+// (a lane: four adjacent outputs = one dword of the destination; the lanes behind the owned ones compute halo columns) and a
+// chunk of rows, and visits the source rows of level s it needs ONE BY ONE, top to bottom:
 //   * source row r arrives by LDS-DMA (buffer_load ... lds: lane j's dword j of the footprint straight into one of the wave's
 //     RW_D LDS slots, RW_D rows ahead, no registers, no workgroup barrier anywhere); every lane takes the two 8-byte windows
 //     that hold the source pixel pairs of its four outputs (the byte gather of resize_quad_win) and converts them to float
@@ -542,35 +543,37 @@ __global__ __launch_bounds__(256) void resize_stream_kernel(
 //   * when r is the lower source row of a destination row (a bit mask from the host says so) that row is made: 16 rounded
 //     weight products + the 4-term FMA chain of spec S5 per lane on full-rate fp32 instructions with VECTOR operands,
 //     v_cvt_pk_u8_f32, one range-checked dword store;
-//   * NLEV == 2: that row of level s + 1 also goes to an LDS row of its own, and the same two steps produce level s + 2 from it
-//     (lanes 0 .. ~52: a strip owns the level-(s+2) column groups whose first source column it owns, so every store is a whole
-//     dword and the levels are partitioned exactly; one halo row of level s + 1 per chunk is computed and not stored).
-// Level s + 1 is never re-read from memory, the chain is 4 launches instead of 7 (8K: 0 -> 1, 2; 2 -> 3, 4; 4 -> 5, 6; 6 -> 7).
-// Per pixel the arithmetic is resize_quad_win's, term by term: bit-identical levels (tests: the chain_rows mode).
+//   * that row of level s + 1 also goes to an LDS row of its own, and the same two steps produce level s + 2 from it -- and so on
+//     up to NLEV levels (a strip owns the column groups of level k + 1 whose first source column it owns at level k, so every
+//     store is a whole dword and the levels are partitioned exactly; the halo columns / one halo row per level and chunk that
+//     the next level's +1 neighbours need are computed and not stored).
+// No level of a launch but the last is re-read from memory, and the chain is 2 -- 4 launches instead of 7 (efx_api.cpp,
+// build_rows_plan: which levels share a launch).  Per pixel the arithmetic is resize_quad_win's, term by term: bit-identical
+// levels (tests: the chain_rows mode).
 // What the first version taught: the CU's ONE scalar unit is the bound of a loop like this -- with ~60 scalar instructions per
 // source row (row / slot bookkeeping, per-row "is a destination row due" compares on v_readlane values, M0 save / restore
 // around every LDS-DMA) the first launch took 21 us with loads, stores AND arithmetic compiled out, and neither the
 // prefetch depth nor the number of waves changed that.  Hence: everything that can be decided ahead is a table
-// (RowsPlanLaunch, efx_api.cpp, spec S5's float expressions): which source rows complete a destination row (two 64-bit masks
-// per chunk), column / row weights, strips; rows beyond the chunk fall outside the buffer resource (no compares); the loop is
-// unrolled by the slot count, so slots and the upper / lower roles of the two converted source rows are static.  The host
-// also checks what the kernel relies on (footprint <= 128 dwords, windows valid, <= 64 source rows per chunk, no clamped +1
-// neighbours: a geometry that fails goes through the tiled kernels).
+// (RowsPlanLaunch, spec S5's float expressions): which source rows complete a destination row (one 64-bit mask per level and
+// chunk), column / row weights, strips; rows beyond the chunk fall outside the buffer resource (no compares); the loop is
+// unrolled by the slot count, so slots and the upper / lower roles of the two converted source rows are static.  What is left
+// is VALU issue: ~80 % busy while the waves live (SQ counters), plus ~5 us per launch that no wave sees.  The host checks what
+// the kernel relies on (footprint <= 128 dwords, windows valid, <= 64 source rows per chunk, no clamped +1 neighbours: a
+// geometry that fails goes through the tiled kernels).
 // ================================================================================================
 #ifndef RW_DBG
-#define RW_DBG 0                                            // investigation builds: 1 no stores, 2 no arithmetic, 4 no loads in the loop, 8 no conversion of source rows, 16 no level s + 2
+#define RW_DBG 0                                            // investigation builds: 1 no stores, 2 no arithmetic
 #endif
 #define RW_LDS_A 528                                        // 128 dwords + the reach of a window read
 #define RW_LDS_B 272                                        // 64 dwords + the same
-#define RW_LDS (RW_D * RW_LDS_A + RW_LDS_B)
 typedef __attribute__((address_space(3))) unsigned char efx_lds_uchar;
 
+struct RowsLevelArgs { uint8_t* dst; int pitch, rows, cols; const int* x; const int4* y; int W; };
 struct RowsArgs {
     const uint8_t* src; int spitch, srows, scols;
-    uint8_t* dstB; int bpitch, brows, bcols;
-    uint8_t* dstC; int cpitch, crows, ccols;
-    const int* xB; const int4* yB; const int* xC; const int4* yC; const int4* strips; const int4* chunks;
-    int WB, WC, nstrips, ntasks;
+    RowsLevelArgs lv[RW_MAXLEV];
+    const int4* strips; const int4* chunks;
+    int nstrips, ntasks, own;
 };
 
 // One dword per lane from a buffer straight into LDS (LDS-DMA: no VGPR destination, so nothing the compiler could copy or
@@ -582,7 +585,7 @@ __device__ __forceinline__ void rows_dma2(const __amdgpu_buffer_rsrc_t rsrc, int
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %0, %3, 0 offen lds\n\tbuffer_load_dword %1, %3, 0 offen offset:256 lds"
                  : : "v"(voff0), "v"(voff1), "s"(lds_dst), "s"(rsrc) : "memory");
 }
-template <int N> __device__ __forceinline__ void rows_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" : : "i"((RW_DBG & 4) ? 0 : N) : "memory"); }
+template <int N> __device__ __forceinline__ void rows_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" : : "i"(N) : "memory"); }
 
 // the source pixel pairs of a lane's four outputs from an LDS row: [left, right] x 4 as floats
 __device__ __forceinline__ void rows_conv(const unsigned char* row, const ResizeWin& w, float (&f)[8])
@@ -620,66 +623,95 @@ __device__ __forceinline__ void rows_lds_order()
     __builtin_amdgcn_wave_barrier();
 }
 
+// per-level state of a wave (every index into these arrays is a compile-time constant after inlining: registers, not memory)
+template <int NLEV>
+struct RowsState {
+    float wa[NLEV][4], wb[NLEV][4];                          // x weights of the lane's four columns
+    ResizeWin win[NLEV];                                     // where their source pixel pairs sit in the level's source row
+    int ytz[NLEV], ytw[NLEV];                                // y weights of the chunk's rows, one row per lane (v_readlane)
+    int off[NLEV];                                           // store offset (a value the range check drops for lanes that own nothing)
+    int pitch[NLEV];
+    __amdgpu_buffer_rsrc_t rsrc[NLEV];
+    unsigned long long mask[NLEV];
+    int made[NLEV];                                          // rows of the level made so far
+    float g[NLEV][2][8];                                     // levels >= 1: converted upper / lower source row
+};
+
+// the row of level K - 1 just made (`packed`, K >= 1) is the next source row of level K
+template <int K, int NLEV>
+__device__ __forceinline__ void rows_push(RowsState<NLEV>& S, unsigned char* rowbuf, int lane, uint32_t packed, const bool (&due)[NLEV])
+{
+    if constexpr (K < NLEV) {
+        unsigned char* row = rowbuf + (K - 1) * RW_LDS_B;
+        *reinterpret_cast<uint32_t*>(row + 4 * lane) = packed;
+        rows_lds_order();
+#pragma unroll
+        for (int q = 0; q < 8; q++) S.g[K][0][q] = S.g[K][1][q];
+        rows_conv(row, S.win[K], S.g[K][1]);
+        if (due[K]) {
+            float wy0 = __int_as_float(__builtin_amdgcn_readlane(S.ytz[K], S.made[K])), wy1 = __int_as_float(__builtin_amdgcn_readlane(S.ytw[K], S.made[K]));
+            asm volatile("" : "+v"(wy0), "+v"(wy1));        // vector registers: a scalar source halves the rate of v_mul / v_fma
+            S.made[K]++;
+            const uint32_t pk = rows_quad(S.g[K][0], S.g[K][1], S.wa[K], S.wb[K], wy0, wy1);
+            if (!(RW_DBG & 1) || pk == 0x12345678u) __builtin_amdgcn_raw_buffer_store_b32(pk, S.rsrc[K], S.off[K], 0, 0);
+            S.off[K] += S.pitch[K];
+            rows_push<K + 1, NLEV>(S, rowbuf, lane, pk, due);
+        }
+    }
+}
+
 template <int NLEV>
 __global__ __launch_bounds__(256) void resize_rows_kernel(const RowsArgs A, Counters* __restrict__ zero, int zero_levels)
 {
-    static_assert((RW_LDS & 15) == 0 && (RW_D & 1) == 0, "LDS rows: 16-byte aligned; an even number of slots");
-    __shared__ __attribute__((aligned(16))) unsigned char s_rows[4 * RW_LDS];
+    constexpr int LDS_WAVE = RW_D * RW_LDS_A + (NLEV > 1 ? (NLEV - 1) * RW_LDS_B : 16);
+    static_assert((LDS_WAVE & 15) == 0 && (RW_D & 1) == 0 && NLEV >= 1 && NLEV <= RW_MAXLEV, "LDS rows: 16-byte aligned; an even number of slots");
+    __shared__ __attribute__((aligned(16))) unsigned char s_rows[4 * LDS_WAVE];
     if (zero && blockIdx.x == 0) efx_zero_counters(zero, zero_levels, threadIdx.x, 256);
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int task = xcd_chunked(blockIdx.x, gridDim.x) * 4 + wave;
     if (task >= A.ntasks) return;
     const int chunk = task / A.nstrips, strip = task - chunk * A.nstrips;
-    const int4 st = A.strips[strip];
-    const int4 k0 = A.chunks[3 * chunk], k1 = A.chunks[3 * chunk + 1], k2 = A.chunks[3 * chunk + 2];
     // (wave-uniform by construction; said so explicitly: the LDS-DMA statements need their descriptor and M0 in scalar registers)
     auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
-    const int ax0 = uni(st.x), nd = uni(st.y);
-    const int a_first = uni(k0.x), a_last = uni(k0.y), b_first = uni(k0.z), b_end = uni(k0.w), c_first = uni(k1.x), c_end = uni(k1.y), na_pad = uni(k1.z);
-    // bit i: source row a_first + i is the lower source row of a row of level s + 1 / that row in turn of one of level s + 2
-    unsigned long long mask_b = ((unsigned long long)(uint32_t)k2.y << 32) | (uint32_t)k2.x;
-    unsigned long long mask_c = ((unsigned long long)(uint32_t)k2.w << 32) | (uint32_t)k2.z;
-    unsigned char* rowA = s_rows + wave * RW_LDS;            // RW_D slots of one source row each
-    unsigned char* rowB = rowA + RW_D * RW_LDS_A;
+    const int4* st = A.strips + RW_STRIP_INT4 * strip;
+    const int4* ck = A.chunks + RW_CHUNK_INT4 * chunk;
+    const int4 st0 = st[0], ck0 = ck[0];
+    const int ax0 = uni(st0.x), nd = uni(st0.y);
+    const int a_first = uni(ck0.x), a_last = uni(ck0.y), na_pad = uni(ck0.z);
+    unsigned char* rowA = s_rows + wave * LDS_WAVE;          // RW_D slots of one source row each
+    unsigned char* rowbuf = rowA + RW_D * RW_LDS_A;          // one row of each level but the last
 
-    // ---- level s + 1: this lane's four columns ----
-    const int bx0 = strip * RW_OWN, bxq = bx0 + 4 * lane;
-    float wa[4], wb[4];
-    ResizeWin win;
-    {
-        const int4 x1 = *reinterpret_cast<const int4*>(A.xB + bxq);
-        const float4 w0 = *reinterpret_cast<const float4*>(A.xB + A.WB + bxq);
-        const float4 w1 = *reinterpret_cast<const float4*>(A.xB + 2 * A.WB + bxq);
-        const int lc[4] = { x1.x - ax0, x1.y - ax0, x1.z - ax0, x1.w - ax0 };
-        win = resize_windows(lc);
-        wa[0] = w0.x; wa[1] = w0.y; wa[2] = w0.z; wa[3] = w0.w;
-        wb[0] = w1.x; wb[1] = w1.y; wb[2] = w1.z; wb[3] = w1.w;
-    }
-    const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(A.dstB, 0, b_end * A.bpitch, 0x00020000);
-    // lanes that own no column of the level (halo lanes, lanes beyond the last column): an offset the range check drops
-    int boff = (lane < RW_OWN / 4 && bxq < A.bcols) ? b_first * A.bpitch + bxq : 0x7ffffff0;
-    const int4 ytb = A.yB[b_first + lane];                           // row table of this chunk, one row per lane (v_readlane)
-
-    // ---- level s + 2: this lane's column group ----
-    float wc[4], wd[4];
-    ResizeWin winC;
-    __amdgpu_buffer_rsrc_t rsrcC = rsrcB;
-    int coff = 0x7ffffff0;
-    int4 ytc = make_int4(0, 0, 0, 0);
-    if (NLEV == 2) {
-        const bool act = lane < st.w;
-        const int cxq = 4 * (st.z + lane);
-        const int4 x1 = *reinterpret_cast<const int4*>(A.xC + cxq);
-        const float4 w0 = *reinterpret_cast<const float4*>(A.xC + A.WC + cxq);
-        const float4 w1 = *reinterpret_cast<const float4*>(A.xC + 2 * A.WC + cxq);
-        const int lc[4] = { act ? x1.x - bx0 : 0, act ? x1.y - bx0 : 0, act ? x1.z - bx0 : 0, act ? x1.w - bx0 : 0 };
-        winC = resize_windows(lc);
-        wc[0] = w0.x; wc[1] = w0.y; wc[2] = w0.z; wc[3] = w0.w;
-        wd[0] = w1.x; wd[1] = w1.y; wd[2] = w1.z; wd[3] = w1.w;
-        rsrcC = __builtin_amdgcn_make_buffer_rsrc(A.dstC, 0, c_end * A.cpitch, 0x00020000);
-        if (act && cxq < A.ccols) coff = c_first * A.cpitch + cxq;
-        ytc = A.yC[c_first + lane];
+    RowsState<NLEV> S;
+#pragma unroll
+    for (int k = 0; k < NLEV; k++) {
+        const RowsLevelArgs& L = A.lv[k];
+        // the lane's four columns: level 0 of the launch by position in the strip, the others by column group
+        const int4 sk = k == 0 ? make_int4(0, 0, 0, 0) : st[k];
+        const int col0 = k == 0 ? strip * A.own + 4 * lane : 4 * (uni(sk.x) + lane);
+        const int nown = k == 0 ? A.own / 4 : uni(sk.y), ncomp = k == 0 ? 64 : uni(sk.z);
+        const int org = k == 0 ? ax0 : (k == 1 ? strip * A.own : 4 * uni(st[k - 1].x));      // source column at LDS byte 0 of its source row
+        const bool act = lane < ncomp;
+        const int4 x1 = *reinterpret_cast<const int4*>(L.x + col0);
+        const float4 w0 = *reinterpret_cast<const float4*>(L.x + L.W + col0);
+        const float4 w1 = *reinterpret_cast<const float4*>(L.x + 2 * L.W + col0);
+        const int lc[4] = { act ? x1.x - org : 0, act ? x1.y - org : 0, act ? x1.z - org : 0, act ? x1.w - org : 0 };
+        S.win[k] = resize_windows(lc);
+        S.wa[k][0] = w0.x; S.wa[k][1] = w0.y; S.wa[k][2] = w0.z; S.wa[k][3] = w0.w;
+        S.wb[k][0] = w1.x; S.wb[k][1] = w1.y; S.wb[k][2] = w1.z; S.wb[k][3] = w1.w;
+        const int4 ckk = ck[1 + k];
+        const int first = uni(ckk.x), store_end = uni(ckk.y);
+        S.rsrc[k] = __builtin_amdgcn_make_buffer_rsrc(L.dst, 0, store_end * L.pitch, 0x00020000);     // rows from store_end on: dropped
+        S.pitch[k] = L.pitch;
+        // lanes that own no column of the level (halo lanes, lanes beyond the last column): an offset the range check drops
+        S.off[k] = (lane < nown && col0 < L.cols) ? first * L.pitch + col0 : 0x7ffffff0;
+        const int4 yt = L.y[first + lane];                   // row table of this chunk, one row per lane
+        S.ytz[k] = yt.z; S.ytw[k] = yt.w;
+        const int4 mk = ck[1 + RW_MAXLEV + k / 2];
+        S.mask[k] = (k & 1) ? (((unsigned long long)(uint32_t)mk.w << 32) | (uint32_t)mk.z) : (((unsigned long long)(uint32_t)mk.y << 32) | (uint32_t)mk.x);
+        S.made[k] = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) { S.g[k][0][q] = 0.f; S.g[k][1][q] = 0.f; }
     }
 
     // ---- source rows: dword j of the footprint by lane j (and j + 64), RW_D rows ahead, straight into the wave's LDS slots ----
@@ -690,14 +722,13 @@ __global__ __launch_bounds__(256) void resize_rows_kernel(const RowsArgs A, Coun
         __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(A.src), 0, a_last * A.spitch + ((A.scols + 3) & ~3), 0x00020000);
     int vo0 = a_first * A.spitch + ax0 + 4 * lane;
     int vo1 = lane + 64 < nd ? vo0 : 0x7ffffff0;            // (the second load's + 256 is its immediate offset)
-    const uint32_t ldsA = (uint32_t)(uintptr_t)(efx_lds_uchar*)s_rows + (uint32_t)wave * RW_LDS;
+    const uint32_t ldsA = (uint32_t)(uintptr_t)(efx_lds_uchar*)s_rows + (uint32_t)wave * LDS_WAVE;
 #pragma unroll
     for (int u = 0; u < RW_D; u++) { rows_dma2(rsrcA, vo0, vo1, ldsA + u * RW_LDS_A); vo0 += A.spitch; vo1 += A.spitch; }
 
-    float f0[8], f1[8], ga[8], gb[8];                        // converted source rows: even / odd slots; level s + 1: upper / lower
+    float f0[8], f1[8];                                      // converted source rows of the even / odd slots
 #pragma unroll
-    for (int i = 0; i < 8; i++) { f0[i] = 0.f; f1[i] = 0.f; ga[i] = 0.f; gb[i] = 0.f; }
-    int ib = 0, ic = 0;                                      // rows of level s + 1 / s + 2 made so far
+    for (int i = 0; i < 8; i++) { f0[i] = 0.f; f1[i] = 0.f; }
 
     for (int i0 = 0; i0 < na_pad; i0 += RW_D) {
 #pragma unroll
@@ -707,36 +738,20 @@ __global__ __launch_bounds__(256) void resize_rows_kernel(const RowsArgs A, Coun
             // source row i0 + u has landed in slot u when at most the loads of the RW_D - 1 rows behind it are in flight (stores
             // issued since count as well: the wait is conservative by the rows they stand for)
             rows_wait_vm<2 * (RW_D - 1)>();
-            if (!(RW_DBG & 8)) rows_conv(rowA + u * RW_LDS_A, win, fcur);
-            if (!(RW_DBG & 4)) rows_dma2(rsrcA, vo0, vo1, ldsA + u * RW_LDS_A);            // the slot's next row (beyond the chunk: dropped)
+            rows_conv(rowA + u * RW_LDS_A, S.win[0], fcur);
+            rows_dma2(rsrcA, vo0, vo1, ldsA + u * RW_LDS_A);            // the slot's next row (beyond the chunk: dropped)
             vo0 += A.spitch; vo1 += A.spitch;
-            const bool due_b = (mask_b & 1ull) != 0;
-            const bool due_c = (mask_c & 1ull) != 0;
-            mask_b >>= 1; mask_c >>= 1;
-            if (due_b) {
-                float wy0 = __int_as_float(__builtin_amdgcn_readlane(ytb.z, ib)), wy1 = __int_as_float(__builtin_amdgcn_readlane(ytb.w, ib));
-                asm volatile("" : "+v"(wy0), "+v"(wy1));    // vector registers: a scalar source halves the rate of v_mul / v_fma
-                ib++;
-                const uint32_t packed = rows_quad(fprev, fcur, wa, wb, wy0, wy1);
-                if (!(RW_DBG & 1) || packed == 0x12345678u)
-                    __builtin_amdgcn_raw_buffer_store_b32(packed, rsrcB, boff, 0, 0);      // rows from b_end on: dropped by the range check
-                boff += A.bpitch;
-                if (NLEV == 2 && !(RW_DBG & 16)) {
-                    // ---- the row just made is the next source row of level s + 2 ----
-                    *reinterpret_cast<uint32_t*>(rowB + 4 * lane) = packed;
-                    rows_lds_order();
+            bool due[NLEV];
 #pragma unroll
-                    for (int q = 0; q < 8; q++) ga[q] = gb[q];
-                    rows_conv(rowB, winC, gb);
-                    if (due_c) {
-                        float vy0 = __int_as_float(__builtin_amdgcn_readlane(ytc.z, ic)), vy1 = __int_as_float(__builtin_amdgcn_readlane(ytc.w, ic));
-                        asm volatile("" : "+v"(vy0), "+v"(vy1));
-                        ic++;
-                        const uint32_t pc = rows_quad(ga, gb, wc, wd, vy0, vy1);
-                        if (!(RW_DBG & 1) || pc == 0x12345678u) __builtin_amdgcn_raw_buffer_store_b32(pc, rsrcC, coff, 0, 0);
-                        coff += A.cpitch;
-                    }
-                }
+            for (int k = 0; k < NLEV; k++) { due[k] = (S.mask[k] & 1ull) != 0; S.mask[k] >>= 1; }
+            if (due[0]) {
+                float wy0 = __int_as_float(__builtin_amdgcn_readlane(S.ytz[0], S.made[0])), wy1 = __int_as_float(__builtin_amdgcn_readlane(S.ytw[0], S.made[0]));
+                asm volatile("" : "+v"(wy0), "+v"(wy1));    // vector registers: a scalar source halves the rate of v_mul / v_fma
+                S.made[0]++;
+                const uint32_t packed = rows_quad(fprev, fcur, S.wa[0], S.wb[0], wy0, wy1);
+                if (!(RW_DBG & 1) || packed == 0x12345678u) __builtin_amdgcn_raw_buffer_store_b32(packed, S.rsrc[0], S.off[0], 0, 0);
+                S.off[0] += S.pitch[0];
+                rows_push<1, NLEV>(S, rowbuf, lane, packed, due);
             }
         }
     }
@@ -2376,24 +2391,29 @@ static hipError_t efx_launch_detect_impl(const DetectLaunch& a, hipStream_t stre
         // dword staging reads up to roundup4(cols) bytes of a row: always inside our own (padded) pyramid levels, inside a
         // caller's image only when its width is a multiple of 4 (otherwise the byte path)
         const int aligned = (((uintptr_t)src | (uintptr_t)spitch) & 3u) == 0 && (s > 0 || (L.cols & 3) == 0);
-        // round 5: two levels per launch by waves walking down strips (resize_rows_kernel); EFX_NO_RESIZE_ROWS: the tiled kernels
+        // round 5: several levels per launch by waves walking down strips (resize_rows_kernel); EFX_NO_RESIZE_ROWS: the tiled kernels
         const RowsPlanLaunch* RP = (a.rows_plan && a.rplan && !a.knobs.no_resize_rows) ? &a.rows_plan[s] : nullptr;
         if (RP && RP->nlev > 0 && aligned && s + RP->nlev <= chain_end) {
-            const LevelDev& C = H.lv[s + RP->nlev];
             RowsArgs ra;
+            memset(&ra, 0, sizeof(ra));
             ra.src = src; ra.spitch = spitch; ra.srows = L.rows; ra.scols = L.cols;
-            ra.dstB = a.pyramid + N.img_off; ra.bpitch = N.pitch; ra.brows = N.rows; ra.bcols = N.cols;
-            ra.dstC = a.pyramid + C.img_off; ra.cpitch = C.pitch; ra.crows = C.rows; ra.ccols = C.cols;
-            ra.xB = reinterpret_cast<const int*>(a.rplan + RP->xB_off); ra.yB = reinterpret_cast<const int4*>(a.rplan + RP->yB_off);
-            ra.xC = reinterpret_cast<const int*>(a.rplan + RP->xC_off); ra.yC = reinterpret_cast<const int4*>(a.rplan + RP->yC_off);
+            for (int k = 0; k < RP->nlev; k++) {
+                const LevelDev& D = H.lv[s + 1 + k];
+                ra.lv[k].dst = a.pyramid + D.img_off; ra.lv[k].pitch = D.pitch; ra.lv[k].rows = D.rows; ra.lv[k].cols = D.cols;
+                ra.lv[k].x = reinterpret_cast<const int*>(a.rplan + RP->x_off[k]); ra.lv[k].y = reinterpret_cast<const int4*>(a.rplan + RP->y_off[k]);
+                ra.lv[k].W = RP->W[k];
+            }
             ra.strips = reinterpret_cast<const int4*>(a.rplan + RP->strip_off); ra.chunks = reinterpret_cast<const int4*>(a.rplan + RP->chunk_off);
-            ra.WB = RP->WB; ra.WC = RP->WC; ra.nstrips = RP->nstrips; ra.ntasks = RP->nstrips * RP->nchunks;
+            ra.nstrips = RP->nstrips; ra.ntasks = RP->nstrips * RP->nchunks; ra.own = RP->own;
             const int nblk = (ra.ntasks + 3) / 4;
             const bool prof = a.prof.begin(100 + s, stream);
-            if (RP->nlev == 2)
-                hipLaunchKernelGGL(resize_rows_kernel<2>, dim3(nblk), dim3(256), 0, stream, ra, zeroed ? nullptr : a.counters, H.nlevels);
-            else
-                hipLaunchKernelGGL(resize_rows_kernel<1>, dim3(nblk), dim3(256), 0, stream, ra, zeroed ? nullptr : a.counters, H.nlevels);
+            Counters* zc = zeroed ? nullptr : a.counters;
+            switch (RP->nlev) {
+            case 1: hipLaunchKernelGGL(resize_rows_kernel<1>, dim3(nblk), dim3(256), 0, stream, ra, zc, H.nlevels); break;
+            case 2: hipLaunchKernelGGL(resize_rows_kernel<2>, dim3(nblk), dim3(256), 0, stream, ra, zc, H.nlevels); break;
+            case 3: hipLaunchKernelGGL(resize_rows_kernel<3>, dim3(nblk), dim3(256), 0, stream, ra, zc, H.nlevels); break;
+            default: hipLaunchKernelGGL(resize_rows_kernel<4>, dim3(nblk), dim3(256), 0, stream, ra, zc, H.nlevels); break;
+            }
             zeroed = true;
             a.prof.end(prof, 100 + s, stream);
             EFX_TRACE_POINT("resize_rows");

@@ -506,50 +506,67 @@ int validate_params(const efx_params& p, std::string& err)
     return EFX_OK;
 }
 
-// Tables of resize_rows_kernel (detect_kernels.hip): for every even source level s a launch that makes level s + 1 and, when it
-// exists, s + 2.  Everything the kernel relies on is checked here; a launch whose geometry does not fit gets nlev = 0 and its
-// levels go through the tiled per-level kernels.  The float expressions are spec S5's (the ones of the plan above).
+#ifndef EFX_ROWS_SPLIT_DEFAULT
+#define EFX_ROWS_SPLIT_DEFAULT "2,2,3"
+#endif
+// Tables of resize_rows_kernel (detect_kernels.hip): which levels share a launch (`split`: levels made per launch, from level 1
+// up), and per launch the column / row / strip / chunk tables.  Everything the kernel relies on is checked here; a launch whose
+// geometry does not fit gets nlev = 0 and its levels go through the tiled per-level kernels.  The float expressions are spec
+// S5's (the ones of the plan above).
 void build_rows_plan(const LevelTable& T, int nlevels, std::vector<int>& blob, RowsPlanLaunch* out)
 {
     auto fbits = [](float f) { int i; memcpy(&i, &f, 4); return i; };
     memset(out, 0, sizeof(RowsPlanLaunch) * EFX_MAX_LEVELS);
     static const int wave_target = getenv("EFX_ROWS_WAVES") ? atoi(getenv("EFX_ROWS_WAVES")) : 3072;      // investigation: waves per launch aimed at
-    for (int s = 0; s + 1 < nlevels; s += (getenv("EFX_ROWS_ONE_LEVEL") ? 1 : 2)) {
+    // levels per launch: every launch costs ~5 us that no wave sees plus ~2 us of set-up, while a deeper launch spends more lanes on
+    // halo columns and idle upper-level lanes and holds fewer waves (registers).  Measured at 8K, chain us per frame
+    // (tools/microbench/rows_split.sh): 2,2,2,1 55.1 | 2,2,3 51.9 | 2,3,2 52.8 | 3,2,2 59.1 | 3,4 58.1 | 4,3 60.5 -- all bit-identical
+    const char* split_env = getenv("EFX_ROWS_SPLIT");              // variant knob (A/B, parity tests), read whenever a geometry is built: e.g. "2,2,2,1"
+    std::vector<int> split;
+    for (const char* p = split_env ? split_env : EFX_ROWS_SPLIT_DEFAULT; *p;) {
+        split.push_back(std::max(1, std::min(RW_MAXLEV, atoi(p))));
+        while (*p && *p != ',') p++;
+        if (*p == ',') p++;
+    }
+    auto align4 = [&]() { while (blob.size() & 3) blob.push_back(0); };
+    size_t si = 0;
+    for (int s = 0; s + 1 < nlevels;) {
+        int nlev = si < split.size() ? split[si] : split.empty() ? 2 : split.back();
+        si++;
+        while (nlev > 1 && (s + nlev >= nlevels || T.lv[s + nlev].rows < 1 || T.lv[s + nlev].cols < 4)) nlev--;
         const LevelDev& A = T.lv[s];
-        const LevelDev& B = T.lv[s + 1];
-        if (A.rows < 2 || A.cols < 8 || B.rows < 1 || B.cols < 4) continue;
-        int nlev = (s + 2 < nlevels && T.lv[s + 2].rows >= 1 && T.lv[s + 2].cols >= 4) ? 2 : 1;
-        static const bool one_level = getenv("EFX_ROWS_ONE_LEVEL") != nullptr;      // investigation: one level per launch
-        if (one_level) nlev = 1;
-        const LevelDev& C = T.lv[s + (nlev == 2 ? 2 : 1)];       // (nlev == 1: unused alias)
-        if (!(B.fx >= 1.f && B.fx <= 1.9f && B.fy >= 1.f && B.fy <= 1.9f)) continue;
-        if (nlev == 2 && !(C.fx >= 1.f && C.fx <= 1.9f && C.fy >= 1.f && C.fy <= 1.9f)) nlev = 1;
+        bool ok = A.rows >= 2 && A.cols >= 8;
+        for (int k = 1; k <= nlev && ok; k++) {
+            const LevelDev& D = T.lv[s + k];
+            ok = D.rows >= 1 && D.cols >= 4 && D.fx >= 1.f && D.fx <= 1.9f && D.fy >= 1.f && D.fy <= 1.9f;
+        }
+        if (!ok) { s += nlev; continue; }
         const size_t mark = blob.size();
         RowsPlanLaunch R;
         memset(&R, 0, sizeof(R));
-        bool ok = true;
-        R.nstrips = (B.cols + RW_OWN - 1) / RW_OWN;
-        // column tables
-        auto xtable = [&](const LevelDev& D, const LevelDev& S, int W) -> unsigned {
-            const unsigned off = (unsigned)(blob.size() * 4);
-            blob.resize(blob.size() + 3 * (size_t)W);
-            int* xt = blob.data() + off / 4;
-            for (int i = 0; i < W; i++) {
+        // ---- column / row tables ----
+        for (int k = 0; k < nlev; k++) {
+            const LevelDev& D = T.lv[s + 1 + k];
+            const LevelDev& S = T.lv[s + k];
+            align4();
+            R.W[k] = ((D.cols + 3) & ~3) + 256 + 8;
+            R.x_off[k] = (unsigned)(blob.size() * 4);
+            blob.resize(blob.size() + 3 * (size_t)R.W[k]);
+            int* xt = blob.data() + R.x_off[k] / 4;
+            for (int i = 0; i < R.W[k]; i++) {
                 const int ox = i < D.cols - 1 ? i : D.cols - 1;
                 const float sx = (float)ox * D.fx;
                 int x1 = (int)floorf(sx);
                 if (x1 > S.cols - 1) x1 = S.cols - 1;
                 const int x2 = x1 + 1;
-                xt[i] = x1; xt[W + i] = fbits(efx_s5_w_hi(ox, D.fx, sx, x2)); xt[2 * W + i] = fbits(efx_s5_w_lo(ox, D.fx, sx, x1));
+                xt[i] = x1; xt[R.W[k] + i] = fbits(efx_s5_w_hi(ox, D.fx, sx, x2)); xt[2 * R.W[k] + i] = fbits(efx_s5_w_lo(ox, D.fx, sx, x1));
+                if (x1 >= S.cols - 1) ok = false;             // a clamped +1 neighbour (fx == 1): the tiled kernels
             }
-            return off;
-        };
-        auto ytable = [&](const LevelDev& D, const LevelDev& S) -> unsigned {
-            while (blob.size() & 3) blob.push_back(0);                      // int4 loads
-            const unsigned off = (unsigned)(blob.size() * 4);
+            align4();
+            R.y_off[k] = (unsigned)(blob.size() * 4);
             const int Hh = D.rows + 64;
             blob.resize(blob.size() + 4 * (size_t)Hh);
-            int* yt = blob.data() + off / 4;
+            int* yt = blob.data() + R.y_off[k] / 4;
             for (int i = 0; i < Hh; i++) {
                 const int oy = i < D.rows - 1 ? i : D.rows - 1;
                 const float sy = (float)oy * D.fy;
@@ -558,113 +575,142 @@ void build_rows_plan(const LevelTable& T, int nlevels, std::vector<int>& blob, R
                 const int y2 = y1 + 1;
                 const int y2r = y2 < S.rows - 1 ? y2 : S.rows - 1;
                 yt[4 * i] = y1; yt[4 * i + 1] = y2r; yt[4 * i + 2] = fbits(efx_s5_w_hi(oy, D.fy, sy, y2)); yt[4 * i + 3] = fbits(efx_s5_w_lo(oy, D.fy, sy, y1));
+                if (y2r != y1 + 1) ok = false;                // clamped bottom (fy == 1): the tiled kernels
             }
-            return off;
-        };
-        while (blob.size() & 3) blob.push_back(0);
-        R.WB = (RW_OWN * R.nstrips + 8 + 3) & ~3;
-        R.xB_off = xtable(B, A, R.WB);
-        R.yB_off = ytable(B, A);
-        if (nlev == 2) {
-            while (blob.size() & 3) blob.push_back(0);
-            R.WC = ((C.cols + 3) & ~3) + 256 + 8;
-            R.xC_off = xtable(C, B, R.WC);
-            R.yC_off = ytable(C, B);
         }
-        const int* xb = blob.data() + R.xB_off / 4;
-        const int* yb = blob.data() + R.yB_off / 4;
-        const int* xc = nlev == 2 ? blob.data() + R.xC_off / 4 : nullptr;
-        const int* yc = nlev == 2 ? blob.data() + R.yC_off / 4 : nullptr;
-        // strips
-        while (blob.size() & 3) blob.push_back(0);
-        R.strip_off = (unsigned)(blob.size() * 4);
-        {
-            std::vector<int> stv(4 * (size_t)R.nstrips);
-            int g = 0;                                                      // next unowned column group of level s + 2
-            const int ngroups = nlev == 2 ? (C.cols + 3) / 4 : 0;
-            for (int j = 0; j < R.nstrips && ok; j++) {
-                const int bx0 = j * RW_OWN;
-                const int ax0 = xb[bx0] & ~3;
-                const int lastx1 = xb[bx0 + 255 < R.WB ? bx0 + 255 : R.WB - 1];
-                const int lastcol = std::min(lastx1 + 1, A.cols - 1);
-                const int nd = ((lastcol - ax0) >> 2) + 1;
-                if (nd > 128) ok = false;
-                if (lastx1 >= A.cols - 1) ok = false;                     // a clamped +1 neighbour (fx == 1): the tiled kernels
-                // every lane's windows (resize_windows: both pixel pairs of an output pair within 8 bytes of an aligned dword)
-                for (int l = 0; l < 64 && ok; l++) {
-                    const int* q = xb + bx0 + 4 * l;
-                    const int oA = (q[0] - ax0) & ~3, oB = (q[2] - ax0) & ~3;
-                    if (q[1] < q[0] || q[1] - ax0 - oA + 1 > 7 || q[3] < q[2] || q[3] - ax0 - oB + 1 > 7 || q[0] < ax0 || q[3] + 1 - ax0 >= 512 + 8) ok = false;
+        if (!ok) { blob.resize(mark); s += nlev; continue; }
+        auto X = [&](int k) { return blob.data() + R.x_off[k] / 4; };
+        auto Y = [&](int k) { return blob.data() + R.y_off[k] / 4; };
+        auto cols_of = [&](int k) { return T.lv[s + 1 + k].cols; };
+        auto rows_of = [&](int k) { return T.lv[s + 1 + k].rows; };
+        // ---- strips: the widest `own` (columns of level s + 1 per strip) whose halo fits the 64 lanes at every level ----
+        std::vector<int> stv;
+        bool found = false;
+        for (int own = nlev == 1 ? 256 : 252; own >= 192 && !found; own -= 4) {
+            const int nstrips = (cols_of(0) + own - 1) / own;
+            stv.assign(4 * RW_STRIP_INT4 * (size_t)nstrips, 0);
+            bool good = true;
+            // owned group ranges, bottom up: level k owns the groups whose first source column lies in the columns level k - 1 owns
+            std::vector<std::vector<int>> glo(nlev, std::vector<int>(nstrips + 1, 0));
+            for (int j = 0; j <= nstrips; j++) glo[0][j] = std::min(j * own, (cols_of(0) + 3) & ~3) / 4;      // (level 0 of the launch: groups of `own` / 4)
+            for (int k = 1; k < nlev; k++) {
+                const int ngroups = (cols_of(k) + 3) / 4;
+                int g = 0;
+                for (int j = 0; j < nstrips; j++) {
+                    glo[k][j] = g;
+                    const int own_end = j == nstrips - 1 ? 0x7fffffff : 4 * glo[k - 1][j + 1];      // columns of level k - 1 this strip owns: up to here
+                    while (g < ngroups && X(k)[4 * g] < own_end) g++;
                 }
-                int cnt = 0;
-                const int g0 = g;
-                if (nlev == 2) {
-                    const int own_end = j == R.nstrips - 1 ? 0x7fffffff : bx0 + RW_OWN;
-                    while (g < ngroups && xc[4 * g] < own_end) {
-                        const int* q = xc + 4 * g;
-                        // the group's source columns lie in the 256 columns of level s + 1 this strip computes
-                        if (q[0] < bx0 || q[3] + 1 - bx0 > 255 || q[3] >= B.cols - 1) ok = false;
-                        const int oA = (q[0] - bx0) & ~3, oB = (q[2] - bx0) & ~3;
-                        if (q[1] < q[0] || q[1] - bx0 - oA + 1 > 7 || q[3] < q[2] || q[3] - bx0 - oB + 1 > 7) ok = false;
-                        g++; cnt++;
+                glo[k][nstrips] = ngroups;
+                if (g != ngroups) good = false;
+            }
+            for (int j = 0; j < nstrips && good; j++) {
+                // computed groups, top down: the owned ones plus what the next level's computed groups read
+                std::vector<int> ncomp(nlev, 0);
+                for (int k = nlev - 1; k >= 1 && good; k--) {
+                    int hi = glo[k][j + 1];                                                            // end of the owned groups
+                    if (k + 1 < nlev && ncomp[k + 1] > 0) {
+                        const int lastcol = std::min(4 * (glo[k + 1][j] + ncomp[k + 1]) - 1, cols_of(k + 1) - 1);
+                        hi = std::max(hi, (X(k + 1)[lastcol] + 1) / 4 + 1);                            // its +1 neighbour's group, inclusive
                     }
-                    if (cnt > 64) ok = false;
+                    ncomp[k] = hi - glo[k][j];
+                    if (ncomp[k] > 64 || ncomp[k] < 0) good = false;
                 }
-                stv[4 * j] = ax0; stv[4 * j + 1] = nd; stv[4 * j + 2] = g0; stv[4 * j + 3] = cnt;
+                if (!good) break;
+                const int bx0 = j * own;
+                // level 0 of the launch computes columns bx0 .. bx0 + 255: enough for level 1's computed groups?
+                if (nlev > 1 && ncomp[1] > 0) {
+                    const int lastcol = std::min(4 * (glo[1][j] + ncomp[1]) - 1, cols_of(1) - 1);
+                    if (X(1)[lastcol] + 1 > bx0 + 255 || X(1)[4 * glo[1][j]] < bx0) good = false;
+                }
+                // windows of every computing lane at every level (resize_windows: both pixel pairs of an output pair within 8 bytes
+                // of an aligned dword), and the 256-column reach of a level's LDS row
+                const int ax0 = X(0)[bx0] & ~3;
+                const int lastx1 = X(0)[std::min(bx0 + 255, R.W[0] - 1)];
+                const int nd = ((std::min(lastx1 + 1, A.cols - 1) - ax0) >> 2) + 1;
+                if (nd > 128) good = false;
+                for (int k = 0; k < nlev && good; k++) {
+                    const int org = k == 0 ? ax0 : k == 1 ? bx0 : 4 * glo[k - 1][j];
+                    const int g0 = k == 0 ? bx0 / 4 : glo[k][j], nc = k == 0 ? 64 : ncomp[k];
+                    for (int l = 0; l < nc && good; l++) {
+                        const int* q = X(k) + 4 * (g0 + l);
+                        const int oA = (q[0] - org) & ~3, oB = (q[2] - org) & ~3;
+                        if (q[0] < org || q[1] < q[0] || q[1] - org - oA + 1 > 7 || q[3] < q[2] || q[3] - org - oB + 1 > 7) good = false;
+                        if (q[3] + 1 - org > (k == 0 ? 511 : 255)) good = false;
+                    }
+                }
+                int* q = stv.data() + 4 * RW_STRIP_INT4 * (size_t)j;
+                q[0] = ax0; q[1] = nd;
+                for (int k = 1; k < nlev; k++) { q[4 * k] = glo[k][j]; q[4 * k + 1] = glo[k][j + 1] - glo[k][j]; q[4 * k + 2] = ncomp[k]; }
             }
-            if (nlev == 2 && g != ngroups) ok = false;
-            blob.insert(blob.end(), stv.begin(), stv.end());
+            if (good) { found = true; R.own = own; R.nstrips = nstrips; }
         }
-        // chunks of rows: of level s + 2 when it is made, else of level s + 1; as many as give ~wave_target waves; at most 64 source
-        // rows (the masks) and 64 rows of either level (row tables: one row per lane) per chunk
+        if (!found) { blob.resize(mark); s += nlev; continue; }
+        align4();
+        R.strip_off = (unsigned)(blob.size() * 4);
+        blob.insert(blob.end(), stv.begin(), stv.end());
+        // ---- chunks of rows of the top level: as many as give ~wave_target waves; at most 64 source rows (the masks) per chunk ----
         {
-            const LevelDev& Top = nlev == 2 ? C : B;
+            const int top = nlev - 1;
             const int want = std::max(1, (wave_target + R.nstrips - 1) / R.nstrips);
-            int rc = (Top.rows + want - 1) / want;
-            const float ftot = nlev == 2 ? C.fy * B.fy : B.fy;
-            const int rc_max = std::max(1, (int)((64 - RW_D - 3) / ftot) - 2);
+            int rc = (rows_of(top) + want - 1) / want;
+            float ftot = 1.f;
+            for (int k = 0; k < nlev; k++) ftot *= T.lv[s + 1 + k].fy;
+            const int rc_max = std::max(1, (int)((64 - RW_D - 2 * nlev) / ftot) - nlev);
             rc = std::max(std::min(8, rc_max), std::min(rc_max, rc));
-            R.nchunks = (Top.rows + rc - 1) / rc;
-            while (blob.size() & 3) blob.push_back(0);
-            R.chunk_off = (unsigned)(blob.size() * 4);
-            std::vector<int> cv(12 * (size_t)R.nchunks, 0);
-            for (int k = 0; k < R.nchunks && ok; k++) {
-                const bool lastk = k == R.nchunks - 1;
-                int b_first, b_end, b_last, c_first = 0, c_end = 0;
-                if (nlev == 2) {
-                    c_first = k * rc; c_end = std::min(c_first + rc, C.rows);
-                    b_first = yc[4 * c_first];                              // y1 of the chunk's first row (0 for k == 0)
-                    b_end = lastk ? B.rows : yc[4 * c_end];
-                    b_last = lastk ? B.rows - 1 : b_end;                    // one halo row: the lower source row of the chunk's last row
-                    if (yc[4 * (c_end - 1) + 1] > b_last) ok = false;
-                    if (c_end - c_first > 64) ok = false;
-                } else {
-                    b_first = k * rc; b_end = std::min(b_first + rc, B.rows); b_last = b_end - 1;
+            R.nchunks = (rows_of(top) + rc - 1) / rc;
+            std::vector<int> cv(4 * RW_CHUNK_INT4 * (size_t)R.nchunks, 0);
+            for (int c = 0; c < R.nchunks && ok; c++) {
+                const bool lastc = c == R.nchunks - 1;
+                int first[RW_MAXLEV], last[RW_MAXLEV], send[RW_MAXLEV];       // rows computed: first .. last; stored: first .. send - 1
+                first[top] = c * rc; send[top] = std::min(first[top] + rc, rows_of(top)); last[top] = send[top] - 1;
+                int nfirst_up = send[top];                                      // first row of the NEXT chunk at the level above
+                for (int k = top - 1; k >= 0; k--) {
+                    first[k] = Y(k + 1)[4 * first[k + 1]];                      // y1 of the first row above
+                    last[k] = Y(k + 1)[4 * last[k + 1] + 1];                    // lower source row of the last row above
+                    send[k] = lastc ? rows_of(k) : Y(k + 1)[4 * nfirst_up];     // where the next chunk starts
+                    if (lastc) last[k] = rows_of(k) - 1;                        // the rows below the top level's last source row belong to the level all the same
+                    nfirst_up = send[k];
+                    if (last[k] < send[k] - 1 || last[k] - first[k] + 1 > 64) ok = false;
                 }
-                if (b_last - b_first + 1 > 64 || b_last < b_first) { ok = false; break; }
-                const int a_first = yb[4 * b_first], a_last = yb[4 * b_last + 1];
+                if (last[top] - first[top] + 1 > 64) ok = false;
+                if (!ok) break;
+                const int a_first = Y(0)[4 * first[0]], a_last = Y(0)[4 * last[0] + 1];
                 const int na = a_last - a_first + 1, na_pad = (na + RW_D - 1) / RW_D * RW_D;
                 if (na_pad > 64) { ok = false; break; }
-                unsigned long long mb = 0, mc = 0;
-                for (int b = b_first; b <= b_last; b++) {
-                    if (yb[4 * b + 1] != yb[4 * b] + 1) ok = false;         // clamped bottom (fy == 1): the tiled kernels
-                    mb |= 1ull << (yb[4 * b + 1] - a_first);
+                // done[k][r - first[k]]: the source row (index in the chunk) that completes row r of level k
+                unsigned long long mask[RW_MAXLEV] = { 0, 0, 0, 0 };
+                std::vector<int> done_prev, done;
+                for (int k = 0; k < nlev; k++) {
+                    done.assign(last[k] - first[k] + 1, 0);
+                    for (int r = first[k]; r <= last[k]; r++) {
+                        const int lower = Y(k)[4 * r + 1];                      // its lower source row, in level k - 1 (source level for k == 0)
+                        int d;
+                        if (k == 0) d = lower - a_first;
+                        else { if (lower < first[k - 1] || lower > last[k - 1]) { ok = false; break; } d = done_prev[lower - first[k - 1]]; }
+                        if (d < 0 || d >= na) { ok = false; break; }
+                        done[r - first[k]] = d;
+                        mask[k] |= 1ull << d;
+                    }
+                    done_prev = done;
+                    if (k > 0 && (mask[k] & ~mask[k - 1])) ok = false;          // a level-k row is made in the iteration that makes its lower source row
                 }
-                for (int cc = c_first; cc < c_end; cc++) {
-                    if (yc[4 * cc + 1] != yc[4 * cc] + 1) ok = false;
-                    const int bq = yc[4 * cc + 1];                          // the row of level s + 1 that completes it ...
-                    if (bq < b_first || bq > b_last) { ok = false; break; }
-                    mc |= 1ull << (yb[4 * bq + 1] - a_first);               // ... is made at this source row
+                int* q = cv.data() + 4 * RW_CHUNK_INT4 * (size_t)c;
+                q[0] = a_first; q[1] = a_last; q[2] = na_pad;
+                for (int k = 0; k < nlev; k++) { q[4 * (1 + k)] = first[k]; q[4 * (1 + k) + 1] = send[k]; }
+                for (int k = 0; k < RW_MAXLEV; k++) {
+                    q[4 * (1 + RW_MAXLEV) + 2 * k] = (int)(uint32_t)mask[k];
+                    q[4 * (1 + RW_MAXLEV) + 2 * k + 1] = (int)(uint32_t)(mask[k] >> 32);
                 }
-                int* q = cv.data() + 12 * k;
-                q[0] = a_first; q[1] = a_last; q[2] = b_first; q[3] = b_end; q[4] = c_first; q[5] = c_end; q[6] = na_pad;
-                q[8] = (int)(uint32_t)mb; q[9] = (int)(uint32_t)(mb >> 32); q[10] = (int)(uint32_t)mc; q[11] = (int)(uint32_t)(mc >> 32);
             }
+            align4();
+            R.chunk_off = (unsigned)(blob.size() * 4);
             blob.insert(blob.end(), cv.begin(), cv.end());
         }
-        if (!ok) { blob.resize(mark); continue; }
+        if (!ok) { blob.resize(mark); s += nlev; continue; }
         R.nlev = nlev;
         out[s] = R;
+        s += nlev;
     }
 }
 

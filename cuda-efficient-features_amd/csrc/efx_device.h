@@ -254,23 +254,27 @@ __host__ __device__ inline float efx_s5_w_lo(int o, float f, float s, int i1)
 //   tile table  int4 per tile: sy0 | ax0 | ndw + (nrow << 8) + (touches the last source column << 16) | tx + (ty << 16)
 struct ResizePlanLevel { unsigned x_off, y_off, t_off; int W; };      // byte offsets into DetectLaunch::rplan; W == 0: no plan
 
-// Plan of one launch of resize_rows_kernel (round 5, detect_kernels.hip): level s -> s + 1 (-> s + 2 when nlev == 2) by waves that
-// walk down strips of RW_OWN destination columns.  Offsets are bytes into DetectLaunch::rplan.
-//   xB / xC   3 x W words: source column x1 | weight of x1 | weight of x1 + 1 per destination column (clamped beyond the last one)
-//   yB / yC   int4 per destination row, padded by 64 rows: y1, min(y1 + 1, rows - 1) | the two weights as float bits
-//   strips    int4 per strip: first source column staged (4-aligned) | dwords of a source row it needs | first group of four
-//             level-(s+2) columns it owns | how many
-//   chunks    3 x int4 per chunk of rows: first / last source row | first row of level s + 1, end of the rows it stores || first / end
-//             row of level s + 2 | source rows padded to the kernel's slot count || two 64-bit masks, bit i: source row i of the chunk
-//             completes a row of level s + 1 / that row completes one of level s + 2
-#define RW_OWN 248
+// Plan of one launch of resize_rows_kernel (round 5, detect_kernels.hip): level s -> s + 1 .. s + nlev by waves that walk down
+// strips of `own` columns of level s + 1.  Offsets are bytes into DetectLaunch::rplan; level index k = 0 is level s + 1.
+//   x[k]      3 x W[k] words: source column x1 | weight of x1 | weight of x1 + 1 per destination column (clamped beyond the last one)
+//   y[k]      int4 per destination row, padded by 64 rows: y1, min(y1 + 1, rows - 1) | the two weights as float bits
+//   strips    RW_MAXLEV x int4 per strip: [first source column staged (4-aligned) | dwords of a source row it needs | 0 | 0], then per level
+//             k >= 1: [first group of four columns the strip computes (= owns) | groups it owns | groups it computes (halo for level k + 1) | 0]
+//   chunks    (1 + RW_MAXLEV + 2) x int4 per chunk of rows: [first / last source row | source rows padded to the kernel's slot count | 0],
+//             per level k: [first row computed (= owned) | end of the rows it stores | 0 | 0], then RW_MAXLEV 64-bit masks: bit i of mask k =
+//             source row i of the chunk completes a row of level k (and, for k >= 1, mask k - 1 has the bit too)
+#define RW_MAXLEV 4
+#define RW_STRIP_INT4 RW_MAXLEV
+#define RW_CHUNK_INT4 (1 + RW_MAXLEV + RW_MAXLEV / 2)
 #ifndef RW_D
 #define RW_D 6                  // source rows in flight per wave = LDS slots = the unroll of the kernel's row loop (even); chunks are padded to it
 #endif
 struct RowsPlanLaunch {
     int nlev;                   // 0: no plan for this source level
-    int nstrips, nchunks, WB, WC;
-    unsigned xB_off, yB_off, xC_off, yC_off, strip_off, chunk_off;
+    int own;                    // columns of level s + 1 a strip owns (a multiple of 4, <= 256: the other lanes compute halo columns)
+    int nstrips, nchunks;
+    int W[RW_MAXLEV];
+    unsigned x_off[RW_MAXLEV], y_off[RW_MAXLEV], strip_off, chunk_off;
 };
 
 struct DetectLaunch {

@@ -666,15 +666,20 @@ def test_equal_responses_suppress_each_other(cef, torch_mod, oracle, period, rad
     assert np.array_equal(got["desc"], ref["desc"])
 
 
-@pytest.mark.parametrize("mode", ["tower", "chain_rows", "chain_streamed", "chain_plain"])
+@pytest.mark.parametrize("mode", ["tower", "chain_rows", "chain_rows:1,1,1,1,1,1,1", "chain_rows:2,2,2,1", "chain_rows:3,4", "chain_rows:4,3", "chain_rows:1,3,2,1",
+                                  "chain_streamed", "chain_plain"])
 @pytest.mark.parametrize("shape,scale", [((480, 640), 1.2), ((501, 703), 1.2), ((333, 1111), 1.1), ((700, 900), 1.5), ((600, 800), 2.0),
                                          ((1201, 2504), 1.2), ((997, 1500), 1.7), ((64, 3000), 1.2), ((2100, 300), 1.25)])
 def test_pyramid_kernel_variants_bit_exact(cef, torch_mod, oracle, monkeypatch, mode, shape, scale):
-    """The four ways a pyramid is produced -- one tower launch (small frames), two levels per launch by waves walking down
-    strips (large frames, round 5: resize_rows_kernel), the streamed per-level kernel and the one-tile-per-workgroup
-    per-level kernel (other scale factors, unaligned sources) -- give the same levels, bit for bit."""
+    """The four ways a pyramid is produced -- one tower launch (small frames), one to four levels per launch by waves walking down
+    strips (large frames, round 5: resize_rows_kernel, with every split of the levels over launches tried here), the streamed
+    per-level kernel and the one-tile-per-workgroup per-level kernel (other scale factors, unaligned sources) -- give the same
+    levels, bit for bit."""
     if mode != "tower":
         monkeypatch.setenv("EFX_NO_TOWER", "1")
+    monkeypatch.delenv("EFX_ROWS_SPLIT", raising=False)
+    if mode.startswith("chain_rows:"):
+        monkeypatch.setenv("EFX_ROWS_SPLIT", mode.split(":")[1])        # levels per launch of resize_rows_kernel (default: efx_api.cpp)
     if mode in ("chain_streamed", "chain_plain"):
         monkeypatch.setenv("EFX_NO_RESIZE_ROWS", "1")
     if mode == "chain_plain":
