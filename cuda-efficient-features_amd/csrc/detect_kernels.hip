@@ -1751,11 +1751,17 @@ __global__ __launch_bounds__(1024) void select_kernel(const LevelTable* __restri
 #endif
     SEL_T(0);
 
-    // output base of this level: sum over lower levels of min(survivors, quota)  (.cpp:292-314)
+    // output base of this level: sum over lower levels of min(survivors, quota)  (.cpp:292-314).  The nlevels x 8 survivor counters
+    // sit in a cache line each: one load per thread and ONE round trip (round 5; every thread walking all of them took 3.5 us of
+    // the kernel's 27: tools/microbench/sel_timing.sh)
+    __shared__ int s_nsub[EFX_MAX_LEVELS * EFX_NSUB];
+    if (tid < T->nlevels * EFX_NSUB) s_nsub[tid] = cnt->surv_total[tid / EFX_NSUB][tid % EFX_NSUB].v;
+    __syncthreads();
     int base = 0, all = 0;
     for (int i = 0; i < T->nlevels; i++) {
         int ns = 0;
-        for (int sub = 0; sub < EFX_NSUB; sub++) ns += cnt->surv_total[i][sub].v;
+#pragma unroll
+        for (int sub = 0; sub < EFX_NSUB; sub++) ns += s_nsub[i * EFX_NSUB + sub];
         const int k = T->lv[i].active ? min(ns, T->lv[i].quota) : 0;
         if (i < l) base += k;
         all += k;
@@ -1779,7 +1785,7 @@ __global__ __launch_bounds__(1024) void select_kernel(const LevelTable* __restri
     int nsub[EFX_NSUB];
     int n = 0, nmaxsub = 0;
 #pragma unroll
-    for (int sub = 0; sub < EFX_NSUB; sub++) { nsub[sub] = cnt->surv_total[l][sub].v; n += nsub[sub]; nmaxsub = max(nmaxsub, nsub[sub]); }
+    for (int sub = 0; sub < EFX_NSUB; sub++) { nsub[sub] = s_nsub[l * EFX_NSUB + sub]; n += nsub[sub]; nmaxsub = max(nmaxsub, nsub[sub]); }
     const Corner* surv = surv_all + L.surv_base;
     const int ntiles = L.tiles_x * L.tiles_y;
     const bool tiles_in_lds = ntiles <= SEL_MAX_TILES;
