@@ -567,6 +567,7 @@ __global__ __launch_bounds__(256) void resize_stream_kernel(
 #define RW_LDS_A 528                                        // 128 dwords + the reach of a window read
 #define RW_LDS_B 272                                        // 64 dwords + the same
 typedef __attribute__((address_space(3))) unsigned char efx_lds_uchar;
+typedef __attribute__((address_space(3))) float efx_lds_float;
 
 struct RowsLevelArgs { uint8_t* dst; int pitch, rows, cols; const int* x; const int4* y; int W; };
 struct RowsArgs {
@@ -628,12 +629,11 @@ template <int NLEV>
 struct RowsState {
     float wa[NLEV][4], wb[NLEV][4];                          // x weights of the lane's four columns
     ResizeWin win[NLEV];                                     // where their source pixel pairs sit in the level's source row
-    int ytz[NLEV], ytw[NLEV];                                // y weights of the chunk's rows, one row per lane (v_readlane)
+    uint32_t yw[NLEV];                                       // y weights of the chunk's next row: LDS byte address (8 bytes per row), read as a broadcast
     int off[NLEV];                                           // store offset (a value the range check drops for lanes that own nothing)
-    int pitch[NLEV];
+    int pitch[NLEV];                                         // (in VECTOR registers: an SGPR source halves the rate of v_add_u32)
     __amdgpu_buffer_rsrc_t rsrc[NLEV];
     unsigned long long mask[NLEV];
-    int made[NLEV];                                          // rows of the level made so far
     float g[NLEV][2][8];                                     // levels >= 1: converted upper / lower source row
 };
 
@@ -649,9 +649,9 @@ __device__ __forceinline__ void rows_push(RowsState<NLEV>& S, unsigned char* row
         for (int q = 0; q < 8; q++) S.g[K][0][q] = S.g[K][1][q];
         rows_conv(row, S.win[K], S.g[K][1]);
         if (due[K]) {
-            float wy0 = __int_as_float(__builtin_amdgcn_readlane(S.ytz[K], S.made[K])), wy1 = __int_as_float(__builtin_amdgcn_readlane(S.ytw[K], S.made[K]));
-            asm volatile("" : "+v"(wy0), "+v"(wy1));        // vector registers: a scalar source halves the rate of v_mul / v_fma
-            S.made[K]++;
+            const efx_lds_float* wy = (const efx_lds_float*)(uintptr_t)S.yw[K];       // every lane the same address: one broadcast LDS read
+            S.yw[K] += 8;
+            const float wy0 = wy[0], wy1 = wy[1];
             const uint32_t pk = rows_quad(S.g[K][0], S.g[K][1], S.wa[K], S.wb[K], wy0, wy1);
             if (!(RW_DBG & 1) || pk == 0x12345678u) __builtin_amdgcn_raw_buffer_store_b32(pk, S.rsrc[K], S.off[K], 0, 0);
             S.off[K] += S.pitch[K];
@@ -663,7 +663,7 @@ __device__ __forceinline__ void rows_push(RowsState<NLEV>& S, unsigned char* row
 template <int NLEV>
 __global__ __launch_bounds__(256) void resize_rows_kernel(const RowsArgs A, Counters* __restrict__ zero, int zero_levels)
 {
-    constexpr int LDS_WAVE = RW_D * RW_LDS_A + (NLEV > 1 ? (NLEV - 1) * RW_LDS_B : 16);
+    constexpr int LDS_WAVE = RW_D * RW_LDS_A + (NLEV - 1) * RW_LDS_B + NLEV * 512;      // source slots | a row of every level but the last | y weights
     static_assert((LDS_WAVE & 15) == 0 && (RW_D & 1) == 0 && NLEV >= 1 && NLEV <= RW_MAXLEV, "LDS rows: 16-byte aligned; an even number of slots");
     __shared__ __attribute__((aligned(16))) unsigned char s_rows[4 * LDS_WAVE];
     if (zero && blockIdx.x == 0) efx_zero_counters(zero, zero_levels, threadIdx.x, 256);
@@ -702,14 +702,15 @@ __global__ __launch_bounds__(256) void resize_rows_kernel(const RowsArgs A, Coun
         const int4 ckk = ck[1 + k];
         const int first = uni(ckk.x), store_end = uni(ckk.y);
         S.rsrc[k] = __builtin_amdgcn_make_buffer_rsrc(L.dst, 0, store_end * L.pitch, 0x00020000);     // rows from store_end on: dropped
-        S.pitch[k] = L.pitch;
+        { int pv = L.pitch; asm volatile("" : "+v"(pv)); S.pitch[k] = pv; }
         // lanes that own no column of the level (halo lanes, lanes beyond the last column): an offset the range check drops
         S.off[k] = (lane < nown && col0 < L.cols) ? first * L.pitch + col0 : 0x7ffffff0;
-        const int4 yt = L.y[first + lane];                   // row table of this chunk, one row per lane
-        S.ytz[k] = yt.z; S.ytw[k] = yt.w;
+        const int4 yt = L.y[first + lane];                   // row table of this chunk: lane i has row first + i -> the wave's LDS table
+        unsigned char* ywk = rowbuf + (NLEV - 1) * RW_LDS_B + k * 512;
+        *reinterpret_cast<int2*>(ywk + 8 * lane) = make_int2(yt.z, yt.w);
+        { uint32_t a = (uint32_t)(uintptr_t)(efx_lds_uchar*)ywk; asm volatile("" : "+v"(a)); S.yw[k] = a; }      // (a vector register: see pitch)
         const int4 mk = ck[1 + RW_MAXLEV + k / 2];
         S.mask[k] = (k & 1) ? (((unsigned long long)(uint32_t)mk.w << 32) | (uint32_t)mk.z) : (((unsigned long long)(uint32_t)mk.y << 32) | (uint32_t)mk.x);
-        S.made[k] = 0;
 #pragma unroll
         for (int q = 0; q < 8; q++) { S.g[k][0][q] = 0.f; S.g[k][1][q] = 0.f; }
     }
@@ -722,9 +723,11 @@ __global__ __launch_bounds__(256) void resize_rows_kernel(const RowsArgs A, Coun
         __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(A.src), 0, a_last * A.spitch + ((A.scols + 3) & ~3), 0x00020000);
     int vo0 = a_first * A.spitch + ax0 + 4 * lane;
     int vo1 = lane + 64 < nd ? vo0 : 0x7ffffff0;            // (the second load's + 256 is its immediate offset)
+    int spitch_v = A.spitch;
+    asm volatile("" : "+v"(spitch_v));                      // vector register: v_add_u32 with an SGPR source is half rate
     const uint32_t ldsA = (uint32_t)(uintptr_t)(efx_lds_uchar*)s_rows + (uint32_t)wave * LDS_WAVE;
 #pragma unroll
-    for (int u = 0; u < RW_D; u++) { rows_dma2(rsrcA, vo0, vo1, ldsA + u * RW_LDS_A); vo0 += A.spitch; vo1 += A.spitch; }
+    for (int u = 0; u < RW_D; u++) { rows_dma2(rsrcA, vo0, vo1, ldsA + u * RW_LDS_A); vo0 += spitch_v; vo1 += spitch_v; }
 
     float f0[8], f1[8];                                      // converted source rows of the even / odd slots
 #pragma unroll
@@ -740,14 +743,16 @@ __global__ __launch_bounds__(256) void resize_rows_kernel(const RowsArgs A, Coun
             rows_wait_vm<2 * (RW_D - 1)>();
             rows_conv(rowA + u * RW_LDS_A, S.win[0], fcur);
             rows_dma2(rsrcA, vo0, vo1, ldsA + u * RW_LDS_A);            // the slot's next row (beyond the chunk: dropped)
-            vo0 += A.spitch; vo1 += A.spitch;
+            vo0 += spitch_v; vo1 += spitch_v;
             bool due[NLEV];
 #pragma unroll
             for (int k = 0; k < NLEV; k++) { due[k] = (S.mask[k] & 1ull) != 0; S.mask[k] >>= 1; }
             if (due[0]) {
-                float wy0 = __int_as_float(__builtin_amdgcn_readlane(S.ytz[0], S.made[0])), wy1 = __int_as_float(__builtin_amdgcn_readlane(S.ytw[0], S.made[0]));
-                asm volatile("" : "+v"(wy0), "+v"(wy1));    // vector registers: a scalar source halves the rate of v_mul / v_fma
-                S.made[0]++;
+                // the row's y weights: vector registers (a scalar source halves the rate of v_mul / v_fma) by ONE broadcast LDS read
+                // (until round 5's last pass: two v_readlane + two v_mov from SGPRs, 16 issue cycles per row and level)
+                const efx_lds_float* wy = (const efx_lds_float*)(uintptr_t)S.yw[0];
+                S.yw[0] += 8;
+                const float wy0 = wy[0], wy1 = wy[1];
                 const uint32_t packed = rows_quad(fprev, fcur, S.wa[0], S.wb[0], wy0, wy1);
                 if (!(RW_DBG & 1) || packed == 0x12345678u) __builtin_amdgcn_raw_buffer_store_b32(packed, S.rsrc[0], S.off[0], 0, 0);
                 S.off[0] += S.pitch[0];
@@ -2275,17 +2280,18 @@ __global__ void copy2d_kernel(const uint8_t* __restrict__ src, size_t spitch, ui
 // Plan of the tower launch (pyramid_tower_kernel): which level it starts from, its tile size and its LDS layout.  The
 // ranges are the kernel's own recurrence evaluated for every tile column / row, so the sizes are exact maxima.
 #ifndef EFX_TOWER_MAX_PX
-#define EFX_TOWER_MAX_PX 9000000      // larger frames keep one launch per level (each fills the chip by itself)
+#define EFX_TOWER_MAX_PX 6000000      // larger frames: the row-walking chain (resize_rows_kernel).  Round 5, 4K (8.3 Mpx), reference protocol,
+                                      // tower / chain: detect 0.143 / 0.145 ms, detectAndCompute BAD512 0.203 / 0.194, HashSIFT512 0.256 / 0.249; FHD: 0.084 / 0.095 detect
 #endif
 static inline int tower_src_host(int o, float f, int n) { const int v = (int)floorf((float)o * f); return v > n - 1 ? n - 1 : v; }
 
-static bool plan_tower(const LevelTable& H, int last, const uint8_t* img0, int pitch0, bool no_tower, TowerArgs* out, size_t* lds_out)
+static bool plan_tower(const LevelTable& H, int last, const uint8_t* img0, int pitch0, bool no_tower, long long max_px, TowerArgs* out, size_t* lds_out)
 {
     if (last < 2) return false;
     // Measured (MI355X, one stream, sync per call): the tower beats the launch chain when the WHOLE pyramid is small
     // (FHD 0.166 -> 0.147 ms, 4K 0.270 -> 0.259 ms per detectAndCompute); fusing only the upper levels of a large frame
     // (8K levels 4..7) does not pay: those levels are as large as a 4K pyramid and the tower recomputes ~1.7x the pixels.
-    if ((long long)H.lv[0].rows * H.lv[0].cols > EFX_TOWER_MAX_PX) return false;
+    if ((long long)H.lv[0].rows * H.lv[0].cols > (max_px > 0 ? max_px : (long long)EFX_TOWER_MAX_PX)) return false;      // (EFX_TOWER_MAX_PX in the environment: tests)
     if (no_tower) return false;                               // EFX_NO_TOWER (tests): exercise the per-level kernels on small frames
     for (int s = 1; s <= last; s++) if (H.lv[s].fx > 3.5f || H.lv[s].fy > 3.5f) return false;     // resize_quad_win: source columns of neighbouring outputs within 8 bytes
     // Tile edge of the top level.  The kernel is a chain of dependent levels, so a workgroup's time hardly shrinks with
@@ -2380,7 +2386,7 @@ static hipError_t efx_launch_detect_impl(const DetectLaunch& a, hipStream_t stre
     while (last + 1 < H.nlevels && H.lv[last + 1].rows > 0 && H.lv[last + 1].cols > 0 && H.lv[last].rows > 0 && H.lv[last].cols > 0) last++;
     TowerArgs tw;
     size_t tw_lds = 0;
-    const bool use_tower = plan_tower(H, last, a.img0, a.pitch0, a.knobs.no_tower != 0, &tw, &tw_lds);
+    const bool use_tower = plan_tower(H, last, a.img0, a.pitch0, a.knobs.no_tower != 0, a.knobs.tower_max_px, &tw, &tw_lds);
     const int chain_end = use_tower ? tw.s0 : last;           // levels 1 .. chain_end by the per-level kernel
     // the counters are zeroed by the first pyramid kernel; a single-level "pyramid" has none: memset command
     bool zeroed = false;

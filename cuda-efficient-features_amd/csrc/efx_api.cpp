@@ -352,10 +352,11 @@ int describer_run(Describer& d, std::string& err, DescribeLaunch a, float* dbg_r
 
 EfxKnobs efx_read_knobs()
 {
-    EfxKnobs k = { 0, 0, 0, 0, 0, 0, 0 };
+    EfxKnobs k = { 0, 0, 0, 0, 0, 0, 0, 0 };
     k.no_tower = getenv("EFX_NO_TOWER") != nullptr;
     k.no_resize_stream = getenv("EFX_NO_RESIZE_STREAM") != nullptr;
     k.no_resize_rows = getenv("EFX_NO_RESIZE_ROWS") != nullptr;     // the tiled per-level kernels instead of resize_rows_kernel
+    k.tower_max_px = getenv("EFX_TOWER_MAX_PX") ? atoll(getenv("EFX_TOWER_MAX_PX")) : 0;   // 0: the built-in limit of the tower launch (detect_kernels.hip)
     k.no_level_blur = getenv("EFX_NO_LEVEL_BLUR") != nullptr;
     { const char* f = getenv("EFX_BLUR_FORK"); k.blur_fork = f ? atoi(f) : EFX_BLUR_FORK_DEFAULT; }   // DetectLaunch::blur_fork
     // BAD behind detectAndCompute: every keypoint blurs its own window (A/B, parity tests)

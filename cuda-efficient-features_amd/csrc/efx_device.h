@@ -171,7 +171,7 @@ __device__ __forceinline__ int efx_wave_incl_scan(int v)
 #else
 #define EFX_DBG(v) 0
 #endif
-struct EfxKnobs { int dbg, dbg_hs, no_tower, no_resize_stream, no_level_blur, blur_fork, no_resize_rows; };
+struct EfxKnobs { int dbg, dbg_hs, no_tower, no_resize_stream, no_level_blur, blur_fork, no_resize_rows; long long tower_max_px; };
 EfxKnobs efx_read_knobs();      // efx_api.cpp
 
 // ---- launchers (host side, defined in the .hip files) ----

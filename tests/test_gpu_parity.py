@@ -67,9 +67,11 @@ def _assert_same_keypoints(got, ref):
 
 
 @pytest.mark.parametrize("shape", [(480, 640), (501, 703), (720, 1280), (1080, 1920), (1520, 2704), (2160, 3840)])
-def test_pyramid_levels_bit_exact(cef, torch_mod, oracle, shape):
+def test_pyramid_levels_bit_exact(cef, torch_mod, oracle, shape, monkeypatch):
     """Spec S5 resize chain (cuda_efficient_features.cpp:136-157).  The shapes cover every tile edge the tower launch
-    picks (plan_tower: 12, 20, 28, 36 with one workgroup per CU, 36 with two)."""
+    picks (plan_tower: 12, 20, 28, 36 with one workgroup per CU, 36 with two; a 4K frame takes the row-walking chain by default
+    since round 5: EFX_TOWER_MAX_PX, read when a context is created, sends it through the tower here)."""
+    monkeypatch.setenv("EFX_TOWER_MAX_PX", "9000000")
     img = synth.synth_frame(shape[0], shape[1], seed=11)
     det = cef.EfficientFeatures.create(1000)
     d_img = _dev(torch_mod, img)            # level 0 aliases the caller's image: keep it alive

@@ -53,8 +53,10 @@ def main(sq_path, lds_path, traffic_path, valu_path, out_path, mix_path=None):
             continue
         valu_launch[k] = round(v["SQ_INSTS_VALU"] / v["n"])
         valu_frame += v["SQ_INSTS_VALU"] / frames
-    if "resize_stream_kernel" in sq:
-        valu_launch["resize_chain"] = round(sq["resize_stream_kernel"]["SQ_INSTS_VALU"] / frames)
+    # the pyramid chain: every resize / tower launch of a frame (round 5: resize_rows_kernel<2> x 2 + <3>; before: resize_stream_kernel x 7)
+    chain = [k for k in sq if (k.startswith("resize_") or k.startswith("pyramid_tower")) and "SQ_INSTS_VALU" in sq[k]]
+    if chain:
+        valu_launch["resize_chain"] = round(sum(sq[k]["SQ_INSTS_VALU"] for k in chain) / frames)
     lds_launch = {k: round(v["SQ_LDS_IDX_ACTIVE"] / v["n"]) for k, v in lds.items()
                   if "SQ_LDS_IDX_ACTIVE" in v and not k.startswith("at::") and not k.startswith("__amd")}
     conf_launch = {k: round(v["SQ_LDS_BANK_CONFLICT"] / v["n"]) for k, v in lds.items()
@@ -75,7 +77,7 @@ def main(sq_path, lds_path, traffic_path, valu_path, out_path, mix_path=None):
         mk = json.load(open(mix_path))["kernels"]
         for name, inst in (("fast_kernel", "fast_kernel"), ("harris_kernel", "harris_kernel<1>"), ("nms_kernel", "nms_kernel<1>"),
                            ("bad_det_kernel", "bad_det_kernel"), ("bad_raw_kernel", "bad_raw_kernel<8>"), ("blur_levels_kernel", "blur_levels_kernel<false>"),
-                           ("resize_chain", "resize_stream_kernel"), ("resize_stream_kernel", "resize_stream_kernel"),
+                           ("resize_chain", "resize_rows_kernel<2>"), ("resize_rows_kernel", "resize_rows_kernel<2>"), ("resize_stream_kernel", "resize_stream_kernel"),
                            ("select_kernel", "select_kernel"), ("emit_kernel", "emit_kernel"), ("angle_kernel", "angle_kernel<false>"),
                            ("angle_tail_kernel", "angle_tail_kernel")):
             if inst in mk:
