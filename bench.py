@@ -294,7 +294,20 @@ def main():
         #                  2 F P + 5 sum P_s + gathers ~ 1.06 GB for the same stage; reported as survey_design_bytes)
         #   resize chain   level s read + level s+1 written, s = 0..6: (2 F - 2) P + P_0 - P_7 ... = sum_s P_s + sum_{s>=1} P_s - P_7
         sumP = float(sum(px))
-        chain_bytes = float(sum(px[:-1]) + sum(px[1:]))
+        # the chain since round 5 (resize_rows_kernel, launches make levels (1,2) (3,4) (5,6,7): EFX_ROWS_SPLIT default): levels 0, 2, 4 are
+        # read, every level >= 1 is written once -- 126 MB at 8K (measured traffic 132 MB, profiles/r05_counters.json `resize_chain`);
+        # the per-level chain of rounds 1 -- 4 read every level once more: sum(px[:-1]) + sum(px[1:]) = 170 MB
+        split = [int(v) for v in os.environ.get("EFX_ROWS_SPLIT", "2,2,3").split(",") if v.strip()]
+        srcs, s_ = [], 0
+        for n_ in split:
+            if s_ >= len(px) - 1:
+                break
+            srcs.append(s_)
+            s_ += n_
+        while s_ < len(px) - 1:
+            srcs.append(s_)
+            s_ += split[-1] if split else 1
+        chain_bytes = float(sum(px[i] for i in srcs) + sum(px[1:]))
         #   blur_levels_kernel (round 4) every level read once, its blurred copy written once: 2 sum_s P_s; the keypoints are then
         #                  described a wave each on the blurred levels (bad_raw_kernel: windows inside the levels + record + descriptor)
         level_blur = bool((lvl == 11).any())
@@ -368,7 +381,8 @@ def main():
         if "fast_kernel" in iso:
             pf_ms = iso_chain + iso["fast_kernel"]["avg_launch_ms"]
             pf_bytes = chain_bytes + iso["fast_kernel"]["algorithmic_bytes"]
-            roof["pyramid_fast"] = {"algorithmic_bytes": pf_bytes, "resize_chain_ms": round(iso_chain, 5),
+            roof["pyramid_fast"] = {"algorithmic_bytes": pf_bytes, "resize_chain_bytes": chain_bytes, "resize_chain_source_levels": srcs,
+                                    "resize_chain_ms": round(iso_chain, 5),
                                     "fast_kernel_ms": iso["fast_kernel"]["avg_launch_ms"], "ms": round(pf_ms, 5),
                                     "achieved": round(pf_bytes / (pf_ms * 1e-3) / 1e9, 1),
                                     "frac": round(pf_bytes / (pf_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),

@@ -61,7 +61,12 @@ def main(sq_path, lds_path, traffic_path, valu_path, out_path, mix_path=None):
                   if "SQ_LDS_IDX_ACTIVE" in v and not k.startswith("at::") and not k.startswith("__amd")}
     conf_launch = {k: round(v["SQ_LDS_BANK_CONFLICT"] / v["n"]) for k, v in lds.items()
                    if "SQ_LDS_BANK_CONFLICT" in v and not k.startswith("at::") and not k.startswith("__amd")}
-    traffic = {k.split("<")[0]: v["bytes_per_launch"] for k, v in json.load(open(traffic_path)).get("per_kernel", {}).items()}
+    tj = json.load(open(traffic_path)).get("per_kernel", {})
+    traffic = {k.split("<")[0]: v["bytes_per_launch"] for k, v in tj.items()}
+    # the pyramid chain per FRAME: every instantiation's launches (resize_rows_kernel<2> twice and <3> once per 8K frame)
+    chain_t = [v for k, v in tj.items() if k.startswith("resize_") or k.startswith("pyramid_tower")]
+    if chain_t:
+        traffic["resize_chain"] = round(sum(v["bytes_per_launch"] * v["dispatches"] for v in chain_t) / frames)
     # issue rates (tools/microbench/valu_rate, round-4 format): a wave64 VALU instruction occupies its SIMD for 2 cycles
     # ("full rate": 32-bit add / sub / logic / right shifts / moves, fp32 add / mul / fma) or 4 ("half rate": everything else the
     # kernels are made of) -- cycles from s_memtime, the clock measured during the run
