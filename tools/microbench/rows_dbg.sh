@@ -1,5 +1,7 @@
 #!/bin/bash
 # usage (GPU box, repo root): tools/microbench/rows_dbg.sh "<RW_DBG values>"  -- investigation builds of resize_rows_kernel (results invalid), kernel times
+# RW_DBG bits: 1 no stores, 2 no arithmetic (the first version also had 4 no loads in the loop, 8 no conversion of source rows, 16 no second level,
+# 32 per-wave time stamps: docs/history/round5.md has what they showed)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 run() {
     timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_sw -o bench -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-configs --sustain-seconds 0 --streams 1 > gpurun_out/bench_sw.log 2>&1
