@@ -209,6 +209,25 @@ __global__ __launch_bounds__(NW * 64) void knn2_mfma_kernel(const uint8_t* __res
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[c][r] = FP4 ? (acc_t)KNN_FP4_BIAS : (acc_t)0;
         const uint8_t* arow = s_tile + li * LP + 16 * lh;
+#ifndef EFX_MATCH_NO_PRELOAD
+        if constexpr (FP4 && CB == 1) {
+            // round 5: all KS fragments requested up front (32 more VGPRs: 114, still four waves per SIMD), the MFMAs back to back
+            // as they arrive (s_waitcnt lgkmcnt(7) .. (0)) instead of two reads - two MFMAs - two reads: 0.425 -> 0.410 ms per
+            // 40 000 x 40 000 x 512-bit call, same box (tools/microbench/match_ab.sh).  Holding three workgroups per CU instead
+            // (85 registers) spills.  -DEFX_MATCH_NO_PRELOAD: the one-ahead form below
+            i32x4 af[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) af[ks] = *reinterpret_cast<const i32x4*>(arow + 32 * ks);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) {
+                const i32x8 a8 = { af[ks][0], af[ks][1], af[ks][2], af[ks][3], 0, 0, 0, 0 };
+                const i32x8 b8 = { bq[0][ks][0], bq[0][ks][1], bq[0][ks][2], bq[0][ks][3], 0, 0, 0, 0 };
+                acc[0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[0], 4, 4, 0, 0, 0, 0);
+            }
+        } else
+#endif
+        {
         // one A fragment ahead; the scheduling barrier keeps the compiler from hoisting all KS fragments (4 VGPRs each)
         i32x4 a = *reinterpret_cast<const i32x4*>(arow);
 #pragma unroll
@@ -226,6 +245,7 @@ __global__ __launch_bounds__(NW * 64) void knn2_mfma_kernel(const uint8_t* __res
             }
             a = an;
             if (CB > 1) __builtin_amdgcn_sched_barrier(0);
+        }
         }
         // C layout: column (query) = lane & 31, row (train) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5): increasing with reg
         const int t0 = tile * 32 + 4 * lh;
@@ -299,7 +319,8 @@ __global__ __launch_bounds__(512) void knn2_fp4_kernel(const uint8_t* __restrict
     constexpr int NPIECE = TT * 32 * NB / 16;              // 16-byte pieces of a step's TT tiles (rows contiguous in memory)
     constexpr int NPF = (NPIECE + NT - 1) / NT;
     const int LOWEST = 0;                                  // key (knn_key: the bits of a positive float) below every real one
-    __shared__ __attribute__((aligned(16))) uint8_t s_tile[TT * 32 * LP];
+    // two copies of a step's tiles taking turns: ONE barrier per step (see knn2_mfma_kernel's DB form; round 5)
+    __shared__ __attribute__((aligned(16))) uint8_t s_tiles[2 * TT * 32 * LP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int q0 = blockIdx.x * 256 + wave * 32;
@@ -321,6 +342,7 @@ __global__ __launch_bounds__(512) void knn2_fp4_kernel(const uint8_t* __restrict
     };
     if (tile0 < tile1) fetch(tile0);
     for (int tile = tile0; tile < tile1; tile += TT) {
+        uint8_t* s_tile = s_tiles + (((tile - tile0) / TT) & 1) * (TT * 32 * LP);
 #pragma unroll
         for (int j = 0; j < NPF; j++) {
             const int piece = tid + NT * j, row = piece / (NB / 16), col = piece - row * (NB / 16);
@@ -334,13 +356,19 @@ __global__ __launch_bounds__(512) void knn2_fp4_kernel(const uint8_t* __restrict
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[tt][r] = KNN_FP4_BIAS;
         const uint8_t* arow = s_tile + li * LP + 16 * lh;
+        // every fragment of the step requested up front, the MFMAs back to back as they arrive (round 5, as knn2_mfma_kernel)
+        i32x4 af[KS][TT];
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++)
+#pragma unroll
+            for (int tt = 0; tt < TT; tt++) af[ks][tt] = *reinterpret_cast<const i32x4*>(arow + tt * 32 * LP + 32 * ks);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) {
             const i32x8 b8 = { bq[ks][0], bq[ks][1], bq[ks][2], bq[ks][3], 0, 0, 0, 0 };
 #pragma unroll
             for (int tt = 0; tt < TT; tt++) {
-                const i32x4 a = *reinterpret_cast<const i32x4*>(arow + tt * 32 * LP + 32 * ks);
-                const i32x8 a8 = { a[0], a[1], a[2], a[3], 0, 0, 0, 0 };
+                const i32x8 a8 = { af[ks][tt][0], af[ks][tt][1], af[ks][tt][2], af[ks][tt][3], 0, 0, 0, 0 };
                 acc[tt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[tt], 4, 4, 0, 0, 0, 0);
             }
         }
@@ -377,7 +405,7 @@ __global__ __launch_bounds__(512) void knn2_fp4_kernel(const uint8_t* __restrict
                 }
             }
         }
-        __syncthreads();                                   // every wave is done with the tiles before they are overwritten
+        // (no barrier here: the next step writes the OTHER copy, and this one is not written again before every wave has passed the next barrier)
     }
     // the two row-halves of a query (lanes l and l + 32) merge their best two; dot -> Hamming distance
     {
