@@ -16,6 +16,7 @@
 #include "efx_device.h"
 #include "bad_affine.h"
 #include <algorithm>
+#include <type_traits>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -588,7 +589,23 @@ __device__ __forceinline__ void rows_dma2(const __amdgpu_buffer_rsrc_t rsrc, int
 }
 template <int N> __device__ __forceinline__ void rows_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" : : "i"(N) : "memory"); }
 
-// the source pixel pairs of a lane's four outputs from an LDS row: [left, right] x 4 as floats
+// the source pixel pairs of a lane's four outputs from an LDS row: the two 8-byte windows (rows_read), then [left, right] x 4 as floats
+struct RowsRaw { uint32_t a0, a1, b0, b1; };
+__device__ __forceinline__ RowsRaw rows_read(const unsigned char* row, const ResizeWin& w)
+{
+    const uint32_t* qa = reinterpret_cast<const uint32_t*>(row + w.offA);
+    const uint32_t* qb = reinterpret_cast<const uint32_t*>(row + w.offB);
+    RowsRaw r; r.a0 = qa[0]; r.a1 = qa[1]; r.b0 = qb[0]; r.b1 = qb[1];
+    return r;
+}
+__device__ __forceinline__ void rows_cvt(const RowsRaw& r, const ResizeWin& w, float (&f)[8])
+{
+    const uint32_t pa = __builtin_amdgcn_perm(r.a1, r.a0, w.selA), pb = __builtin_amdgcn_perm(r.b1, r.b0, w.selB);
+    f[0] = (float)(pa & 0xffu); f[1] = (float)((pa >> 8) & 0xffu); f[2] = (float)((pa >> 16) & 0xffu); f[3] = (float)(pa >> 24);
+    f[4] = (float)(pb & 0xffu); f[5] = (float)((pb >> 8) & 0xffu); f[6] = (float)((pb >> 16) & 0xffu); f[7] = (float)(pb >> 24);
+    // the row's pixels are in registers at this point (the conversions cannot sink below it): its LDS bytes may be overwritten
+    asm volatile("" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]));
+}
 __device__ __forceinline__ void rows_conv(const unsigned char* row, const ResizeWin& w, float (&f)[8])
 {
     const uint32_t* qa = reinterpret_cast<const uint32_t*>(row + w.offA);
@@ -629,7 +646,8 @@ template <int NLEV>
 struct RowsState {
     float wa[NLEV][4], wb[NLEV][4];                          // x weights of the lane's four columns
     ResizeWin win[NLEV];                                     // where their source pixel pairs sit in the level's source row
-    uint32_t yw[NLEV];                                       // y weights of the chunk's next row: LDS byte address (8 bytes per row), read as a broadcast
+    uint32_t yw[NLEV];                                       // y weights of the chunk's rows: LDS byte address (8 bytes per row) of the row after next
+    float wy0[NLEV], wy1[NLEV];                              // ... of the NEXT row of the level: fetched (one broadcast LDS read) when the previous row is made
     int off[NLEV];                                           // store offset (a value the range check drops for lanes that own nothing)
     int pitch[NLEV];                                         // (in VECTOR registers: an SGPR source halves the rate of v_add_u32)
     __amdgpu_buffer_rsrc_t rsrc[NLEV];
@@ -637,7 +655,18 @@ struct RowsState {
     float g[NLEV][2][8];                                     // levels >= 1: converted upper / lower source row
 };
 
-// the row of level K - 1 just made (`packed`, K >= 1) is the next source row of level K
+// the y weights of level K's next row: every lane reads the same 8 bytes (a broadcast), a whole row ahead of their use
+template <int K, int NLEV>
+__device__ __forceinline__ void rows_next_weights(RowsState<NLEV>& S)
+{
+    const efx_lds_float* wy = (const efx_lds_float*)(uintptr_t)S.yw[K];
+    S.wy0[K] = wy[0]; S.wy1[K] = wy[1];
+    S.yw[K] += 8;
+}
+
+// the row of level K - 1 just made (`packed`, K >= 1) is the next source row of level K.  (Measured and dropped, round 5: the
+// levels >= 1 ONE SOURCE ROW BEHIND -- windows requested when a row is made, converted when the next one arrives, as the source
+// rows of the first level are handled in the main loop: bit-identical, 18.6 / 13.6 us per launch against 18.3 / 13.1.)
 template <int K, int NLEV>
 __device__ __forceinline__ void rows_push(RowsState<NLEV>& S, unsigned char* rowbuf, int lane, uint32_t packed, const bool (&due)[NLEV])
 {
@@ -649,10 +678,8 @@ __device__ __forceinline__ void rows_push(RowsState<NLEV>& S, unsigned char* row
         for (int q = 0; q < 8; q++) S.g[K][0][q] = S.g[K][1][q];
         rows_conv(row, S.win[K], S.g[K][1]);
         if (due[K]) {
-            const efx_lds_float* wy = (const efx_lds_float*)(uintptr_t)S.yw[K];       // every lane the same address: one broadcast LDS read
-            S.yw[K] += 8;
-            const float wy0 = wy[0], wy1 = wy[1];
-            const uint32_t pk = rows_quad(S.g[K][0], S.g[K][1], S.wa[K], S.wb[K], wy0, wy1);
+            const uint32_t pk = rows_quad(S.g[K][0], S.g[K][1], S.wa[K], S.wb[K], S.wy0[K], S.wy1[K]);
+            rows_next_weights<K>(S);
             if (!(RW_DBG & 1) || pk == 0x12345678u) __builtin_amdgcn_raw_buffer_store_b32(pk, S.rsrc[K], S.off[K], 0, 0);
             S.off[K] += S.pitch[K];
             rows_push<K + 1, NLEV>(S, rowbuf, lane, pk, due);
@@ -715,6 +742,13 @@ __global__ __launch_bounds__(256) void resize_rows_kernel(const RowsArgs A, Coun
         for (int q = 0; q < 8; q++) { S.g[k][0][q] = 0.f; S.g[k][1][q] = 0.f; }
     }
 
+    rows_lds_order();                                        // the weight tables are in LDS
+    { auto first_w = [&](auto kc) { rows_next_weights<decltype(kc)::value>(S); };
+      first_w(std::integral_constant<int, 0>());
+      if constexpr (NLEV > 1) first_w(std::integral_constant<int, 1>());
+      if constexpr (NLEV > 2) first_w(std::integral_constant<int, 2>());
+      if constexpr (NLEV > 3) first_w(std::integral_constant<int, 3>()); }
+
     // ---- source rows: dword j of the footprint by lane j (and j + 64), RW_D rows ahead, straight into the wave's LDS slots ----
     // Branch-free: the resource ends with the chunk's last source row, lanes beyond the footprint carry an offset beyond
     // every resource -- the hardware range check drops those loads (no traffic, zeros land) -- so the number of loads in flight
@@ -733,27 +767,30 @@ __global__ __launch_bounds__(256) void resize_rows_kernel(const RowsArgs A, Coun
 #pragma unroll
     for (int i = 0; i < 8; i++) { f0[i] = 0.f; f1[i] = 0.f; }
 
+    // A source row's window reads are issued ONE ITERATION AHEAD of their conversion, so that the LDS round trip runs beside the
+    // previous row's arithmetic instead of in front of this row's (round 5, last pass).
+    // Source row i has landed in its slot when at most the loads of the rows behind it are in flight (stores issued since count
+    // as well: the waits are conservative by the rows they stand for).
+    rows_wait_vm<2 * (RW_D - 1)>();
+    RowsRaw raw = rows_read(rowA, S.win[0]);
     for (int i0 = 0; i0 < na_pad; i0 += RW_D) {
 #pragma unroll
         for (int u = 0; u < RW_D; u++) {
             float (&fcur)[8] = (u & 1) ? f1 : f0;
             float (&fprev)[8] = (u & 1) ? f0 : f1;
-            // source row i0 + u has landed in slot u when at most the loads of the RW_D - 1 rows behind it are in flight (stores
-            // issued since count as well: the wait is conservative by the rows they stand for)
-            rows_wait_vm<2 * (RW_D - 1)>();
-            rows_conv(rowA + u * RW_LDS_A, S.win[0], fcur);
+            rows_cvt(raw, S.win[0], fcur);                              // source row i0 + u (read in the previous iteration)
+            rows_wait_vm<2 * (RW_D - 2)>();                             // row i0 + u + 1 has landed (rows up to i0 + u + RW_D - 1 are issued)
+            raw = rows_read(rowA + ((u + 1) % RW_D) * RW_LDS_A, S.win[0]);
             rows_dma2(rsrcA, vo0, vo1, ldsA + u * RW_LDS_A);            // the slot's next row (beyond the chunk: dropped)
             vo0 += spitch_v; vo1 += spitch_v;
             bool due[NLEV];
 #pragma unroll
             for (int k = 0; k < NLEV; k++) { due[k] = (S.mask[k] & 1ull) != 0; S.mask[k] >>= 1; }
             if (due[0]) {
-                // the row's y weights: vector registers (a scalar source halves the rate of v_mul / v_fma) by ONE broadcast LDS read
-                // (until round 5's last pass: two v_readlane + two v_mov from SGPRs, 16 issue cycles per row and level)
-                const efx_lds_float* wy = (const efx_lds_float*)(uintptr_t)S.yw[0];
-                S.yw[0] += 8;
-                const float wy0 = wy[0], wy1 = wy[1];
-                const uint32_t packed = rows_quad(fprev, fcur, S.wa[0], S.wb[0], wy0, wy1);
+                // the row's y weights sit in vector registers (a scalar source halves the rate of v_mul / v_fma), fetched by ONE
+                // broadcast LDS read when the previous row was made (first versions: two v_readlane + two v_mov per row and level)
+                const uint32_t packed = rows_quad(fprev, fcur, S.wa[0], S.wb[0], S.wy0[0], S.wy1[0]);
+                rows_next_weights<0>(S);
                 if (!(RW_DBG & 1) || packed == 0x12345678u) __builtin_amdgcn_raw_buffer_store_b32(packed, S.rsrc[0], S.off[0], 0, 0);
                 S.off[0] += S.pitch[0];
                 rows_push<1, NLEV>(S, rowbuf, lane, packed, due);

@@ -320,7 +320,8 @@ __global__ __launch_bounds__(512) void knn2_fp4_kernel(const uint8_t* __restrict
     constexpr int NPF = (NPIECE + NT - 1) / NT;
     const int LOWEST = 0;                                  // key (knn_key: the bits of a positive float) below every real one
     // two copies of a step's tiles taking turns: ONE barrier per step (see knn2_mfma_kernel's DB form; round 5)
-    __shared__ __attribute__((aligned(16))) uint8_t s_tiles[2 * TT * 32 * LP];
+    constexpr bool DBUF = KS * TT <= 8;                    // (the 512-bit two-tile investigation form keeps one copy and two barriers: registers)
+    __shared__ __attribute__((aligned(16))) uint8_t s_tiles[(DBUF ? 2 : 1) * TT * 32 * LP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int q0 = blockIdx.x * 256 + wave * 32;
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(512) void knn2_fp4_kernel(const uint8_t* __restrict
     };
     if (tile0 < tile1) fetch(tile0);
     for (int tile = tile0; tile < tile1; tile += TT) {
-        uint8_t* s_tile = s_tiles + (((tile - tile0) / TT) & 1) * (TT * 32 * LP);
+        uint8_t* s_tile = s_tiles + (DBUF ? (((tile - tile0) / TT) & 1) * (TT * 32 * LP) : 0);
 #pragma unroll
         for (int j = 0; j < NPF; j++) {
             const int piece = tid + NT * j, row = piece / (NB / 16), col = piece - row * (NB / 16);
@@ -356,20 +357,34 @@ __global__ __launch_bounds__(512) void knn2_fp4_kernel(const uint8_t* __restrict
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[tt][r] = KNN_FP4_BIAS;
         const uint8_t* arow = s_tile + li * LP + 16 * lh;
-        // every fragment of the step requested up front, the MFMAs back to back as they arrive (round 5, as knn2_mfma_kernel)
-        i32x4 af[KS][TT];
+        if constexpr (DBUF) {
+            // every fragment of the step requested up front (32 VGPRs), the MFMAs back to back as they arrive (round 5, as knn2_mfma_kernel)
+            i32x4 af[KS][TT];
 #pragma unroll
-        for (int ks = 0; ks < KS; ks++)
+            for (int ks = 0; ks < KS; ks++)
 #pragma unroll
-            for (int tt = 0; tt < TT; tt++) af[ks][tt] = *reinterpret_cast<const i32x4*>(arow + tt * 32 * LP + 32 * ks);
-        __builtin_amdgcn_sched_barrier(0);
+                for (int tt = 0; tt < TT; tt++) af[ks][tt] = *reinterpret_cast<const i32x4*>(arow + tt * 32 * LP + 32 * ks);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ks = 0; ks < KS; ks++) {
-            const i32x8 b8 = { bq[ks][0], bq[ks][1], bq[ks][2], bq[ks][3], 0, 0, 0, 0 };
+            for (int ks = 0; ks < KS; ks++) {
+                const i32x8 b8 = { bq[ks][0], bq[ks][1], bq[ks][2], bq[ks][3], 0, 0, 0, 0 };
 #pragma unroll
-            for (int tt = 0; tt < TT; tt++) {
-                const i32x8 a8 = { af[ks][tt][0], af[ks][tt][1], af[ks][tt][2], af[ks][tt][3], 0, 0, 0, 0 };
-                acc[tt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[tt], 4, 4, 0, 0, 0, 0);
+                for (int tt = 0; tt < TT; tt++) {
+                    const i32x8 a8 = { af[ks][tt][0], af[ks][tt][1], af[ks][tt][2], af[ks][tt][3], 0, 0, 0, 0 };
+                    acc[tt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[tt], 4, 4, 0, 0, 0, 0);
+                }
+            }
+        } else {
+            // (512 bits x two tiles, the EFX_MATCH_TT = 2 investigation form: sixteen fragments would spill)
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) {
+                const i32x8 b8 = { bq[ks][0], bq[ks][1], bq[ks][2], bq[ks][3], 0, 0, 0, 0 };
+#pragma unroll
+                for (int tt = 0; tt < TT; tt++) {
+                    const i32x4 a = *reinterpret_cast<const i32x4*>(arow + tt * 32 * LP + 32 * ks);
+                    const i32x8 a8 = { a[0], a[1], a[2], a[3], 0, 0, 0, 0 };
+                    acc[tt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[tt], 4, 4, 0, 0, 0, 0);
+                }
             }
         }
 #pragma unroll
@@ -405,7 +420,8 @@ __global__ __launch_bounds__(512) void knn2_fp4_kernel(const uint8_t* __restrict
                 }
             }
         }
-        // (no barrier here: the next step writes the OTHER copy, and this one is not written again before every wave has passed the next barrier)
+        // (DBUF: no barrier here: the next step writes the OTHER copy, and this one is not written again before every wave has passed the next barrier)
+        if (!DBUF) __syncthreads();
     }
     // the two row-halves of a query (lanes l and l + 32) merge their best two; dot -> Hamming distance
     {

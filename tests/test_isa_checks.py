@@ -55,4 +55,4 @@ def test_rows_kernel_owns_m0(asm):
         outside = re.sub(r";;#ASMSTART.*?;;#ASMEND", "", body, flags=re.S)
         uses = [l.strip() for l in outside.splitlines() if re.search(r"\bm0\b", l) and not l.strip().startswith((";", "."))]
         assert not uses, f"{name}: the compiler uses M0 outside the LDS-DMA statements: {uses[:4]}"
-        assert body.count("offen lds") >= 4 and "s_waitcnt vmcnt(10)" in body
+        assert body.count("offen lds") >= 4 and "s_waitcnt vmcnt(10)" in body and "s_waitcnt vmcnt(8)" in body
