@@ -31,6 +31,9 @@
 #include <stdlib.h>
 
 #define HS_KPAD 132   // 129 padded to a multiple of 4 floats (row pitch of the fp32 weights)
+#ifndef HS_PP
+#define HS_PP 36      // row pitch of the rectified patch in LDS (bytes)
+#endif
 #define HS_KB 144     // K of the bf16 projection: 129 padded to 9 MFMA steps of 16
 
 namespace {
@@ -128,7 +131,10 @@ __global__ __launch_bounds__(256) void patch_sift_kernel(
 {
     const int dbg = EFX_DBG(dbg_arg);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ uint8_t s_patch[32 * 32];
+    // Patch rows HS_PP bytes apart.  With 32 the gradient reads of a wave -- 16 cells x 4 pixels: x = 8 (cell & 3) + w, y = 8 (cell >> 2) --
+    // met in FOUR banks, four rows deep (rows 8 apart are 256 bytes = one bank row apart); 36 puts the 16 cells' dwords in 16
+    // different banks, and the warp's 8 x 8 stores likewise (-DHS_PP=32: the old pitch, A/B)
+    __shared__ __attribute__((aligned(4))) uint8_t s_patch[32 * HS_PP];
     // Histogram in 15.17 fixed point (order-independent integer sums; a bin collects at most 64 pixel-weights x 361 of
     // magnitude < 2^15, so 17 fractional bits fill an unsigned 32-bit counter).  A pixel votes for TWO adjacent orientation bins of
     // each of four cells: the pair goes out as ONE 64-bit LDS atomic on two packed 32-bit counters (a counter stays below
@@ -226,7 +232,7 @@ __global__ __launch_bounds__(256) void patch_sift_kernel(
                 if (iv > 255) iv = 255;
                 val = (uint8_t)iv;
             }
-            s_patch[(y0 + 8 * k) * 32 + x] = val;
+            s_patch[(y0 + 8 * k) * HS_PP + x] = val;
         }
     }
     __syncthreads();
@@ -250,8 +256,8 @@ __global__ __launch_bounds__(256) void patch_sift_kernel(
             for (int k = 0; k < 4; k++) {
                 const int y = y0 + 2 * k;
                 if (y >= 30) continue;
-                const uint8_t* pc = s_patch + (y + 1) * 32 + (x + 1);
-                const int idx = (int)pc[1] - (int)pc[-1], idy = (int)pc[-32] - (int)pc[32];
+                const uint8_t* pc = s_patch + (y + 1) * HS_PP + (x + 1);
+                const int idx = (int)pc[1] - (int)pc[-1], idy = (int)pc[-HS_PP] - (int)pc[HS_PP];
                 // scaleO * atan2f(dy, dx) and sqrtf(dx^2 + dy^2): dx, dy are integers in [-255, 255], so the host tabulates
                 // the CPU code's own libm results for all 511 x 511 gradients (hash_sift.cpp:254-258)
                 const efx_u32x2 gw = __builtin_amdgcn_raw_buffer_load_b64(lut_rsrc, (idy * 511 + idx + 255 * 512) * 8, 0, 0);
