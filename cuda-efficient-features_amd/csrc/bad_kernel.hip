@@ -473,6 +473,9 @@ __global__ __launch_bounds__(256) void bad_det_kernel(
 // Measured (MI355X, C3: 40 000 keypoints of a 4K frame, profiles/r03_c3_*): the kernel is bound by the LDS pipe -- the
 // random box gathers cost 3.4 cycles per 32 lanes in bank conflicts -- with the VALU 60 % busy beside it.
 // ================================================================================================
+#ifndef BAD_RAW_CB
+#define BAD_RAW_CB 8                 // rows the column prefix reads ahead of its adds (divides 24)
+#endif
 #define BAD_RAW_JP BAD_J_PITCH                             // u16 entries per integral row (25 dwords)
 #define BAD_RAW_WAVE_LDS 4912                             // 49 * 50 * 2 = 4900, rounded to 16
 
@@ -571,20 +574,38 @@ __global__ __launch_bounds__(256) void bad_raw_kernel(
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // ---- column prefix in place (lane = column pair), modulo 2^16 per column ----
-        if (lane < JD) {
-            Jd[lane] = 0u;
-            u16x2 run = { 0, 0 };
+        // ---- column prefix in place (lane = column pair), modulo 2^16 per column.  Round 5: in TWO halves side by side -- lanes 0 .. 24
+        //      run down plane rows 1 .. 24, lanes 32 .. 56 down rows 25 .. 48 (24 dependent steps instead of 48: the phase was 15 of
+        //      the kernel's 62 us, tools/experiments/README.md) --, then rows 25 .. 48 receive row 24's totals, two rows per pass on
+        //      50 lanes, no chain.  Integer sums modulo 2^16: the order does not matter. ----
+        {
+            const int half = lane >> 5, col = lane & 31;
+            if (col < JD) {
+                if (half == 0) Jd[col] = 0u;
+                const int rb = 1 + (S / 2) * half;
+                u16x2 run = { 0, 0 };
 #pragma unroll
-            for (int r0 = 0; r0 < S; r0 += 8) {
-                uint32_t v[8];
+                for (int r0 = 0; r0 < S / 2; r0 += BAD_RAW_CB) {
+                    uint32_t v[BAD_RAW_CB];
 #pragma unroll
-                for (int i = 0; i < 8; i++) v[i] = Jd[(r0 + i + 1) * JD + lane];
+                    for (int i = 0; i < BAD_RAW_CB; i++) v[i] = Jd[(rb + r0 + i) * JD + col];
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    run = run + __builtin_bit_cast(u16x2, v[i]);
-                    Jd[(r0 + i + 1) * JD + lane] = __builtin_bit_cast(uint32_t, run);
+                    for (int i = 0; i < BAD_RAW_CB; i++) {
+                        run = run + __builtin_bit_cast(u16x2, v[i]);
+                        Jd[(rb + r0 + i) * JD + col] = __builtin_bit_cast(uint32_t, run);
+                    }
                 }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int g = lane >= JD ? 1 : 0, c = lane - JD * g;
+            if (lane < 2 * JD) {
+                const u16x2 tot = __builtin_bit_cast(u16x2, Jd[(S / 2) * JD + c]);
+                uint32_t v[S / 4];
+#pragma unroll
+                for (int j = 0; j < S / 4; j++) v[j] = Jd[(S / 2 + 1 + g + 2 * j) * JD + c];
+#pragma unroll
+                for (int j = 0; j < S / 4; j++) Jd[(S / 2 + 1 + g + 2 * j) * JD + c] = __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, v[j]) + tot));
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
