@@ -783,6 +783,28 @@ def test_level_blur_paths_equal_oracle(cef, torch_mod, oracle, cols, monkeypatch
     monkeypatch.delenv("EFX_NO_LEVEL_BLUR", raising=False)
 
 
+@pytest.mark.parametrize("kind", ["flat", "half_flat", "smooth"])
+def test_frames_with_empty_tiles(cef, torch_mod, oracle, kind):
+    """Tiles without FAST corners leave harris_kernel / nms_kernel at once (round 5): a constant frame (no corner anywhere), a frame
+    whose lower half is constant (empty tiles beside full ones, at every level) and a 1/f^2 frame (nothing above the threshold)."""
+    torch = torch_mod
+    if kind == "flat":
+        img = np.full((1080, 1920), 128, np.uint8)
+    elif kind == "half_flat":
+        img = np.concatenate([synth.synth_frame(540, 1920, seed=5), np.full((540, 1920), 60, np.uint8)])
+    else:
+        img = synth.powerlaw_frame(720, 1280, seed=3, beta=2.0, contrast=40.0)
+    img = np.ascontiguousarray(img)
+    det = cef.EfficientFeatures.create(5000, dtype=cef.EfficientFeatures.BAD_256)
+    kps, desc, cnt = det.detectAndComputeAsync(torch.from_numpy(img).cuda()); torch.cuda.synchronize()
+    n = int(cnt.item())
+    ref = oracle.detect_and_compute(img, nfeatures=5000, desc_type=oracle.BAD_256)
+    assert n == ref["n"]
+    assert (n > 0) == (kind == "half_flat")
+    assert np.array_equal(kps[:, :n].cpu().numpy().view(np.uint32), ref["kps"].view(np.uint32))
+    assert np.array_equal(desc[:n].cpu().numpy(), ref["desc"])
+
+
 def test_detect_and_compute_is_graph_capturable(cef, torch_mod, oracle):
     """The whole detectAndCompute launch sequence (17 kernels, no host synchronisation, no allocation once the context has seen
     the geometry) can be captured into a HIP graph and replayed: same keypoints and descriptors as the direct call and as the
