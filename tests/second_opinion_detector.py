@@ -184,9 +184,10 @@ def ic_angle(img, x, y):
     return f32(a * (180.0 / math.pi)), (m01, m10)
 
 
-def detect_and_compute(img, nfeatures, scale_factor=1.2, nlevels=8, fast_threshold=20, nonmax_radius=15, bad_bits=0):
+def detect_and_compute(img, nfeatures, scale_factor=1.2, nlevels=8, fast_threshold=20, nonmax_radius=15, bad_bits=0, hashsift=False):
     """detectAndComputeAsync (.cpp:225-321), firstLevel 0, no mask.  Returns (5 x N float32 rows, N x bad_bits / 8 bytes or None,
-    per-level statistics).  Output order: levels ascending, canonical order inside a level (spec S1)."""
+    per-level statistics).  Output order: levels ascending, canonical order inside a level (spec S1).  hashsift: instead of BAD
+    bytes, the HashSIFT 129-vectors of the keypoints (hash_sift.cpp on the blurred level, cropping scale 1: createDescriber, .cpp:58-62)."""
     geo = pyramid_geometry(img.shape[0], img.shape[1], scale_factor, nlevels)
     quota = level_quotas(nfeatures, scale_factor, nlevels)
     level = img
@@ -214,7 +215,10 @@ def detect_and_compute(img, nfeatures, scale_factor=1.2, nlevels=8, fast_thresho
         if n == 0:
             continue
         ang = np.array([ic_angle(level, int(x), int(y))[0] for x, y in zip(xs, ys)], np.float32)
-        if bad_bits:
+        if hashsift:
+            kp = np.stack([xs.astype(np.float32), ys.astype(np.float32), np.full(n, PATCH_SIZE, np.float32), ang], 1)
+            desc_out.append(so.hashsift_vectors(gaussian7(level), kp, 1.0)[0])
+        elif bad_bits:
             blur = gaussian7(level)                                         # .cpp:305: the describer sees the blurred level,
             kp = np.stack([xs.astype(np.float32), ys.astype(np.float32), np.full(n, PATCH_SIZE, np.float32), ang], 1)   # convertKeypoints: size 31
             desc_out.append(so.bad_describe(blur, kp, bad_bits, scale_factor=1.0))      # createDescriber: BAD::create(1, ..) (.cpp:53-56)
@@ -229,5 +233,8 @@ def detect_and_compute(img, nfeatures, scale_factor=1.2, nlevels=8, fast_thresho
         r[4] = f32(scale * f32(PATCH_SIZE))
         rows_out.append(r)
     kps = np.concatenate(rows_out, axis=1) if rows_out else np.zeros((5, 0), np.float32)
-    desc = (np.concatenate(desc_out, axis=0) if desc_out else np.zeros((0, bad_bits // 8), np.uint8)) if bad_bits else None
+    if hashsift:
+        desc = np.concatenate(desc_out, axis=0) if desc_out else np.zeros((0, 129), np.float32)
+    else:
+        desc = (np.concatenate(desc_out, axis=0) if desc_out else np.zeros((0, bad_bits // 8), np.uint8)) if bad_bits else None
     return kps, desc, stats

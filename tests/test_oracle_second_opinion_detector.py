@@ -72,3 +72,21 @@ def test_whole_flow_other_parameters(oracle):
     img = synth.powerlaw_frame(280, 360, seed=9, beta=1.1, contrast=70.0)
     _compare(oracle, img, nfeatures=300, nlevels=3, bits=256, scale_factor=1.5, fast_threshold=12, nonmax_radius=7)
     _compare(oracle, img, nfeatures=300, nlevels=6, bits=0, scale_factor=1.1, fast_threshold=30, nonmax_radius=20)
+
+
+@pytest.mark.parametrize("nbits", [256, 512])
+def test_whole_flow_hashsift(oracle, nbits):
+    """detectAndCompute with a HashSIFT describer: the oracle's descriptor bytes against the second restatement's 129-vectors of the
+    same keypoints on the blurred level (tests/second_opinion.py), projected in double -- bits equal wherever the projection is
+    not within float rounding of zero."""
+    from tests import second_opinion as so
+    img = synth.synth_frame(280, 380, seed=41, density=1.5)
+    _, vec, _ = sod.detect_and_compute(img, 200, nlevels=3, hashsift=True)
+    got = oracle.detect_and_compute(img, nfeatures=200, nlevels=3, desc_type=2 if nbits == 256 else 3)
+    assert got["n"] == len(vec) > 100
+    want, T = so.hashsift_bits(vec, nbits)
+    decided = np.abs(T) > 1e-3
+    bg = np.unpackbits(got["desc"], axis=1).astype(bool)
+    bw = np.unpackbits(want, axis=1).astype(bool)
+    assert np.array_equal(bg[decided], bw[decided])
+    assert decided.mean() > 0.999
