@@ -482,10 +482,13 @@ __global__ __launch_bounds__(256) void bad_det_kernel(
 template <int NIT>            // descriptor words of 64 bits: 4 (BAD256) or 8 (BAD512)
 __global__ __launch_bounds__(256) void bad_raw_kernel(
     const int* __restrict__ d_count, int n, const BadParamsDev* __restrict__ P, const Affine* __restrict__ aff,
-    uint8_t* __restrict__ desc, size_t desc_pitch)
+    uint8_t* __restrict__ desc, size_t desc_pitch, int batched, size_t aff_stride, const FrameOut counts, const FrameDesc descs)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int S = 48, JP = BAD_RAW_JP, JD = JP / 2;
+    if (batched) {       // frame blockIdx.y of a batched detectAndCompute: its count, records and descriptor matrix
+        d_count = counts.count[blockIdx.y]; desc = descs.desc[blockIdx.y]; aff += blockIdx.y * aff_stride;
+    }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int count = d_count ? min(*d_count, n) : n;
@@ -700,18 +703,18 @@ void efx_gaussian_taps_host(float taps[7])
 // the BORDER_REFLECT_101 pixels of the right edge are a fixed pattern of register moves in lanes 62 / 63 (by r = number of
 // valid pixels in that dword), as the left edge's are in lane 0 of strip 0.  Regular strips do not store columns >= xs
 // (the anchored strip owns them), so none of the columns they do store needs a pixel beyond the level.
-struct BlurLevel { const uint8_t* src; uint8_t* dst; int spitch, dpitch, rows, cols, bytes, n_reg, nstrips, xs, task_end; };
+struct BlurLevel { const uint8_t* src; uint8_t* dst; int spitch, dpitch, rows, cols, bytes, n_reg, nstrips, xs, task_end, src_img0; };
 struct BlurLevelsArgs { int nlevels, total, nr; BlurLevel lv[EFX_MAX_LEVELS]; };     // nr: output rows of a dword-path task (7 .. BLV_ROWS)
 
 // the generic form: 10 input pixels per lane as byte loads at reflected columns (any alignment, any size)
-__device__ __forceinline__ void blur_task_bytes(const BlurLevel& L, int strip, int chunk, int lane, const float (&tp)[7])
+__device__ __forceinline__ void blur_task_bytes(const BlurLevel& L, const uint8_t* Lsrc, uint8_t* Ldst, int strip, int chunk, int lane, const float (&tp)[7])
 {
     constexpr int NR = BLV_ROWS_BYTES;
     const int rows = L.rows, cols = L.cols, spitch = L.spitch, dpitch = L.dpitch;
     const int x = strip * 256 + lane * 4;
     const int y0 = chunk * NR;
     const int nout = min(NR, rows - y0);
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(L.src), 0, (rows - 1) * spitch + cols, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(Lsrc), 0, (rows - 1) * spitch + cols, 0x00020000);
     int cidx[10];
 #pragma unroll
     for (int k = 0; k < 10; k++) cidx[k] = efx_reflect101(x - 3 + k, cols);
@@ -731,7 +734,7 @@ __device__ __forceinline__ void blur_task_bytes(const BlurLevel& L, int strip, i
     float R[7][4];
 #pragma unroll
     for (int i = 0; i < 6; i++) rowpass(y0 - 3 + i, R[i]);
-    uint8_t* drow = L.dst + (size_t)y0 * dpitch + x;
+    uint8_t* drow = Ldst + (size_t)y0 * dpitch + x;
     for (int base = 0; base < nout; base += 7) {
 #pragma unroll
         for (int u = 0; u < 7; u++) {
@@ -753,7 +756,7 @@ __device__ __forceinline__ void blur_task_bytes(const BlurLevel& L, int strip, i
 }
 
 // the dword path: straight-line rows (no branch but the loop's), loads two rows ahead, stores through a range-checked resource
-__device__ __forceinline__ void blur_task_dwords(const BlurLevel& L, int strip, int chunk, int lane, const float (&tp)[7], int nr)
+__device__ __forceinline__ void blur_task_dwords(const BlurLevel& L, const uint8_t* Lsrc, uint8_t* Ldst, int strip, int chunk, int lane, const float (&tp)[7], int nr)
 {
     const int rows = L.rows, cols = L.cols, spitch = L.spitch, dpitch = L.dpitch;
     const bool anchored = strip == L.n_reg;                // wave-uniform
@@ -763,10 +766,10 @@ __device__ __forceinline__ void blur_task_dwords(const BlurLevel& L, int strip, 
     const int nout = min(nr, rows - y0);
     // a row's dwords up to roundup4(cols) are memory we may read (own levels: padded rows; a caller's aligned level 0: its pitch
     // is a multiple of 4); beyond that -- and left of the level, where the offset wraps -- the range check returns 0
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(L.src), 0, (rows - 1) * spitch + ((cols + 3) & ~3), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(Lsrc), 0, (rows - 1) * spitch + ((cols + 3) & ~3), 0x00020000);
     // rows of this task only, and (regular strips) columns left of the anchored strip only: everything else is an offset the
     // range check drops.  Destination rows are padded to 256 bytes: the dword of a row's last pixels is inside the row
-    const __amdgpu_buffer_rsrc_t dsrc = __builtin_amdgcn_make_buffer_rsrc(L.dst, 0, (y0 + nout) * dpitch, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dsrc = __builtin_amdgcn_make_buffer_rsrc(Ldst, 0, (y0 + nout) * dpitch, 0x00020000);
     const int dx = (anchored || x < L.xs) ? x : 0x40000000;
     const int r = cols - ((cols - 1) & ~3);                // valid pixels in the level's last dword: 1 .. 4
     struct Raw { uint32_t a, b, c; };
@@ -855,7 +858,8 @@ __device__ __forceinline__ void blur_task_dwords(const BlurLevel& L, int strip, 
 // spills at seven waves per SIMD -- a kernel with scratch costs ~25 us of dispatch stall per launch on this runtime (round 4: the
 // HIP-event pair around the launch read 88 us where the kernel itself ran 57)
 template <bool BYTES>
-__global__ __launch_bounds__(256, BYTES ? 7 : BLV_WAVES) void blur_levels_kernel(const BlurLevelsArgs A, float tp0, float tp1, float tp2, float tp3)
+__global__ __launch_bounds__(256, BYTES ? 7 : BLV_WAVES) void blur_levels_kernel(const BlurLevelsArgs A, float tp0, float tp1, float tp2, float tp3,
+                                                                                    const FrameIn in, size_t pyr_stride, size_t blur_stride)
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -871,13 +875,22 @@ __global__ __launch_bounds__(256, BYTES ? 7 : BLV_WAVES) void blur_levels_kernel
     // row read the taps from SGPRs and the kernel took 68 instead of 57 us
     asm volatile("" : "+v"(tp0), "+v"(tp1), "+v"(tp2), "+v"(tp3));
     const float tp[7] = { tp0, tp1, tp2, tp3, tp2, tp1, tp0 };
-    if (BYTES) blur_task_bytes(L, strip, chunk, lane, tp);
-    else blur_task_dwords(L, strip, chunk, lane, tp, A.nr);
+    // this frame's (blockIdx.y) source level and blurred copy
+    const uint8_t* Lsrc = L.src_img0 ? in.img0[blockIdx.y] : L.src + blockIdx.y * pyr_stride;
+    uint8_t* Ldst = L.dst + blockIdx.y * blur_stride;
+    if (BYTES) blur_task_bytes(L, Lsrc, Ldst, strip, chunk, lane, tp);
+    else blur_task_dwords(L, Lsrc, Ldst, strip, chunk, lane, tp, A.nr);
 }
 
 hipError_t efx_launch_blur_levels(const LevelTable& H, const uint8_t* img0, int pitch0, const uint8_t* pyramid, uint8_t* blurred,
-                                  int blur0_pitch, size_t blur_levels_off, const ProfRec& prof_rec, hipStream_t stream)
+                                  int blur0_pitch, size_t blur_levels_off, const ProfRec& prof_rec, hipStream_t stream,
+                                  int nframes, const FrameIn& in_frames, const FrameStride& fs)
 {
+    const int NF = nframes > 0 ? nframes : 1;
+    FrameIn in = in_frames;
+    if (NF == 1) in.img0[0] = img0;
+    uintptr_t img_bits = 0;              // level 0's alignment must hold for every frame's image
+    for (int f = 0; f < NF; f++) img_bits |= reinterpret_cast<uintptr_t>(in.img0[f]);
     // Rows per task of the dword path: 63 on large pyramids (a task recomputes 6 rows of the row pass: 10 %), fewer on small ones
     // -- an FHD pyramid has 400 tasks of 63 rows for 1024 SIMDs, and a lone wave issues one VALU instruction per 4 cycles: the
     // kernel then took 25 us of a 110 us call.  The smallest multiple of 7 that still leaves ~3000 tasks, but not below 14
@@ -890,11 +903,11 @@ hipError_t efx_launch_blur_levels(const LevelTable& H, const uint8_t* img0, int 
             if (!L.active || L.rows <= 0 || L.cols <= 0) continue;
             const uint8_t* src = l == 0 ? img0 : pyramid + L.img_off;
             const int spitch = l == 0 ? pitch0 : L.pitch;
-            const bool aligned = ((((uintptr_t)src) | (uintptr_t)spitch) & 3u) == 0;
+            const bool aligned = (((l == 0 ? img_bits : (uintptr_t)src) | (uintptr_t)spitch) & 3u) == 0;
             const bool bytes = !(aligned && L.cols >= 512 && L.rows >= 16);
             BlurLevelsArgs& T = A[bytes ? 1 : 0];
             BlurLevel& B = T.lv[T.nlevels++];
-            B.src = src; B.spitch = spitch;
+            B.src = src; B.spitch = spitch; B.src_img0 = l == 0 ? 1 : 0;
             B.dst = l == 0 ? blurred : blurred + blur_levels_off + L.img_off;
             B.dpitch = l == 0 ? blur0_pitch : L.pitch;
             B.rows = L.rows; B.cols = L.cols;
@@ -910,7 +923,7 @@ hipError_t efx_launch_blur_levels(const LevelTable& H, const uint8_t* img0, int 
             }
             B.task_end = T.total;
         }
-        if (A[0].total + A[1].total >= 3072) break;
+        if ((A[0].total + A[1].total) * NF >= 3072) break;
     }
     if (A[0].total + A[1].total == 0) return hipSuccess;
     float t[7];
@@ -919,8 +932,8 @@ hipError_t efx_launch_blur_levels(const LevelTable& H, const uint8_t* img0, int 
     for (int k = 0; k < 2; k++) {
         if (A[k].total == 0) continue;
         const int nblk = ((A[k].total + 3) / 4 + EFX_NXCD - 1) / EFX_NXCD * EFX_NXCD;     // xcd_chunked wants whole rounds
-        if (k == 0) hipLaunchKernelGGL(blur_levels_kernel<false>, dim3(nblk), dim3(256), 0, stream, A[k], t[0], t[1], t[2], t[3]);
-        else hipLaunchKernelGGL(blur_levels_kernel<true>, dim3(nblk), dim3(256), 0, stream, A[k], t[0], t[1], t[2], t[3]);
+        if (k == 0) hipLaunchKernelGGL(blur_levels_kernel<false>, dim3(nblk, NF), dim3(256), 0, stream, A[k], t[0], t[1], t[2], t[3], in, fs.pyramid, fs.blurred);
+        else hipLaunchKernelGGL(blur_levels_kernel<true>, dim3(nblk, NF), dim3(256), 0, stream, A[k], t[0], t[1], t[2], t[3], in, fs.pyramid, fs.blurred);
     }
     prof_rec.end(prof, 11, stream);
     return hipGetLastError();
@@ -950,12 +963,14 @@ hipError_t efx_launch_bad(const DescribeLaunch& a, const BadParamsDev* d_params,
     if (a.blur && a.level_blurred) {
         // the records point at BLURRED level images (efx_launch_blur_levels ran on this stream): a wave per keypoint, no blur
         // of its own.  detect_common sets level_blurred only under bad_raw_kernel's conditions (S == 48, box edges <= 16)
+        const int batched = a.nframes > 1 ? 1 : 0;
+        const int NF = batched ? a.nframes : 1;
         if (a.nbits == 256)
-            hipLaunchKernelGGL(bad_raw_kernel<4>, dim3((a.n + 3) / 4), dim3(256), 4 * BAD_RAW_WAVE_LDS, stream, a.d_count, a.n, d_params, aff,
-                               a.desc, a.desc_pitch);
+            hipLaunchKernelGGL(bad_raw_kernel<4>, dim3((a.n + 3) / 4, NF), dim3(256), 4 * BAD_RAW_WAVE_LDS, stream, a.d_count, a.n, d_params, aff,
+                               a.desc, a.desc_pitch, batched, a.aff_stride, a.counts, a.descs);
         else
-            hipLaunchKernelGGL(bad_raw_kernel<8>, dim3((a.n + 3) / 4), dim3(256), 4 * BAD_RAW_WAVE_LDS, stream, a.d_count, a.n, d_params, aff,
-                               a.desc, a.desc_pitch);
+            hipLaunchKernelGGL(bad_raw_kernel<8>, dim3((a.n + 3) / 4, NF), dim3(256), 4 * BAD_RAW_WAVE_LDS, stream, a.d_count, a.n, d_params, aff,
+                               a.desc, a.desc_pitch, batched, a.aff_stride, a.counts, a.descs);
         return hipGetLastError();
     }
     if (a.blur) {
@@ -982,10 +997,10 @@ hipError_t efx_launch_bad(const DescribeLaunch& a, const BadParamsDev* d_params,
             // computeAsync on detector-sized keypoints: a wave per keypoint, four keypoints per workgroup
             if (a.nbits == 256)
                 hipLaunchKernelGGL(bad_raw_kernel<4>, dim3((a.n + 3) / 4), dim3(256), 4 * BAD_RAW_WAVE_LDS, stream, a.d_count, a.n, d_params, aff,
-                                   a.desc, a.desc_pitch);
+                                   a.desc, a.desc_pitch, 0, 0, a.counts, a.descs);
             else
                 hipLaunchKernelGGL(bad_raw_kernel<8>, dim3((a.n + 3) / 4), dim3(256), 4 * BAD_RAW_WAVE_LDS, stream, a.d_count, a.n, d_params, aff,
-                                   a.desc, a.desc_pitch);
+                                   a.desc, a.desc_pitch, 0, 0, a.counts, a.descs);
             return hipGetLastError();
         }
         if (S == 48 && a.uniform_size) {

@@ -234,6 +234,12 @@ __device__ __forceinline__ void efx_zero_counters(Counters* __restrict__ c, int 
     for (int i = tid; i < nwords; i += nthreads) tail[i] = 0;
 }
 
+// Frame of a batched pyramid launch (blockIdx.y): the source level is the caller's image of that frame (src_is_img0) or the
+// frame's copy of a pyramid level; destinations are pyramid levels.
+struct FramePyr { FrameIn in; size_t stride; int src_is_img0; };
+// ... of a batched detector launch: the caller's images and the distances between the frames' copies of the context's buffers
+struct FrameSet { FrameIn in; FrameStride fs; };
+
 // Four horizontally adjacent outputs of the bilinear resize (spec S5), the arithmetic all three resize kernels share.
 // ra / rb: the two source rows in LDS, lc[k]: the LDS column of output k's left source pixel (its right neighbour is the
 // next byte), wa / wb: the x weights, wy0 / wy1: the y weights.  Per output the expression of the reference, term by term, as
@@ -323,11 +329,13 @@ template <int NT>
 __global__ __launch_bounds__(NT) void resize_kernel(
     const uint8_t* __restrict__ src, int spitch, int rows, int cols, int aligned,
     uint8_t* __restrict__ dst, int dpitch, int drows, int dcols, float fx, float fy, int tiles_x, int tiles_y, int lpitch, int ytab_off,
-    Counters* __restrict__ zero, int zero_levels)
+    Counters* __restrict__ zero, int zero_levels, const FramePyr fp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
-    if (zero && blockIdx.x == 0) efx_zero_counters(zero, zero_levels, tid, NT);
+    src = fp.src_is_img0 ? fp.in.img0[blockIdx.y] : src + blockIdx.y * fp.stride;
+    dst += blockIdx.y * fp.stride;
+    if (zero && blockIdx.x == 0) efx_zero_counters(zero + blockIdx.y, zero_levels, tid, NT);
     const int tile = xcd_chunked(blockIdx.x, tiles_x * tiles_y);
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int ox0 = tx * EFX_TILE, oy0 = ty * EFX_TILE;
@@ -442,12 +450,14 @@ __global__ __launch_bounds__(256) void resize_stream_kernel(
     const uint8_t* __restrict__ src, int spitch, int rows, int cols,
     uint8_t* __restrict__ dst, int dpitch, int drows, int dcols, int tiles_x, int tiles_y,
     const int* __restrict__ xtab, int W, const int4* __restrict__ ytab_g, const int4* __restrict__ ttab,
-    Counters* __restrict__ zero, int zero_levels)
+    Counters* __restrict__ zero, int zero_levels, const FramePyr fp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NP = RS_ROWS / 8;                         // 8 rows per pass
     const int tid = threadIdx.x;
-    if (zero && blockIdx.x == 0) efx_zero_counters(zero, zero_levels, tid, 256);
+    src = fp.src_is_img0 ? fp.in.img0[blockIdx.y] : src + blockIdx.y * fp.stride;
+    dst += blockIdx.y * fp.stride;
+    if (zero && blockIdx.x == 0) efx_zero_counters(zero + blockIdx.y, zero_levels, tid, 256);
     // XCD x owns the x-th contiguous eighth of the tiles, its workgroups stride through it
     const int ntiles = tiles_x * tiles_y;
     const int Wg = gridDim.x / EFX_NXCD, xcd = blockIdx.x % EFX_NXCD, wg = blockIdx.x / EFX_NXCD;
@@ -581,7 +591,9 @@ struct RowsArgs {
 // One dword per lane from a buffer straight into LDS (LDS-DMA: no VGPR destination, so nothing the compiler could copy or
 // wait for): lane i's dword lands at lds_dst + 4 i (+ 256 for the second load, whose immediate offset counts on both sides).
 // The compiler does not count these loads -- the kernel waits for them itself (rows_wait_vm).  M0 is written in the statement
-// that reads it and not restored: nothing else in this kernel uses it (checked in the ISA: tools/isa_dump.sh).
+// that reads it and not restored: nothing else in this kernel uses it (checked in the ISA: tools/isa_dump.sh,
+// tests/test_isa_checks.py).  (ADVICE r5 asked for "m0" in the clobber list: this compiler treats M0 as a RESERVED register --
+// "clobbering them may lead to undefined behaviour", -Winline-asm -- so the ISA test stays the guard.)
 __device__ __forceinline__ void rows_dma2(const __amdgpu_buffer_rsrc_t rsrc, int voff0, int voff1, uint32_t lds_dst)
 {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %0, %3, 0 offen lds\n\tbuffer_load_dword %1, %3, 0 offen offset:256 lds"
@@ -688,12 +700,14 @@ __device__ __forceinline__ void rows_push(RowsState<NLEV>& S, unsigned char* row
 }
 
 template <int NLEV>
-__global__ __launch_bounds__(256) void resize_rows_kernel(const RowsArgs A, Counters* __restrict__ zero, int zero_levels)
+__global__ __launch_bounds__(256) void resize_rows_kernel(const RowsArgs A, Counters* __restrict__ zero, int zero_levels, const FramePyr fp)
 {
     constexpr int LDS_WAVE = RW_D * RW_LDS_A + (NLEV - 1) * RW_LDS_B + NLEV * 512;      // source slots | a row of every level but the last | y weights
     static_assert((LDS_WAVE & 15) == 0 && (RW_D & 1) == 0 && NLEV >= 1 && NLEV <= RW_MAXLEV, "LDS rows: 16-byte aligned; an even number of slots");
     __shared__ __attribute__((aligned(16))) unsigned char s_rows[4 * LDS_WAVE];
-    if (zero && blockIdx.x == 0) efx_zero_counters(zero, zero_levels, threadIdx.x, 256);
+    if (zero && blockIdx.x == 0) efx_zero_counters(zero + blockIdx.y, zero_levels, threadIdx.x, 256);
+    const size_t foff = blockIdx.y * fp.stride;              // this frame's copy of the pyramid
+    const uint8_t* const srcA = fp.src_is_img0 ? fp.in.img0[blockIdx.y] : A.src + foff;
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int task = xcd_chunked(blockIdx.x, gridDim.x) * 4 + wave;
@@ -728,7 +742,7 @@ __global__ __launch_bounds__(256) void resize_rows_kernel(const RowsArgs A, Coun
         S.wb[k][0] = w1.x; S.wb[k][1] = w1.y; S.wb[k][2] = w1.z; S.wb[k][3] = w1.w;
         const int4 ckk = ck[1 + k];
         const int first = uni(ckk.x), store_end = uni(ckk.y);
-        S.rsrc[k] = __builtin_amdgcn_make_buffer_rsrc(L.dst, 0, store_end * L.pitch, 0x00020000);     // rows from store_end on: dropped
+        S.rsrc[k] = __builtin_amdgcn_make_buffer_rsrc(L.dst + foff, 0, store_end * L.pitch, 0x00020000);     // rows from store_end on: dropped
         { int pv = L.pitch; asm volatile("" : "+v"(pv)); S.pitch[k] = pv; }
         // lanes that own no column of the level (halo lanes, lanes beyond the last column): an offset the range check drops
         S.off[k] = (lane < nown && col0 < L.cols) ? first * L.pitch + col0 : 0x7ffffff0;
@@ -754,7 +768,7 @@ __global__ __launch_bounds__(256) void resize_rows_kernel(const RowsArgs A, Coun
     // every resource -- the hardware range check drops those loads (no traffic, zeros land) -- so the number of loads in flight
     // is the same at every row and the wait below is a constant.
     const __amdgpu_buffer_rsrc_t rsrcA =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(A.src), 0, a_last * A.spitch + ((A.scols + 3) & ~3), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(srcA), 0, a_last * A.spitch + ((A.scols + 3) & ~3), 0x00020000);
     int vo0 = a_first * A.spitch + ax0 + 4 * lane;
     int vo1 = lane + 64 < nd ? vo0 : 0x7ffffff0;            // (the second load's + 256 is its immediate offset)
     int spitch_v = A.spitch;
@@ -825,10 +839,12 @@ __device__ __forceinline__ int tower_src(int o, float f, int n) { const int v = 
 
 template <int NT>
 __global__ __launch_bounds__(NT) void pyramid_tower_kernel(const LevelTable* __restrict__ T, const uint8_t* __restrict__ img0, int pitch0,
-                                                            uint8_t* __restrict__ pyramid, TowerArgs A, Counters* __restrict__ zero)
+                                                            uint8_t* __restrict__ pyramid, TowerArgs A, Counters* __restrict__ zero, const FramePyr fp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (zero && blockIdx.x == 0) efx_zero_counters(zero, T->nlevels, threadIdx.x, NT);
+    img0 = fp.in.img0[blockIdx.y];
+    pyramid += blockIdx.y * fp.stride;
+    if (zero && blockIdx.x == 0) efx_zero_counters(zero + blockIdx.y, T->nlevels, threadIdx.x, NT);
     __shared__ int s_rng[EFX_MAX_LEVELS][8];        // per level: lox, hix, ownlox, ownhix, loy, hiy, ownloy, ownhiy
     const int tid = threadIdx.x;
     const int tile = xcd_chunked(blockIdx.x, A.tiles_x * A.tiles_y);
@@ -1054,9 +1070,13 @@ __device__ __forceinline__ void efx_tile_of(const LevelTable* T, int gt, int& l,
 __global__ __launch_bounds__(256) void fast_kernel(
     const LevelTable* __restrict__ T, const uint8_t* __restrict__ img0, int pitch0, int aligned0,
     const uint8_t* __restrict__ pyramid, int threshold, const uint8_t* __restrict__ mask, int mask_pitch,
-    uint32_t* __restrict__ cand_xy_all, TileHdr* __restrict__ hdr_all, Counters* __restrict__ cnt, int dbg_arg)
+    uint32_t* __restrict__ cand_xy_all, TileHdr* __restrict__ hdr_all, Counters* __restrict__ cnt, int dbg_arg, const FrameSet F)
 {
     const int dbg = EFX_DBG(dbg_arg);
+    {   // this frame's buffers (blockIdx.y)
+        const size_t f = blockIdx.y;
+        img0 = F.in.img0[f]; pyramid += f * F.fs.pyramid; cand_xy_all += f * F.fs.cand; hdr_all += f * F.fs.hdr; cnt += f;
+    }
     __shared__ __attribute__((aligned(16))) uint32_t s_tile[EFX_LT * (EFX_LP / 4)];
     __shared__ unsigned long long s_bitmap[EFX_TILE];
     __shared__ uint16_t s_list[EFX_TILE * EFX_TILE];     // quick-test survivors (block << 5 | bit), read by the full test and by the append
@@ -1243,9 +1263,14 @@ template <int NW>
 __global__ __launch_bounds__(64 * NW) void harris_kernel(
     const LevelTable* __restrict__ T, const uint8_t* __restrict__ img0, int pitch0, int aligned0,
     const uint8_t* __restrict__ pyramid, const uint32_t* __restrict__ cand_xy_all, Corner* __restrict__ cand_all, Corner* __restrict__ cmax_all,
-    TileHdr* __restrict__ hdr_all, Counters* __restrict__ cnt, int dbg_arg)
+    TileHdr* __restrict__ hdr_all, Counters* __restrict__ cnt, int dbg_arg, const FrameSet F)
 {
     const int dbg = EFX_DBG(dbg_arg);
+    {
+        const size_t f = blockIdx.y;
+        img0 = F.in.img0[f]; pyramid += f * F.fs.pyramid; cand_xy_all += f * F.fs.cand; cand_all += f * F.fs.cand;
+        cmax_all += f * F.fs.cmax; hdr_all += f * F.fs.hdr; cnt += f;
+    }
     __shared__ unsigned long long s_cellmax[EFX_CELLS_PER_TILE];
     __shared__ unsigned s_celltie[EFX_CELLS_PER_TILE];     // largest response key that two corners of the cell share
     const int lane = threadIdx.x;                           // 0 .. 64 NW - 1: a corner slot of the round, not the hardware lane
@@ -1377,9 +1402,13 @@ __global__ __launch_bounds__(64 * NW) void harris_kernel(
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void nms_kernel(const LevelTable* __restrict__ T, TileHdr* __restrict__ hdr,
                                                  const Corner* __restrict__ cand_all, const Corner* __restrict__ cmax_all,
-                                                 Corner* __restrict__ surv_all, Counters* __restrict__ cnt, int radius, int dbg_arg)
+                                                 Corner* __restrict__ surv_all, Counters* __restrict__ cnt, int radius, int dbg_arg, const FrameStride fs)
 {
     const int dbg = EFX_DBG(dbg_arg);
+    {
+        const size_t f = blockIdx.y;
+        hdr += f * fs.hdr; cand_all += f * fs.cand; cmax_all += f * fs.cmax; surv_all += f * fs.surv; cnt += f;
+    }
     __shared__ Corner s_hme_all[NW][NMS_HCAP];
     __shared__ uint16_t s_hidx_all[NW][NMS_HCAP];
     __shared__ uint16_t s_hneed_all[NW][NMS_HCAP];         // block_radius 1: the cells (bit q = cell q of the 3x3) that hold a rival
@@ -1784,9 +1813,11 @@ __global__ __launch_bounds__(64 * NW) void nms_kernel(const LevelTable* __restri
 // passes over the survivors below the 15 bits already decided, and a separate counting pass.
 __global__ __launch_bounds__(1024) void select_kernel(const LevelTable* __restrict__ T, TileHdr* __restrict__ hdr,
                                                       const Corner* __restrict__ surv_all, Counters* __restrict__ cnt,
-                                                      int capacity, int* __restrict__ d_count)
+                                                      int capacity, const FrameOut out, const FrameStride fs)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sel_smem[];
+    int* const d_count = out.count[blockIdx.y];
+    hdr += blockIdx.y * fs.hdr; surv_all += blockIdx.y * fs.surv; cnt += blockIdx.y;
     int* s_hist = reinterpret_cast<int*>(sel_smem);                          // pass 1: SEL_TOP_BINS ints
     // pass 2 (the histogram is dead): candidate list | 256-bin histograms of the LDS radix passes | per-tile counts
     unsigned long long* s_list = reinterpret_cast<unsigned long long*>(sel_smem);
@@ -2118,9 +2149,11 @@ __device__ __forceinline__ float atan2_deg(int m01, int m10)
 __global__ __launch_bounds__(64) void emit_kernel(const LevelTable* __restrict__ T, const TileHdr* __restrict__ hdr,
                                                   const Corner* __restrict__ surv_all, const Counters* __restrict__ cnt,
                                                   const uint8_t* __restrict__ img0, int pitch0, const uint8_t* __restrict__ pyramid,
-                                                  uint8_t* __restrict__ kps, size_t kps_pitch, int capacity,
-                                                  float4* __restrict__ kp4, int* __restrict__ kp_level)
+                                                  size_t kps_pitch, int capacity,
+                                                  float4* __restrict__ kp4, int* __restrict__ kp_level, const FrameOut out, const FrameStride fs)
 {
+    uint8_t* const kps = out.kps[blockIdx.y];
+    hdr += blockIdx.y * fs.hdr; surv_all += blockIdx.y * fs.surv; cnt += blockIdx.y; kp4 += blockIdx.y * fs.kp; kp_level += blockIdx.y * fs.kp;
     // EMIT_TPW tiles per wave, 64 / EMIT_TPW lanes each (round 3): a tile has three survivors on average and the kernel is a
     // chain of dependent loads per wave (tile word -> header -> survivors), so its time is the number of waves the chip must
     // cycle through: 25 500 one-tile waves took 3.1 rounds of the chip's 8192 wave slots
@@ -2176,13 +2209,22 @@ __global__ __launch_bounds__(64) void emit_kernel(const LevelTable* __restrict__
 // TAIL: the workgroup also turns its ANGLE_KP moments into angles (and records) itself, on ANGLE_KP lanes of one wave -- the
 // form for small frames, where a second launch costs more than those ~1100 serial instructions (FHD: 7 us against 4.8 + 4.6)
 template <bool TAIL>
-__global__ __launch_bounds__(ANGLE_KP * 32) void angle_kernel(const LevelTable* __restrict__ T, const int* __restrict__ d_count, int capacity,
+__global__ __launch_bounds__(ANGLE_KP * 32) void angle_kernel(const LevelTable* __restrict__ T, int capacity,
                                                     const uint8_t* __restrict__ img0, int pitch0, const uint8_t* __restrict__ pyramid,
                                                     float4* __restrict__ kp4, const int* __restrict__ kp_level,
-                                                    uint8_t* __restrict__ kps, size_t kps_pitch,
+                                                    int want_kps, size_t kps_pitch,
                                                     Affine* __restrict__ aff, float bad_scale, float bad_reach, int bad_smax, int bad_sfixed,
-                                                    const uint8_t* __restrict__ rec_img0, int rec_pitch0, const uint8_t* __restrict__ rec_levels)
+                                                    const uint8_t* __restrict__ rec_img0, int rec_pitch0, const uint8_t* __restrict__ rec_levels, int rec_blurred,
+                                                    const FrameSet F, const FrameOut out)
 {
+    const size_t fr = blockIdx.y;
+    const int* const d_count = out.count[fr];
+    uint8_t* const kps = want_kps ? out.kps[fr] : nullptr;
+    img0 = F.in.img0[fr]; pyramid += fr * F.fs.pyramid; kp4 += fr * F.fs.kp; kp_level += fr * F.fs.kp;
+    if (aff) aff += fr * F.fs.kp;
+    // the image the describer's records refer to: the frame's raw levels, or its blurred copies
+    rec_img0 = rec_blurred ? rec_img0 + fr * F.fs.blurred : img0;
+    rec_levels = rec_blurred ? rec_levels + fr * F.fs.blurred : pyramid;
     // The intensity-centroid moments m01, m10 of every keypoint's patch; two keypoints per wave (31 of each 32 lanes hold
     // one patch column), ANGLE_KP per workgroup.  The moments are left in the .z / .w words of the keypoint's kp4 entry
     // (integer bits); angle_tail_kernel turns them into the angle.  (Until round 3 the double-precision atan2 / cos / sin
@@ -2254,13 +2296,21 @@ __global__ __launch_bounds__(ANGLE_KP * 32) void angle_kernel(const LevelTable* 
 // The angle from the moments (calcAngles, .cu:376-390; the double-precision atan2 of spec S7), one lane per keypoint; the
 // kp4 entry gets its size and angle, the caller's matrix its angle row and -- behind a BAD describer -- the keypoint's
 // record (rectifyBoxes' double cos / sin, bad_affine.h), which saves bad_affine_kernel's launch.
-__global__ __launch_bounds__(64) void angle_tail_kernel(const LevelTable* __restrict__ T, const int* __restrict__ d_count, int capacity,
+__global__ __launch_bounds__(64) void angle_tail_kernel(const LevelTable* __restrict__ T, int capacity,
                                                         const uint8_t* __restrict__ img0, int pitch0, const uint8_t* __restrict__ pyramid,
                                                         float4* __restrict__ kp4, const int* __restrict__ kp_level,
-                                                        uint8_t* __restrict__ kps, size_t kps_pitch,
+                                                        int want_kps, size_t kps_pitch,
                                                         Affine* __restrict__ aff, float bad_scale, float bad_reach, int bad_smax, int bad_sfixed,
-                                                        const uint8_t* __restrict__ rec_img0, int rec_pitch0, const uint8_t* __restrict__ rec_levels)
+                                                        const uint8_t* __restrict__ rec_img0, int rec_pitch0, const uint8_t* __restrict__ rec_levels, int rec_blurred,
+                                                        const FrameSet F, const FrameOut out)
 {
+    const size_t fr = blockIdx.y;
+    const int* const d_count = out.count[fr];
+    uint8_t* const kps = want_kps ? out.kps[fr] : nullptr;
+    img0 = F.in.img0[fr]; pyramid += fr * F.fs.pyramid; kp4 += fr * F.fs.kp; kp_level += fr * F.fs.kp;
+    if (aff) aff += fr * F.fs.kp;
+    rec_img0 = rec_blurred ? rec_img0 + fr * F.fs.blurred : img0;
+    rec_levels = rec_blurred ? rec_levels + fr * F.fs.blurred : pyramid;
     const int count = min(*d_count, capacity);
     const int k = (int)blockIdx.x * 64 + (int)threadIdx.x;
     if (k >= count) return;
@@ -2428,6 +2478,18 @@ static hipError_t efx_launch_detect_impl(const DetectLaunch& a, hipStream_t stre
 {
     const LevelTable& H = *a.h_table;
     hipError_t e = hipSuccess;
+    // frames of this launch (blockIdx.y of every kernel); a single-frame caller fills only the scalar fields
+    const int B = a.nframes > 0 ? a.nframes : 1;
+    if (B > EFX_MAX_BATCH) return hipErrorInvalidValue;
+    FrameSet F;
+    F.in = a.in; F.fs = a.fs;
+    FrameOut out = a.out;
+    if (B == 1) { F.in.img0[0] = a.img0; out.kps[0] = static_cast<uint8_t*>(a.d_keypoints); out.count[0] = a.d_count; }
+    FramePyr fp;
+    fp.in = F.in; fp.stride = a.fs.pyramid; fp.src_is_img0 = 0;
+    // alignment decisions about level 0 hold for every frame of the launch: the address bits of all the images, OR-ed
+    uintptr_t img_bits = 0;
+    for (int f = 0; f < B; f++) img_bits |= reinterpret_cast<uintptr_t>(F.in.img0[f]);
 
     // pyramid chain (calcImagePyramid, .cpp:136-157): level s+1 from level s.  The large lower levels get one launch each;
     // the small upper levels (launch- and latency-bound one by one) are produced by ONE tower launch from level s0.
@@ -2435,12 +2497,12 @@ static hipError_t efx_launch_detect_impl(const DetectLaunch& a, hipStream_t stre
     while (last + 1 < H.nlevels && H.lv[last + 1].rows > 0 && H.lv[last + 1].cols > 0 && H.lv[last].rows > 0 && H.lv[last].cols > 0) last++;
     TowerArgs tw;
     size_t tw_lds = 0;
-    const bool use_tower = plan_tower(H, last, a.img0, a.pitch0, a.knobs.no_tower != 0, a.knobs.tower_max_px, &tw, &tw_lds);
+    const bool use_tower = plan_tower(H, last, reinterpret_cast<const uint8_t*>(img_bits), a.pitch0, a.knobs.no_tower != 0, a.knobs.tower_max_px, &tw, &tw_lds);
     const int chain_end = use_tower ? tw.s0 : last;           // levels 1 .. chain_end by the per-level kernel
     // the counters are zeroed by the first pyramid kernel; a single-level "pyramid" has none: memset command
     bool zeroed = false;
     if (chain_end == 0 && !use_tower) {
-        e = hipMemsetAsync(a.counters, 0, sizeof(Counters), stream);
+        e = hipMemsetAsync(a.counters, 0, sizeof(Counters) * (size_t)B, stream);
         if (e != hipSuccess) return e;
         zeroed = true;
     }
@@ -2451,7 +2513,7 @@ static hipError_t efx_launch_detect_impl(const DetectLaunch& a, hipStream_t stre
         const int spitch = s == 0 ? a.pitch0 : L.pitch;
         // dword staging reads up to roundup4(cols) bytes of a row: always inside our own (padded) pyramid levels, inside a
         // caller's image only when its width is a multiple of 4 (otherwise the byte path)
-        const int aligned = (((uintptr_t)src | (uintptr_t)spitch) & 3u) == 0 && (s > 0 || (L.cols & 3) == 0);
+        const int aligned = (((s == 0 ? img_bits : (uintptr_t)src) | (uintptr_t)spitch) & 3u) == 0 && (s > 0 || (L.cols & 3) == 0);
         // round 5: several levels per launch by waves walking down strips (resize_rows_kernel); EFX_NO_RESIZE_ROWS: the tiled kernels
         const RowsPlanLaunch* RP = (a.rows_plan && a.rplan && !a.knobs.no_resize_rows) ? &a.rows_plan[s] : nullptr;
         if (RP && RP->nlev > 0 && aligned && s + RP->nlev <= chain_end) {
@@ -2469,11 +2531,12 @@ static hipError_t efx_launch_detect_impl(const DetectLaunch& a, hipStream_t stre
             const int nblk = (ra.ntasks + 3) / 4;
             const bool prof = a.prof.begin(100 + s, stream);
             Counters* zc = zeroed ? nullptr : a.counters;
+            fp.src_is_img0 = s == 0;
             switch (RP->nlev) {
-            case 1: hipLaunchKernelGGL(resize_rows_kernel<1>, dim3(nblk), dim3(256), 0, stream, ra, zc, H.nlevels); break;
-            case 2: hipLaunchKernelGGL(resize_rows_kernel<2>, dim3(nblk), dim3(256), 0, stream, ra, zc, H.nlevels); break;
-            case 3: hipLaunchKernelGGL(resize_rows_kernel<3>, dim3(nblk), dim3(256), 0, stream, ra, zc, H.nlevels); break;
-            default: hipLaunchKernelGGL(resize_rows_kernel<4>, dim3(nblk), dim3(256), 0, stream, ra, zc, H.nlevels); break;
+            case 1: hipLaunchKernelGGL(resize_rows_kernel<1>, dim3(nblk, B), dim3(256), 0, stream, ra, zc, H.nlevels, fp); break;
+            case 2: hipLaunchKernelGGL(resize_rows_kernel<2>, dim3(nblk, B), dim3(256), 0, stream, ra, zc, H.nlevels, fp); break;
+            case 3: hipLaunchKernelGGL(resize_rows_kernel<3>, dim3(nblk, B), dim3(256), 0, stream, ra, zc, H.nlevels, fp); break;
+            default: hipLaunchKernelGGL(resize_rows_kernel<4>, dim3(nblk, B), dim3(256), 0, stream, ra, zc, H.nlevels, fp); break;
             }
             zeroed = true;
             a.prof.end(prof, 100 + s, stream);
@@ -2490,6 +2553,7 @@ static hipError_t efx_launch_detect_impl(const DetectLaunch& a, hipStream_t stre
         const int ntiles = N.tiles_x * N.tiles_y;
         const bool no_stream = a.knobs.no_resize_stream != 0;     // EFX_NO_RESIZE_STREAM (tests): force the one-tile-per-workgroup kernel
         const ResizePlanLevel* R = a.rplan_lv ? &a.rplan_lv[s + 1] : nullptr;
+        fp.src_is_img0 = s == 0;
         if (aligned && R && R->W != 0 && a.rplan && !no_stream) {
             // streamed variant: a grid the chip holds at once (8 workgroups of 256 threads per CU), a multiple of the 8 XCDs
             static std::atomic<int> s_slots_a{0};
@@ -2501,14 +2565,14 @@ static hipError_t efx_launch_detect_impl(const DetectLaunch& a, hipStream_t stre
                 s_slots_a.store(s_slots, std::memory_order_relaxed);
             }
             const int per_xcd = std::min(s_slots / EFX_NXCD, (ntiles + EFX_NXCD - 1) / EFX_NXCD);
-            hipLaunchKernelGGL(resize_stream_kernel, dim3(per_xcd * EFX_NXCD), dim3(256), RS_YTAB + EFX_TILE * 16, stream, src, spitch, L.rows, L.cols,
+            hipLaunchKernelGGL(resize_stream_kernel, dim3(per_xcd * EFX_NXCD, B), dim3(256), RS_YTAB + EFX_TILE * 16, stream, src, spitch, L.rows, L.cols,
                                a.pyramid + N.img_off, N.pitch, N.rows, N.cols, N.tiles_x, N.tiles_y,
                                reinterpret_cast<const int*>(a.rplan + R->x_off), R->W, reinterpret_cast<const int4*>(a.rplan + R->y_off),
-                               reinterpret_cast<const int4*>(a.rplan + R->t_off), zeroed ? nullptr : a.counters, H.nlevels);
+                               reinterpret_cast<const int4*>(a.rplan + R->t_off), zeroed ? nullptr : a.counters, H.nlevels, fp);
         } else
-        hipLaunchKernelGGL((resize_kernel<256>), dim3(ntiles), dim3(256), lds, stream, src, spitch, L.rows, L.cols, aligned,
+        hipLaunchKernelGGL((resize_kernel<256>), dim3(ntiles, B), dim3(256), lds, stream, src, spitch, L.rows, L.cols, aligned,
                            a.pyramid + N.img_off, N.pitch, N.rows, N.cols, N.fx, N.fy, N.tiles_x, N.tiles_y, lpitch, ytab_off,
-                           zeroed ? nullptr : a.counters, H.nlevels);
+                           zeroed ? nullptr : a.counters, H.nlevels, fp);
         zeroed = true;
         a.prof.end(prof, 100 + s, stream);
         EFX_TRACE_POINT("resize");
@@ -2517,8 +2581,8 @@ static hipError_t efx_launch_detect_impl(const DetectLaunch& a, hipStream_t stre
         const bool prof = a.prof.begin(100 + tw.s0, stream);
         if (tw_lds > 64 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pyramid_tower_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tw_lds);
-        hipLaunchKernelGGL((pyramid_tower_kernel<1024>), dim3(tw.tiles_x * tw.tiles_y), dim3(1024), tw_lds, stream, a.d_table, a.img0,
-                           a.pitch0, a.pyramid, tw, zeroed ? nullptr : a.counters);
+        hipLaunchKernelGGL((pyramid_tower_kernel<1024>), dim3(tw.tiles_x * tw.tiles_y, B), dim3(1024), tw_lds, stream, a.d_table, a.img0,
+                           a.pitch0, a.pyramid, tw, zeroed ? nullptr : a.counters, fp);
         zeroed = true;
         a.prof.end(prof, 100 + tw.s0, stream);
         EFX_TRACE_POINT("tower");
@@ -2539,7 +2603,7 @@ static hipError_t efx_launch_detect_impl(const DetectLaunch& a, hipStream_t stre
             if (e2 != hipSuccess) return e2;
             st = a.side; forked = true; *forked_out = true;
         }
-        hipError_t e2 = efx_launch_blur_levels(H, a.img0, a.pitch0, a.pyramid, a.blurred, a.blur0_pitch, a.blur_levels_off, a.prof, st);
+        hipError_t e2 = efx_launch_blur_levels(H, a.img0, a.pitch0, a.pyramid, a.blurred, a.blur0_pitch, a.blur_levels_off, a.prof, st, B, F.in, a.fs);
         if (e2 == hipSuccess && forked) e2 = hipEventRecord(a.ev_join, a.side);
         EFX_TRACE_POINT("blur");
         return e2;
@@ -2557,22 +2621,22 @@ static hipError_t efx_launch_detect_impl(const DetectLaunch& a, hipStream_t stre
     }
 #endif
     {
-        const int aligned0 = (((uintptr_t)a.img0 | (uintptr_t)a.pitch0) & 3u) == 0;
+        const int aligned0 = ((img_bits | (uintptr_t)a.pitch0) & 3u) == 0;
         bool prof = a.prof.begin(0, stream);
-        hipLaunchKernelGGL(fast_kernel, dim3(H.total_tiles), dim3(256), 0, stream, a.d_table, a.img0, a.pitch0, aligned0,
-                           a.pyramid, a.threshold, a.mask, a.mask_pitch, a.cand_xy, a.hdr, a.counters, a.knobs.dbg & 15);
+        hipLaunchKernelGGL(fast_kernel, dim3(H.total_tiles, B), dim3(256), 0, stream, a.d_table, a.img0, a.pitch0, aligned0,
+                           a.pyramid, a.threshold, a.mask, a.mask_pitch, a.cand_xy, a.hdr, a.counters, a.knobs.dbg & 15, F);
         a.prof.end(prof, 0, stream);
         EFX_TRACE_POINT("fast");
         prof = a.prof.begin(1, stream);
         if (H.total_tiles <= EFX_NMS_WIDE_TILES)
-            hipLaunchKernelGGL(harris_kernel<4>, dim3(H.total_tiles + H.nlevels), dim3(256), 0, stream, a.d_table, a.img0, a.pitch0, aligned0, a.pyramid,
-                               a.cand_xy, a.cand, a.cmax, a.hdr, a.counters, a.knobs.dbg & 15);
+            hipLaunchKernelGGL(harris_kernel<4>, dim3(H.total_tiles + H.nlevels, B), dim3(256), 0, stream, a.d_table, a.img0, a.pitch0, aligned0, a.pyramid,
+                               a.cand_xy, a.cand, a.cmax, a.hdr, a.counters, a.knobs.dbg & 15, F);
         else if (H.total_tiles <= EFX_NMS_MID_TILES)
-            hipLaunchKernelGGL(harris_kernel<EFX_NMS_MID_NW>, dim3(H.total_tiles + H.nlevels), dim3(64 * EFX_NMS_MID_NW), 0, stream, a.d_table, a.img0, a.pitch0, aligned0, a.pyramid,
-                               a.cand_xy, a.cand, a.cmax, a.hdr, a.counters, a.knobs.dbg & 15);
+            hipLaunchKernelGGL(harris_kernel<EFX_NMS_MID_NW>, dim3(H.total_tiles + H.nlevels, B), dim3(64 * EFX_NMS_MID_NW), 0, stream, a.d_table, a.img0, a.pitch0, aligned0, a.pyramid,
+                               a.cand_xy, a.cand, a.cmax, a.hdr, a.counters, a.knobs.dbg & 15, F);
         else
-            hipLaunchKernelGGL(harris_kernel<1>, dim3(H.total_tiles + H.nlevels), dim3(64), 0, stream, a.d_table, a.img0, a.pitch0, aligned0, a.pyramid,
-                               a.cand_xy, a.cand, a.cmax, a.hdr, a.counters, a.knobs.dbg & 15);
+            hipLaunchKernelGGL(harris_kernel<1>, dim3(H.total_tiles + H.nlevels, B), dim3(64), 0, stream, a.d_table, a.img0, a.pitch0, aligned0, a.pyramid,
+                               a.cand_xy, a.cand, a.cmax, a.hdr, a.counters, a.knobs.dbg & 15, F);
         a.prof.end(prof, 1, stream);
         EFX_TRACE_POINT("harris");
         e = launch_blur(2);
@@ -2581,14 +2645,14 @@ static hipError_t efx_launch_detect_impl(const DetectLaunch& a, hipStream_t stre
     bool prof = a.prof.begin(2, stream);
     // several waves per tile when the tiles alone do not fill the chip (256 CUs x 32 waves)
     if (H.total_tiles <= EFX_NMS_WIDE_TILES)
-        hipLaunchKernelGGL(nms_kernel<4>, dim3(H.total_tiles), dim3(256), 0, stream, a.d_table, a.hdr, a.cand, a.cmax, a.surv,
-                           a.counters, a.nonmax_radius, a.knobs.dbg >> 4);
+        hipLaunchKernelGGL(nms_kernel<4>, dim3(H.total_tiles, B), dim3(256), 0, stream, a.d_table, a.hdr, a.cand, a.cmax, a.surv,
+                           a.counters, a.nonmax_radius, a.knobs.dbg >> 4, a.fs);
     else if (H.total_tiles <= EFX_NMS_MID_TILES)
-        hipLaunchKernelGGL(nms_kernel<EFX_NMS_MID_NW>, dim3(H.total_tiles), dim3(64 * EFX_NMS_MID_NW), 0, stream, a.d_table, a.hdr, a.cand, a.cmax, a.surv,
-                           a.counters, a.nonmax_radius, a.knobs.dbg >> 4);
+        hipLaunchKernelGGL(nms_kernel<EFX_NMS_MID_NW>, dim3(H.total_tiles, B), dim3(64 * EFX_NMS_MID_NW), 0, stream, a.d_table, a.hdr, a.cand, a.cmax, a.surv,
+                           a.counters, a.nonmax_radius, a.knobs.dbg >> 4, a.fs);
     else
-        hipLaunchKernelGGL(nms_kernel<1>, dim3(H.total_tiles), dim3(64), 0, stream, a.d_table, a.hdr, a.cand, a.cmax, a.surv,
-                           a.counters, a.nonmax_radius, a.knobs.dbg >> 4);
+        hipLaunchKernelGGL(nms_kernel<1>, dim3(H.total_tiles, B), dim3(64), 0, stream, a.d_table, a.hdr, a.cand, a.cmax, a.surv,
+                           a.counters, a.nonmax_radius, a.knobs.dbg >> 4, a.fs);
     a.prof.end(prof, 2, stream);
     EFX_TRACE_POINT("nms");
     e = launch_blur(3);
@@ -2610,31 +2674,32 @@ static hipError_t efx_launch_detect_impl(const DetectLaunch& a, hipStream_t stre
         }
         if (st == 2) return hipErrorInvalidConfiguration;   // efx_api.cpp: EFX_ERR_UNSUPPORTED, "select_kernel needs 128 KB of LDS"
     }
-    hipLaunchKernelGGL(select_kernel, dim3(H.nlevels), dim3(1024), SEL_LDS_BYTES, stream, a.d_table, a.hdr, a.surv, a.counters,
-                       a.capacity, a.d_count);
+    hipLaunchKernelGGL(select_kernel, dim3(H.nlevels, B), dim3(1024), SEL_LDS_BYTES, stream, a.d_table, a.hdr, a.surv, a.counters,
+                       a.capacity, out, a.fs);
     EFX_TRACE_POINT("select");
-    hipLaunchKernelGGL(emit_kernel, dim3((H.total_tiles + EMIT_TPW - 1) / EMIT_TPW), dim3(64), 0, stream, a.d_table, a.hdr, a.surv, a.counters,
-                       a.img0, a.pitch0, a.pyramid, (uint8_t*)a.d_keypoints, a.kps_pitch, a.capacity, a.kp4, a.kp_level);
+    hipLaunchKernelGGL(emit_kernel, dim3((H.total_tiles + EMIT_TPW - 1) / EMIT_TPW, B), dim3(64), 0, stream, a.d_table, a.hdr, a.surv, a.counters,
+                       a.img0, a.pitch0, a.pyramid, a.kps_pitch, a.capacity, a.kp4, a.kp_level, out, a.fs);
     EFX_TRACE_POINT("emit");
     if (a.capacity > 0) {
         // the image the describer's records refer to: the raw levels, or their blurred copies (blur_levels_kernel above)
         const uint8_t* rec_img0 = a.blurred ? a.blurred : a.img0;
         const int rec_pitch0 = a.blurred ? a.blur0_pitch : a.pitch0;
         const uint8_t* rec_levels = a.blurred ? a.blurred + a.blur_levels_off : a.pyramid;
+        const int rec_blurred = a.blurred ? 1 : 0;
         int nmax = 0;
         for (int s = 0; s < H.nlevels; s++) if (H.lv[s].active) nmax += H.lv[s].quota;
         if (nmax > a.capacity) nmax = a.capacity;
         if (nmax > 0 && use_tower) {
             // small frames (the ones whose pyramid is one tower launch): angles and records in the same launch
-            hipLaunchKernelGGL(angle_kernel<true>, dim3((nmax + ANGLE_KP - 1) / ANGLE_KP), dim3(ANGLE_KP * 32), 0, stream, a.d_table, a.d_count, a.capacity,
-                               a.img0, a.pitch0, a.pyramid, a.kp4, a.kp_level, (uint8_t*)a.d_keypoints, a.kps_pitch,
-                               static_cast<Affine*>(a.bad_affine), a.bad_scale, a.bad_reach, a.bad_smax, a.bad_sfixed, rec_img0, rec_pitch0, rec_levels);
+            hipLaunchKernelGGL(angle_kernel<true>, dim3((nmax + ANGLE_KP - 1) / ANGLE_KP, B), dim3(ANGLE_KP * 32), 0, stream, a.d_table, a.capacity,
+                               a.img0, a.pitch0, a.pyramid, a.kp4, a.kp_level, 1, a.kps_pitch,
+                               static_cast<Affine*>(a.bad_affine), a.bad_scale, a.bad_reach, a.bad_smax, a.bad_sfixed, rec_img0, rec_pitch0, rec_levels, rec_blurred, F, out);
         } else if (nmax > 0) {
-            hipLaunchKernelGGL(angle_kernel<false>, dim3((nmax + ANGLE_KP - 1) / ANGLE_KP), dim3(ANGLE_KP * 32), 0, stream, a.d_table, a.d_count, a.capacity,
-                               a.img0, a.pitch0, a.pyramid, a.kp4, a.kp_level, nullptr, 0, nullptr, 0.f, 0.f, 0, 0, nullptr, 0, nullptr);
-            hipLaunchKernelGGL(angle_tail_kernel, dim3((nmax + 63) / 64), dim3(64), 0, stream, a.d_table, a.d_count, a.capacity,
-                               a.img0, a.pitch0, a.pyramid, a.kp4, a.kp_level, (uint8_t*)a.d_keypoints, a.kps_pitch,
-                               static_cast<Affine*>(a.bad_affine), a.bad_scale, a.bad_reach, a.bad_smax, a.bad_sfixed, rec_img0, rec_pitch0, rec_levels);
+            hipLaunchKernelGGL(angle_kernel<false>, dim3((nmax + ANGLE_KP - 1) / ANGLE_KP, B), dim3(ANGLE_KP * 32), 0, stream, a.d_table, a.capacity,
+                               a.img0, a.pitch0, a.pyramid, a.kp4, a.kp_level, 0, 0, nullptr, 0.f, 0.f, 0, 0, nullptr, 0, nullptr, 0, F, out);
+            hipLaunchKernelGGL(angle_tail_kernel, dim3((nmax + 63) / 64, B), dim3(64), 0, stream, a.d_table, a.capacity,
+                               a.img0, a.pitch0, a.pyramid, a.kp4, a.kp_level, 1, a.kps_pitch,
+                               static_cast<Affine*>(a.bad_affine), a.bad_scale, a.bad_reach, a.bad_smax, a.bad_sfixed, rec_img0, rec_pitch0, rec_levels, rec_blurred, F, out);
         }
     }
     a.prof.end(prof, 3, stream);
@@ -2656,14 +2721,16 @@ hipError_t efx_debug_rerun_stages(const DetectLaunch& a, int stages, hipStream_t
 {
     const LevelTable& H = *a.h_table;
     const int aligned0 = (((uintptr_t)a.img0 | (uintptr_t)a.pitch0) & 3u) == 0;
+    FrameSet F;
+    F.in = a.in; F.fs = a.fs; F.in.img0[0] = a.img0;
     hipError_t e = hipMemsetAsync(&a.counters->surv_total[0][0], 0, sizeof(a.counters->surv_total), stream);
     if (e != hipSuccess) return e;
     if (stages & 1)
         hipLaunchKernelGGL(harris_kernel<1>, dim3(H.total_tiles + H.nlevels), dim3(64), 0, stream, a.d_table, a.img0, a.pitch0, aligned0, a.pyramid,
-                           a.cand_xy, a.cand, a.cmax, a.hdr, a.counters, 0);
+                           a.cand_xy, a.cand, a.cmax, a.hdr, a.counters, 0, F);
     if (stages & 2)
         hipLaunchKernelGGL(nms_kernel<1>, dim3(H.total_tiles), dim3(64), 0, stream, a.d_table, a.hdr, a.cand, a.cmax, a.surv,
-                           a.counters, a.nonmax_radius, 0);
+                           a.counters, a.nonmax_radius, 0, a.fs);
     return hipGetLastError();
 }
 #endif

@@ -314,8 +314,9 @@ int describer_run(Describer& d, std::string& err, DescribeLaunch a, float* dbg_r
     const bool prof = a.prof.begin(10, stream);
     struct ProfEnd { const ProfRec& p; bool on; hipStream_t st; ~ProfEnd() { p.end(on, 10, st); } } prof_end{a.prof, prof, stream};
     if (d.kind == 0) {
-        HIP_TRY(err, d.responses.reserve((size_t)a.n * sizeof(Affine)));
-        a.bad_affine = d.responses.p;
+        // (behind a batched detect the records of all frames are already there: frame f's at frame_affine_off / f * aff_stride)
+        HIP_TRY(err, d.responses.reserve(((size_t)a.n + a.frame_affine_off + (a.nframes > 1 ? (size_t)(a.nframes - 1) * a.aff_stride : 0)) * sizeof(Affine)));
+        a.bad_affine = static_cast<Affine*>(d.responses.p) + a.frame_affine_off;
         a.bad_det_tables = d.ubox_max_side <= 16 ? 2 : 1;      // describer_init builds ubox for d.scale and size 31
         a.bad_no_raw = d.no_raw;
         hipError_t e = efx_launch_bad(a, static_cast<const BadParamsDev*>(d.params.p), d.reach, stream);
@@ -352,13 +353,15 @@ int describer_run(Describer& d, std::string& err, DescribeLaunch a, float* dbg_r
 
 EfxKnobs efx_read_knobs()
 {
-    EfxKnobs k = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    EfxKnobs k = {};
     k.no_tower = getenv("EFX_NO_TOWER") != nullptr;
     k.no_resize_stream = getenv("EFX_NO_RESIZE_STREAM") != nullptr;
     k.no_resize_rows = getenv("EFX_NO_RESIZE_ROWS") != nullptr;     // the tiled per-level kernels instead of resize_rows_kernel
     k.tower_max_px = getenv("EFX_TOWER_MAX_PX") ? atoll(getenv("EFX_TOWER_MAX_PX")) : 0;   // 0: the built-in limit of the tower launch (detect_kernels.hip)
     k.no_level_blur = getenv("EFX_NO_LEVEL_BLUR") != nullptr;
     { const char* f = getenv("EFX_BLUR_FORK"); k.blur_fork = f ? atoi(f) : EFX_BLUR_FORK_DEFAULT; }   // DetectLaunch::blur_fork
+    k.blur_fork_min_px = getenv("EFX_BLUR_FORK_MIN_PX") ? atoll(getenv("EFX_BLUR_FORK_MIN_PX")) : 0;  // 0: the built-in gate of the per-call fork decision
+    k.no_batch = getenv("EFX_NO_BATCH") != nullptr;       // the batched entry point as a loop of single-frame calls (A/B, parity tests)
     // BAD behind detectAndCompute: every keypoint blurs its own window (A/B, parity tests)
     const char* d = getenv("EFX_DEBUG");
     const char* h = getenv("EFX_DEBUG_HS");
@@ -408,7 +411,10 @@ struct efx_context {
     hipStream_t side = nullptr;     // side stream + fork / join events of the level blur (DetectLaunch::blur_fork), on first use
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int idle_streak = 0;            // consecutive calls that found their stream idle (where the level blur runs: detect_common)
-    size_t cand_slots = 0;          // records in `cand`; the coordinate-only array of the same length follows them
+    size_t cand_slots = 0;          // records in `cand` PER FRAME; the coordinate-only arrays of the same length follow the frames' records
+    int g_frames = 0;               // frames the per-frame buffers were reserved for (batched launches: detect_frames)
+    FrameStride fs = {};            // distance between the frames' copies inside the buffers (efx_device.h)
+    int last_frames = 1;            // frames of the last detect call (the summary mirror reads the LAST one)
     Summary* h_mirror = nullptr;    // host copy of the last frame's summary, filled on demand by fetch_summary()
     int n_out_max = 0;              // sum of the active levels' quotas
     bool arena_full = false;        // corner / survivor arenas sized for the worst case (set after a frame overflowed them)
@@ -691,6 +697,7 @@ void build_rows_plan(const LevelTable& T, int nlevels, std::vector<int>& blob, R
                         else { if (lower < first[k - 1] || lower > last[k - 1]) { ok = false; break; } d = done_prev[lower - first[k - 1]]; }
                         if (d < 0 || d >= na) { ok = false; break; }
                         done[r - first[k]] = d;
+                        if ((mask[k] >> d) & 1ull) { ok = false; break; }      // two rows of a level completed by one source row: the kernel makes one row per bit
                         mask[k] |= 1ull << d;
                     }
                     done_prev = done;
@@ -716,10 +723,11 @@ void build_rows_plan(const LevelTable& T, int nlevels, std::vector<int>& blob, R
 }
 
 // pyramid geometry, quotas, caps (calcImagePyramid .cpp:136-157, calcNumFeaturesPerLevel :159-174, :252)
-int build_geometry(efx_context* c, int rows, int cols)
+int build_geometry(efx_context* c, int rows, int cols, int nframes = 1)
 {
     const efx_params& p = c->p;
-    if (c->g_rows == rows && c->g_cols == cols && c->g_arena_full == c->arena_full && memcmp(&c->g_p, &p, sizeof(p)) == 0) return EFX_OK;
+    if (c->g_rows == rows && c->g_cols == cols && c->g_arena_full == c->arena_full && c->g_frames >= nframes && memcmp(&c->g_p, &p, sizeof(p)) == 0) return EFX_OK;
+    const size_t NF = (size_t)std::max(nframes, c->g_rows == rows && c->g_cols == cols ? c->g_frames : 1);      // buffers never shrink
     LevelTable& T = c->h_table;
     memset(&T, 0, sizeof(T));
     T.nlevels = p.nlevels;
@@ -808,15 +816,21 @@ int build_geometry(efx_context* c, int rows, int cols)
 
     // the level table is followed by one packed word per tile (efx_pack_tile / efx_tile_of)
     HIP_TRY(c->err, c->d_table.reserve(sizeof(LevelTable) + (size_t)(tiles + 1) * sizeof(uint32_t)));
-    HIP_TRY(c->err, c->pyramid.reserve(pyr + 256));
-    HIP_TRY(c->err, c->hdr.reserve((size_t)(tiles + 1) * sizeof(TileHdr)));
-    // corner records, followed by the coordinate-only array fast_kernel fills (harris_kernel writes whole records from it)
-    HIP_TRY(c->err, c->cand.reserve((ncand + 1) * (sizeof(Corner) + sizeof(uint32_t))));
+    // everything below exists once per frame of a batched launch, `fs` apart
+    c->fs.pyramid = align_up(pyr + 256, 256);
+    c->fs.hdr = (size_t)tiles + 1;
+    c->fs.cand = ncand + 1;
+    c->fs.surv = nsurv + 1;
+    c->fs.cmax = ncmax + 1;
+    HIP_TRY(c->err, c->pyramid.reserve(c->fs.pyramid * NF));
+    HIP_TRY(c->err, c->hdr.reserve(c->fs.hdr * NF * sizeof(TileHdr)));
+    // corner records, followed by the coordinate-only arrays fast_kernel fills (harris_kernel writes whole records from them)
+    HIP_TRY(c->err, c->cand.reserve(c->fs.cand * NF * (sizeof(Corner) + sizeof(uint32_t))));
     c->cand_slots = ncand + 1;
-    HIP_TRY(c->err, c->surv.reserve((nsurv + 1) * sizeof(Corner)));
-    HIP_TRY(c->err, c->cmax.reserve((ncmax + 1) * sizeof(Corner)));
-    HIP_TRY(c->err, c->counters.reserve(sizeof(Counters)));
-    HIP_TRY(c->err, c->count.reserve(sizeof(int)));
+    HIP_TRY(c->err, c->surv.reserve(c->fs.surv * NF * sizeof(Corner)));
+    HIP_TRY(c->err, c->cmax.reserve(c->fs.cmax * NF * sizeof(Corner)));
+    HIP_TRY(c->err, c->counters.reserve(sizeof(Counters) * NF));
+    HIP_TRY(c->err, c->count.reserve(sizeof(int) * EFX_MAX_BATCH));
     if (!c->h_mirror) {
         c->h_mirror = new (std::nothrow) Summary;
         if (!c->h_mirror) return set_err(c->err, EFX_ERR_NOMEM, "out of host memory");
@@ -893,7 +907,7 @@ int build_geometry(efx_context* c, int rows, int cols)
             HIP_TRY(c->err, hipMemcpy(c->rplan.p, blob.data(), blob.size() * 4, hipMemcpyHostToDevice));
         }
     }
-    c->g_rows = rows; c->g_cols = cols; c->g_p = p; c->g_arena_full = c->arena_full;
+    c->g_rows = rows; c->g_cols = cols; c->g_p = p; c->g_arena_full = c->arena_full; c->g_frames = (int)NF;
     return EFX_OK;
 }
 
@@ -911,36 +925,57 @@ void consume_sticky_overflow(efx_context* c)
     c->arena_full = true;
 }
 
-int detect_common(efx_context* c, const uint8_t* d_image, int rows, int cols, size_t pitch,
-                  void* d_keypoints, size_t kps_pitch, uint8_t* d_desc, size_t desc_pitch,
-                  int capacity, int* d_count, hipStream_t stream, const uint8_t* d_mask = nullptr, size_t mask_pitch = 0)
+// nframes same-sized frames through ONE launch of every kernel (round 6; SURVEY 8b "batched variants"): frame f reads
+// d_images[f] and writes d_keypoints[f] / d_desc[f] / d_counts[f]; everything in between lives in the context's buffers, once per
+// frame (build_geometry: FrameStride).  nframes == 1 is the plain detectAsync / detectAndComputeAsync call.
+int detect_frames(efx_context* c, int nframes, const uint8_t* const* d_images, int rows, int cols, size_t pitch,
+                  void* const* d_keypoints, size_t kps_pitch, uint8_t* const* d_descs, size_t desc_pitch,
+                  int capacity, int* const* d_counts, hipStream_t stream, const uint8_t* d_mask = nullptr, size_t mask_pitch = 0)
 {
+    if (nframes < 1 || nframes > EFX_MAX_BATCH) return set_err(c->err, EFX_ERR_BAD_ARG, "a launch takes 1 .. %d frames", EFX_MAX_BATCH);
     if (d_mask && mask_pitch < (size_t)cols) return set_err(c->err, EFX_ERR_BAD_ARG, "mask must be an 8-bit image of the frame size");
+    if (d_mask && nframes > 1) return set_err(c->err, EFX_ERR_BAD_ARG, "a mask belongs to one frame");
     // CV_Assert(_image.type() == CV_8U) etc. (.cpp:228-229)
-    if (!d_image || rows <= 0 || cols <= 0 || pitch < (size_t)cols) return set_err(c->err, EFX_ERR_BAD_ARG, "bad image arguments");
+    if (!d_images || rows <= 0 || cols <= 0 || pitch < (size_t)cols) return set_err(c->err, EFX_ERR_BAD_ARG, "bad image arguments");
     if (capacity < 0) return set_err(c->err, EFX_ERR_BAD_ARG, "capacity must be >= 0");
-    if (d_keypoints && (kps_pitch < (size_t)capacity * 4 || (kps_pitch & 3))) return set_err(c->err, EFX_ERR_BAD_ARG, "kps_pitch too small or unaligned");
-    if (d_desc && desc_pitch < (size_t)efx_descriptor_size(c)) return set_err(c->err, EFX_ERR_BAD_ARG, "desc_pitch smaller than the descriptor");
+    const bool want_kps = d_keypoints && d_keypoints[0];
+    const bool want_desc = d_descs && d_descs[0];
+    for (int f = 0; f < nframes; f++) {
+        if (!d_images[f]) return set_err(c->err, EFX_ERR_BAD_ARG, "bad image arguments");
+        if (want_kps != (d_keypoints && d_keypoints[f] != nullptr) || want_desc != (d_descs && d_descs[f] != nullptr))
+            return set_err(c->err, EFX_ERR_BAD_ARG, "either every frame of a batch has a keypoint / descriptor matrix or none");
+    }
+    if (want_kps && (kps_pitch < (size_t)capacity * 4 || (kps_pitch & 3))) return set_err(c->err, EFX_ERR_BAD_ARG, "kps_pitch too small or unaligned");
+    if (want_desc && desc_pitch < (size_t)efx_descriptor_size(c)) return set_err(c->err, EFX_ERR_BAD_ARG, "desc_pitch smaller than the descriptor");
     int rc = validate_params(c->p, c->err);
     if (rc) return rc;
     QuiesceScope quiesce(c, stream);
     consume_sticky_overflow(c);
-    rc = build_geometry(c, rows, cols);
+    rc = build_geometry(c, rows, cols, nframes);
     if (rc) return rc;
+    const size_t NF = (size_t)nframes;
     const int cap_alloc = capacity > 0 ? capacity : 1;
-    HIP_TRY(c->err, c->kp4.reserve((size_t)cap_alloc * sizeof(float4)));
-    HIP_TRY(c->err, c->kp_level.reserve((size_t)cap_alloc * sizeof(int)));
+    HIP_TRY(c->err, c->kp4.reserve((size_t)cap_alloc * NF * sizeof(float4)));
+    HIP_TRY(c->err, c->kp_level.reserve((size_t)cap_alloc * NF * sizeof(int)));
 
     DetectLaunch a;
     memset(&a, 0, sizeof(a));
-    a.img0 = d_image; a.pitch0 = (int)pitch;
+    a.nframes = nframes;
+    a.fs = c->fs;
+    a.fs.kp = (size_t)cap_alloc;
+    for (int f = 0; f < nframes; f++) {
+        a.in.img0[f] = d_images[f];
+        a.out.kps[f] = want_kps ? static_cast<uint8_t*>(d_keypoints[f]) : nullptr;
+        a.out.count[f] = (d_counts && d_counts[f]) ? d_counts[f] : static_cast<int*>(c->count.p) + f;
+    }
+    a.img0 = d_images[0]; a.pitch0 = (int)pitch;
     a.pyramid = static_cast<uint8_t*>(c->pyramid.p);
     a.d_table = static_cast<const LevelTable*>(c->d_table.p);
     a.h_table = &c->h_table;
     a.hdr = static_cast<TileHdr*>(c->hdr.p);
     a.rplan = static_cast<const unsigned char*>(c->rplan.p); a.rplan_lv = c->rplan_lv; a.rows_plan = c->rows_plan;
     a.cand = static_cast<Corner*>(c->cand.p);
-    a.cand_xy = reinterpret_cast<uint32_t*>(a.cand + c->cand_slots);
+    a.cand_xy = reinterpret_cast<uint32_t*>(a.cand + c->fs.cand * NF);
     a.surv = static_cast<Corner*>(c->surv.p);
     a.cmax = static_cast<Corner*>(c->cmax.p);
     a.counters = static_cast<Counters*>(c->counters.p);
@@ -949,8 +984,8 @@ int detect_common(efx_context* c, const uint8_t* d_image, int rows, int cols, si
     a.first_level = c->p.first_level;
     a.knobs = c->knobs;
     a.mask = d_mask; a.mask_pitch = (int)mask_pitch;
-    a.d_keypoints = d_keypoints; a.kps_pitch = kps_pitch; a.capacity = capacity;
-    a.d_count = d_count ? d_count : static_cast<int*>(c->count.p);
+    a.d_keypoints = want_kps ? d_keypoints[0] : nullptr; a.kps_pitch = kps_pitch; a.capacity = capacity;
+    a.d_count = a.out.count[0];
     a.kp4 = static_cast<float4*>(c->kp4.p);
     a.kp_level = static_cast<int*>(c->kp_level.p);
     if (!c->prof_start.empty() && (c->prof_calls++ % c->prof_stride) == 0) {
@@ -960,8 +995,8 @@ int detect_common(efx_context* c, const uint8_t* d_image, int rows, int cols, si
     // BAD behind detectAndCompute: angle_kernel writes the describer's per-keypoint records (no bad_affine_kernel launch)
     const int n_desc = capacity < c->n_out_max ? capacity : c->n_out_max;     // the bound angle_kernel uses: sum of the active quotas
     bool affine_ready = false, level_blurred = false;
-    if (d_desc && capacity > 0 && c->desc.kind == 0 && n_desc > 0) {
-        HIP_TRY(c->err, c->desc.responses.reserve((size_t)n_desc * sizeof(Affine)));
+    if (want_desc && capacity > 0 && c->desc.kind == 0 && n_desc > 0) {
+        HIP_TRY(c->err, c->desc.responses.reserve((size_t)cap_alloc * NF * sizeof(Affine)));      // frame f's records at f * cap_alloc (FrameStride::kp)
         const int S = efx_bad_smax_for((float)EFX_PATCH_SIZE, c->desc.scale, c->desc.reach);
         a.bad_affine = c->desc.responses.p; a.bad_scale = c->desc.scale; a.bad_reach = c->desc.reach;
         a.bad_smax = S; a.bad_sfixed = S == 48 ? 48 : 0;
@@ -975,7 +1010,8 @@ int detect_common(efx_context* c, const uint8_t* d_image, int rows, int cols, si
                 if (H.lv[l].rows > 0) lv_bytes = std::max(lv_bytes, (size_t)H.lv[l].img_off + (size_t)H.lv[l].pitch * H.lv[l].rows);
             const int p0 = (int)align_up((size_t)cols, 256);
             const size_t l0_bytes = H.lv[0].active ? (size_t)p0 * rows : 0;
-            HIP_TRY(c->err, c->blurred.reserve(l0_bytes + lv_bytes + 256));
+            a.fs.blurred = align_up(l0_bytes + lv_bytes + 256, 256);
+            HIP_TRY(c->err, c->blurred.reserve(a.fs.blurred * NF));
             a.blurred = static_cast<uint8_t*>(c->blurred.p); a.blur0_pitch = p0; a.blur_levels_off = l0_bytes;
             level_blurred = true;
             a.blur_fork = c->knobs.blur_fork;
@@ -988,9 +1024,10 @@ int detect_common(efx_context* c, const uint8_t* d_image, int rows, int cols, si
                 // reference's call-then-wait protocol, 8K (103 M level pixels) 0.430 -> 0.408 ms, 4K (26 M) 0.195 -> 0.199, FHD 0.115 -> 0.122
                 size_t level_px = 0;
                 for (int l = 0; l < H.nlevels; l++) level_px += (size_t)H.lv[l].rows * H.lv[l].cols;
-                // (EFX_BLUR_FORK_MIN_PX: the gate, for tests that exercise the per-call decision on small frames)
-                static const size_t min_px = getenv("EFX_BLUR_FORK_MIN_PX") ? (size_t)atoll(getenv("EFX_BLUR_FORK_MIN_PX")) : (size_t)50 * 1000 * 1000;
-                if (!a.prof.start && level_px >= min_px) {
+                // (EFX_BLUR_FORK_MIN_PX: the gate, for tests that exercise the per-call decision on small frames; read per
+                // context with the other knobs -- ADVICE r5: a process-wide static made the path depend on test collection order)
+                const size_t min_px = c->knobs.blur_fork_min_px > 0 ? (size_t)c->knobs.blur_fork_min_px : (size_t)50 * 1000 * 1000;
+                if (!a.prof.start && level_px >= min_px && nframes == 1) {
                     if (hipStreamIsCapturing(stream, &cs) != hipSuccess) (void)hipGetLastError();
                     else if (cs == hipStreamCaptureStatusNone) {
                         const hipError_t q = hipStreamQuery(stream);
@@ -1019,16 +1056,16 @@ int detect_common(efx_context* c, const uint8_t* d_image, int rows, int cols, si
     if (e == hipErrorInvalidConfiguration)
         return set_err(c->err, EFX_ERR_UNSUPPORTED, "this device refuses the 128 KB of dynamic LDS select_kernel needs (MI355X has 160 KB per CU)");
     if (e != hipSuccess) return set_err(c->err, EFX_ERR_HIP, "detect launch failed: %s", hipGetErrorString(e));
-    c->has_frame = true; c->last_img0 = d_image; c->last_pitch0 = (int)pitch;
+    c->has_frame = true; c->last_img0 = d_images[0]; c->last_pitch0 = (int)pitch; c->last_frames = nframes;
 #ifdef EFX_DEBUG_BUILD
     c->last_launch = a; c->last_launch.prof = ProfRec{};
 #endif
 
-    if (d_desc && capacity > 0) {
+    if (want_desc && capacity > 0) {
         // blur + describe per level (.cpp:302-307), here one launch over the keypoints of all levels
         DescribeLaunch dl;
         memset(&dl, 0, sizeof(dl));
-        dl.img0 = d_image; dl.pitch0 = (int)pitch; dl.rows0 = rows; dl.cols0 = cols;
+        dl.img0 = d_images[0]; dl.pitch0 = (int)pitch; dl.rows0 = rows; dl.cols0 = cols;
         dl.pyramid = a.pyramid; dl.d_table = a.d_table;
         dl.kp4 = a.kp4; dl.kp_level = a.kp_level; dl.d_count = a.d_count;
         dl.n = n_desc;
@@ -1037,12 +1074,35 @@ int detect_common(efx_context* c, const uint8_t* d_image, int rows, int cols, si
         dl.blur = 1;
         dl.max_size = (float)EFX_PATCH_SIZE;
         dl.uniform_size = 1;
-        dl.desc = d_desc; dl.desc_pitch = desc_pitch;
+        dl.desc = d_descs[0]; dl.desc_pitch = desc_pitch;
         dl.prof = a.prof;
-        rc = describer_run(c->desc, c->err, dl, nullptr, nullptr, stream);
-        if (rc) return rc;
+        if (nframes > 1 && level_blurred) {
+            // every frame's keypoints in one launch of bad_raw_kernel (the records point at each frame's blurred levels)
+            dl.nframes = nframes; dl.aff_stride = (size_t)cap_alloc;
+            for (int f = 0; f < nframes; f++) { dl.counts.count[f] = a.out.count[f]; dl.descs.desc[f] = d_descs[f]; }
+            rc = describer_run(c->desc, c->err, dl, nullptr, nullptr, stream);
+            if (rc) return rc;
+        } else {
+            // (HashSIFT, and BAD outside bad_raw_kernel's conditions, behind a batch: one describe per frame on the frame's buffers)
+            for (int f = 0; f < nframes; f++) {
+                DescribeLaunch df = dl;
+                df.img0 = d_images[f]; df.pyramid = a.pyramid + f * a.fs.pyramid;
+                df.kp4 = a.kp4 + f * a.fs.kp; df.kp_level = a.kp_level + f * a.fs.kp; df.d_count = a.out.count[f];
+                df.desc = d_descs[f];
+                df.frame_affine_off = (size_t)f * cap_alloc;
+                rc = describer_run(c->desc, c->err, df, nullptr, nullptr, stream);
+                if (rc) return rc;
+            }
+        }
     }
     return EFX_OK;
+}
+
+int detect_common(efx_context* c, const uint8_t* d_image, int rows, int cols, size_t pitch,
+                  void* d_keypoints, size_t kps_pitch, uint8_t* d_desc, size_t desc_pitch,
+                  int capacity, int* d_count, hipStream_t stream, const uint8_t* d_mask = nullptr, size_t mask_pitch = 0)
+{
+    return detect_frames(c, 1, &d_image, rows, cols, pitch, &d_keypoints, kps_pitch, &d_desc, desc_pitch, capacity, &d_count, stream, d_mask, mask_pitch);
 }
 
 // detectAndCompute(useProvidedKeypoints = true), spec S13: pyramid only, then blur + describe on the keypoints' levels
@@ -1285,13 +1345,35 @@ int efx_detect_and_compute_batch_async(efx_context* const* ctxs, void* const* st
                                        uint8_t* const* d_descriptors, size_t desc_pitch, int capacity, int* const* d_counts)
 {
     if (!ctxs || nctx <= 0 || nframes < 0 || !d_images || !d_keypoints || !d_counts) return EFX_ERR_BAD_ARG;
-    for (int i = 0; i < nframes; i++) {
-        efx_context* c = ctxs[i % nctx];
-        if (!c) return EFX_ERR_BAD_ARG;
-        const int rc = detect_common(c, d_images[i], rows, cols, pitch, d_keypoints[i], kps_pitch,
-                                     d_descriptors ? d_descriptors[i] : nullptr, desc_pitch, capacity, d_counts[i],
-                                     streams ? (hipStream_t)streams[i % nctx] : nullptr);
-        if (rc) return rc;
+    for (int j = 0; j < nctx && j < nframes; j++) if (!ctxs[j]) return EFX_ERR_BAD_ARG;
+    // Context j owns the frames j, j + nctx, j + 2 nctx, ...: they go through ONE launch of every kernel, EFX_MAX_BATCH at a time
+    // (frame = blockIdx.y; detect_frames).  EFX_NO_BATCH=1: one single-frame call per frame, in frame order (the round-5 form).
+    if (ctxs[0]->knobs.no_batch) {
+        for (int i = 0; i < nframes; i++) {
+            const int rc = detect_common(ctxs[i % nctx], d_images[i], rows, cols, pitch, d_keypoints[i], kps_pitch,
+                                         d_descriptors ? d_descriptors[i] : nullptr, desc_pitch, capacity, d_counts[i],
+                                         streams ? (hipStream_t)streams[i % nctx] : nullptr);
+            if (rc) return rc;
+        }
+        return EFX_OK;
+    }
+    // round-robin over the contexts, so that every stream has work early
+    const int per_ctx_max = (nframes + nctx - 1) / nctx;
+    for (int k0 = 0; k0 < per_ctx_max; k0 += EFX_MAX_BATCH) {
+        for (int j = 0; j < nctx; j++) {
+            const uint8_t* img[EFX_MAX_BATCH]; void* kps[EFX_MAX_BATCH]; uint8_t* desc[EFX_MAX_BATCH]; int* cnt[EFX_MAX_BATCH];
+            int nb = 0;
+            for (int k = k0; k < k0 + EFX_MAX_BATCH; k++) {
+                const int i = j + k * nctx;
+                if (i >= nframes) break;
+                img[nb] = d_images[i]; kps[nb] = d_keypoints[i]; desc[nb] = d_descriptors ? d_descriptors[i] : nullptr; cnt[nb] = d_counts[i];
+                nb++;
+            }
+            if (nb == 0) continue;
+            const int rc = detect_frames(ctxs[j], nb, img, rows, cols, pitch, kps, kps_pitch, desc, desc_pitch, capacity, cnt,
+                                         streams ? (hipStream_t)streams[j] : nullptr);
+            if (rc) return rc;
+        }
     }
     return EFX_OK;
 }
@@ -1321,7 +1403,7 @@ int efx_compute_kp4_async(efx_context* ctx, const uint8_t* d_image, int rows, in
 static int fetch_summary(const efx_context* ctx)
 {
     if (!ctx->h_mirror || !ctx->counters.p) return EFX_ERR_BAD_ARG;
-    const Counters* dc = static_cast<const Counters*>(ctx->counters.p);
+    const Counters* dc = static_cast<const Counters*>(ctx->counters.p) + (ctx->last_frames - 1);     // the last frame of a batched launch
     return hipMemcpy(ctx->h_mirror, &dc->sum, sizeof(Summary), hipMemcpyDeviceToHost) == hipSuccess ? EFX_OK : EFX_ERR_HIP;
 }
 

@@ -24,6 +24,7 @@
 #define EFX_PATCH_SIZE 31      // cuda_efficient_features.cpp:33
 #define EFX_NXCD 8
 #define EFX_NSUB 8             // sub-arrays / allocation counters per level
+#define EFX_MAX_BATCH 16       // frames of one size a context runs through ONE launch of every kernel (blockIdx.y = frame)
 
 struct LevelDev {
     int rows, cols;
@@ -81,6 +82,23 @@ struct Counters {               // zeroed at the start of every frame
     int level_out_base[EFX_MAX_LEVELS + 1];
     unsigned long long thresh[EFX_MAX_LEVELS];   // selection threshold key per level
     Summary sum;
+};
+
+// Frame-batched launches (round 6; SURVEY 8b "batched variants (..., nframes)"): every kernel of the detect path takes the tiles /
+// strips / keypoints of `nframes` same-sized frames in one launch, frame = blockIdx.y.  The frames share the level table, the tile
+// words and the resize plans (pure geometry); everything that holds pixels or results exists once per frame, `stride` apart
+// inside the context's buffers.  The caller's per-frame pointers travel as by-value kernel arguments (no table upload).
+struct FrameIn { const uint8_t* img0[EFX_MAX_BATCH]; };                       // level 0 of every frame (same rows, cols, pitch)
+struct FrameOut { uint8_t* kps[EFX_MAX_BATCH]; int* count[EFX_MAX_BATCH]; };  // 5 x capacity matrices (may be null), device N
+struct FrameDesc { uint8_t* desc[EFX_MAX_BATCH]; };                           // descriptor matrices
+struct FrameStride {            // distance between two frames' copies, in ELEMENTS of the buffer's type (0 is fine for one frame)
+    size_t pyramid;             // bytes
+    size_t hdr;                 // TileHdr
+    size_t cand;                // Corner records == uint32_t coordinate words (the two arrays are indexed alike)
+    size_t surv;                // Corner
+    size_t cmax;                // Corner
+    size_t kp;                  // float4 / int (kp4, kp_level), and Affine records (bad_affine)
+    size_t blurred;             // bytes
 };
 
 #if defined(__HIPCC__)
@@ -171,7 +189,7 @@ __device__ __forceinline__ int efx_wave_incl_scan(int v)
 #else
 #define EFX_DBG(v) 0
 #endif
-struct EfxKnobs { int dbg, dbg_hs, no_tower, no_resize_stream, no_level_blur, blur_fork, no_resize_rows; long long tower_max_px; };
+struct EfxKnobs { int dbg, dbg_hs, no_tower, no_resize_stream, no_level_blur, blur_fork, no_resize_rows, no_batch; long long tower_max_px, blur_fork_min_px; };
 EfxKnobs efx_read_knobs();      // efx_api.cpp
 
 // ---- launchers (host side, defined in the .hip files) ----
@@ -278,6 +296,8 @@ struct RowsPlanLaunch {
 };
 
 struct DetectLaunch {
+    int nframes;                // frames in this launch (1 .. EFX_MAX_BATCH); frame 0's pointers are also the scalar fields below
+    FrameIn in; FrameOut out; FrameStride fs;
     const unsigned char* rplan; const ResizePlanLevel* rplan_lv;      // device blob, host index by destination level
     const RowsPlanLaunch* rows_plan;                                  // host array indexed by SOURCE level (null: none)
     const uint8_t* img0;        // level 0 (caller's image)
@@ -338,11 +358,16 @@ struct DescribeLaunch {
     int level_blurred;                                     // ... and they point at blurred level images: describe without a blur (bad_raw_kernel)
     int dbg_hs;                                            // EFX_DEBUG_HS (EFX_DEBUG_BUILD builds only)
     ProfRec prof;
+    // batched describe behind a batched detect (bad_raw_kernel on blurred levels only): nframes > 1, frame = blockIdx.y; the
+    // records of frame f start at bad_affine + f * aff_stride, its count is counts.count[f], its descriptors descs.desc[f]
+    int nframes; size_t aff_stride; FrameOut counts; FrameDesc descs;
+    size_t frame_affine_off;                               // a single frame of a batch described on its own: its records start here (Affine entries)
 };
 
 hipError_t efx_launch_bad(const DescribeLaunch& a, const BadParamsDev* d_params, float reach, hipStream_t stream);
 hipError_t efx_launch_blur_levels(const LevelTable& H, const uint8_t* img0, int pitch0, const uint8_t* pyramid, uint8_t* blurred,
-                                  int blur0_pitch, size_t blur_levels_off, const ProfRec& prof_rec, hipStream_t stream);
+                                  int blur0_pitch, size_t blur_levels_off, const ProfRec& prof_rec, hipStream_t stream,
+                                  int nframes, const FrameIn& in, const FrameStride& fs);
 
 #define EFX_HS_REC_BYTES 64
 struct HashSiftDev {

@@ -487,7 +487,13 @@ int efx_knn2_mfma_resident_workgroups(int desc_bytes, int fp4)
     const void* f;
     if (!fp4) f = desc_bytes == 32 ? reinterpret_cast<const void*>(&knn2_mfma_kernel<256, 1, 8, false>) : reinterpret_cast<const void*>(&knn2_mfma_kernel<512, 1, 8, false>);
     else if (tt == 2) f = desc_bytes == 32 ? reinterpret_cast<const void*>(&knn2_fp4_kernel<256, 2>) : reinterpret_cast<const void*>(&knn2_fp4_kernel<512, 2>);
-    else f = desc_bytes == 32 ? reinterpret_cast<const void*>(&knn2_mfma_kernel<256, 1, 8, true>) : reinterpret_cast<const void*>(&knn2_mfma_kernel<512, 1, 8, true, true>);
+    else {
+        // the 512-bit variant the launcher will pick: double-buffered unless EFX_MATCH_NO_DB (read once per process there, too), so
+        // that the chunks are sized by the occupancy of the kernel that runs
+        static const bool no_db = getenv("EFX_MATCH_NO_DB") != nullptr;
+        f = desc_bytes == 32 ? reinterpret_cast<const void*>(&knn2_mfma_kernel<256, 1, 8, true>)
+          : no_db ? reinterpret_cast<const void*>(&knn2_mfma_kernel<512, 1, 8, true>) : reinterpret_cast<const void*>(&knn2_mfma_kernel<512, 1, 8, true, true>);
+    }
     int per_cu = 0, dev = 0, cus = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, f, 512, 0) != hipSuccess || per_cu < 1) per_cu = 2;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;

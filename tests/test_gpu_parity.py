@@ -10,8 +10,6 @@ from tools import synth
 pytestmark = pytest.mark.gpu
 
 import os
-# the per-call fork decision of the level blur has a pixel gate read once per process (test_level_blur_side_stream_is_chosen_per_call)
-os.environ.setdefault("EFX_BLUR_FORK_MIN_PX", "400000")
 
 
 @pytest.fixture(scope="module")
@@ -844,11 +842,13 @@ def test_level_blur_side_stream_is_chosen_per_call(cef, torch_mod, oracle, monke
     side stream when the call's stream had nothing pending at this call and at the one before -- a caller that waits for
     every frame -- and on the call's stream otherwise.  Same keypoints and descriptors either way, also when the two kinds of call
     alternate on one context, on two user streams, and for different frames in the same buffers.
-    The per-call decision only applies to pyramids of >= 50 M pixels; EFX_BLUR_FORK_MIN_PX (read once per process, so set for the
-    whole module by the fixture below) lowers the gate so that these 600 x 800 frames take it ("auto"), and EFX_BLUR_FORK = 1 / 2 /
+    The per-call decision only applies to pyramids of >= 50 M pixels; EFX_BLUR_FORK_MIN_PX (read with the other knobs when a context
+    is created -- ADVICE r5: it used to be a process-wide static set at module import, which changed the path of every other GPU test
+    module collected with this one) lowers the gate so that these 600 x 800 frames take it ("auto"), and EFX_BLUR_FORK = 1 / 2 /
     3 (read when a context is created) forces the fork behind the pyramid / harris_kernel / nms_kernel on every call: fork / join
     events reused across streams, the side stream shared by consecutive calls."""
     torch = torch_mod
+    monkeypatch.setenv("EFX_BLUR_FORK_MIN_PX", "400000")
     if fork == "auto":
         monkeypatch.delenv("EFX_BLUR_FORK", raising=False)
     else:
