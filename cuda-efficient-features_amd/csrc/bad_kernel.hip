@@ -493,6 +493,9 @@ __global__ __launch_bounds__(256) void bad_raw_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int count = d_count ? min(*d_count, n) : n;
     const int ngroups = (count + 3) >> 2;
+    // (Round 6, measured and dropped: a grid capped at ~32 K workgroups per launch whose workgroups take the groups g, g + gridDim.x,
+    // ... -- no tens of thousands of empty workgroups when a frame yields a fraction of the capacity -- cost the 8K frame rate 9 %:
+    // the loop around this body changes its schedule.)
     if ((int)blockIdx.x >= ngroups) return;
     const int kid = xcd_chunked(blockIdx.x, ngroups) * 4 + wave;      // neighbouring keypoints share an XCD's L2
     if (kid >= count) return;                                         // wave-uniform
@@ -965,11 +968,12 @@ hipError_t efx_launch_bad(const DescribeLaunch& a, const BadParamsDev* d_params,
         // of its own.  detect_common sets level_blurred only under bad_raw_kernel's conditions (S == 48, box edges <= 16)
         const int batched = a.nframes > 1 ? 1 : 0;
         const int NF = batched ? a.nframes : 1;
+        const int raw_grid = (a.n + 3) / 4;
         if (a.nbits == 256)
-            hipLaunchKernelGGL(bad_raw_kernel<4>, dim3((a.n + 3) / 4, NF), dim3(256), 4 * BAD_RAW_WAVE_LDS, stream, a.d_count, a.n, d_params, aff,
+            hipLaunchKernelGGL(bad_raw_kernel<4>, dim3(raw_grid, NF), dim3(256), 4 * BAD_RAW_WAVE_LDS, stream, a.d_count, a.n, d_params, aff,
                                a.desc, a.desc_pitch, batched, a.aff_stride, a.counts, a.descs);
         else
-            hipLaunchKernelGGL(bad_raw_kernel<8>, dim3((a.n + 3) / 4, NF), dim3(256), 4 * BAD_RAW_WAVE_LDS, stream, a.d_count, a.n, d_params, aff,
+            hipLaunchKernelGGL(bad_raw_kernel<8>, dim3(raw_grid, NF), dim3(256), 4 * BAD_RAW_WAVE_LDS, stream, a.d_count, a.n, d_params, aff,
                                a.desc, a.desc_pitch, batched, a.aff_stride, a.counts, a.descs);
         return hipGetLastError();
     }

@@ -2384,13 +2384,15 @@ __global__ void copy2d_kernel(const uint8_t* __restrict__ src, size_t spitch, ui
 #endif
 static inline int tower_src_host(int o, float f, int n) { const int v = (int)floorf((float)o * f); return v > n - 1 ? n - 1 : v; }
 
-static bool plan_tower(const LevelTable& H, int last, const uint8_t* img0, int pitch0, bool no_tower, long long max_px, TowerArgs* out, size_t* lds_out)
+static bool plan_tower(const LevelTable& H, int last, const uint8_t* img0, int pitch0, bool no_tower, long long max_px, int nframes, TowerArgs* out, size_t* lds_out)
 {
     if (last < 2) return false;
     // Measured (MI355X, one stream, sync per call): the tower beats the launch chain when the WHOLE pyramid is small
     // (FHD 0.166 -> 0.147 ms, 4K 0.270 -> 0.259 ms per detectAndCompute); fusing only the upper levels of a large frame
     // (8K levels 4..7) does not pay: those levels are as large as a 4K pyramid and the tower recomputes ~1.7x the pixels.
-    if ((long long)H.lv[0].rows * H.lv[0].cols > (max_px > 0 ? max_px : (long long)EFX_TOWER_MAX_PX)) return false;      // (EFX_TOWER_MAX_PX in the environment: tests)
+    // (a batch of frames is judged by ALL its pixels: the tower recomputes ~1.7x the pixels and only pays while the chain's three
+    // launches would be latency-bound -- sixteen FHD frames are an 8K frame's worth of work)
+    if ((long long)H.lv[0].rows * H.lv[0].cols * nframes > (max_px > 0 ? max_px : (long long)EFX_TOWER_MAX_PX)) return false;      // (EFX_TOWER_MAX_PX in the environment: tests)
     if (no_tower) return false;                               // EFX_NO_TOWER (tests): exercise the per-level kernels on small frames
     for (int s = 1; s <= last; s++) if (H.lv[s].fx > 3.5f || H.lv[s].fy > 3.5f) return false;     // resize_quad_win: source columns of neighbouring outputs within 8 bytes
     // Tile edge of the top level.  The kernel is a chain of dependent levels, so a workgroup's time hardly shrinks with
@@ -2490,6 +2492,8 @@ static hipError_t efx_launch_detect_impl(const DetectLaunch& a, hipStream_t stre
     // alignment decisions about level 0 hold for every frame of the launch: the address bits of all the images, OR-ed
     uintptr_t img_bits = 0;
     for (int f = 0; f < B; f++) img_bits |= reinterpret_cast<uintptr_t>(F.in.img0[f]);
+    // several waves per tile (harris_kernel, nms_kernel) only while the tiles of the whole launch do not fill the chip
+    const long long launch_tiles = (long long)H.total_tiles * B;
 
     // pyramid chain (calcImagePyramid, .cpp:136-157): level s+1 from level s.  The large lower levels get one launch each;
     // the small upper levels (launch- and latency-bound one by one) are produced by ONE tower launch from level s0.
@@ -2497,7 +2501,7 @@ static hipError_t efx_launch_detect_impl(const DetectLaunch& a, hipStream_t stre
     while (last + 1 < H.nlevels && H.lv[last + 1].rows > 0 && H.lv[last + 1].cols > 0 && H.lv[last].rows > 0 && H.lv[last].cols > 0) last++;
     TowerArgs tw;
     size_t tw_lds = 0;
-    const bool use_tower = plan_tower(H, last, reinterpret_cast<const uint8_t*>(img_bits), a.pitch0, a.knobs.no_tower != 0, a.knobs.tower_max_px, &tw, &tw_lds);
+    const bool use_tower = plan_tower(H, last, reinterpret_cast<const uint8_t*>(img_bits), a.pitch0, a.knobs.no_tower != 0, a.knobs.tower_max_px, B, &tw, &tw_lds);
     const int chain_end = use_tower ? tw.s0 : last;           // levels 1 .. chain_end by the per-level kernel
     // the counters are zeroed by the first pyramid kernel; a single-level "pyramid" has none: memset command
     bool zeroed = false;
@@ -2628,10 +2632,10 @@ static hipError_t efx_launch_detect_impl(const DetectLaunch& a, hipStream_t stre
         a.prof.end(prof, 0, stream);
         EFX_TRACE_POINT("fast");
         prof = a.prof.begin(1, stream);
-        if (H.total_tiles <= EFX_NMS_WIDE_TILES)
+        if (launch_tiles <= EFX_NMS_WIDE_TILES)
             hipLaunchKernelGGL(harris_kernel<4>, dim3(H.total_tiles + H.nlevels, B), dim3(256), 0, stream, a.d_table, a.img0, a.pitch0, aligned0, a.pyramid,
                                a.cand_xy, a.cand, a.cmax, a.hdr, a.counters, a.knobs.dbg & 15, F);
-        else if (H.total_tiles <= EFX_NMS_MID_TILES)
+        else if (launch_tiles <= EFX_NMS_MID_TILES)
             hipLaunchKernelGGL(harris_kernel<EFX_NMS_MID_NW>, dim3(H.total_tiles + H.nlevels, B), dim3(64 * EFX_NMS_MID_NW), 0, stream, a.d_table, a.img0, a.pitch0, aligned0, a.pyramid,
                                a.cand_xy, a.cand, a.cmax, a.hdr, a.counters, a.knobs.dbg & 15, F);
         else
@@ -2644,10 +2648,10 @@ static hipError_t efx_launch_detect_impl(const DetectLaunch& a, hipStream_t stre
     }
     bool prof = a.prof.begin(2, stream);
     // several waves per tile when the tiles alone do not fill the chip (256 CUs x 32 waves)
-    if (H.total_tiles <= EFX_NMS_WIDE_TILES)
+    if (launch_tiles <= EFX_NMS_WIDE_TILES)
         hipLaunchKernelGGL(nms_kernel<4>, dim3(H.total_tiles, B), dim3(256), 0, stream, a.d_table, a.hdr, a.cand, a.cmax, a.surv,
                            a.counters, a.nonmax_radius, a.knobs.dbg >> 4, a.fs);
-    else if (H.total_tiles <= EFX_NMS_MID_TILES)
+    else if (launch_tiles <= EFX_NMS_MID_TILES)
         hipLaunchKernelGGL(nms_kernel<EFX_NMS_MID_NW>, dim3(H.total_tiles, B), dim3(64 * EFX_NMS_MID_NW), 0, stream, a.d_table, a.hdr, a.cand, a.cmax, a.surv,
                            a.counters, a.nonmax_radius, a.knobs.dbg >> 4, a.fs);
     else

@@ -413,6 +413,7 @@ struct efx_context {
     int idle_streak = 0;            // consecutive calls that found their stream idle (where the level blur runs: detect_common)
     size_t cand_slots = 0;          // records in `cand` PER FRAME; the coordinate-only arrays of the same length follow the frames' records
     int g_frames = 0;               // frames the per-frame buffers were reserved for (batched launches: detect_frames)
+    int g_plan_frames = 0;          // frames per launch the row-walking pyramid plan was chunked for (build_rows_plan)
     FrameStride fs = {};            // distance between the frames' copies inside the buffers (efx_device.h)
     int last_frames = 1;            // frames of the last detect call (the summary mirror reads the LAST one)
     Summary* h_mirror = nullptr;    // host copy of the last frame's summary, filled on demand by fetch_summary()
@@ -520,7 +521,7 @@ int validate_params(const efx_params& p, std::string& err)
 // up), and per launch the column / row / strip / chunk tables.  Everything the kernel relies on is checked here; a launch whose
 // geometry does not fit gets nlev = 0 and its levels go through the tiled per-level kernels.  The float expressions are spec
 // S5's (the ones of the plan above).
-void build_rows_plan(const LevelTable& T, int nlevels, std::vector<int>& blob, RowsPlanLaunch* out)
+void build_rows_plan(const LevelTable& T, int nlevels, int nframes, std::vector<int>& blob, RowsPlanLaunch* out)
 {
     auto fbits = [](float f) { int i; memcpy(&i, &f, 4); return i; };
     memset(out, 0, sizeof(RowsPlanLaunch) * EFX_MAX_LEVELS);
@@ -659,7 +660,9 @@ void build_rows_plan(const LevelTable& T, int nlevels, std::vector<int>& blob, R
         // ---- chunks of rows of the top level: as many as give ~wave_target waves; at most 64 source rows (the masks) per chunk ----
         {
             const int top = nlev - 1;
-            const int want = std::max(1, (wave_target + R.nstrips - 1) / R.nstrips);
+            // (the frames of a batched launch share the plan: the launch has nframes x these waves, so its chunks are longer and
+            // recompute fewer halo rows)
+            const int want = std::max(1, (wave_target + R.nstrips * nframes - 1) / (R.nstrips * nframes));
             int rc = (rows_of(top) + want - 1) / want;
             float ftot = 1.f;
             for (int k = 0; k < nlev; k++) ftot *= T.lv[s + 1 + k].fy;
@@ -726,7 +729,7 @@ void build_rows_plan(const LevelTable& T, int nlevels, std::vector<int>& blob, R
 int build_geometry(efx_context* c, int rows, int cols, int nframes = 1)
 {
     const efx_params& p = c->p;
-    if (c->g_rows == rows && c->g_cols == cols && c->g_arena_full == c->arena_full && c->g_frames >= nframes && memcmp(&c->g_p, &p, sizeof(p)) == 0) return EFX_OK;
+    if (c->g_rows == rows && c->g_cols == cols && c->g_arena_full == c->arena_full && c->g_frames >= nframes && c->g_plan_frames == nframes && memcmp(&c->g_p, &p, sizeof(p)) == 0) return EFX_OK;
     const size_t NF = (size_t)std::max(nframes, c->g_rows == rows && c->g_cols == cols ? c->g_frames : 1);      // buffers never shrink
     LevelTable& T = c->h_table;
     memset(&T, 0, sizeof(T));
@@ -901,13 +904,13 @@ int build_geometry(efx_context* c, int rows, int cols, int nframes = 1)
                     if (ndw > 32 || nrow > 80) R.W = 0;          // footprint beyond what the streamed kernel stages: no plan
                 }
         }
-        build_rows_plan(T, p.nlevels, blob, c->rows_plan);
+        build_rows_plan(T, p.nlevels, nframes, blob, c->rows_plan);
         if (!blob.empty()) {
             HIP_TRY(c->err, c->rplan.reserve(blob.size() * 4));
             HIP_TRY(c->err, hipMemcpy(c->rplan.p, blob.data(), blob.size() * 4, hipMemcpyHostToDevice));
         }
     }
-    c->g_rows = rows; c->g_cols = cols; c->g_p = p; c->g_arena_full = c->arena_full; c->g_frames = (int)NF;
+    c->g_rows = rows; c->g_cols = cols; c->g_p = p; c->g_arena_full = c->arena_full; c->g_frames = (int)NF; c->g_plan_frames = nframes;
     return EFX_OK;
 }
 
