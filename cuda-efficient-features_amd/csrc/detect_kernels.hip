@@ -221,22 +221,17 @@ __device__ __forceinline__ float harris_rows(const uint8_t* p0, int P)
 }
 
 // The frame's counters are zeroed by workgroup 0 of the frame's first kernel (a memset command of its own costs ~5 us
-// on the critical path of every frame): only the words that are read need it -- the per-level allocation counters of the
-// levels in use and the small tables behind them.
-__device__ __forceinline__ void efx_zero_counters(Counters* __restrict__ c, int nlevels, int tid, int nthreads)
+// on the critical path of every frame): the small per-frame struct and the per-row sums.
+__device__ __forceinline__ void efx_zero_counters(Counters* __restrict__ c, RowCtr* __restrict__ rows, int nrows, int tid, int nthreads)
 {
-    for (int i = tid; i < nlevels * EFX_NSUB; i += nthreads) {
-        c->cand_total[i / EFX_NSUB][i % EFX_NSUB].v = 0;
-        c->surv_total[i / EFX_NSUB][i % EFX_NSUB].v = 0;
-    }
-    int* tail = c->level_out_base;                      // level_out_base, thresh, sum: contiguous plain words
-    const int nwords = (int)((sizeof(Counters) - offsetof(Counters, level_out_base)) / sizeof(int));
-    for (int i = tid; i < nwords; i += nthreads) tail[i] = 0;
+    int* w = reinterpret_cast<int*>(c);
+    for (int i = tid; i < (int)(sizeof(Counters) / sizeof(int)); i += nthreads) w[i] = 0;
+    for (int i = tid; i < nrows; i += nthreads) { rows[i].cand = 0; rows[i].surv = 0; }
 }
 
 // Frame of a batched pyramid launch (blockIdx.y): the source level is the caller's image of that frame (src_is_img0) or the
 // frame's copy of a pyramid level; destinations are pyramid levels.
-struct FramePyr { FrameIn in; size_t stride; int src_is_img0; };
+struct FramePyr { FrameIn in; size_t stride; int src_is_img0; RowCtr* zrows; size_t rows_stride; };
 // ... of a batched detector launch: the caller's images and the distances between the frames' copies of the context's buffers
 struct FrameSet { FrameIn in; FrameStride fs; };
 
@@ -335,7 +330,7 @@ __global__ __launch_bounds__(NT) void resize_kernel(
     const int tid = threadIdx.x;
     src = fp.src_is_img0 ? fp.in.img0[blockIdx.y] : src + blockIdx.y * fp.stride;
     dst += blockIdx.y * fp.stride;
-    if (zero && blockIdx.x == 0) efx_zero_counters(zero + blockIdx.y, zero_levels, tid, NT);
+    if (zero && blockIdx.x == 0) efx_zero_counters(zero + blockIdx.y, fp.zrows + blockIdx.y * fp.rows_stride, zero_levels, tid, NT);
     const int tile = xcd_chunked(blockIdx.x, tiles_x * tiles_y);
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int ox0 = tx * EFX_TILE, oy0 = ty * EFX_TILE;
@@ -457,7 +452,7 @@ __global__ __launch_bounds__(256) void resize_stream_kernel(
     const int tid = threadIdx.x;
     src = fp.src_is_img0 ? fp.in.img0[blockIdx.y] : src + blockIdx.y * fp.stride;
     dst += blockIdx.y * fp.stride;
-    if (zero && blockIdx.x == 0) efx_zero_counters(zero + blockIdx.y, zero_levels, tid, 256);
+    if (zero && blockIdx.x == 0) efx_zero_counters(zero + blockIdx.y, fp.zrows + blockIdx.y * fp.rows_stride, zero_levels, tid, 256);
     // XCD x owns the x-th contiguous eighth of the tiles, its workgroups stride through it
     const int ntiles = tiles_x * tiles_y;
     const int Wg = gridDim.x / EFX_NXCD, xcd = blockIdx.x % EFX_NXCD, wg = blockIdx.x / EFX_NXCD;
@@ -705,7 +700,7 @@ __global__ __launch_bounds__(256) void resize_rows_kernel(const RowsArgs A, Coun
     constexpr int LDS_WAVE = RW_D * RW_LDS_A + (NLEV - 1) * RW_LDS_B + NLEV * 512;      // source slots | a row of every level but the last | y weights
     static_assert((LDS_WAVE & 15) == 0 && (RW_D & 1) == 0 && NLEV >= 1 && NLEV <= RW_MAXLEV, "LDS rows: 16-byte aligned; an even number of slots");
     __shared__ __attribute__((aligned(16))) unsigned char s_rows[4 * LDS_WAVE];
-    if (zero && blockIdx.x == 0) efx_zero_counters(zero + blockIdx.y, zero_levels, threadIdx.x, 256);
+    if (zero && blockIdx.x == 0) efx_zero_counters(zero + blockIdx.y, fp.zrows + blockIdx.y * fp.rows_stride, zero_levels, threadIdx.x, 256);
     const size_t foff = blockIdx.y * fp.stride;              // this frame's copy of the pyramid
     const uint8_t* const srcA = fp.src_is_img0 ? fp.in.img0[blockIdx.y] : A.src + foff;
     const int lane = lane_id();
@@ -844,7 +839,7 @@ __global__ __launch_bounds__(NT) void pyramid_tower_kernel(const LevelTable* __r
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     img0 = fp.in.img0[blockIdx.y];
     pyramid += blockIdx.y * fp.stride;
-    if (zero && blockIdx.x == 0) efx_zero_counters(zero + blockIdx.y, T->nlevels, threadIdx.x, NT);
+    if (zero && blockIdx.x == 0) efx_zero_counters(zero + blockIdx.y, fp.zrows + blockIdx.y * fp.rows_stride, T->total_rows, threadIdx.x, NT);
     __shared__ int s_rng[EFX_MAX_LEVELS][8];        // per level: lox, hix, ownlox, ownhix, loy, hiy, ownloy, ownhiy
     const int tid = threadIdx.x;
     const int tile = xcd_chunked(blockIdx.x, A.tiles_x * A.tiles_y);
@@ -1070,12 +1065,13 @@ __device__ __forceinline__ void efx_tile_of(const LevelTable* T, int gt, int& l,
 __global__ __launch_bounds__(256) void fast_kernel(
     const LevelTable* __restrict__ T, const uint8_t* __restrict__ img0, int pitch0, int aligned0,
     const uint8_t* __restrict__ pyramid, int threshold, const uint8_t* __restrict__ mask, int mask_pitch,
-    uint32_t* __restrict__ cand_xy_all, TileHdr* __restrict__ hdr_all, Counters* __restrict__ cnt, int dbg_arg, const FrameSet F)
+    unsigned char* __restrict__ slots, uint16_t* __restrict__ tcount, RowCtr* __restrict__ rowsum, TileHdr* __restrict__ hdr_all, int dbg_arg, const FrameSet F)
 {
     const int dbg = EFX_DBG(dbg_arg);
     {   // this frame's buffers (blockIdx.y)
         const size_t f = blockIdx.y;
-        img0 = F.in.img0[f]; pyramid += f * F.fs.pyramid; cand_xy_all += f * F.fs.cand; hdr_all += f * F.fs.hdr; cnt += f;
+        img0 = F.in.img0[f]; pyramid += f * F.fs.pyramid; slots += f * F.fs.slots; tcount += f * F.fs.hdr; rowsum += f * F.fs.rows;
+        hdr_all += f * F.fs.hdr;
     }
     __shared__ __attribute__((aligned(16))) uint32_t s_tile[EFX_LT * (EFX_LP / 4)];
     __shared__ unsigned long long s_bitmap[EFX_TILE];
@@ -1083,7 +1079,6 @@ __global__ __launch_bounds__(256) void fast_kernel(
     __shared__ __attribute__((aligned(16))) int s_scan[8];     // two one-barrier scans: [0, 4) and [4, 8)
     __shared__ uint16_t s_rowoff[256];                          // phase 3: corners before row rr of cell c (canonical order), index 16 c + rr
     __shared__ int s_celloff[EFX_CELLS_PER_TILE + 1];
-    __shared__ int s_start;
 
     const int tid = threadIdx.x;
     // heaviest tiles first: the upper pyramid levels have the densest corners, so they must not form the tail
@@ -1099,7 +1094,6 @@ __global__ __launch_bounds__(256) void fast_kernel(
     const bool aligned = l == 0 ? aligned0 != 0 : true;
     const int x0 = tx * EFX_TILE, y0 = ty * EFX_TILE;
     const uint8_t* tb = reinterpret_cast<const uint8_t*>(s_tile);
-    uint32_t* cand_xy = cand_xy_all + L.cand_base;
     TileHdr* hdr = hdr_all + L.tile_base;
 
     // ---- phase 0: tile + halo -> LDS.  72 rows x 72 bytes as 9 x 8-byte pieces per row (the global address is
@@ -1220,34 +1214,38 @@ __global__ __launch_bounds__(256) void fast_kernel(
         if (rr == 0) s_celloff[cell] = pre;
         if (tid == 0) {
             s_celloff[EFX_CELLS_PER_TILE] = total;
-            s_start = total > 0 ? atomicAdd(&cnt->cand_total[l][tile & (EFX_NSUB - 1)].v, total) : 0;
-            // the arenas are sized for a corner density, not for the worst case (efx_api.cpp, build_geometry): a frame that
-            // does not fit is void -- every later kernel of the frame returns at once, N = 0, the host enlarges the arenas
-            if ((unsigned)(s_start + total) > L.cand_sub_cap) efx_raise_overflow(T, cnt);
+            // The tile's count goes to the compact per-tile array and into its tile row's sum: a tile's canonical rank in the level
+            // is the sum of the rows above + the counts left of it in its row (harris_kernel) -- no allocation, no scan pass, and a
+            // frame of any density fits (round 6; until then a corner arena sized for a density, and void frames beyond it)
+            tcount[gt] = (uint16_t)total;
+            if (total > 0) __hip_atomic_fetch_add(&rowsum[L.row_base + ty].cand, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
-
-        // ---- phase 4: append the corner coordinates to the level's corner array (responses: harris_kernel).  The lanes
-        //      walk the survivor list of phase 1 again; a survivor whose bit is set is a corner and its place is the count
-        //      before its row + the set bits left of it in the row.  (Until round 3 every row's thread wrote its corners to
-        //      an LDS list in a loop that ran as often as the fullest row of the wave had corners, and a second loop copied
-        //      the list out: ~130 instructions per tile more.) ----
-        const int start = s_start;
-        for (int idx = tid; idx < nq; idx += 256) {
-            const int e = s_list[idx];
-            const int blk = e >> 5, b = e & 31;
-            const int lx = ((blk & 15) << 2) + (b >> 3), ly = ((blk >> 4) << 2) + 7 - (b & 7);
-            const unsigned word = reinterpret_cast<const unsigned*>(s_bitmap)[ly * 2 + (lx >> 5)];
-            if ((word >> (lx & 31)) & 1u) {
-                const unsigned rowbits = (word >> (lx & 16)) & 0xffffu;            // the row of the corner's 16 x 16 cell
-                const int k = (int)s_rowoff[((((ly >> 4) << 2) + (lx >> 4)) << 4) + (ly & 15)] + __popc(rowbits & ((1u << (lx & 15)) - 1u));
-                if ((unsigned)(start + k) < L.cand_sub_cap)
-                    cand_xy[(size_t)(tile & (EFX_NSUB - 1)) * L.cand_sub_cap + start + k] = (uint32_t)(x0 + lx) | ((uint32_t)(y0 + ly) << 16);
-            }
-        }
         TileHdr* h = hdr + tile;
         if (tid <= EFX_CELLS_PER_TILE) h->cell_off[tid] = (uint16_t)s_celloff[tid];
-        if (tid == 32) { h->cand_start = (uint32_t)start; h->cand_rank = 0; h->surv_start = 0; h->surv_count = 0; h->out_off = 0; }
+        if (tid == 32) { h->cand_start = 0; h->surv_count = 0; h->out_off = 0; }
+        if (total == 0) return;
+
+        // ---- phase 4: the corners to the tile's 512-byte slot (responses: harris_kernel).  Up to 256 of them as a list of 16-bit
+        //      tile coordinates (x | y << 6) in canonical order: the lanes walk the survivor list of phase 1 again; a survivor whose
+        //      bit is set is a corner and its place is the count before its row + the set bits left of it in the row.  More (a tile
+        //      of a very dense frame): the 64 x 64 bitmap itself, harris_kernel enumerates it ----
+        if (total <= EFX_SLOT_LIST) {
+            uint16_t* slot = reinterpret_cast<uint16_t*>(slots + (size_t)gt * EFX_SLOT_BYTES);
+            for (int idx = tid; idx < nq; idx += 256) {
+                const int e = s_list[idx];
+                const int blk = e >> 5, b = e & 31;
+                const int lx = ((blk & 15) << 2) + (b >> 3), ly = ((blk >> 4) << 2) + 7 - (b & 7);
+                const unsigned word = reinterpret_cast<const unsigned*>(s_bitmap)[ly * 2 + (lx >> 5)];
+                if ((word >> (lx & 31)) & 1u) {
+                    const unsigned rowbits = (word >> (lx & 16)) & 0xffffu;            // the row of the corner's 16 x 16 cell
+                    const int k = (int)s_rowoff[((((ly >> 4) << 2) + (lx >> 4)) << 4) + (ly & 15)] + __popc(rowbits & ((1u << (lx & 15)) - 1u));
+                    slot[k] = (uint16_t)(lx | (ly << 6));
+                }
+            }
+        } else if (tid < EFX_TILE) {
+            reinterpret_cast<unsigned long long*>(slots + (size_t)gt * EFX_SLOT_BYTES)[tid] = s_bitmap[tid];
+        }
     }
 }
 
@@ -1256,52 +1254,41 @@ __global__ __launch_bounds__(256) void fast_kernel(
 // straight from the level image (L2 / Infinity Cache hits: fast_kernel has just read it) as one 12-byte load per
 // row -- measured faster than staging the tile in LDS again (117 vs 130 us per 8K frame).
 // Also leaves the strongest corner of every 16x16 cell (the quick test of the NMS kernel).
+// Round 6: the kernel also PLACES the tile's corners: the tile's canonical rank in its level is the sum of the tile rows above
+// it (RowCtr, summed by fast_kernel's atomics) + the counts of the tiles left of it -- loads that depend on the tile's
+// coordinates only, i.e. they travel with the header's -- and the records go to cand[rank + k].  The level's array holds exactly
+// cap = cvRound(0.1 w h) records (.cpp:252): corners of rank >= cap do not exist (spec S2: the first `cap` in canonical order),
+// so nothing is allocated and no frame can overflow anything.
 // ================================================================================================
+// inclusive scan inside each 16-lane row of the wave (DPP row_shr, no LDS)
+__device__ __forceinline__ int efx_row16_incl_scan(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);     // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);     // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);     // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);     // row_shr:8
+    return v;
+}
+
 // NW waves per tile (round 3, as nms_kernel): frames whose tiles do not fill the chip by themselves spread a tile's corners
 // over several waves (the corners are independent; the per-cell maxima meet in LDS atomics).
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void harris_kernel(
     const LevelTable* __restrict__ T, const uint8_t* __restrict__ img0, int pitch0, int aligned0,
-    const uint8_t* __restrict__ pyramid, const uint32_t* __restrict__ cand_xy_all, Corner* __restrict__ cand_all, Corner* __restrict__ cmax_all,
-    TileHdr* __restrict__ hdr_all, Counters* __restrict__ cnt, int dbg_arg, const FrameSet F)
+    const uint8_t* __restrict__ pyramid, const unsigned char* __restrict__ slots, const uint16_t* __restrict__ tcount, const RowCtr* __restrict__ rows,
+    Corner* __restrict__ cand_all, Corner* __restrict__ cmax_all, TileHdr* __restrict__ hdr_all, int dbg_arg, const FrameSet F)
 {
     const int dbg = EFX_DBG(dbg_arg);
     {
         const size_t f = blockIdx.y;
-        img0 = F.in.img0[f]; pyramid += f * F.fs.pyramid; cand_xy_all += f * F.fs.cand; cand_all += f * F.fs.cand;
-        cmax_all += f * F.fs.cmax; hdr_all += f * F.fs.hdr; cnt += f;
+        img0 = F.in.img0[f]; pyramid += f * F.fs.pyramid; slots += f * F.fs.slots; tcount += f * F.fs.hdr; rows += f * F.fs.rows;
+        cand_all += f * F.fs.cand; cmax_all += f * F.fs.cmax; hdr_all += f * F.fs.hdr;
     }
     __shared__ unsigned long long s_cellmax[EFX_CELLS_PER_TILE];
     __shared__ unsigned s_celltie[EFX_CELLS_PER_TILE];     // largest response key that two corners of the cell share
+    __shared__ uint16_t s_xy[EFX_SLOT_LIST];               // bitmap tiles: a chunk of the corners' tile coordinates in canonical order
+    __shared__ int s_rank;
     const int lane = threadIdx.x;                           // 0 .. 64 NW - 1: a corner slot of the round, not the hardware lane
-    if (cnt->sum.overflow) return;                          // void frame (arena overflow in fast_kernel)
-    if ((int)blockIdx.x >= T->total_tiles) {
-        if (lane >= 64) return;                             // the tile-rank scan below is one wave's work
-        // One extra workgroup per level: canonical rank of every tile's first corner = exclusive scan of the tile counts
-        // in tile order, needed to apply the 10 % cap deterministically (spec S2).  Only consulted (and only computed)
-        // when the level has more corners than its cap, i.e. on pathological frames; it rides in this launch because a
-        // launch of its own costs ~5 us of every frame.  fast_kernel, the launch before this one, wrote the counts.
-        const int l = (int)blockIdx.x - T->total_tiles;
-        const LevelDev& L = T->lv[l];
-        if (!L.active) return;
-        int lvl_total = 0;
-        for (int sub = 0; sub < EFX_NSUB; sub++) lvl_total += cnt->cand_total[l][sub].v;
-        if (lvl_total <= L.cap) return;
-        const int n = L.tiles_x * L.tiles_y;
-        TileHdr* h = hdr_all + L.tile_base;
-        // a lane owns a contiguous chunk of tiles: its loads are independent of each other (one memory round trip per
-        // pass instead of one per 64 tiles)
-        const int chunk = (n + 63) >> 6;
-        const int t_begin = min(lane * chunk, n), t_end = min(t_begin + chunk, n);
-        int mine = 0;
-        for (int t = t_begin; t < t_end; t++) mine += (int)h[t].cell_off[EFX_CELLS_PER_TILE];
-        int running = wave_incl_scan(mine) - mine;
-        for (int t = t_begin; t < t_end; t++) {
-            h[t].cand_rank = (uint32_t)running;
-            running += (int)h[t].cell_off[EFX_CELLS_PER_TILE];
-        }
-        return;
-    }
     const int gt = T->total_tiles - 1 - xcd_interleaved(blockIdx.x, T->total_tiles);      // densest tiles first
     int l, tx, ty;
     efx_tile_of(T, gt, l, tx, ty);
@@ -1311,52 +1298,97 @@ __global__ __launch_bounds__(64 * NW) void harris_kernel(
     const uint8_t* src = l == 0 ? img0 : pyramid + L.img_off;
     const int spitch = l == 0 ? pitch0 : L.pitch;
     const bool aligned = l == 0 ? aligned0 != 0 : true;
-    const TileHdr& h = hdr_all[L.tile_base + tile];
-    const int total = h.cell_off[EFX_CELLS_PER_TILE];
-#ifndef EFX_NO_RANGE_CHECKS
-    if (total > EFX_TILE * EFX_TILE || (size_t)h.cand_start + (size_t)total > (size_t)L.cand_sub_cap) {      // header out of range: void frame
-        if (lane == 0) efx_raise_overflow(T, cnt);
-        return;
+    TileHdr& h = hdr_all[L.tile_base + tile];
+    const int total = min((int)h.cell_off[EFX_CELLS_PER_TILE], EFX_TILE * EFX_TILE);
+    // the tile's canonical rank: loads that need the tile's coordinates only (one memory round trip, beside the header's)
+    int rank = 0;
+    if (lane < 64) {
+        for (int i = lane; i < ty; i += 64) rank += rows[L.row_base + i].cand;
+        const uint16_t* tc = tcount + L.tile_base + ty * L.tiles_x;
+        for (int i = lane; i < tx; i += 64) rank += (int)tc[i];
     }
-#endif
-    const size_t first = L.cand_base + (size_t)(tile & (EFX_NSUB - 1)) * L.cand_sub_cap + h.cand_start;
-    Corner* cand = cand_all + first;
-    const uint32_t* cand_xy = cand_xy_all + first;
-    if (total == 0) {
-        // a tile without corners: sixteen empty cell maxima, no barrier (smooth frames: most tiles; see nms_kernel)
+    auto empty_cells = [&]() {
+        // a tile without (valid) corners: sixteen empty cell maxima (smooth frames: most tiles; see nms_kernel)
         if (lane < EFX_CELLS_PER_TILE) {
             Corner best; best.xy = 0xffffffffu; best.resp = -3.0e38f;
             cmax_all[L.cmax_base + (size_t)(ty * 4 + (lane >> 2)) * (L.tiles_x * 4) + tx * 4 + (lane & 3)] = best;
         }
-        return;
+    };
+    if (total == 0) { empty_cells(); return; }              // no barrier (the header is workgroup-uniform)
+    if (lane < 64) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) rank += __shfl_xor(rank, d, 64);
     }
+    if (NW > 1) {
+        if (lane == 0) s_rank = rank;
+        __syncthreads();
+        rank = s_rank;
+    }
+    if (lane == 0) h.cand_start = (uint32_t)rank;           // nms_kernel: where this tile's (and its neighbours') lists start
+    const int n_valid = min(max(L.cap - rank, 0), total);   // the cap in canonical order (spec S2; cuda_fast.cu:245)
+    if (n_valid == 0) { empty_cells(); return; }
+    Corner* cand = cand_all + L.cand_base + (size_t)rank;
     if (lane < EFX_CELLS_PER_TILE) { s_cellmax[lane] = 0ull; s_celltie[lane] = 0u; }
     __syncthreads();
-    const uint32_t tile_xy = ((uint32_t)tx << 6) | ((uint32_t)ty << 22);      // what the tile bits of a coordinate word must be
-    for (int k = lane; k < total; k += 64 * NW) {
-        const uint32_t xy_in = cand_xy[k];
-        // a coordinate that is not of this tile was never written by fast_kernel (stores of freshly
-        // mapped arenas lost under heavy oversubscription).  Here it is only forced into the tile (a no-op for a valid one:
-        // three instructions; raising the void-frame flag here cost 5 us of the kernel's 57), so that nothing faults; the
-        // record keeps the word as it was read, and nms_kernel -- which checks every record it owns -- voids the frame.
-#ifdef EFX_NO_RANGE_CHECKS                                   // INVESTIGATION builds: what the checks cost
-        const uint32_t xy = xy_in;
-        const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
-#else
-        const uint32_t xy = (xy_in & 0x003f003fu) | tile_xy;
-        const int x = (int)(xy & 0xffffu), y = min((int)(xy >> 16), L.rows - 1);
-#endif
+
+    // one corner: response, record, cell maximum
+    auto corner = [&](int k, unsigned lxy) {
+        const int x = tx * EFX_TILE + (int)(lxy & 63u), y = min(ty * EFX_TILE + (int)(lxy >> 6), L.rows - 1);
+        const uint32_t xy = (uint32_t)x | ((uint32_t)(ty * EFX_TILE + (int)(lxy >> 6)) << 16);
         const uint8_t* c = src + (size_t)y * spitch + x;
         const float resp = (dbg & 4) ? 1.f : (aligned ? harris_rows(c - 4 * spitch - 4, spitch) : harris_bytes(c, spitch));
-        Corner rec; rec.xy = xy_in; rec.resp = resp;
-        cand[k] = rec;                                      // whole records: full-line stores (fast_kernel's coordinate array likewise)
+        Corner rec; rec.xy = xy; rec.resp = resp;
+        cand[k] = rec;                                      // whole records, consecutive lanes: full-line stores
         // strongest corner of the 16x16 cell: 64-bit max of (response key, xy).  A corner that finds its own response
         // already there has an equal twin in the cell; if that response ends up being the cell's maximum, the NMS quick
         // test must not treat the stored corner as the only one of that strength (equal responses suppress each other).
-        const int cell = ((y >> 4) & 3) * 4 + ((x >> 4) & 3);
+        const int cell = (int)((lxy >> 10) & 3u) * 4 + (int)((lxy >> 4) & 3u);
         const unsigned long long key = (efx_select_key(0u, resp) & 0xffffffff00000000ull) | xy;
         const unsigned long long old = atomicMax(&s_cellmax[cell], key);
         if ((unsigned)(old >> 32) == (unsigned)(key >> 32)) atomicMax(&s_celltie[cell], (unsigned)(key >> 32));
+    };
+
+    if (total <= EFX_SLOT_LIST) {
+        // the common case: fast_kernel left the tile coordinates as a list in canonical order
+        const uint16_t* slot = reinterpret_cast<const uint16_t*>(slots + (size_t)gt * EFX_SLOT_BYTES);
+        for (int k = lane; k < n_valid; k += 64 * NW) corner(k, (unsigned)slot[k] & 0xfffu);
+    } else {
+        // a tile of a very dense frame: the slot holds the 64 x 64 bitmap.  Lane r of wave 0 owns row r, i.e. one row of four
+        // cells; it pops its bits cell column by cell column into an LDS chunk of 256 corners at their canonical places (a
+        // segment's first place = the cell's offset + the bits of the rows above it in the cell), the workgroup computes the
+        // chunk, and so on: every bit is popped once
+        unsigned seg[4] = { 0u, 0u, 0u, 0u };
+        int base[4] = { 0, 0, 0, 0 };
+        if (lane < 64) {
+            const unsigned long long rb = reinterpret_cast<const unsigned long long*>(slots + (size_t)gt * EFX_SLOT_BYTES)[lane];
+            const uint2 co = *reinterpret_cast<const uint2*>(&h.cell_off[(lane >> 4) * 4]);      // the offsets of this row's four cells
+            const int coff[4] = { (int)(co.x & 0xffffu), (int)(co.x >> 16), (int)(co.y & 0xffffu), (int)(co.y >> 16) };
+#pragma unroll
+            for (int cx = 0; cx < 4; cx++) {
+                seg[cx] = (unsigned)(rb >> (16 * cx)) & 0xffffu;
+                const int c = __popc(seg[cx]);
+                base[cx] = coff[cx] + efx_row16_incl_scan(c) - c;
+            }
+        }
+        for (int c0 = 0; c0 < n_valid; c0 += EFX_SLOT_LIST) {
+            const int end = min(c0 + EFX_SLOT_LIST, n_valid);
+            if (lane < 64) {
+#pragma unroll
+                for (int cx = 0; cx < 4; cx++) {
+                    while (__ballot(seg[cx] != 0u && base[cx] < end) != 0ull) {
+                        if (seg[cx] != 0u && base[cx] < end) {
+                            const int b = __ffs(seg[cx]) - 1;
+                            seg[cx] &= seg[cx] - 1u;
+                            if (base[cx] >= c0) s_xy[base[cx] - c0] = (uint16_t)((16 * cx + b) | (lane << 6));
+                            base[cx]++;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            for (int k = c0 + lane; k < end; k += 64 * NW) corner(k, (unsigned)s_xy[k - c0]);
+            __syncthreads();
+        }
     }
     __syncthreads();
     if (lane < EFX_CELLS_PER_TILE) {
@@ -1402,12 +1434,14 @@ __global__ __launch_bounds__(64 * NW) void harris_kernel(
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void nms_kernel(const LevelTable* __restrict__ T, TileHdr* __restrict__ hdr,
                                                  const Corner* __restrict__ cand_all, const Corner* __restrict__ cmax_all,
-                                                 Corner* __restrict__ surv_all, Counters* __restrict__ cnt, int radius, int dbg_arg, const FrameStride fs)
+                                                 Corner* __restrict__ surv_all, RowCtr* __restrict__ rows, int* __restrict__ hist,
+                                                 Counters* __restrict__ cnt, int radius, int dbg_arg, const FrameStride fs)
 {
     const int dbg = EFX_DBG(dbg_arg);
     {
         const size_t f = blockIdx.y;
-        hdr += f * fs.hdr; cand_all += f * fs.cand; cmax_all += f * fs.cmax; surv_all += f * fs.surv; cnt += f;
+        hdr += f * fs.hdr; cand_all += f * fs.cand; cmax_all += f * fs.cmax; surv_all += f * fs.cand; rows += f * fs.rows; hist += f * fs.hist;
+        cnt += f;
     }
     __shared__ Corner s_hme_all[NW][NMS_HCAP];
     __shared__ uint16_t s_hidx_all[NW][NMS_HCAP];
@@ -1455,11 +1489,8 @@ __global__ __launch_bounds__(64 * NW) void nms_kernel(const LevelTable* __restri
             }
         }
     }
-    // the per-cell maxima include corners beyond the 10 % cap; when the cap is active (pathological frames) a cell
-    // maximum is a valid suppressor only if its whole tile lies below the cap
-    int lvl_total = 0;
-    for (int sub = 0; sub < EFX_NSUB; sub++) lvl_total += cnt->cand_total[l][sub].v;
-    const bool capped = lvl_total > L.cap;              // only then the canonical ranks were computed
+    // (the per-cell maxima are taken over the corners below the 10 % cap only -- harris_kernel computes no others --, so a cell
+    // maximum is always a valid suppressor; until round 6 they included corners beyond the cap and had to be screened here)
     // the cell maxima are fetched in the same memory round trip as the headers (both only need the tile's coordinates)
     // a cell beyond the grid is an EMPTY cell (harris_kernel's encoding: no coordinate, the lowest response): the
     // neighbourhood of IsMaxPoint is clipped to the grid (.cu:70-73), so such a cell holds nothing -- and phase A may rely on
@@ -1478,23 +1509,14 @@ __global__ __launch_bounds__(64 * NW) void nms_kernel(const LevelTable* __restri
         if (lane < 9) {
             const TileHdr* nh = reinterpret_cast<const TileHdr*>(&s_nb[lane][0]);
             const unsigned tot = nh->cell_off[EFX_CELLS_PER_TILE];
-            bad = tot > (unsigned)(EFX_TILE * EFX_TILE) || (size_t)nh->cand_start + tot > (size_t)L.cand_sub_cap;
+            bad = tot > (unsigned)(EFX_TILE * EFX_TILE);      // (list ranges are clipped to the level's cap where they are used)
         }
         if (__ballot(bad) != 0ull) {
             if (tid == 0) efx_raise_overflow(T, cnt);
             return;
         }
     }
-    if (tid < 36) {
-        if (capped && cell_exists) {
-            // a cell of a tile that is cut by the cap may hold invalid corners: its maximum must not suppress anything,
-            // but the cell may still hold a valid rival -> "infinitely strong, infinitely far": never kills, always
-            // sends the corner to the exact scan of that cell (whose list is clipped at the cap)
-            const TileHdr* nh = reinterpret_cast<const TileHdr*>(&s_nb[((cy >> 2) - ty + 1) * 3 + ((cx >> 2) - tx + 1)][0]);
-            if ((int)nh->cand_rank + (int)nh->cell_off[EFX_CELLS_PER_TILE] > L.cap) { cm.xy = 0x7fff7fffu; cm.resp = __int_as_float(0x7f800000); }
-        }
-        s_cm[tid / 6][tid % 6] = cm;
-    }
+    if (tid < 36) s_cm[tid / 6][tid % 6] = cm;
     __syncthreads();
     // header of the tile that holds cell (bx, by): the LDS copy when it is a neighbour (always, up to radius 64)
     auto nhdr = [&](int bx, int by) -> const TileHdr* {
@@ -1504,11 +1526,12 @@ __global__ __launch_bounds__(64 * NW) void nms_kernel(const LevelTable* __restri
         return &hl[nty * L.tiles_x + ntx];
     };
     const TileHdr& h = *reinterpret_cast<const TileHdr*>(&s_nb[4][0]);
-    const Corner* own = cand + (size_t)(tile & (EFX_NSUB - 1)) * L.cand_sub_cap + h.cand_start;
+    // a tile's corners start at its canonical rank in the level; those of rank >= cap do not exist (spec S2; cuda_fast.cu:245)
+    const unsigned own_start = min(h.cand_start, (unsigned)L.cap);
+    const Corner* own = cand + own_start;
 
     const int n_own = h.cell_off[EFX_CELLS_PER_TILE];
-    int n_valid = capped ? L.cap - (int)h.cand_rank : n_own;   // cap in canonical order (spec S2; cuda_fast.cu:245)
-    n_valid = n_valid < 0 ? 0 : (n_valid > n_own ? n_own : n_valid);
+    const int n_valid = min(L.cap - (int)own_start, n_own);
     if (dbg == 1) return;
 
     const int image_radius = radius * radius;           // cvCeil(radius * radius), .cu:291
@@ -1517,11 +1540,6 @@ __global__ __launch_bounds__(64 * NW) void nms_kernel(const LevelTable* __restri
     const int gwp = L.tiles_x * 4;                      // row pitch of the per-cell maxima table
     const Corner* cmax = cmax_all + L.cmax_base;
     const bool quick_ok = block_radius <= 2;
-    auto usable = [&](int bx, int by) -> bool {
-        if (!capped) return true;
-        const TileHdr* nh = nhdr(bx, by);
-        return (int)nh->cand_rank + (int)nh->cell_off[EFX_CELLS_PER_TILE] <= L.cap;
-    };
     const int span = 2 * block_radius + 1;
     const int ncell = span * span;
     const int grp = lane >> 3, sub = lane & 7;
@@ -1578,8 +1596,8 @@ __global__ __launch_bounds__(64 * NW) void nms_kernel(const LevelTable* __restri
                         const int c = (by & 3) * 4 + (bx & 3);
                         lb[q] = nh2->cell_off[c];
                         le[q] = nh2->cell_off[c + 1];
-                        if (capped) le[q] = min(le[q], L.cap - (int)nh2->cand_rank);       // corners beyond the cap do not exist
-                        lbase[q] = (unsigned)(((by >> 2) * L.tiles_x + (bx >> 2)) & (EFX_NSUB - 1)) * L.cand_sub_cap + nh2->cand_start;
+                        lbase[q] = min(nh2->cand_start, (unsigned)L.cap);
+                        le[q] = min(le[q], L.cap - (int)lbase[q]);                         // corners beyond the cap do not exist
                     }
                 }
                 unsigned gneed = ((unsigned)(__ballot(le[0] > lb[0]) >> (grp * 8)) & 0xffu) |
@@ -1611,13 +1629,12 @@ __global__ __launch_bounds__(64 * NW) void nms_kernel(const LevelTable* __restri
                     const int bx = bx1 - block_radius + ox, by = by1 - block_radius + oy;
                     if (act && ci < ncell && bx >= cx0 && bx <= cx1 && by >= cy0 && by <= cy1) {
                         const TileHdr* nh2 = nhdr(bx, by);
-                        const int nt = (by >> 2) * L.tiles_x + (bx >> 2);
                         const int c = (by & 3) * 4 + (bx & 3);
-                        const int nn = capped ? L.cap - (int)nh2->cand_rank : 65536;
+                        lbase[q] = min(nh2->cand_start, (unsigned)L.cap);
+                        const int nn = L.cap - (int)lbase[q];
                         lb[q] = nh2->cell_off[c];
                         le[q] = nh2->cell_off[c + 1];
                         if (le[q] > nn) le[q] = nn;
-                        lbase[q] = (unsigned)(nt & (EFX_NSUB - 1)) * L.cand_sub_cap + nh2->cand_start;
                         // a cell whose strongest corner is weaker than this corner cannot suppress it: skip the cell
                         if (quick_ok && le[q] > lb[q] && cmax[by * gwp + bx].resp < m.resp) le[q] = lb[q];
                         // nor can a cell whose nearest pixel is not inside the radius
@@ -1728,7 +1745,7 @@ __global__ __launch_bounds__(64 * NW) void nms_kernel(const LevelTable* __restri
                             const Corner o = cmax[by * gwp + bx];
                             const uint32_t oxy = o.xy & ~EFX_CMAX_TIE;
                             const int dx = mx - (int)(oxy & 0xffff), dy = my - (int)(oxy >> 16);
-                            if (oxy != me.xy && me.resp <= o.resp && dx * dx + dy * dy < image_radius && usable(bx, by)) hard = false;
+                            if (oxy != me.xy && me.resp <= o.resp && dx * dx + dy * dy < image_radius) hard = false;
                         }
                 }
             }
@@ -1757,227 +1774,224 @@ __global__ __launch_bounds__(64 * NW) void nms_kernel(const LevelTable* __restri
     // lane r holds the survivor ballot of round r
     const unsigned long long my_round_mask = s_keep[lane];
     const int nsurv = __shfl(wave_incl_scan(__popcll(my_round_mask)), 63, 64);
-    int start = 0;
-    if (lane == 0 && nsurv > 0) {
-        start = atomicAdd(&cnt->surv_total[l][tile & (EFX_NSUB - 1)].v, nsurv);
-        if ((unsigned)(start + nsurv) > L.surv_sub_cap) efx_raise_overflow(T, cnt);      // void frame, see fast_kernel
-    }
-    start = __shfl(start, 0, 64);
-    // second pass: write the survivors in canonical order
-    Corner* surv = surv_all + L.surv_base + (size_t)(tile & (EFX_NSUB - 1)) * L.surv_sub_cap;
+    // second pass: the survivors in canonical order, at the tile's own place in the level's index space (round 6: no allocation --
+    // a tile has at most as many survivors as corners, and its corners' places are its own); their number joins the tile row's sum
+    // and every survivor one bin of the level's key histogram (select_kernel finds the quota's threshold bin there without a pass
+    // over the survivors; emit_kernel withdraws the same counts, so the histogram is zero again when the frame is done)
+    Corner* surv = surv_all + L.cand_base + own_start;
+    int* lhist = hist + (size_t)l * EFX_HIST_BINS;
     int base = 0, round = 0;
     for (int k0 = 0; k0 < n_valid; k0 += 64, round++) {
         const unsigned long long m = (unsigned long long)(unsigned)__shfl((int)(my_round_mask & 0xffffffffu), round, 64) |
                                      ((unsigned long long)(unsigned)__shfl((int)(my_round_mask >> 32), round, 64) << 32);
-        const int slot = start + base + __popcll(m & ((1ull << lane) - 1ull));
-        if (((m >> lane) & 1ull) && (unsigned)slot < L.surv_sub_cap) surv[(size_t)slot] = own[k0 + lane];
+        const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+        if ((m >> lane) & 1ull) {
+            const Corner c = own[k0 + lane];
+            surv[slot] = c;
+            __hip_atomic_fetch_add(&lhist[efx_hist_word((uint32_t)(efx_select_key(c.xy, c.resp) >> (64 - EFX_HIST_BITS)))], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         base += __popcll(m);
     }
-    if (lane == 0) { hl[tile].surv_start = (uint32_t)start; hl[tile].surv_count = (uint32_t)nsurv; }
+    if (lane == 0) {
+        hl[tile].surv_count = (uint32_t)nsurv;
+        if (nsurv > 0) __hip_atomic_fetch_add(&rows[L.row_base + ty].surv, nsurv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // ================================================================================================
-// Kernel D: per-level quota (limitPoints, .cu:344-358, spec S3) + output offsets.  One workgroup per
-// level: if the survivors exceed the quota, an MSB-first radix select over the 64-bit keys
-// (response desc, raster asc) finds the quota-th largest key; then the selected survivors of every tile
-// are counted and scanned in canonical tile order to give each tile its output offset.
+// Kernel D: per-level quota (limitPoints, .cu:344-358, spec S3) + output offsets.
+// Round 6: the kernel is spread over the chip (until then: ONE workgroup of 1024 threads and 132 KB of LDS per level, i.e. eight
+// CUs of 256, 27 us alone and up to 330 us when it had to wait for a free CU behind other frames' kernels):
+//   leaders   workgroup l < nlevels: the level's survivor count (sum of its tile rows' sums) and, when it exceeds the quota, the
+//             bin b* of the 15-bit key histogram that holds the quota-th largest key -- nms_kernel has filled the histogram, so
+//             no pass over the survivors is needed: 128 bins per thread as 32 coalesced int4, one scan, the owner's bins again;
+//   counters  the other workgroups, a lane per tile (256 tiles each): they wait for their level's leader (a flag; the leaders
+//             have the lowest workgroup numbers, are dispatched first and wait for nobody), count the tile's survivors above
+//             b*, and append the keys OF b* -- a few dozen on real frames -- to the level's list;
+//   last      the counting workgroup that finishes a level last (a counter per level) ranks the list in LDS -> the exact
+//             threshold key, adds the list's selected keys to their tiles' counts and scans the counts in canonical tile order:
+//             every tile's output offset.
+// A bin with more than EFX_SEL_LIST_CAP keys (synthetic frames with thousands of equal responses): the last workgroup runs
+// 12-bit radix passes over the level's tiles itself (slow, exact).
 // ================================================================================================
-// INVESTIGATION (-DEFX_SEL_TIMING builds only): thread 0 of level 0's workgroup prints its phase times (10 ns ticks)
-#ifdef EFX_SEL_TIMING
-#define SEL_T(i) do { if (l == 0 && tid == 0) sel_t[i] = wall_clock64(); } while (0)
-#else
-#define SEL_T(i) do { } while (0)
-#endif
-#define SEL_BITS 12
-#define SEL_BINS (1 << SEL_BITS)
-#define SEL_MAX_TILES 12288          // per-tile counts of one level in LDS (48 KB); larger levels take the tile-parallel path
-#define SEL_TOP_BITS 15              // first pass: histogram of the keys' top bits (sign, exponent, 6 mantissa bits of the response)
-#define SEL_TOP_BINS (1 << SEL_TOP_BITS)
-#define SEL_LIST_CAP 4096            // keys of the threshold's bin that are ranked in LDS; more (thousands of near-equal responses): radix passes
-#define SEL_LDS_BYTES (SEL_TOP_BINS * 4)      // dynamic LDS: the histogram; later the candidate list / the per-tile counts
+#define SEL_NT 256
+#define SEL_ILP 8                     // survivors a counting lane has in flight
 
-// One workgroup per level.  What the kernel's time is made of (level 0 of the 8K benchmark frame, 22 593 survivors,
-// -DEFX_SEL_TIMING build, tools/microbench/sel_timing.sh): launch 4.5 us, counters 3.5, pass 1 5.3, threshold bin 2.3,
-// pass 2 + ranking 7.4, tile scan 1.3, header stores 0.9.  A pass over the survivors costs ~5 us whatever feeds it -- keys
-// held in registers, one batch of 24 loads or three of 8, sub-arrays interleaved against TLB misses were all measured and
-// changed nothing: it is 1024 threads' per-key instructions on ONE CU (16 waves on 4 SIMDs) plus one trip to memory.  So
-// the lever is the NUMBER of passes -- round 3: TWO instead of up to seven (31.6 -> 26 us) -- and spreading a level over
-// several workgroups would need three grid-wide hand-offs through memory (~2.5 us each across XCDs), i.e. no gain:
-//   1  histogram of the top 15 key bits (128 KB of LDS counters) -> the bin b* that holds the quota-th largest key, and how
-//      many keys of that bin are wanted;
-//   2  keys above b* are selected for sure: they are counted into their tiles at once; the keys OF b* (a few dozen on real
-//      frames: a bin is 1/64 of an octave of the response wide) go to an LDS list, are ranked there -- by counting for short
-//      lists, by radix passes over the list otherwise -- and the selected ones are then counted into their tiles as well.
-//   Then the tiles' output offsets (exclusive scan in canonical order).
-// A bin with more than SEL_LIST_CAP keys (synthetic frames with thousands of equal responses) falls back to 12-bit radix
-// passes over the survivors below the 15 bits already decided, and a separate counting pass.
-__global__ __launch_bounds__(1024) void select_kernel(const LevelTable* __restrict__ T, TileHdr* __restrict__ hdr,
-                                                      const Corner* __restrict__ surv_all, Counters* __restrict__ cnt,
-                                                      int capacity, const FrameOut out, const FrameStride fs)
+// a bounded wait for a flag another workgroup of this launch raises (the leaders precede the counters in dispatch order and
+// never wait themselves, so the wait always ends; the bound only keeps a broken build from hanging the GPU)
+__device__ __forceinline__ bool efx_wait_flag(const int* flag)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char sel_smem[];
+    for (int spin = 0; spin < (1 << 22); spin++) {
+        if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0) return true;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(SEL_NT) void select_kernel(const LevelTable* __restrict__ T, TileHdr* __restrict__ hdr,
+                                                        const Corner* __restrict__ surv_all, const RowCtr* __restrict__ rows,
+                                                        const int* __restrict__ hist, unsigned long long* __restrict__ sel_list,
+                                                        uint32_t* __restrict__ nsel, Counters* __restrict__ cnt,
+                                                        int capacity, const FrameOut out, const FrameStride fs)
+{
+    {
+        const size_t f = blockIdx.y;
+        hdr += f * fs.hdr; surv_all += f * fs.cand; rows += f * fs.rows; hist += f * fs.hist; sel_list += f * fs.list; nsel += f * fs.hdr; cnt += f;
+    }
     int* const d_count = out.count[blockIdx.y];
-    hdr += blockIdx.y * fs.hdr; surv_all += blockIdx.y * fs.surv; cnt += blockIdx.y;
-    int* s_hist = reinterpret_cast<int*>(sel_smem);                          // pass 1: SEL_TOP_BINS ints
-    // pass 2 (the histogram is dead): candidate list | 256-bin histograms of the LDS radix passes | per-tile counts
-    unsigned long long* s_list = reinterpret_cast<unsigned long long*>(sel_smem);
-    int* s_sub = reinterpret_cast<int*>(sel_smem + SEL_LIST_CAP * 8);
-    int* s_cnt = reinterpret_cast<int*>(sel_smem + SEL_LIST_CAP * 8 + 1024);
-    static_assert(SEL_LIST_CAP * 8 + 1024 + SEL_MAX_TILES * 4 <= SEL_LDS_BYTES, "pass-2 layout fits the histogram's storage");
-    __shared__ int s_scan[20];
-    __shared__ int s_bin, s_rem, s_n;
+    __shared__ __attribute__((aligned(16))) int s_scan[8];
+    __shared__ int s_own, s_want, s_bin, s_inbin, s_rem, s_last[EFX_MAX_LEVELS], s_m;
     __shared__ unsigned long long s_thresh;
+    __shared__ unsigned long long s_keys[EFX_SEL_LIST_CAP];      // the last workgroup's list (16 KB); the slow path's 4096-bin histogram
+    __shared__ int s_sub[256];
+    const int tid = threadIdx.x, nl = T->nlevels;
+    constexpr int TOPSH = 64 - EFX_HIST_BITS;
 
-    const int l = blockIdx.x;
-    const LevelDev& L = T->lv[l];
-    const int tid = threadIdx.x;
-#ifdef EFX_SEL_TIMING
-    unsigned long long sel_t[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-#endif
-    SEL_T(0);
-
-    // output base of this level: sum over lower levels of min(survivors, quota)  (.cpp:292-314).  The nlevels x 8 survivor counters
-    // sit in a cache line each: one load per thread and ONE round trip (round 5; every thread walking all of them took 3.5 us of
-    // the kernel's 27: tools/microbench/sel_timing.sh)
-    __shared__ int s_nsub[EFX_MAX_LEVELS * EFX_NSUB];
-    if (tid < T->nlevels * EFX_NSUB) s_nsub[tid] = cnt->surv_total[tid / EFX_NSUB][tid % EFX_NSUB].v;
-    __syncthreads();
-    int base = 0, all = 0;
-    for (int i = 0; i < T->nlevels; i++) {
-        int ns = 0;
-#pragma unroll
-        for (int sub = 0; sub < EFX_NSUB; sub++) ns += s_nsub[i * EFX_NSUB + sub];
-        const int k = T->lv[i].active ? min(ns, T->lv[i].quota) : 0;
-        if (i < l) base += k;
-        all += k;
-    }
-    if (tid == 0) {
-        cnt->level_out_base[l] = base;
-        if (l == T->nlevels - 1) cnt->level_out_base[T->nlevels] = all;
-        if (l == 0) { const int n = all < capacity ? all : capacity; cnt->sum.n_out = n; if (d_count) *d_count = n; }
-    }
-    SEL_T(1);
-    if (!L.active) { if (tid == 0) { cnt->sum.kept[l] = 0; cnt->thresh[l] = 0; } return; }
-    if (cnt->sum.overflow) {
-        // void frame (arena overflow): N = 0, nothing is selected, emitted or described
+    if ((int)blockIdx.x < nl) {
+        // ---------------- leader of level l ----------------
+        const int l = blockIdx.x;
+        const LevelDev& L = T->lv[l];
+        int part = 0, partc = 0;
+        for (int i = tid; i < L.tiles_y; i += SEL_NT) { part += rows[L.row_base + i].surv; partc += rows[L.row_base + i].cand; }
+        int n, nc;
+        (void)block_excl_scan4(part, s_scan, &n);
+        (void)block_excl_scan4(partc, s_scan + 4, &nc);
+        const bool none = !L.active || L.quota <= 0 || cnt->sum.overflow != 0;      // nothing is selected (void frame: N = 0)
+        if (tid == 0) { s_bin = none ? EFX_HIST_BINS : -1; s_inbin = 0; s_rem = 0; }
+        __syncthreads();
+        if (!none && n > L.quota) {
+            const int* lh = hist + (size_t)l * EFX_HIST_BINS;
+            const int own = SEL_NT - 1 - tid;                   // bins 128 own .. 128 own + 127: thread 0 owns the top
+            int sum = 0;
+#pragma unroll 8
+            for (int v = 0; v < 32; v++) {
+                const int4 q = *reinterpret_cast<const int4*>(lh + v * (EFX_HIST_BINS / 32) + 4 * own);
+                sum += (q.x + q.y) + (q.z + q.w);
+            }
+            int tot;
+            const int before = block_excl_scan4(sum, s_scan, &tot);
+            if (before < L.quota && L.quota <= before + sum) { s_own = own; s_want = L.quota - before; }      // exactly one thread
+            __syncthreads();
+            if (tid < 64) {
+                // the owner's 128 bins from the top, two per lane
+                const int want = s_want, b_hi = s_own * 128 + 127 - 2 * tid, b_lo = b_hi - 1;
+                const int c_hi = lh[efx_hist_word((uint32_t)b_hi)], c_lo = lh[efx_hist_word((uint32_t)b_lo)];
+                const int incl = wave_incl_scan(c_hi + c_lo), excl = incl - (c_hi + c_lo);
+                if (excl < want && want <= excl + c_hi) { s_bin = b_hi; s_inbin = c_hi; s_rem = want - excl; }
+                else if (excl + c_hi < want && want <= incl) { s_bin = b_lo; s_inbin = c_lo; s_rem = want - excl - c_hi; }
+            }
+            __syncthreads();
+        }
         if (tid == 0) {
-            cnt->sum.kept[l] = 0; cnt->thresh[l] = ~0ull;
-            if (l == 0) { cnt->sum.n_out = 0; if (d_count) *d_count = 0; }
+            SelLevel& S = cnt->sel[l];
+            S.n = n; S.bin = s_bin; S.in_bin = s_inbin; S.remaining = s_rem;
+            S.kmin = none ? 0 : min(n, L.quota);
+            cnt->sum.surv[l] = n; cnt->sum.cand[l] = nc;
+            __hip_atomic_store(&S.ready, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
         return;
     }
 
-    int nsub[EFX_NSUB];
-    int n = 0, nmaxsub = 0;
+    // ---------------- counting workgroup: a lane per tile ----------------
+    const int w = (int)blockIdx.x - nl;
+    const int gt = w * EFX_SEL_WG_TILES + tid;
+    const bool valid = gt < T->total_tiles;
+    int l = 0, tx = 0, ty = 0;
+    if (valid) efx_tile_of(T, gt, l, tx, ty);
+    const LevelDev& L = T->lv[l];
+    unsigned start = 0; int sc = 0;
+    if (valid && L.active) {
+        start = min(hdr[gt].cand_start, (unsigned)L.cap);
+        sc = min((int)min(hdr[gt].surv_count, (uint32_t)(EFX_TILE * EFX_TILE)), L.cap - (int)start);
+    }
+    const bool ok = valid ? efx_wait_flag(&cnt->sel[l].ready) : true;
+    int bin = EFX_HIST_BINS, in_bin = 0, rem = 0;
+    if (valid && ok) { bin = cnt->sel[l].bin; in_bin = cnt->sel[l].in_bin; rem = cnt->sel[l].remaining; }
+    if (bin == EFX_HIST_BINS) sc = 0;
+    const bool all_bin = rem == in_bin, listed = !all_bin && in_bin <= EFX_SEL_LIST_CAP;
+    const Corner* q = surv_all + L.cand_base + start;
+    unsigned long long* lst = sel_list + (size_t)l * EFX_SEL_LIST_CAP;
+    int c = 0;
+    {
+        int scmax = sc;
 #pragma unroll
-    for (int sub = 0; sub < EFX_NSUB; sub++) { nsub[sub] = s_nsub[l * EFX_NSUB + sub]; n += nsub[sub]; nmaxsub = max(nmaxsub, nsub[sub]); }
-    const Corner* surv = surv_all + L.surv_base;
-    const int ntiles = L.tiles_x * L.tiles_y;
-    const bool tiles_in_lds = ntiles <= SEL_MAX_TILES;
-
-    // one pass over the level's survivors: entries i, i + 1024, i + 2048 of all 8 sub-arrays per step -- 24 independent loads
-    // in flight, ONE memory round trip for levels of up to 3072 survivors per sub-array (every level of the benchmark
-    // frames).  The loads are unconditional (index clamped into the sub-array: the arena is ours whatever the counts say),
-    // so that they are not serialised by exec-mask bookkeeping; what lies beyond a count is skipped afterwards.
-    constexpr int SEL_BATCH = 3;
-    const uint2* surv2 = reinterpret_cast<const uint2*>(surv);
-    const unsigned capm1 = L.surv_sub_cap - 1u;
-    auto for_each_key = [&](auto&& f) {
-        for (int i0 = 0; i0 < nmaxsub; i0 += SEL_BATCH * 1024) {
-            uint2 c[SEL_BATCH][EFX_NSUB];
+        for (int d = 32; d >= 1; d >>= 1) scmax = max(scmax, __shfl_xor(scmax, d, 64));
+        for (int j0 = 0; j0 < scmax; j0 += SEL_ILP) {
+            Corner s[SEL_ILP];
 #pragma unroll
-            for (int h = 0; h < SEL_BATCH; h++)
+            for (int u = 0; u < SEL_ILP; u++) s[u] = q[min(j0 + u, max(sc - 1, 0))];       // unconditional loads: one round trip per step
 #pragma unroll
-                for (int sub = 0; sub < EFX_NSUB; sub++)
-                    c[h][sub] = surv2[(unsigned)sub * L.surv_sub_cap + min((unsigned)(i0 + tid + 1024 * h), capm1)];
-#pragma unroll
-            for (int h = 0; h < SEL_BATCH; h++)
-#pragma unroll
-                for (int sub = 0; sub < EFX_NSUB; sub++)
-                    if (i0 + tid + 1024 * h < nsub[sub]) f(efx_select_key(c[h][sub].x, __uint_as_float(c[h][sub].y)), c[h][sub].x);
-        }
-    };
-    auto tile_of = [&](uint32_t xy) -> int { return (int)((xy >> 16) >> 6) * L.tiles_x + (int)((xy & 0xffffu) >> 6); };
-
-    unsigned long long thresh = 0;
-    bool counted = false;                    // the per-tile counts of the selected survivors are in s_cnt
-    if (L.quota <= 0) {
-        thresh = ~0ull;                      // a level whose quota rounds to 0 keeps nothing (no key reaches this value)
-    } else if (n > L.quota) {
-        // ---- pass 1: histogram of the top bits ----
-        {
-            int4* z = reinterpret_cast<int4*>(s_hist);
-            for (int i = tid; i < SEL_TOP_BINS / 4; i += 1024) z[i] = make_int4(0, 0, 0, 0);
-        }
-        __syncthreads();
-        for_each_key([&](unsigned long long k, uint32_t) { atomicAdd(&s_hist[(int)(k >> (64 - SEL_TOP_BITS))], 1); });
-        __syncthreads();
-        SEL_T(2);
-        // walk the bins from the top: thread t owns the 32 bins [hi - 32 t - 31, hi - 32 t]
-        {
-            constexpr int PER = SEL_TOP_BINS / 1024;
-            const int top = SEL_TOP_BINS - 1 - tid * PER;
-            int sum = 0;
-#pragma unroll
-            for (int j = 0; j < PER; j += 4) {
-                const int4 v = *reinterpret_cast<const int4*>(&s_hist[top - j - 3]);
-                sum += v.x + v.y + v.z + v.w;
-            }
-            int tot;
-            const int before = block_excl_scan<16>(sum, s_scan, &tot);
-            if (before < L.quota && L.quota <= before + sum) { s_bin = top; s_rem = L.quota - before; }     // the owner of the bin
-            __syncthreads();
-            if (tid < 64) {
-                // its 32 bins, from the top, one per lane of wave 0
-                const int b = s_bin - tid;
-                const int c = tid < PER ? s_hist[b] : 0;
-                const int incl = wave_incl_scan(c);
-                const int want = s_rem;
-                const bool hit = tid < PER && incl - c < want && want <= incl;
-                __builtin_amdgcn_wave_barrier();
-                if (hit) { s_bin = b; s_rem = want - (incl - c); s_n = c; }
+            for (int u = 0; u < SEL_ILP; u++) {
+                if (j0 + u < sc) {
+                    const unsigned long long key = efx_select_key(s[u].xy, s[u].resp);
+                    const int kb = (int)(key >> TOPSH);
+                    if (kb > bin || (kb == bin && all_bin)) c++;
+                    else if (kb == bin && listed) {
+                        const int pos = atomicAdd(&cnt->sel[l].list_n, 1);
+                        if (pos < EFX_SEL_LIST_CAP) lst[pos] = key;
+                    }
+                }
             }
         }
-        __syncthreads();
-        const int bin = s_bin, in_bin = s_n;
-        int remaining = s_rem;
-        unsigned long long prefix = (unsigned long long)bin;     // decided high bits, right-aligned
-        int decided = SEL_TOP_BITS;
-        __syncthreads();                                         // the histogram's storage is reused below
-        SEL_T(3);
-        if (remaining == in_bin) {
-            thresh = prefix << (64 - decided);                   // every key of the bin is wanted: its lower edge
-        } else if (in_bin <= SEL_LIST_CAP) {
-            // ---- pass 2: keys above the bin -> their tiles' counts; the bin's keys -> LDS list ----
-            if (tid == 0) s_n = 0;
-            if (tiles_in_lds) for (int t = tid; t < ntiles; t += 1024) s_cnt[t] = 0;
+    }
+    if (valid) nsel[gt] = (uint32_t)c;
+    // ---- which levels does this workgroup complete? ----
+    if (tid < EFX_MAX_LEVELS) s_last[tid] = 0;
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+        int l0, l1, tx_, ty_;
+        efx_tile_of(T, w * EFX_SEL_WG_TILES, l0, tx_, ty_);
+        efx_tile_of(T, min(w * EFX_SEL_WG_TILES + EFX_SEL_WG_TILES - 1, T->total_tiles - 1), l1, tx_, ty_);
+        for (int i = l0; i <= l1; i++)
+            if (atomicAdd(&cnt->sel[i].done, 1) == T->lv[i].sel_wgs - 1) s_last[i] = 1;
+    }
+    __syncthreads();
+    for (int fl = 0; fl < nl; fl++) {
+        if (!s_last[fl]) continue;                              // workgroup-uniform
+        // ---------------- last workgroup of level fl: threshold key, counts, scan ----------------
+        __threadfence();
+        const LevelDev& F = T->lv[fl];
+        const int ntiles = F.tiles_x * F.tiles_y;
+        // every leader's share of N (the leaders wait for nobody)
+        int base = 0, all = 0;
+        for (int i = 0; i < nl; i++) {
+            (void)efx_wait_flag(&cnt->sel[i].ready);
+            const int k = __hip_atomic_load(&cnt->sel[i].kmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (i < fl) base += k;
+            all += k;
+        }
+        const int fbin = cnt->sel[fl].bin, fin = cnt->sel[fl].in_bin, frem = cnt->sel[fl].remaining;
+        unsigned long long thresh = 0ull;
+        if (fbin == EFX_HIST_BINS) thresh = ~0ull;              // nothing is selected (no key reaches this value)
+        else if (fbin < 0) thresh = 0ull;                       // every survivor is
+        else if (frem == fin) thresh = (unsigned long long)fbin << TOPSH;      // every key of the bin is wanted: its lower edge
+        else if (fin <= EFX_SEL_LIST_CAP) {
+            const int m = min(__hip_atomic_load(&cnt->sel[fl].list_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), EFX_SEL_LIST_CAP);      // == fin
+            const unsigned long long* gl = sel_list + (size_t)fl * EFX_SEL_LIST_CAP;
+            for (int i = tid; i < m; i += SEL_NT) s_keys[i] = __hip_atomic_load(&gl[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
-            for_each_key([&](unsigned long long k, uint32_t xy) {
-                const int b = (int)(k >> (64 - SEL_TOP_BITS));
-                if (b == bin) s_list[atomicAdd(&s_n, 1)] = k;
-                else if (b > bin && tiles_in_lds) atomicAdd(&s_cnt[tile_of(xy)], 1);
-            });
-            __syncthreads();
-            const int m = s_n;                                   // == in_bin
-            if (m <= 128) {
-                // rank by counting: the key with exactly remaining - 1 larger keys (keys are unique)
+            if (m <= SEL_NT) {
+                // rank by counting: the key with exactly frem - 1 larger keys (keys are unique)
                 if (tid < m) {
-                    const unsigned long long mine = s_list[tid];
+                    const unsigned long long mine = s_keys[tid];
                     int larger = 0;
-                    for (int j = 0; j < m; j++) larger += s_list[j] > mine ? 1 : 0;
-                    if (larger == remaining - 1) s_thresh = mine;
+                    for (int j = 0; j < m; j++) larger += s_keys[j] > mine ? 1 : 0;
+                    if (larger == frem - 1) s_thresh = mine;
                 }
                 __syncthreads();
                 thresh = s_thresh;
             } else {
                 // MSB-first radix select over the LDS list, 8-bit digits below the decided bits
+                unsigned long long prefix = (unsigned long long)fbin;
+                int decided = EFX_HIST_BITS, remaining = frem;
                 while (decided < 64) {
                     const int width = (64 - decided) < 8 ? (64 - decided) : 8;
                     const int shift = 64 - decided - width;
-                    if (tid < 256) s_sub[tid] = 0;
+                    s_sub[tid] = 0;
                     __syncthreads();
-                    for (int i = tid; i < m; i += 1024) {
-                        const unsigned long long k = s_list[i];
+                    for (int i = tid; i < m; i += SEL_NT) {
+                        const unsigned long long k = s_keys[i];
                         if ((k >> (64 - decided)) == prefix) atomicAdd(&s_sub[(int)((k >> shift) & ((1u << width) - 1))], 1);
                     }
                     __syncthreads();
@@ -1989,13 +2003,13 @@ __global__ __launch_bounds__(1024) void select_kernel(const LevelTable* __restri
                         int before = wave_incl_scan(sum) - sum;
 #pragma unroll
                         for (int j = 0; j < 4; j++) {
-                            if (before < remaining && remaining <= before + loc[j]) { s_bin = 255 - (tid * 4 + j); s_rem = remaining - before; s_n = loc[j]; }
+                            if (before < remaining && remaining <= before + loc[j]) { s_bin = 255 - (tid * 4 + j); s_rem = remaining - before; s_m = loc[j]; }
                             before += loc[j];
                         }
                     }
                     __syncthreads();
                     prefix = (prefix << width) | (unsigned long long)s_bin;
-                    const int cnt_bin = s_n;
+                    const int cnt_bin = s_m;
                     remaining = s_rem;
                     decided += width;
                     __syncthreads();
@@ -2003,109 +2017,89 @@ __global__ __launch_bounds__(1024) void select_kernel(const LevelTable* __restri
                 }
                 thresh = prefix;
             }
-            if (tiles_in_lds) {
-                // the selected keys of the bin join the counts
-                for (int i = tid; i < m; i += 1024) {
-                    const unsigned long long k = s_list[i];
-                    if (k >= thresh) atomicAdd(&s_cnt[tile_of(0xffffffffu - (uint32_t)k)], 1);     // the key's low word is ~xy
+            // the list's selected keys join their tiles' counts
+            for (int i = tid; i < m; i += SEL_NT) {
+                const unsigned long long k = s_keys[i];
+                if (k >= thresh) {
+                    const uint32_t xy = 0xffffffffu - (uint32_t)k;      // the key's low word is ~xy
+                    atomicAdd(&nsel[F.tile_base + (int)((xy >> 16) >> 6) * F.tiles_x + (int)((xy & 0xffffu) >> 6)], 1u);
                 }
-                counted = true;
             }
+            __threadfence();
+            __syncthreads();
         } else {
-            // thousands of keys in one bin: 12-bit radix passes over the survivors, below the bits already decided
+            // thousands of keys in one bin: 12-bit radix passes over the level's survivors, below the bits already decided
+            int* s_hist = reinterpret_cast<int*>(s_keys);        // 4096 bins
+            auto for_each_key = [&](auto&& f) {
+                for (int t = tid; t < ntiles; t += SEL_NT) {
+                    const TileHdr& th = hdr[F.tile_base + t];
+                    const unsigned st = min(th.cand_start, (unsigned)F.cap);
+                    const int n2 = min((int)min(th.surv_count, (uint32_t)(EFX_TILE * EFX_TILE)), F.cap - (int)st);
+                    const Corner* q2 = surv_all + F.cand_base + st;
+                    for (int j = 0; j < n2; j++) f(efx_select_key(q2[j].xy, q2[j].resp), t);
+                }
+            };
+            unsigned long long prefix = (unsigned long long)fbin;
+            int decided = EFX_HIST_BITS, remaining = frem;
             while (decided < 64) {
-                const int width = (64 - decided) < SEL_BITS ? (64 - decided) : SEL_BITS;
+                const int width = (64 - decided) < 12 ? (64 - decided) : 12;
                 const int shift = 64 - decided - width;
-                for (int i = tid; i < SEL_BINS; i += 1024) s_hist[i] = 0;
+                for (int i = tid; i < 4096; i += SEL_NT) s_hist[i] = 0;
                 __syncthreads();
-                for_each_key([&](unsigned long long k, uint32_t) {
+                for_each_key([&](unsigned long long k, int) {
                     if ((k >> (64 - decided)) == prefix) atomicAdd(&s_hist[(int)((k >> shift) & ((1u << width) - 1))], 1);
                 });
                 __syncthreads();
-                // walk the bins from the top: thread t owns bins [hi-4t-3, hi-4t]
+                // walk the bins from the top: thread t owns bins [hi - 16 t - 15, hi - 16 t]
                 const int nb = 1 << width;
-                int loc[4]; int sum = 0;
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int b = nb - 1 - (tid * 4 + j);
-                    loc[j] = b >= 0 ? s_hist[b] : 0;
-                    sum += loc[j];
-                }
+                int sum = 0;
+                for (int j = 0; j < 16; j++) { const int b = nb - 1 - (tid * 16 + j); sum += b >= 0 ? s_hist[b] : 0; }
                 int tot;
-                int before = block_excl_scan<16>(sum, s_scan, &tot);
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int b = nb - 1 - (tid * 4 + j);
-                    if (b >= 0 && before < remaining && remaining <= before + loc[j]) { s_bin = b; s_rem = remaining - before; }
-                    before += loc[j];
+                int before = block_excl_scan4(sum, s_scan, &tot);
+                for (int j = 0; j < 16; j++) {
+                    const int b = nb - 1 - (tid * 16 + j);
+                    const int cb = b >= 0 ? s_hist[b] : 0;
+                    if (b >= 0 && before < remaining && remaining <= before + cb) { s_bin = b; s_rem = remaining - before; s_m = cb; }
+                    before += cb;
                 }
                 __syncthreads();
-                const int cnt_bin = s_hist[s_bin];
                 prefix = (prefix << width) | (unsigned long long)s_bin;
+                const int cnt_bin = s_m;
                 remaining = s_rem;
                 decided += width;
                 __syncthreads();
-                // every key of the chosen bin is wanted: the threshold is the bin's lower edge, no more passes
                 if (remaining == cnt_bin) { prefix = decided < 64 ? (prefix << (64 - decided)) : prefix; decided = 64; }
             }
             thresh = prefix;                 // exactly `quota` keys are >= thresh (keys are unique)
-        }
-        __syncthreads();
-    }
-    if (tid == 0) cnt->thresh[l] = thresh;
-    SEL_T(4);
-
-    // ---- selected survivors per tile (unless pass 2 has counted them), exclusive scan in canonical tile order ----
-    TileHdr* hl = hdr + L.tile_base;
-    int running = 0;
-    if (tiles_in_lds) {
-        if (!counted) {
-            // survivor-parallel: a survivor knows its tile from its coordinates, so the level's survivor arrays are read
-            // once, coalesced, and the per-tile counts live in LDS
-            for (int t = tid; t < ntiles; t += 1024) s_cnt[t] = 0;
+            // the counting pass left the bin's keys out: add the selected ones
+            for_each_key([&](unsigned long long k, int t) {
+                if ((int)(k >> TOPSH) == fbin && k >= thresh) atomicAdd(&nsel[F.tile_base + t], 1u);
+            });
+            __threadfence();
             __syncthreads();
-            for_each_key([&](unsigned long long k, uint32_t xy) { if (k >= thresh) atomicAdd(&s_cnt[tile_of(xy)], 1); });
+        }
+        // ---- the tiles' output offsets: exclusive scan of the counts in canonical tile order; a thread owns a chunk ----
+        const int chunk = (ntiles + SEL_NT - 1) / SEL_NT;
+        const int t0 = min(tid * chunk, ntiles), t1 = min(t0 + chunk, ntiles);
+        const uint32_t* ns = nsel + F.tile_base;
+        int local = 0;
+        for (int t = t0; t < t1; t++) local += (int)__hip_atomic_load(&ns[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int tot;
+        int pre = block_excl_scan4(local, s_scan + 4, &tot);
+        TileHdr* hl = hdr + F.tile_base;
+        for (int t = t0; t < t1; t++) { hl[t].out_off = (uint32_t)(base + pre); pre += (int)__hip_atomic_load(&ns[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        if (tid == 0) {
+            cnt->thresh[fl] = thresh;
+            cnt->level_out_base[fl] = base;
+            cnt->sum.kept[fl] = tot;
+            if (fl == 0) {
+                const int n = all < capacity ? all : capacity;
+                cnt->level_out_base[nl] = all;
+                cnt->sum.n_out = n;
+                if (d_count) *d_count = n;
+            }
         }
         __syncthreads();
-        SEL_T(5);
-        // exclusive scan over the tiles: a thread owns a contiguous chunk
-        const int chunk = (ntiles + 1023) / 1024;
-        const int t0 = tid * chunk, t1 = min(t0 + chunk, ntiles);
-        int local = 0;
-        for (int t = t0; t < t1; t++) local += s_cnt[t];
-        int tot;
-        int pre = block_excl_scan<16>(local, s_scan, &tot);
-        SEL_T(6);
-        for (int t = t0; t < t1; t++) { hl[t].out_off = (uint32_t)(base + pre); pre += s_cnt[t]; }
-        running = tot;
-    } else {
-        for (int t0 = 0; t0 < ntiles; t0 += 1024) {
-            const int t = t0 + tid;
-            int c = 0;
-            if (t < ntiles) {
-                const int sc = (int)hl[t].surv_count;
-                const Corner* q = surv + (size_t)(t & (EFX_NSUB - 1)) * L.surv_sub_cap + hl[t].surv_start;
-                for (int j = 0; j < sc; j++) c += efx_select_key(q[j].xy, q[j].resp) >= thresh ? 1 : 0;
-            }
-            int tot;
-            const int pre = block_excl_scan<16>(c, s_scan, &tot);
-            if (t < ntiles) hl[t].out_off = (uint32_t)(base + running + pre);
-            running += tot;
-        }
-    }
-    SEL_T(7);
-#ifdef EFX_SEL_TIMING
-    if (l == 0 && tid == 0)
-        printf("select l0 ticks(10ns): base %llu | pass1 %llu | bin %llu | pass2+rank %llu | count %llu | scan %llu | hdr %llu | total %llu\n",
-               sel_t[1] - sel_t[0], sel_t[2] - sel_t[1], sel_t[3] - sel_t[2], sel_t[4] - sel_t[3], sel_t[5] - sel_t[4], sel_t[6] - sel_t[5],
-               sel_t[7] - sel_t[6], sel_t[7] - sel_t[0]);
-#endif
-    if (tid == 0) {
-        cnt->sum.kept[l] = running;
-        cnt->sum.surv[l] = n;
-        int nc = 0;
-        for (int sub = 0; sub < EFX_NSUB; sub++) nc += cnt->cand_total[l][sub].v;
-        cnt->sum.cand[l] = nc;
     }
 }
 
@@ -2150,10 +2144,11 @@ __global__ __launch_bounds__(64) void emit_kernel(const LevelTable* __restrict__
                                                   const Corner* __restrict__ surv_all, const Counters* __restrict__ cnt,
                                                   const uint8_t* __restrict__ img0, int pitch0, const uint8_t* __restrict__ pyramid,
                                                   size_t kps_pitch, int capacity,
-                                                  float4* __restrict__ kp4, int* __restrict__ kp_level, const FrameOut out, const FrameStride fs)
+                                                  float4* __restrict__ kp4, int* __restrict__ kp_level, int* __restrict__ hist, const FrameOut out, const FrameStride fs)
 {
     uint8_t* const kps = out.kps[blockIdx.y];
-    hdr += blockIdx.y * fs.hdr; surv_all += blockIdx.y * fs.surv; cnt += blockIdx.y; kp4 += blockIdx.y * fs.kp; kp_level += blockIdx.y * fs.kp;
+    hdr += blockIdx.y * fs.hdr; surv_all += blockIdx.y * fs.cand; cnt += blockIdx.y; kp4 += blockIdx.y * fs.kp; kp_level += blockIdx.y * fs.kp;
+    hist += blockIdx.y * fs.hist;
     // EMIT_TPW tiles per wave, 64 / EMIT_TPW lanes each (round 3): a tile has three survivors on average and the kernel is a
     // chain of dependent loads per wave (tile word -> header -> survivors), so its time is the number of waves the chip must
     // cycle through: 25 500 one-tile waves took 3.1 rounds of the chip's 8192 wave slots
@@ -2164,22 +2159,31 @@ __global__ __launch_bounds__(64) void emit_kernel(const LevelTable* __restrict__
     int l = 0, tx = 0, ty = 0;
     if (tile_ok) efx_tile_of(T, gt, l, tx, ty);
     const LevelDev& L = T->lv[l];
-    const bool act = tile_ok && L.active && !cnt->sum.overflow;
-    const int sc = act ? (int)hdr[gt].surv_count : 0;
+    const bool act = tile_ok && L.active;               // (a void frame's threshold is above every key: nothing is selected)
+    const unsigned start = act ? min(hdr[gt].cand_start, (unsigned)L.cap) : 0u;
+    const int sc = act ? min((int)min(hdr[gt].surv_count, (uint32_t)(EFX_TILE * EFX_TILE)), L.cap - (int)start) : 0;
     const int out_off = act ? (int)hdr[gt].out_off : 0;
     int sc_max = sc;
 #pragma unroll
     for (int d = LPT; d < 64; d <<= 1) sc_max = max(sc_max, __shfl_xor(sc_max, d, 64));
     if (sc_max == 0) return;
     const unsigned long long thresh = cnt->thresh[l];
-    const Corner* q = surv_all + L.surv_base + (size_t)((gt - L.tile_base) & (EFX_NSUB - 1)) * L.surv_sub_cap + (act ? hdr[gt].surv_start : 0u);
+    const Corner* q = surv_all + L.cand_base + start;
+    int* lhist = hist + (size_t)l * EFX_HIST_BINS;
 
     int running = 0;
     for (int i0 = 0; i0 < sc_max; i0 += LPT) {
         const int i = i0 + sub;
         Corner c; c.xy = 0; c.resp = 0.f;
         bool sel = false;
-        if (i < sc) { c = q[i]; sel = efx_select_key(c.xy, c.resp) >= thresh; }
+        if (i < sc) {
+            c = q[i];
+            const unsigned long long key = efx_select_key(c.xy, c.resp);
+            sel = key >= thresh;
+            // every survivor's count leaves the level's key histogram again (nms_kernel added it, select_kernel has read it): the
+            // histogram is zero when the frame is done, without a pass that clears its 128 KB per level
+            __hip_atomic_fetch_add(&lhist[efx_hist_word((uint32_t)(key >> (64 - EFX_HIST_BITS)))], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         const unsigned m = (unsigned)(__ballot(sel) >> (LPT * part)) & (unsigned)((1ull << LPT) - 1ull);     // this tile's lanes
         const int rank = __popc(m & ((1u << sub) - 1u));
         const int out = out_off + running + rank;
@@ -2488,7 +2492,7 @@ static hipError_t efx_launch_detect_impl(const DetectLaunch& a, hipStream_t stre
     FrameOut out = a.out;
     if (B == 1) { F.in.img0[0] = a.img0; out.kps[0] = static_cast<uint8_t*>(a.d_keypoints); out.count[0] = a.d_count; }
     FramePyr fp;
-    fp.in = F.in; fp.stride = a.fs.pyramid; fp.src_is_img0 = 0;
+    fp.in = F.in; fp.stride = a.fs.pyramid; fp.src_is_img0 = 0; fp.zrows = a.rows; fp.rows_stride = a.fs.rows;
     // alignment decisions about level 0 hold for every frame of the launch: the address bits of all the images, OR-ed
     uintptr_t img_bits = 0;
     for (int f = 0; f < B; f++) img_bits |= reinterpret_cast<uintptr_t>(F.in.img0[f]);
@@ -2507,6 +2511,7 @@ static hipError_t efx_launch_detect_impl(const DetectLaunch& a, hipStream_t stre
     bool zeroed = false;
     if (chain_end == 0 && !use_tower) {
         e = hipMemsetAsync(a.counters, 0, sizeof(Counters) * (size_t)B, stream);
+        if (e == hipSuccess && a.rows) e = hipMemsetAsync(a.rows, 0, sizeof(RowCtr) * (B > 1 ? a.fs.rows * (size_t)B : (size_t)H.total_rows), stream);
         if (e != hipSuccess) return e;
         zeroed = true;
     }
@@ -2537,10 +2542,10 @@ static hipError_t efx_launch_detect_impl(const DetectLaunch& a, hipStream_t stre
             Counters* zc = zeroed ? nullptr : a.counters;
             fp.src_is_img0 = s == 0;
             switch (RP->nlev) {
-            case 1: hipLaunchKernelGGL(resize_rows_kernel<1>, dim3(nblk, B), dim3(256), 0, stream, ra, zc, H.nlevels, fp); break;
-            case 2: hipLaunchKernelGGL(resize_rows_kernel<2>, dim3(nblk, B), dim3(256), 0, stream, ra, zc, H.nlevels, fp); break;
-            case 3: hipLaunchKernelGGL(resize_rows_kernel<3>, dim3(nblk, B), dim3(256), 0, stream, ra, zc, H.nlevels, fp); break;
-            default: hipLaunchKernelGGL(resize_rows_kernel<4>, dim3(nblk, B), dim3(256), 0, stream, ra, zc, H.nlevels, fp); break;
+            case 1: hipLaunchKernelGGL(resize_rows_kernel<1>, dim3(nblk, B), dim3(256), 0, stream, ra, zc, H.total_rows, fp); break;
+            case 2: hipLaunchKernelGGL(resize_rows_kernel<2>, dim3(nblk, B), dim3(256), 0, stream, ra, zc, H.total_rows, fp); break;
+            case 3: hipLaunchKernelGGL(resize_rows_kernel<3>, dim3(nblk, B), dim3(256), 0, stream, ra, zc, H.total_rows, fp); break;
+            default: hipLaunchKernelGGL(resize_rows_kernel<4>, dim3(nblk, B), dim3(256), 0, stream, ra, zc, H.total_rows, fp); break;
             }
             zeroed = true;
             a.prof.end(prof, 100 + s, stream);
@@ -2572,11 +2577,11 @@ static hipError_t efx_launch_detect_impl(const DetectLaunch& a, hipStream_t stre
             hipLaunchKernelGGL(resize_stream_kernel, dim3(per_xcd * EFX_NXCD, B), dim3(256), RS_YTAB + EFX_TILE * 16, stream, src, spitch, L.rows, L.cols,
                                a.pyramid + N.img_off, N.pitch, N.rows, N.cols, N.tiles_x, N.tiles_y,
                                reinterpret_cast<const int*>(a.rplan + R->x_off), R->W, reinterpret_cast<const int4*>(a.rplan + R->y_off),
-                               reinterpret_cast<const int4*>(a.rplan + R->t_off), zeroed ? nullptr : a.counters, H.nlevels, fp);
+                               reinterpret_cast<const int4*>(a.rplan + R->t_off), zeroed ? nullptr : a.counters, H.total_rows, fp);
         } else
         hipLaunchKernelGGL((resize_kernel<256>), dim3(ntiles, B), dim3(256), lds, stream, src, spitch, L.rows, L.cols, aligned,
                            a.pyramid + N.img_off, N.pitch, N.rows, N.cols, N.fx, N.fy, N.tiles_x, N.tiles_y, lpitch, ytab_off,
-                           zeroed ? nullptr : a.counters, H.nlevels, fp);
+                           zeroed ? nullptr : a.counters, H.total_rows, fp);
         zeroed = true;
         a.prof.end(prof, 100 + s, stream);
         EFX_TRACE_POINT("resize");
@@ -2615,32 +2620,23 @@ static hipError_t efx_launch_detect_impl(const DetectLaunch& a, hipStream_t stre
     e = launch_blur(0);
     if (e == hipSuccess) e = launch_blur(1);
     if (e != hipSuccess) return e;
-#ifdef EFX_DEBUG_BUILD
-    if (g_trace) {          // poison the corner arenas, so that entries fast_kernel never stores show up in the digest
-        size_t ncand = 0;
-        for (int l = 0; l < H.nlevels; l++) if (H.lv[l].active) ncand = std::max<size_t>(ncand, H.lv[l].cand_base + (size_t)H.lv[l].cand_sub_cap * EFX_NSUB);
-        (void)hipMemsetAsync(a.cand, 0xFF, ncand * sizeof(Corner), stream);
-        (void)hipMemsetAsync(a.cand_xy, 0xFF, ncand * sizeof(uint32_t), stream);
-        if (getenv("EFX_TRACE_SYNC_POISON")) (void)hipStreamSynchronize(stream);
-    }
-#endif
     {
         const int aligned0 = ((img_bits | (uintptr_t)a.pitch0) & 3u) == 0;
         bool prof = a.prof.begin(0, stream);
         hipLaunchKernelGGL(fast_kernel, dim3(H.total_tiles, B), dim3(256), 0, stream, a.d_table, a.img0, a.pitch0, aligned0,
-                           a.pyramid, a.threshold, a.mask, a.mask_pitch, a.cand_xy, a.hdr, a.counters, a.knobs.dbg & 15, F);
+                           a.pyramid, a.threshold, a.mask, a.mask_pitch, a.slots, a.tcount, a.rows, a.hdr, a.knobs.dbg & 15, F);
         a.prof.end(prof, 0, stream);
         EFX_TRACE_POINT("fast");
         prof = a.prof.begin(1, stream);
         if (launch_tiles <= EFX_NMS_WIDE_TILES)
-            hipLaunchKernelGGL(harris_kernel<4>, dim3(H.total_tiles + H.nlevels, B), dim3(256), 0, stream, a.d_table, a.img0, a.pitch0, aligned0, a.pyramid,
-                               a.cand_xy, a.cand, a.cmax, a.hdr, a.counters, a.knobs.dbg & 15, F);
+            hipLaunchKernelGGL(harris_kernel<4>, dim3(H.total_tiles, B), dim3(256), 0, stream, a.d_table, a.img0, a.pitch0, aligned0, a.pyramid,
+                               a.slots, a.tcount, a.rows, a.cand, a.cmax, a.hdr, a.knobs.dbg & 15, F);
         else if (launch_tiles <= EFX_NMS_MID_TILES)
-            hipLaunchKernelGGL(harris_kernel<EFX_NMS_MID_NW>, dim3(H.total_tiles + H.nlevels, B), dim3(64 * EFX_NMS_MID_NW), 0, stream, a.d_table, a.img0, a.pitch0, aligned0, a.pyramid,
-                               a.cand_xy, a.cand, a.cmax, a.hdr, a.counters, a.knobs.dbg & 15, F);
+            hipLaunchKernelGGL(harris_kernel<EFX_NMS_MID_NW>, dim3(H.total_tiles, B), dim3(64 * EFX_NMS_MID_NW), 0, stream, a.d_table, a.img0, a.pitch0, aligned0, a.pyramid,
+                               a.slots, a.tcount, a.rows, a.cand, a.cmax, a.hdr, a.knobs.dbg & 15, F);
         else
-            hipLaunchKernelGGL(harris_kernel<1>, dim3(H.total_tiles + H.nlevels, B), dim3(64), 0, stream, a.d_table, a.img0, a.pitch0, aligned0, a.pyramid,
-                               a.cand_xy, a.cand, a.cmax, a.hdr, a.counters, a.knobs.dbg & 15, F);
+            hipLaunchKernelGGL(harris_kernel<1>, dim3(H.total_tiles, B), dim3(64), 0, stream, a.d_table, a.img0, a.pitch0, aligned0, a.pyramid,
+                               a.slots, a.tcount, a.rows, a.cand, a.cmax, a.hdr, a.knobs.dbg & 15, F);
         a.prof.end(prof, 1, stream);
         EFX_TRACE_POINT("harris");
         e = launch_blur(2);
@@ -2650,39 +2646,23 @@ static hipError_t efx_launch_detect_impl(const DetectLaunch& a, hipStream_t stre
     // several waves per tile when the tiles alone do not fill the chip (256 CUs x 32 waves)
     if (launch_tiles <= EFX_NMS_WIDE_TILES)
         hipLaunchKernelGGL(nms_kernel<4>, dim3(H.total_tiles, B), dim3(256), 0, stream, a.d_table, a.hdr, a.cand, a.cmax, a.surv,
-                           a.counters, a.nonmax_radius, a.knobs.dbg >> 4, a.fs);
+                           a.rows, a.hist, a.counters, a.nonmax_radius, a.knobs.dbg >> 4, a.fs);
     else if (launch_tiles <= EFX_NMS_MID_TILES)
         hipLaunchKernelGGL(nms_kernel<EFX_NMS_MID_NW>, dim3(H.total_tiles, B), dim3(64 * EFX_NMS_MID_NW), 0, stream, a.d_table, a.hdr, a.cand, a.cmax, a.surv,
-                           a.counters, a.nonmax_radius, a.knobs.dbg >> 4, a.fs);
+                           a.rows, a.hist, a.counters, a.nonmax_radius, a.knobs.dbg >> 4, a.fs);
     else
         hipLaunchKernelGGL(nms_kernel<1>, dim3(H.total_tiles, B), dim3(64), 0, stream, a.d_table, a.hdr, a.cand, a.cmax, a.surv,
-                           a.counters, a.nonmax_radius, a.knobs.dbg >> 4, a.fs);
+                           a.rows, a.hist, a.counters, a.nonmax_radius, a.knobs.dbg >> 4, a.fs);
     a.prof.end(prof, 2, stream);
     EFX_TRACE_POINT("nms");
     e = launch_blur(3);
     if (e != hipSuccess) return e;
     prof = a.prof.begin(3, stream);
-    {
-        // 128 KB of dynamic LDS: above the default limit of a launch; raised once per device (atomics: contexts launch from several
-        // threads), and a refusal -- a device with less LDS -- is reported as such instead of as an opaque launch failure
-        static std::atomic<int> attr_state[64];             // 0 not tried, 1 ok, 2 refused
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        const bool slot = dev >= 0 && dev < 64;
-        int st = slot ? attr_state[dev].load(std::memory_order_acquire) : 0;
-        if (st == 0) {
-            const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SEL_LDS_BYTES);
-            st = ea == hipSuccess ? 1 : 2;
-            if (ea != hipSuccess) (void)hipGetLastError();
-            if (slot) attr_state[dev].store(st, std::memory_order_release);
-        }
-        if (st == 2) return hipErrorInvalidConfiguration;   // efx_api.cpp: EFX_ERR_UNSUPPORTED, "select_kernel needs 128 KB of LDS"
-    }
-    hipLaunchKernelGGL(select_kernel, dim3(H.nlevels, B), dim3(1024), SEL_LDS_BYTES, stream, a.d_table, a.hdr, a.surv, a.counters,
-                       a.capacity, out, a.fs);
+    hipLaunchKernelGGL(select_kernel, dim3(H.nlevels + (H.total_tiles + EFX_SEL_WG_TILES - 1) / EFX_SEL_WG_TILES, B), dim3(SEL_NT), 0, stream, a.d_table, a.hdr,
+                       a.surv, a.rows, a.hist, a.sel_list, a.nsel, a.counters, a.capacity, out, a.fs);
     EFX_TRACE_POINT("select");
     hipLaunchKernelGGL(emit_kernel, dim3((H.total_tiles + EMIT_TPW - 1) / EMIT_TPW, B), dim3(64), 0, stream, a.d_table, a.hdr, a.surv, a.counters,
-                       a.img0, a.pitch0, a.pyramid, a.kps_pitch, a.capacity, a.kp4, a.kp_level, out, a.fs);
+                       a.img0, a.pitch0, a.pyramid, a.kps_pitch, a.capacity, a.kp4, a.kp_level, a.hist, out, a.fs);
     EFX_TRACE_POINT("emit");
     if (a.capacity > 0) {
         // the image the describer's records refer to: the raw levels, or their blurred copies (blur_levels_kernel above)
@@ -2719,24 +2699,9 @@ static hipError_t efx_launch_detect_impl(const DetectLaunch& a, hipStream_t stre
 }
 
 #ifdef EFX_DEBUG_BUILD
-// INVESTIGATION (16-process discrepancy): run harris_kernel (stages & 1) and / or nms_kernel (stages & 2)
-// again on the buffers of the last frame; the survivor counters are reset first.  Not part of the product path.
-hipError_t efx_debug_rerun_stages(const DetectLaunch& a, int stages, hipStream_t stream)
-{
-    const LevelTable& H = *a.h_table;
-    const int aligned0 = (((uintptr_t)a.img0 | (uintptr_t)a.pitch0) & 3u) == 0;
-    FrameSet F;
-    F.in = a.in; F.fs = a.fs; F.in.img0[0] = a.img0;
-    hipError_t e = hipMemsetAsync(&a.counters->surv_total[0][0], 0, sizeof(a.counters->surv_total), stream);
-    if (e != hipSuccess) return e;
-    if (stages & 1)
-        hipLaunchKernelGGL(harris_kernel<1>, dim3(H.total_tiles + H.nlevels), dim3(64), 0, stream, a.d_table, a.img0, a.pitch0, aligned0, a.pyramid,
-                           a.cand_xy, a.cand, a.cmax, a.hdr, a.counters, 0, F);
-    if (stages & 2)
-        hipLaunchKernelGGL(nms_kernel<1>, dim3(H.total_tiles), dim3(64), 0, stream, a.d_table, a.hdr, a.cand, a.cmax, a.surv,
-                           a.counters, a.nonmax_radius, 0, a.fs);
-    return hipGetLastError();
-}
+// INVESTIGATION (rounds 1-3: the 16-process discrepancy): reran harris_kernel / nms_kernel on the buffers of
+// the last frame.  The stages now leave per-row sums and a key histogram that a second run would add to again: not supported.
+hipError_t efx_debug_rerun_stages(const DetectLaunch&, int, hipStream_t) { return hipErrorNotSupported; }
 #endif
 
 hipError_t efx_launch_convert_keypoints(const void* d_keypoints, size_t kps_pitch, int n, float4* kp4, hipStream_t stream)

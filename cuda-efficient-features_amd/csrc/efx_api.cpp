@@ -23,12 +23,6 @@ int efx_knn2_mfma_resident_workgroups(int desc_bytes, int fp4);
 #include <mutex>
 #include <vector>
 
-#ifdef EFX_DEBUG_BUILD
-// INVESTIGATION (EFX_TRACE=1): see trace_digest below
-extern void (*efx_trace_hook)(const DetectLaunch&, const char*);
-static void trace_digest(const DetectLaunch& a, const char* name);
-#endif
-
 // learned parameter blobs, embedded by params_embed.S
 extern "C" {
 extern const unsigned char efx_blob_bad256[], efx_blob_bad512[], efx_blob_hashsift256[], efx_blob_hashsift512[];
@@ -405,26 +399,24 @@ struct efx_context {
     efx_params g_p;
     LevelTable h_table;
     DevBuf d_table, pyramid, hdr, cand, cmax, surv, counters, kp4, kp_level, img, kps, descout, count, maskbuf;
+    DevBuf slots, tcount, nsel, rowsum, hist, sel_list;            // round 6: per-tile corner slots / counts, per-row sums, key histograms (efx_device.h)
+    bool hist_clean = false;        // the key histograms are zero (nms_kernel adds, emit_kernel withdraws: they stay zero across frames
+                                    // unless a call failed half-way or the buffer is new)
     DevBuf rplan; ResizePlanLevel rplan_lv[EFX_MAX_LEVELS];        // resize plan (tables of resize_stream_kernel)
     RowsPlanLaunch rows_plan[EFX_MAX_LEVELS];                       // ... and of resize_rows_kernel, by source level
     DevBuf blurred;                 // blurred copies of the pyramid levels for the BAD describer (blur_levels_kernel), on first use
     hipStream_t side = nullptr;     // side stream + fork / join events of the level blur (DetectLaunch::blur_fork), on first use
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int idle_streak = 0;            // consecutive calls that found their stream idle (where the level blur runs: detect_common)
-    size_t cand_slots = 0;          // records in `cand` PER FRAME; the coordinate-only arrays of the same length follow the frames' records
     int g_frames = 0;               // frames the per-frame buffers were reserved for (batched launches: detect_frames)
     int g_plan_frames = 0;          // frames per launch the row-walking pyramid plan was chunked for (build_rows_plan)
     FrameStride fs = {};            // distance between the frames' copies inside the buffers (efx_device.h)
     int last_frames = 1;            // frames of the last detect call (the summary mirror reads the LAST one)
     Summary* h_mirror = nullptr;    // host copy of the last frame's summary, filled on demand by fetch_summary()
     int n_out_max = 0;              // sum of the active levels' quotas
-    bool arena_full = false;        // corner / survivor arenas sized for the worst case (set after a frame overflowed them)
-    bool g_arena_full = false;      // ... as the cached geometry was built
     std::vector<hipStream_t> streams;   // streams this context has launched on since it last waited for them (ctx_quiesce)
     hipStream_t active_stream = nullptr; bool has_active = false;   // the stream of the call on the stack (QuiesceScope)
-    int* h_overflow = nullptr;      // sticky overflow word: pinned host memory the kernels store to (LevelTable::host_overflow)
-    int* d_overflow = nullptr;      // ... its device address
-    int overflow_events = 0;        // observations of the word set: >= 1 void frame each (efx_overflow_events)
+    int overflow_events = 0;        // void frames this context has reported (efx_last_count: arena contents that failed their range checks)
     DetectLaunch last_launch;       // investigation (efx_debug_rerun): the last frame's launch arguments
     bool has_frame = false;
     const uint8_t* last_img0 = nullptr; int last_pitch0 = 0;
@@ -475,9 +467,9 @@ struct efx_context {
         if (ev_join) (void)hipEventDestroy(ev_join);
         blurred.release();
         rplan.release(); d_table.release(); pyramid.release(); hdr.release(); cand.release(); cmax.release(); surv.release(); counters.release();
+        slots.release(); tcount.release(); nsel.release(); rowsum.release(); hist.release(); sel_list.release();
         kp4.release(); kp_level.release(); img.release(); kps.release(); descout.release(); count.release(); maskbuf.release();
         delete h_mirror;
-        if (h_overflow) (void)hipHostFree(h_overflow);
         for (hipEvent_t e : prof_start) (void)hipEventDestroy(e);
         for (hipEvent_t e : prof_stop) (void)hipEventDestroy(e);
         tl_quiesce = prev;
@@ -729,24 +721,11 @@ void build_rows_plan(const LevelTable& T, int nlevels, int nframes, std::vector<
 int build_geometry(efx_context* c, int rows, int cols, int nframes = 1)
 {
     const efx_params& p = c->p;
-    if (c->g_rows == rows && c->g_cols == cols && c->g_arena_full == c->arena_full && c->g_frames >= nframes && c->g_plan_frames == nframes && memcmp(&c->g_p, &p, sizeof(p)) == 0) return EFX_OK;
+    if (c->g_rows == rows && c->g_cols == cols && c->g_frames >= nframes && c->g_plan_frames == nframes && memcmp(&c->g_p, &p, sizeof(p)) == 0) return EFX_OK;
     const size_t NF = (size_t)std::max(nframes, c->g_rows == rows && c->g_cols == cols ? c->g_frames : 1);      // buffers never shrink
     LevelTable& T = c->h_table;
     memset(&T, 0, sizeof(T));
     T.nlevels = p.nlevels;
-    if (!c->h_overflow) {
-        // best effort: without the word the overflow is still reported through efx_last_count / efx_last_level_stats
-        void* hp = nullptr; void* dp = nullptr;
-        if (hipHostMalloc(&hp, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
-            c->h_overflow = static_cast<int*>(hp); c->d_overflow = static_cast<int*>(dp);
-            *c->h_overflow = 0;
-        } else {
-            if (hp) (void)hipHostFree(hp);
-            (void)hipGetLastError();
-        }
-    }
-    T.host_overflow = c->d_overflow;
-
     int quota[EFX_MAX_LEVELS];
     {
         const double factor = (double)(1 / p.scale_factor);       // float division widened to double (.cpp:164)
@@ -756,8 +735,8 @@ int build_geometry(efx_context* c, int rows, int cols, int nframes = 1)
         quota[p.nlevels - 1] = p.nfeatures - sum > 0 ? p.nfeatures - sum : 0;
     }
     float scale = 1.f;
-    size_t pyr = 0, ncand = 0, nsurv = 0, ncmax = 0;
-    int tiles = 0;
+    size_t pyr = 0, ncand = 0, ncmax = 0;
+    int tiles = 0, trows = 0;
     for (int s = 0; s < p.nlevels; s++) {
         LevelDev& L = T.lv[s];
         if (s > 0) scale *= p.scale_factor;
@@ -784,33 +763,26 @@ int build_geometry(efx_context* c, int rows, int cols, int nframes = 1)
                 L.fy = (float)(1.0 / ((double)L.rows / (double)P.rows));
             }
         }
+        // The level's corner and survivor arrays hold EXACTLY cap records: a tile's corners start at the tile's canonical rank in
+        // the level, corners of rank >= cap do not exist (spec S2; the reference keeps cvRound(0.1 w h) per level, .cpp:252), and a
+        // tile's survivors sit at its corners' places.  Nothing is allocated on the device, so no frame -- whatever its corner
+        // density -- can overflow anything.  (Rounds 2-5: arenas sized for a corner density of 1/8 with atomic chunk allocation;
+        // a denser frame was void and the context regrew to 2.1 GB at 8K.)
         L.cand_base = ncand;
-        L.surv_base = nsurv;
         L.cmax_base = ncmax;
+        L.row_base = trows;
         ncmax += (size_t)L.tiles_x * 4 * L.tiles_y * 4;
-        if (L.active) {
-            // sub-array k holds the tiles with (tile & 7) == k; a 64x64 tile has at most 4096 corners.
-            // Worst-case arenas (every pixel a corner) cost 8 + 6.4 bytes per pyramid pixel: 1.5 GB for an 8K frame.  Large
-            // levels are therefore sized for a corner DENSITY -- 1/8 of the pixels for FAST corners (the reference keeps at
-            // most 1/10, .cpp:252; the benchmark frames have 1/37), 1/32 for NMS survivors (all the corners when the NMS
-            // radius is below 4 px) -- with an eighth / a quarter of slack for the imbalance between the sub-arrays (12 bytes per
-            // FAST corner slot: the record and the coordinate word fast_kernel writes).  A frame that does
-            // not fit raises Summary::overflow on the device and is void (N = 0); the host then switches the context to
-            // worst-case arenas (arena_full) and reports EFX_ERR_OVERFLOW / reruns (efx_last_count, host_detect_impl).
-            const size_t tiles_per_sub = ((size_t)L.tiles_x * L.tiles_y + EFX_NSUB - 1) / EFX_NSUB;
-            const size_t cfull = tiles_per_sub * EFX_TILE * EFX_TILE;
-            const size_t sfull = cfull < (size_t)L.cap ? cfull : (size_t)L.cap;
-            size_t csub = cfull, ssub = sfull;
-            if (!c->arena_full && (size_t)L.rows * L.cols > EFX_ARENA_DENSITY_MIN_PX) {
-                csub = std::min(cfull, cfull / 8 + cfull / 64);
-                ssub = std::min(sfull, p.nonmax_radius < 4 ? csub : cfull / 32 + cfull / 128);
-            }
-            L.cand_sub_cap = (unsigned)csub;
-            L.surv_sub_cap = (unsigned)ssub;
-            ncand += csub * EFX_NSUB;
-            nsurv += ssub * EFX_NSUB;
-        }
+        trows += L.tiles_y;
+        if (L.active) ncand += (size_t)L.cap + 64;      // (+ 64: a wave's clamped look-ahead loads stay inside the array)
     }
+    // counting workgroups of select_kernel (EFX_SEL_WG_TILES consecutive tiles each) that hold tiles of a level
+    for (int s = 0; s < p.nlevels; s++) {
+        LevelDev& L = T.lv[s];
+        const int nt = L.tiles_x * L.tiles_y;
+        L.sel_wg0 = L.tile_base / EFX_SEL_WG_TILES;
+        L.sel_wgs = nt > 0 ? (L.tile_base + nt - 1) / EFX_SEL_WG_TILES - L.sel_wg0 + 1 : 0;
+    }
+    T.total_rows = trows;
     T.total_tiles = tiles;
     // upper bound of N: calcNumFeaturesPerLevel rounds every level up, so the quotas can sum to more than nfeatures
     c->n_out_max = 0;
@@ -822,15 +794,27 @@ int build_geometry(efx_context* c, int rows, int cols, int nframes = 1)
     // everything below exists once per frame of a batched launch, `fs` apart
     c->fs.pyramid = align_up(pyr + 256, 256);
     c->fs.hdr = (size_t)tiles + 1;
-    c->fs.cand = ncand + 1;
-    c->fs.surv = nsurv + 1;
+    c->fs.cand = ncand + 64;
+    c->fs.slots = ((size_t)tiles + 1) * EFX_SLOT_BYTES;
+    c->fs.rows = (size_t)trows + 1;
+    c->fs.hist = (size_t)p.nlevels * EFX_HIST_BINS;
+    c->fs.list = (size_t)p.nlevels * EFX_SEL_LIST_CAP;
     c->fs.cmax = ncmax + 1;
     HIP_TRY(c->err, c->pyramid.reserve(c->fs.pyramid * NF));
     HIP_TRY(c->err, c->hdr.reserve(c->fs.hdr * NF * sizeof(TileHdr)));
-    // corner records, followed by the coordinate-only arrays fast_kernel fills (harris_kernel writes whole records from them)
-    HIP_TRY(c->err, c->cand.reserve(c->fs.cand * NF * (sizeof(Corner) + sizeof(uint32_t))));
-    c->cand_slots = ncand + 1;
-    HIP_TRY(c->err, c->surv.reserve(c->fs.surv * NF * sizeof(Corner)));
+    HIP_TRY(c->err, c->cand.reserve(c->fs.cand * NF * sizeof(Corner)));
+    HIP_TRY(c->err, c->surv.reserve(c->fs.cand * NF * sizeof(Corner)));
+    HIP_TRY(c->err, c->slots.reserve(c->fs.slots * NF));
+    HIP_TRY(c->err, c->tcount.reserve(c->fs.hdr * NF * sizeof(uint16_t)));
+    HIP_TRY(c->err, c->nsel.reserve(c->fs.hdr * NF * sizeof(uint32_t)));
+    HIP_TRY(c->err, c->rowsum.reserve(c->fs.rows * NF * sizeof(RowCtr)));
+    {
+        const void* before = c->hist.p; const size_t before_bytes = c->hist.bytes;
+        HIP_TRY(c->err, c->hist.reserve(c->fs.hist * NF * sizeof(int)));
+        if (c->hist.p != before || c->hist.bytes != before_bytes) c->hist_clean = false;
+    }
+    c->hist_clean = false;          // (the levels' places in the buffer move with the geometry)
+    HIP_TRY(c->err, c->sel_list.reserve(c->fs.list * NF * sizeof(unsigned long long)));
     HIP_TRY(c->err, c->cmax.reserve(c->fs.cmax * NF * sizeof(Corner)));
     HIP_TRY(c->err, c->counters.reserve(sizeof(Counters) * NF));
     HIP_TRY(c->err, c->count.reserve(sizeof(int) * EFX_MAX_BATCH));
@@ -910,22 +894,8 @@ int build_geometry(efx_context* c, int rows, int cols, int nframes = 1)
             HIP_TRY(c->err, hipMemcpy(c->rplan.p, blob.data(), blob.size() * 4, hipMemcpyHostToDevice));
         }
     }
-    c->g_rows = rows; c->g_cols = cols; c->g_p = p; c->g_arena_full = c->arena_full; c->g_frames = (int)NF; c->g_plan_frames = nframes;
+    c->g_rows = rows; c->g_cols = cols; c->g_p = p; c->g_frames = (int)NF; c->g_plan_frames = nframes;
     return EFX_OK;
-}
-
-// An earlier frame of this context overflowed the density-sized arenas (it was void: N = 0).  The kernels left a sticky
-// word in host memory; a caller that only ever reads d_count never calls efx_last_count, so the enlargement happens here,
-// at the start of the next call, without a synchronisation.  (A frame still in flight may set the word again after it was
-// cleared: harmless, the arenas are already at their worst-case size by then.)
-void consume_sticky_overflow(efx_context* c)
-{
-    if (!c->h_overflow) return;
-    volatile int* w = c->h_overflow;
-    if (*w == 0) return;
-    *w = 0;
-    c->overflow_events++;
-    c->arena_full = true;
 }
 
 // nframes same-sized frames through ONE launch of every kernel (round 6; SURVEY 8b "batched variants"): frame f reads
@@ -953,7 +923,6 @@ int detect_frames(efx_context* c, int nframes, const uint8_t* const* d_images, i
     int rc = validate_params(c->p, c->err);
     if (rc) return rc;
     QuiesceScope quiesce(c, stream);
-    consume_sticky_overflow(c);
     rc = build_geometry(c, rows, cols, nframes);
     if (rc) return rc;
     const size_t NF = (size_t)nframes;
@@ -978,8 +947,19 @@ int detect_frames(efx_context* c, int nframes, const uint8_t* const* d_images, i
     a.hdr = static_cast<TileHdr*>(c->hdr.p);
     a.rplan = static_cast<const unsigned char*>(c->rplan.p); a.rplan_lv = c->rplan_lv; a.rows_plan = c->rows_plan;
     a.cand = static_cast<Corner*>(c->cand.p);
-    a.cand_xy = reinterpret_cast<uint32_t*>(a.cand + c->fs.cand * NF);
     a.surv = static_cast<Corner*>(c->surv.p);
+    a.slots = static_cast<unsigned char*>(c->slots.p);
+    a.tcount = static_cast<uint16_t*>(c->tcount.p);
+    a.nsel = static_cast<uint32_t*>(c->nsel.p);
+    a.rows = static_cast<RowCtr*>(c->rowsum.p);
+    a.hist = static_cast<int*>(c->hist.p);
+    a.sel_list = static_cast<unsigned long long*>(c->sel_list.p);
+    if (!c->hist_clean) {
+        // nms_kernel adds to the key histograms, emit_kernel withdraws the same counts: they are zero between frames, and only a new
+        // buffer (or a call that failed half-way) needs clearing
+        HIP_TRY(c->err, hipMemsetAsync(c->hist.p, 0, c->hist.bytes, stream));
+    }
+    c->hist_clean = false;          // ... until this call's launches are all enqueued
     a.cmax = static_cast<Corner*>(c->cmax.p);
     a.counters = static_cast<Counters*>(c->counters.p);
     a.threshold = c->p.fast_threshold;
@@ -1052,13 +1032,9 @@ int detect_frames(efx_context* c, int nframes, const uint8_t* const* d_images, i
             if (a.blur_fork >= 1 && a.blur_fork <= 3) { a.side = c->side; a.ev_fork = c->ev_fork; a.ev_join = c->ev_join; }
         }
     }
-#ifdef EFX_DEBUG_BUILD
-    efx_trace_hook = trace_digest;
-#endif
     hipError_t e = efx_launch_detect(a, stream);
-    if (e == hipErrorInvalidConfiguration)
-        return set_err(c->err, EFX_ERR_UNSUPPORTED, "this device refuses the 128 KB of dynamic LDS select_kernel needs (MI355X has 160 KB per CU)");
     if (e != hipSuccess) return set_err(c->err, EFX_ERR_HIP, "detect launch failed: %s", hipGetErrorString(e));
+    c->hist_clean = true;
     c->has_frame = true; c->last_img0 = d_images[0]; c->last_pitch0 = (int)pitch; c->last_frames = nframes;
 #ifdef EFX_DEBUG_BUILD
     c->last_launch = a; c->last_launch.prof = ProfRec{};
@@ -1131,6 +1107,7 @@ int compute_provided(efx_context* c, const uint8_t* d_image, int rows, int cols,
     a.d_table = static_cast<const LevelTable*>(c->d_table.p);
     a.h_table = &c->h_table;
     a.counters = static_cast<Counters*>(c->counters.p);
+    a.rows = static_cast<RowCtr*>(c->rowsum.p);
     a.knobs = c->knobs;
     a.pyramid_only = 1;
     hipError_t e = efx_launch_detect(a, stream);
@@ -1410,15 +1387,16 @@ static int fetch_summary(const efx_context* ctx)
     return hipMemcpy(ctx->h_mirror, &dc->sum, sizeof(Summary), hipMemcpyDeviceToHost) == hipSuccess ? EFX_OK : EFX_ERR_HIP;
 }
 
-// A frame that overflowed the density-sized arenas is void: switch the context to worst-case arenas and say so.
+// A void frame (N = 0): arena contents failed their range checks on the device ("lost stores" under heavy
+// oversubscription).  Since round 6 no frame CONTENT can cause it: the arenas hold the reference's own 10 % cap and nothing is
+// allocated on the device.
 static int check_overflow(const efx_context* ctx)
 {
     if (!ctx->h_mirror->overflow) return EFX_OK;
     efx_context* c = const_cast<efx_context*>(ctx);
-    c->arena_full = true;
-    if (c->h_overflow && *(volatile int*)c->h_overflow) { *(volatile int*)c->h_overflow = 0; c->overflow_events++; }
-    return set_err(c->err, EFX_ERR_OVERFLOW, "the frame had more FAST corners / NMS survivors than the scratch arenas hold (they are sized "
-                   "for a corner density of 1/8); the arenas are enlarged to the worst case from the next call on: repeat the call");
+    c->overflow_events++;
+    return set_err(c->err, EFX_ERR_OVERFLOW, "the frame is void: records in the context's scratch arenas failed their range checks (not a property of "
+                   "the frame: see DESIGN.md section 7); repeat the call");
 }
 
 int efx_last_count(const efx_context* ctx, int* n)
@@ -1429,100 +1407,6 @@ int efx_last_count(const efx_context* ctx, int* n)
     *n = ctx->h_mirror->n_out;
     return check_overflow(ctx);
 }
-
-#ifdef EFX_DEBUG_BUILD
-// INVESTIGATION: EFX_TRACE=1 -- digest of the corner coordinates (through the tile headers) after every launch
-static void trace_digest(const DetectLaunch& a, const char* name)
-{
-    if (strcmp(name, "fast") && strcmp(name, "harris") && strcmp(name, "nms") && strcmp(name, "angle")) return;
-    const LevelTable& T = *a.h_table;
-    size_t ncand = 0;
-    for (int l = 0; l < T.nlevels; l++) if (T.lv[l].active) ncand = std::max<size_t>(ncand, T.lv[l].cand_base + (size_t)T.lv[l].cand_sub_cap * EFX_NSUB);
-    std::vector<TileHdr> hdr((size_t)T.total_tiles);
-    std::vector<Corner> cand(ncand);
-    static Counters cn;
-    if (hipMemcpy(hdr.data(), a.hdr, hdr.size() * sizeof(TileHdr), hipMemcpyDeviceToHost) != hipSuccess) return;
-    if (hipMemcpy(cand.data(), a.cand, cand.size() * sizeof(Corner), hipMemcpyDeviceToHost) != hipSuccess) return;
-    if (!strcmp(name, "fast")) {         // harris_kernel has not assembled the records yet: the coordinates are in cand_xy
-        std::vector<uint32_t> xy(ncand);
-        if (hipMemcpy(xy.data(), a.cand_xy, xy.size() * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) return;
-        for (size_t i = 0; i < ncand; i++) cand[i].xy = xy[i];
-    }
-    if (hipMemcpy(&cn, a.counters, sizeof(Counters), hipMemcpyDeviceToHost) != hipSuccess) return;
-    unsigned long long hx = 0; long long nsum = 0; int bad_range = 0, unwritten = 0, off_tile = 0;
-    for (int l = 0; l < T.nlevels; l++) {
-        const LevelDev& L = T.lv[l];
-        if (!L.active) continue;
-        for (int t = 0; t < L.tiles_x * L.tiles_y; t++) {
-            const TileHdr& th = hdr[L.tile_base + t];
-            const int n = th.cell_off[EFX_CELLS_PER_TILE];
-            nsum += n;
-            if ((size_t)th.cand_start + n > L.cand_sub_cap) { bad_range++; continue; }
-            const Corner* q = cand.data() + L.cand_base + (size_t)(t & (EFX_NSUB - 1)) * L.cand_sub_cap + th.cand_start;
-            int uw = 0, ot = 0;
-            for (int k = 0; k < n; k++) {
-                if (q[k].xy == 0xffffffffu) uw++;
-                else if ((int)((q[k].xy & 0xffff) >> 6) != t % L.tiles_x || (int)((q[k].xy >> 16) >> 6) != t / L.tiles_x) ot++;
-            }
-            unwritten += uw; off_tile += ot;
-            if ((uw || ot) && !strcmp(name, "fast"))
-                fprintf(stderr, "efx-trace   level %d tile %d (sub %d): start %u count %d unwritten %d wrong-tile %d | sub total %d\n", l, t, t & 7,
-                        th.cand_start, n, uw, ot, cn.cand_total[l][t & 7].v);
-            for (int k = 0; k < n; k++) { unsigned long long h = 1469598103934665603ull; for (int b = 0; b < 4; b++) { h ^= (q[k].xy >> (8 * b)) & 0xff; h *= 1099511628211ull; } hx += h; }
-        }
-    }
-    int tot0 = 0; for (int sub = 0; sub < EFX_NSUB; sub++) tot0 += cn.cand_total[0][sub].v;
-    fprintf(stderr, "efx-trace digest after %s: xy %llu corners %lld counter_total_l0 %d bad_ranges %d unwritten %d in_wrong_tile %d\n", name, hx & 0x7fffffffull, nsum, tot0, bad_range, unwritten, off_tile);
-    fflush(stderr);
-}
-
-// INVESTIGATION ONLY (not declared in include/efx.h): repeat harris (stages & 1) / nms (stages & 2) on the last frame's
-// buffers and return the per-level survivor totals of the repeated run (tools/microbench/fuzz_stress.py)
-int efx_debug_rerun(efx_context* ctx, int stages, int* surv_totals, int nlevels_max)
-{
-    if (!ctx || !ctx->has_frame || !surv_totals) return EFX_ERR_BAD_ARG;
-    HIP_TRY(ctx->err, hipDeviceSynchronize());
-    hipError_t e = efx_debug_rerun_stages(ctx->last_launch, stages, nullptr);
-    if (e != hipSuccess) return set_err(ctx->err, EFX_ERR_HIP, "rerun failed: %s", hipGetErrorString(e));
-    HIP_TRY(ctx->err, hipDeviceSynchronize());
-    static Counters h;
-    HIP_TRY(ctx->err, hipMemcpy(&h, ctx->counters.p, sizeof(Counters), hipMemcpyDeviceToHost));
-    for (int l = 0; l < nlevels_max && l < ctx->h_table.nlevels; l++) {
-        int t = 0;
-        for (int sub = 0; sub < EFX_NSUB; sub++) t += h.surv_total[l][sub].v;
-        surv_totals[l] = t;
-    }
-    // order-independent digests of what nms_kernel reads: the corners {xy, resp} of every tile (through the headers), the
-    // per-cell maxima, the headers' candidate fields; and of the pyramid
-    if (nlevels_max >= 8) {
-        auto fnv = [](const void* p, size_t n, unsigned long long hsh) { const unsigned char* b = static_cast<const unsigned char*>(p); for (size_t i = 0; i < n; i++) { hsh ^= b[i]; hsh *= 1099511628211ull; } return hsh; };
-        std::vector<unsigned char> hdr(ctx->hdr.bytes), cand(ctx->cand.bytes), cmax(ctx->cmax.bytes), pyr(ctx->pyramid.bytes);
-        HIP_TRY(ctx->err, hipMemcpy(hdr.data(), ctx->hdr.p, hdr.size(), hipMemcpyDeviceToHost));
-        HIP_TRY(ctx->err, hipMemcpy(cand.data(), ctx->cand.p, cand.size(), hipMemcpyDeviceToHost));
-        HIP_TRY(ctx->err, hipMemcpy(cmax.data(), ctx->cmax.p, cmax.size(), hipMemcpyDeviceToHost));
-        HIP_TRY(ctx->err, hipMemcpy(pyr.data(), ctx->pyramid.p, pyr.size(), hipMemcpyDeviceToHost));
-        unsigned long long hc = 0, hx = 0, hh = 0;
-        const LevelTable& T = ctx->h_table;
-        const TileHdr* H = reinterpret_cast<const TileHdr*>(hdr.data());
-        const Corner* C = reinterpret_cast<const Corner*>(cand.data());
-        for (int l = 0; l < T.nlevels; l++) {
-            const LevelDev& L = T.lv[l];
-            if (!L.active) continue;
-            for (int t = 0; t < L.tiles_x * L.tiles_y; t++) {
-                const TileHdr& th = H[L.tile_base + t];
-                const int n = th.cell_off[EFX_CELLS_PER_TILE];
-                const Corner* q = C + L.cand_base + (size_t)(t & (EFX_NSUB - 1)) * L.cand_sub_cap + th.cand_start;
-                for (int k = 0; k < n; k++) { hx += fnv(&q[k].xy, 4, 1469598103934665603ull); hc += fnv(&q[k], 8, 1469598103934665603ull); }
-                hh += fnv(th.cell_off, sizeof(th.cell_off), 1469598103934665603ull + t);
-            }
-        }
-        surv_totals[4] = (int)(hx & 0x7fffffff); surv_totals[5] = (int)(hc & 0x7fffffff);
-        surv_totals[6] = (int)(fnv(cmax.data(), (size_t)T.lv[T.nlevels - 1].cmax_base * 8, 1469598103934665603ull) & 0x7fffffff);
-        surv_totals[7] = (int)((fnv(pyr.data(), pyr.size(), 1469598103934665603ull) ^ hh) & 0x7fffffff);
-    }
-    return EFX_OK;
-}
-#endif
 
 int efx_overflow_events(const efx_context* ctx) { return ctx ? ctx->overflow_events : 0; }
 int efx_tracked_streams(const efx_context* ctx) { return ctx ? (int)ctx->streams.size() : 0; }

@@ -2,10 +2,12 @@
 //
 // HBM layout of one context (all owned by the context, grow-only, reused across frames):
 //   pyramid   : levels 1..n-1, u8, row pitch rounded up to 256 B (level 0 is the caller's image, aliased)
-//   cand      : per level, compact array of FAST corners {xy, harris} (8 B), filled tile by tile; the
-//               physical order of tiles is arbitrary (atomic chunk allocation), the logical order is given
-//               by the tile headers (canonical order)
-//   surv      : per level, compact array of radius-NMS survivors (8 B), same scheme
+//   slots     : one 512-B slot per 64x64 tile: the tile's FAST corners as 16-bit tile coordinates in canonical order (up to 256),
+//               or its 64 x 64 corner bitmap (more) -- fixed size, whatever the frame holds (round 6)
+//   cand      : per level EXACTLY cap = cvRound(0.1 w h) records {xy, harris} (8 B) (.cpp:252): the level's corners in canonical
+//               order; a tile's corners start at its canonical rank, corners of rank >= cap do not exist (spec S2)
+//   surv      : per level, the radius-NMS survivors of a tile at the tile's place in `cand`'s index space (same size: no
+//               allocation, nothing can overflow)
 //   tile_hdr  : one 64-B header per 64x64 tile of every level
 //   kp4/lvl   : float4 {x, y, 31, angle} level-local keypoints + their level, input of the describers
 #pragma once
@@ -23,7 +25,12 @@
 #define EFX_HALF_PATCH 15      // cuda_efficient_features.cpp:34
 #define EFX_PATCH_SIZE 31      // cuda_efficient_features.cpp:33
 #define EFX_NXCD 8
-#define EFX_NSUB 8             // sub-arrays / allocation counters per level
+#define EFX_SLOT_LIST 256       // a tile with at most this many FAST corners leaves them as a list in its slot, else as a bitmap
+#define EFX_SLOT_BYTES 512      // 256 x u16 == 64 x u64
+#define EFX_HIST_BITS 15        // selection histogram: top bits of the 64-bit key (sign, exponent, 6 mantissa bits of the response)
+#define EFX_HIST_BINS (1 << EFX_HIST_BITS)
+#define EFX_SEL_LIST_CAP 2048   // keys of the threshold's bin that are ranked exactly in LDS (more: the slow radix path of select_kernel)
+#define EFX_SEL_WG_TILES 256    // tiles per counting workgroup of select_kernel (lane per tile)
 #define EFX_MAX_BATCH 16       // frames of one size a context runs through ONE launch of every kernel (blockIdx.y = frame)
 
 struct LevelDev {
@@ -37,50 +44,61 @@ struct LevelDev {
     float fx, fy;               // resize factors with THIS level as destination: src = dst * f
     int active;                 // s >= firstLevel
     unsigned long long img_off; // byte offset of the level in the pyramid buffer (levels >= 1)
-    unsigned long long cand_base;   // entry offset of the level in the cand array
-    unsigned long long surv_base;   // entry offset of the level in the surv array
+    unsigned long long cand_base;   // entry offset of the level in the cand AND surv arrays: the sum of the lower levels' caps
     unsigned long long cmax_base;   // entry offset of the level in the per-cell maxima table (tiles_x*4 x tiles_y*4)
-    unsigned int cand_sub_cap;      // each level's arrays are split into EFX_NSUB sub-arrays (tile & 7) so that
-    unsigned int surv_sub_cap;      // chunk allocation contends on 8 counters instead of 1 (11.5 ns per same-word atomic)
+    int row_base;                   // index of the level's first tile row in the per-row counters (RowCtr)
+    int sel_wg0, sel_wgs;           // counting workgroups of select_kernel that hold tiles of this level: first, how many
 };
 
 struct LevelTable {
     int nlevels;
     int total_tiles;
-    // Sticky "a frame overflowed the density-sized arenas" word in pinned, device-mapped HOST memory (null: none).  The
-    // kernels that raise Summary::overflow also store 1 here (system scope); the host looks at it -- a plain load, no
-    // synchronisation -- at the start of the context's next call and enlarges the arenas, so that an asynchronous caller who
-    // never asks for the summary does not lose every dense frame (efx_api.cpp, detect_common)
-    int* host_overflow;
+    int total_rows;                 // tile rows of all levels (RowCtr entries)
+    int pad_;
     LevelDev lv[EFX_MAX_LEVELS];
 };
 
 struct __attribute__((aligned(64))) TileHdr {
-    uint32_t cand_start;        // physical start of the tile's corners in sub-array (tile & 7) of the level's cand array
-    uint32_t cand_rank;         // canonical rank of the tile's first corner (exclusive scan over tiles)
-    uint32_t surv_start;        // physical start of the tile's survivors in the level's surv array
-    uint32_t surv_count;
-    uint32_t out_off;           // output index of the tile's first selected survivor
-    uint16_t cell_off[EFX_CELLS_PER_TILE + 1];   // start of each cell's corners inside the tile list
-    uint16_t pad[5];
+    uint32_t cand_start;        // canonical rank of the tile's first corner in its level == where its corners (cand) and survivors
+                                // (surv) start in the level's arrays (harris_kernel; may exceed the level's cap: then none exist)
+    uint32_t surv_count;        // nms_kernel
+    uint32_t out_off;           // output index of the tile's first selected survivor (select_kernel)
+    uint32_t pad0;
+    uint16_t cell_off[EFX_CELLS_PER_TILE + 1];   // start of each cell's corners inside the tile list (fast_kernel)
+    uint16_t pad[7];
 };
 static_assert(sizeof(TileHdr) == 64, "TileHdr must be 64 bytes");
 
-struct __attribute__((aligned(128))) PaddedCounter { int v; int pad[31]; };   // one allocation counter per 128-B line:
-                                                    // same-line atomics serialise (11.5 ns each) even on different words
+// Per tile row of a level: the FAST corners and the NMS survivors of its tiles, summed by fire-and-forget atomics (fast_kernel,
+// nms_kernel).  One 128-B line per row: atomics on one line serialise at ~11.5 ns each, returning or not
+// (tools/microbench/atomic_ff.cpp), so a row's ~120 updates cost ~1.4 us spread over the kernel, a level's 8 000 on one line 94 us.
+// A tile's canonical rank = the sums of the rows above it + the counts of the tiles left of it (harris_kernel): no scan pass.
+struct __attribute__((aligned(128))) RowCtr { int cand; int surv; int pad[30]; };
+// select_kernel's per-level state: written by the level's leader workgroup, read by the counting workgroups
+struct SelLevel {
+    int n;                      // survivors of the level
+    int bin;                    // threshold bin of the key histogram (-1: every survivor is selected)
+    int in_bin;                 // keys in that bin
+    int remaining;              // ... of which the largest `remaining` are selected (== in_bin: all of them, no ranking)
+    int list_n;                 // keys of the bin appended to the level's list so far
+    int done;                   // counting workgroups of the level that have finished
+    int ready;                  // the fields above are valid (release / acquire)
+    int kmin;                   // min(n, quota): the level's share of N
+};
 struct Summary {                // what the host mirror receives (written by select_kernel)
     int cand[EFX_MAX_LEVELS];
     int surv[EFX_MAX_LEVELS];
     int kept[EFX_MAX_LEVELS];           // after quota
     int n_out;                          // N written to the caller
     int dbg;
-    int overflow;                       // a corner / survivor sub-array was too small for this frame: the frame is void (N = 0)
+    int overflow;                       // arena contents failed their range checks ("lost stores"): the frame is
+                                        // void (N = 0).  Since round 6 NO frame content can raise it: the arenas hold the reference's own
+                                        // 10 % cap (.cpp:252) and nothing is allocated
 };
-struct Counters {               // zeroed at the start of every frame
-    PaddedCounter cand_total[EFX_MAX_LEVELS][EFX_NSUB];
-    PaddedCounter surv_total[EFX_MAX_LEVELS][EFX_NSUB];
+struct Counters {               // zeroed at the start of every frame (efx_zero_counters)
     int level_out_base[EFX_MAX_LEVELS + 1];
     unsigned long long thresh[EFX_MAX_LEVELS];   // selection threshold key per level
+    SelLevel sel[EFX_MAX_LEVELS];
     Summary sum;
 };
 
@@ -94,8 +112,11 @@ struct FrameDesc { uint8_t* desc[EFX_MAX_BATCH]; };                           //
 struct FrameStride {            // distance between two frames' copies, in ELEMENTS of the buffer's type (0 is fine for one frame)
     size_t pyramid;             // bytes
     size_t hdr;                 // TileHdr
-    size_t cand;                // Corner records == uint32_t coordinate words (the two arrays are indexed alike)
-    size_t surv;                // Corner
+    size_t cand;                // Corner records (cand and surv are indexed alike)
+    size_t slots;               // bytes (EFX_SLOT_BYTES per tile) == 2 x the tile-count words (uint16_t) and 4 x the selected-count words
+    size_t rows;                // RowCtr
+    size_t hist;                // ints (EFX_HIST_BINS per level)
+    size_t list;                // unsigned long long (EFX_SEL_LIST_CAP per level)
     size_t cmax;                // Corner
     size_t kp;                  // float4 / int (kp4, kp_level), and Affine records (bad_affine)
     size_t blurred;             // bytes
@@ -112,12 +133,12 @@ __device__ __forceinline__ float4 efx_load_keypoint(const float4* __restrict__ k
     return make_float4((float)(short)(loc & 0xffff), (float)(short)(loc >> 16), 31.f, ang);
 }
 
-// the frame is void (arena overflow, or arena contents that fail their range checks): device flag + the host's sticky word
-__device__ __forceinline__ void efx_raise_overflow(const LevelTable* T, Counters* cnt)
-{
-    cnt->sum.overflow = 1;
-    if (T->host_overflow) __hip_atomic_store(T->host_overflow, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
+// the frame is void: arena contents that fail their range checks (never a property of the frame itself, see Summary::overflow)
+__device__ __forceinline__ void efx_raise_overflow(const LevelTable*, Counters* cnt) { cnt->sum.overflow = 1; }
+// word of key-histogram bin b: neighbouring bins lie 4 KB apart, so that the survivors' updates (responses of one frame crowd into
+// a few hundred neighbouring bins) spread over ~1000 lines instead of a few dozen, and a thread that owns 128 consecutive bins
+// reads them as 32 coalesced int4 (select_kernel's leader)
+__host__ __device__ inline uint32_t efx_hist_word(uint32_t b) { return ((b & 31u) << (EFX_HIST_BITS - 5)) | (b >> 5); }
 #endif
 
 // One packed word per tile behind the level table: level | tx << 5 | ty << 15.  The level field must hold EFX_MAX_LEVELS
@@ -307,7 +328,12 @@ struct DetectLaunch {
     const LevelTable* h_table;  // host copy (same contents)
     TileHdr* hdr;
     Corner* cand;
-    uint32_t* cand_xy;          // coordinates of the FAST corners, indexed like `cand` (fast_kernel -> harris_kernel)
+    unsigned char* slots;       // EFX_SLOT_BYTES per tile: corner list or bitmap (fast_kernel -> harris_kernel)
+    uint16_t* tcount;           // FAST corners per tile, compact (the row part of a tile's canonical rank)
+    uint32_t* nsel;             // selected survivors per tile (select_kernel's counting pass -> its scan)
+    RowCtr* rows;               // per tile row: corner / survivor sums
+    int* hist;                  // key histogram of the survivors, EFX_HIST_BINS per level (nms_kernel adds, emit_kernel withdraws)
+    unsigned long long* sel_list;   // keys of the threshold's bin, EFX_SEL_LIST_CAP per level
     Corner* cmax;               // strongest corner of every 16x16 cell (quick test of the NMS)
     Corner* surv;
     Counters* counters;

@@ -1,7 +1,8 @@
-"""Right-sized scratch arenas: large pyramid levels get corner / survivor arenas sized for a corner
-density (1/8 of the pixels; the reference keeps at most 1/10, cuda_efficient_features.cpp:252) instead of "every pixel is a
-corner".  A frame that does not fit is void on the device (N = 0, flag raised); the host enlarges the arenas: the async
-API reports EFX_ERR_OVERFLOW at the next query and the repeated call is exact, the synchronous API reruns by itself."""
+"""Scratch arenas bounded by the reference's own 10 % candidate cap (round 6).  A level's corner and survivor
+arrays hold exactly cvRound(0.1 w h) records (cuda_efficient_features.cpp:252, cuda_fast.cu:216-219,245) at canonical ranks; the
+tiles' corners travel from fast_kernel to harris_kernel in fixed 512-byte slots.  Nothing is allocated on the device, so a valid
+frame is NEVER void, whatever its corner density (rounds 2-5: arenas sized for a density of 1/8, a denser frame came back with
+N = 0 once and the context regrew to 2.1 GB at 8K)."""
 import numpy as np
 import pytest
 
@@ -45,33 +46,60 @@ def test_8k_context_is_below_400_mb(cef):
     assert cef.trimMemory() >= held and cef.cachedBytes() == 0
 
 
-def test_overflowing_frame_is_void_then_exact(cef, oracle):
-    """Uniform noise has ~25 % FAST corners at threshold 20: above the 1/8 the arenas of a > 2 Mpx level are sized for."""
+def _dense_check(cef, oracle, img, nfeatures, **kw):
+    """One asynchronous call on a fresh context: the frame comes back complete (never void), equal to the oracle."""
     import torch
-    img = synth.noise_frame(1300, 1900, seed=11)                  # level 0: 2.47 Mpx
     d_img = torch.from_numpy(img).cuda()
-    det = cef.EfficientFeatures.create(3000, dtype=cef.EfficientFeatures.BAD_256)
+    det = cef.EfficientFeatures.create(nfeatures, kw.get("scale_factor", 1.2), kw.get("nlevels", 8), 0, kw.get("fast_threshold", 20),
+                                       kw.get("nonmax_radius", 15), cef.EfficientFeatures.BAD_256)
+    before = None
     kps, desc, cnt = det.detectAndComputeAsync(d_img)
     torch.cuda.synchronize()
-    assert int(cnt.item()) == 0                                    # void frame: nothing written
-    with pytest.raises(cef.EfxError) as e:
-        det.lastCount()
-    assert e.value.status == cef.EFX_ERR_OVERFLOW
-    small = det.deviceBytes()
-    kps, desc, cnt = det.detectAndComputeAsync(d_img)              # the arenas are worst-case now
-    torch.cuda.synchronize()
-    n = det.lastCount()
-    assert det.deviceBytes() > small
+    n = int(cnt.item())
+    before = det.deviceBytes()
+    assert det.lastCount() == n and det.overflowEvents() == 0          # no EFX_ERR_OVERFLOW, nothing to repeat
     prev = oracle.set_threads(32)
-    ref = oracle.detect_and_compute(img, nfeatures=3000, desc_type=oracle.BAD_256)
+    ref = oracle.detect_and_compute(img, nfeatures=nfeatures, desc_type=oracle.BAD_256, **kw)
     oracle.set_threads(prev)
-    assert n == ref["n"] == int(cnt.item())
-    assert ref["stats"]["n_candidates"][0] > ref["stats"]["n_after_cap"][0]      # the 10 % cap is active as well
+    assert n == ref["n"] > 0
     assert np.array_equal(kps[:, :n].cpu().numpy().view(np.uint32), ref["kps"].view(np.uint32))
     assert np.array_equal(desc[:n].cpu().numpy(), ref["desc"])
+    # the same frame again: same answer, and the context has not grown (nothing is ever "enlarged to the worst case")
+    kps2, desc2, cnt2 = det.detectAndComputeAsync(d_img)
+    torch.cuda.synchronize()
+    assert int(cnt2.item()) == n and torch.equal(kps2[:, :n], kps[:, :n]) and torch.equal(desc2[:n], desc[:n])
+    assert det.deviceBytes() == before
+    return ref, det
 
 
-def test_synchronous_api_reruns_by_itself(cef, oracle):
+def test_dense_frame_is_never_void(cef, oracle):
+    """Uniform noise has ~25 % FAST corners at threshold 20 -- above the 1/8 the arenas of rounds 2-5 were sized for (the frame
+    then came back void, N = 0, and the context regrew to the worst case).  Round 6: a level's arrays hold exactly the reference's
+    cap of cvRound(0.1 w h) records (cuda_efficient_features.cpp:252) at canonical ranks; nothing is allocated on the device, so
+    the FIRST asynchronous call returns the complete frame."""
+    img = synth.noise_frame(1300, 1900, seed=11)                  # level 0: 2.47 Mpx
+    ref, _ = _dense_check(cef, oracle, img, 3000)
+    assert ref["stats"]["n_candidates"][0] > ref["stats"]["n_after_cap"][0]      # the 10 % cap is active
+
+
+@pytest.mark.parametrize("case", ["threshold0", "radius0", "checker", "white_noise_small_cap"])
+def test_worst_case_frames_are_never_void(cef, oracle, case):
+    """The densest frames there are: FAST threshold 0 on noise (nearly every interior pixel a corner: tiles of 4096 corners, the
+    bitmap form of the tile slots), NMS radius 0 (every corner below the cap survives: survivors == cap), a checkerboard (a corner
+    at every crossing, thousands of equal responses: the slow radix path of select_kernel), and a tiny nfeatures on a dense frame."""
+    if case == "threshold0":
+        _dense_check(cef, oracle, synth.noise_frame(700, 900, seed=21), 5000, fast_threshold=0)
+    elif case == "radius0":
+        _dense_check(cef, oracle, synth.noise_frame(800, 1000, seed=22), 4000, nonmax_radius=0)
+    elif case == "checker":
+        y, x = np.mgrid[0:900, 0:1100]
+        img = ((((x // 5) + (y // 5)) & 1) * 200).astype(np.uint8)
+        _dense_check(cef, oracle, img, 3000, nonmax_radius=3)
+    else:
+        _dense_check(cef, oracle, synth.noise_frame(1000, 1400, seed=23), 40, nonmax_radius=0, fast_threshold=5)
+
+
+def test_synchronous_api_on_a_dense_frame(cef, oracle):
     img = synth.noise_frame(1300, 1900, seed=12)
     det = cef.EfficientFeatures.create(2000, dtype=cef.EfficientFeatures.BAD_256)
     kps = det.detect(img)
@@ -83,49 +111,39 @@ def test_synchronous_api_reruns_by_itself(cef, oracle):
     assert np.array_equal(kps["x"], k["x"].astype(np.float32)) and np.array_equal(kps["y"], k["y"].astype(np.float32))
 
 
-def test_async_only_caller_recovers_without_polling(cef, oracle):
-    """a caller that reads d_count directly and never asks for the summary.  The first dense frame is void; the
-    device leaves a sticky flag that the context's NEXT call consumes (no synchronisation, no efx_last_count): the arenas
-    are enlarged and the second frame is exact."""
-    import torch
-    img = synth.noise_frame(1300, 1900, seed=13)
-    d_img = torch.from_numpy(img).cuda()
-    det = cef.EfficientFeatures.create(3000, dtype=cef.EfficientFeatures.BAD_256)
-    kps, desc, cnt = det.detectAndComputeAsync(d_img)
-    torch.cuda.synchronize()
-    assert int(cnt.item()) == 0 and det.overflowEvents() == 0      # void; nobody has looked yet
-    small = det.deviceBytes()
-    kps, desc, cnt = det.detectAndComputeAsync(d_img)              # consumes the flag, enlarges, runs
-    torch.cuda.synchronize()
-    n = int(cnt.item())
-    assert det.overflowEvents() == 1 and det.deviceBytes() > small
-    prev = oracle.set_threads(32)
-    ref = oracle.detect_and_compute(img, nfeatures=3000, desc_type=oracle.BAD_256)
-    oracle.set_threads(prev)
-    assert n == ref["n"] > 0
-    assert np.array_equal(kps[:, :n].cpu().numpy().view(np.uint32), ref["kps"].view(np.uint32))
-    assert np.array_equal(desc[:n].cpu().numpy(), ref["desc"])
-    assert det.lastCount() == n                                     # no stale EFX_ERR_OVERFLOW
-
-
-def test_batch_reports_void_frames(cef):
-    """The batched entry point with callers that only read the count tensors: Batch.overflowEvents() tells them that
-    frames came back void (N = 0) and must be run again; the second run is complete."""
+def test_batch_of_dense_frames_is_complete_on_the_first_run(cef):
+    """The batched entry point with a caller that only reads the count tensors: dense frames are complete at once."""
     import torch
     img = torch.from_numpy(synth.noise_frame(1300, 1900, seed=14)).cuda()
     n = 2
     dets = [cef.EfficientFeatures.create(2000, dtype=cef.EfficientFeatures.BAD_256) for _ in range(n)]
     streams = [torch.cuda.Stream() for _ in range(n)]
-    kps = [torch.zeros((5, 2000), dtype=torch.float32, device="cuda") for _ in range(n)]
-    desc = [torch.zeros((2000, 32), dtype=torch.uint8, device="cuda") for _ in range(n)]
-    cnt = [torch.zeros(1, dtype=torch.int32, device="cuda") for _ in range(n)]
-    b = cef.Batch(dets, streams, [img] * n, kps, desc, cnt, 2000)
+    kps = [torch.zeros((5, 2000), dtype=torch.float32, device="cuda") for _ in range(2 * n)]
+    desc = [torch.zeros((2000, 32), dtype=torch.uint8, device="cuda") for _ in range(2 * n)]
+    cnt = [torch.zeros(1, dtype=torch.int32, device="cuda") for _ in range(2 * n)]
+    b = cef.Batch(dets, streams, [img] * (2 * n), kps, desc, cnt, 2000)
     b.run(); torch.cuda.synchronize()
-    assert [int(c.item()) for c in cnt] == [0, 0] and b.overflowEvents() == 0        # void, nobody has looked yet
-    b.run(); torch.cuda.synchronize()                                                # every context consumes its flag first
-    assert b.overflowEvents() == n
-    assert all(int(c.item()) > 0 for c in cnt) and int(cnt[0].item()) == int(cnt[1].item())
-    assert torch.equal(kps[0], kps[1]) and torch.equal(desc[0], desc[1])
+    assert b.overflowEvents() == 0
+    assert all(int(c.item()) == int(cnt[0].item()) > 0 for c in cnt)
+    assert all(torch.equal(k, kps[0]) for k in kps) and all(torch.equal(d, desc[0]) for d in desc)
+
+
+def test_8k_dense_frame_first_call_and_footprint(cef):
+    """the 1 / f^1.0 8K frame (13 % FAST corners: the 10 % cap active on every level) returns its 40 000
+    keypoints on the FIRST asynchronous call, and the context stays below 0.7 GB whatever it is shown."""
+    import torch
+    img = torch.from_numpy(synth.powerlaw_frame(4320, 7680, seed=1000, beta=1.0, contrast=45.0)).cuda()
+    det = cef.EfficientFeatures.create(40000, dtype=cef.EfficientFeatures.BAD_512)
+    kps, desc, cnt = det.detectAndComputeAsync(img)
+    torch.cuda.synchronize()
+    assert int(cnt.item()) == 40000 and det.lastCount() == 40000 and det.overflowEvents() == 0
+    st = det.lastLevelStats()
+    assert st[0]["n_candidates"] > 0.1 * 4320 * 7680              # more corners than the level's cap
+    assert det.deviceBytes() <= 0.7e9, det.deviceBytes()
+    noise = torch.randint(0, 256, (4320, 7680), dtype=torch.uint8, device="cuda")
+    det.detectAndComputeAsync(noise, kps, desc, cnt)
+    torch.cuda.synchronize()
+    assert int(cnt.item()) == 40000 and det.deviceBytes() <= 0.7e9
 
 
 def test_regrow_keeps_the_calling_stream_tracked(cef, oracle):

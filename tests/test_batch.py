@@ -34,13 +34,12 @@ def _dev(torch, a):
 def _single(cef, torch, d_img, nfeatures, dtype, describe=True, **kw):
     det = cef.EfficientFeatures.create(nfeatures, kw.get("scale_factor", 1.2), kw.get("nlevels", 8), kw.get("first_level", 0),
                                        kw.get("fast_threshold", 20), kw.get("nonmax_radius", 15), dtype)
-    for _ in range(2):          # (a frame that overflows density-sized arenas is void once: the second call is the answer)
-        if describe:
-            kps, desc, cnt = det.detectAndComputeAsync(d_img)
-        else:
-            kps, cnt = det.detectAsync(d_img)
-            desc = None
-        torch.cuda.synchronize()
+    if describe:
+        kps, desc, cnt = det.detectAndComputeAsync(d_img)
+    else:
+        kps, cnt = det.detectAsync(d_img)
+        desc = None
+    torch.cuda.synchronize()
     n = int(cnt.item())
     return n, kps[:, :n].cpu().numpy().view(np.uint32), None if desc is None else desc[:n].cpu().numpy()
 
@@ -56,9 +55,9 @@ def _run_batch(cef, torch, d_imgs, nfeatures, dtype, nctx=1, describe=True, runs
     cnt = [torch.full((1,), -1, dtype=torch.int32, device="cuda") for _ in d_imgs]
     torch.cuda.synchronize()
     b = cef.Batch(dets, streams, d_imgs, kps, desc, cnt, nfeatures)
-    for _ in range(max(runs, 2)):
+    for _ in range(runs):
         b.run()
-        torch.cuda.synchronize()
+    torch.cuda.synchronize()
     out = []
     for i in range(len(d_imgs)):
         n = int(cnt[i].item())
