@@ -1287,6 +1287,7 @@ __global__ __launch_bounds__(64 * NW) void harris_kernel(
     __shared__ unsigned long long s_cellmax[EFX_CELLS_PER_TILE];
     __shared__ unsigned s_celltie[EFX_CELLS_PER_TILE];     // largest response key that two corners of the cell share
     __shared__ uint16_t s_xy[EFX_SLOT_LIST];               // bitmap tiles: a chunk of the corners' tile coordinates in canonical order
+    __shared__ unsigned s_enum[4][64];                     // ... and the enumeration state of row r's four segments
     __shared__ int s_rank;
     const int lane = threadIdx.x;                           // 0 .. 64 NW - 1: a corner slot of the round, not the hardware lane
     const int gt = T->total_tiles - 1 - xcd_interleaved(blockIdx.x, T->total_tiles);      // densest tiles first
@@ -1302,11 +1303,22 @@ __global__ __launch_bounds__(64 * NW) void harris_kernel(
     const int total = min((int)h.cell_off[EFX_CELLS_PER_TILE], EFX_TILE * EFX_TILE);
     // the tile's canonical rank: loads that need the tile's coordinates only (one memory round trip, beside the header's)
     int rank = 0;
+#ifdef EFX_X_NO_RANK
+    rank = tile * 8;
+#else
     if (lane < 64) {
-        for (int i = lane; i < ty; i += 64) rank += rows[L.row_base + i].cand;
+        // two tile rows and two tiles per lane are requested unconditionally (indices clamped), beside the header: ONE round trip.
+        // (A loop with a data-dependent trip count waits for every load where it is issued: measured 7 us of this kernel's 61.)
+        const RowCtr* rp = rows + L.row_base;
         const uint16_t* tc = tcount + L.tile_base + ty * L.tiles_x;
-        for (int i = lane; i < tx; i += 64) rank += (int)tc[i];
+        const int ym = max(ty - 1, 0), xm = max(tx - 1, 0);
+        const int v0 = rp[min(lane, ym)].cand, v1 = rp[min(lane + 64, ym)].cand;
+        const int w0 = (int)tc[min(lane, xm)], w1 = (int)tc[min(lane + 64, xm)];
+        rank = (lane < ty ? v0 : 0) + (lane + 64 < ty ? v1 : 0) + (lane < tx ? w0 : 0) + (lane + 64 < tx ? w1 : 0);
+        for (int i = lane + 128; i < ty; i += 64) rank += rp[i].cand;       // levels of more than 8192 pixels per side
+        for (int i = lane + 128; i < tx; i += 64) rank += (int)tc[i];
     }
+#endif
     auto empty_cells = [&]() {
         // a tile without (valid) corners: sixteen empty cell maxima (smooth frames: most tiles; see nms_kernel)
         if (lane < EFX_CELLS_PER_TILE) {
@@ -1315,10 +1327,9 @@ __global__ __launch_bounds__(64 * NW) void harris_kernel(
         }
     };
     if (total == 0) { empty_cells(); return; }              // no barrier (the header is workgroup-uniform)
-    if (lane < 64) {
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) rank += __shfl_xor(rank, d, 64);
-    }
+#ifndef EFX_X_NO_RANK
+    if (lane < 64) rank = __builtin_amdgcn_readlane(wave_incl_scan(rank), 63);      // DPP steps, no LDS round trips
+#endif
     if (NW > 1) {
         if (lane == 0) s_rank = rank;
         __syncthreads();
@@ -1348,7 +1359,11 @@ __global__ __launch_bounds__(64 * NW) void harris_kernel(
         if ((unsigned)(old >> 32) == (unsigned)(key >> 32)) atomicMax(&s_celltie[cell], (unsigned)(key >> 32));
     };
 
+#ifdef EFX_X_NO_BITMAP
+    if (true) {
+#else
     if (total <= EFX_SLOT_LIST) {
+#endif
         // the common case: fast_kernel left the tile coordinates as a list in canonical order
         const uint16_t* slot = reinterpret_cast<const uint16_t*>(slots + (size_t)gt * EFX_SLOT_BYTES);
         for (int k = lane; k < n_valid; k += 64 * NW) corner(k, (unsigned)slot[k] & 0xfffu);
@@ -1357,17 +1372,17 @@ __global__ __launch_bounds__(64 * NW) void harris_kernel(
         // cells; it pops its bits cell column by cell column into an LDS chunk of 256 corners at their canonical places (a
         // segment's first place = the cell's offset + the bits of the rows above it in the cell), the workgroup computes the
         // chunk, and so on: every bit is popped once
-        unsigned seg[4] = { 0u, 0u, 0u, 0u };
-        int base[4] = { 0, 0, 0, 0 };
+        // (the lanes' enumeration state -- what is left of a row's four segments, the next place of each -- rests in LDS between the
+        // chunks: held in registers across the Harris arithmetic it cost the whole kernel a wave of occupancy per SIMD)
         if (lane < 64) {
             const unsigned long long rb = reinterpret_cast<const unsigned long long*>(slots + (size_t)gt * EFX_SLOT_BYTES)[lane];
             const uint2 co = *reinterpret_cast<const uint2*>(&h.cell_off[(lane >> 4) * 4]);      // the offsets of this row's four cells
             const int coff[4] = { (int)(co.x & 0xffffu), (int)(co.x >> 16), (int)(co.y & 0xffffu), (int)(co.y >> 16) };
 #pragma unroll
             for (int cx = 0; cx < 4; cx++) {
-                seg[cx] = (unsigned)(rb >> (16 * cx)) & 0xffffu;
-                const int c = __popc(seg[cx]);
-                base[cx] = coff[cx] + efx_row16_incl_scan(c) - c;
+                const unsigned sg = (unsigned)(rb >> (16 * cx)) & 0xffffu;
+                const int c = __popc(sg);
+                s_enum[cx][lane] = sg | ((unsigned)(coff[cx] + efx_row16_incl_scan(c) - c) << 16);
             }
         }
         for (int c0 = 0; c0 < n_valid; c0 += EFX_SLOT_LIST) {
@@ -1375,14 +1390,17 @@ __global__ __launch_bounds__(64 * NW) void harris_kernel(
             if (lane < 64) {
 #pragma unroll
                 for (int cx = 0; cx < 4; cx++) {
-                    while (__ballot(seg[cx] != 0u && base[cx] < end) != 0ull) {
-                        if (seg[cx] != 0u && base[cx] < end) {
-                            const int b = __ffs(seg[cx]) - 1;
-                            seg[cx] &= seg[cx] - 1u;
-                            if (base[cx] >= c0) s_xy[base[cx] - c0] = (uint16_t)((16 * cx + b) | (lane << 6));
-                            base[cx]++;
+                    unsigned sg = s_enum[cx][lane] & 0xffffu;
+                    int bs = (int)(s_enum[cx][lane] >> 16);
+                    while (__ballot(sg != 0u && bs < end) != 0ull) {
+                        if (sg != 0u && bs < end) {
+                            const int b = __ffs(sg) - 1;
+                            sg &= sg - 1u;
+                            if (bs >= c0) s_xy[bs - c0] = (uint16_t)((16 * cx + b) | (lane << 6));
+                            bs++;
                         }
                     }
+                    s_enum[cx][lane] = sg | ((unsigned)bs << 16);
                 }
             }
             __syncthreads();
@@ -1777,7 +1795,7 @@ __global__ __launch_bounds__(64 * NW) void nms_kernel(const LevelTable* __restri
     // second pass: the survivors in canonical order, at the tile's own place in the level's index space (round 6: no allocation --
     // a tile has at most as many survivors as corners, and its corners' places are its own); their number joins the tile row's sum
     // and every survivor one bin of the level's key histogram (select_kernel finds the quota's threshold bin there without a pass
-    // over the survivors; emit_kernel withdraws the same counts, so the histogram is zero again when the frame is done)
+    // over the survivors; its counting pass withdraws the same counts, so the histogram is zero again when the frame is done)
     Corner* surv = surv_all + L.cand_base + own_start;
     int* lhist = hist + (size_t)l * EFX_HIST_BINS;
     int base = 0, round = 0;
@@ -1803,34 +1821,54 @@ __global__ __launch_bounds__(64 * NW) void nms_kernel(const LevelTable* __restri
 // Round 6: the kernel is spread over the chip (until then: ONE workgroup of 1024 threads and 132 KB of LDS per level, i.e. eight
 // CUs of 256, 27 us alone and up to 330 us when it had to wait for a free CU behind other frames' kernels):
 //   leaders   workgroup l < nlevels: the level's survivor count (sum of its tile rows' sums) and, when it exceeds the quota, the
-//             bin b* of the 15-bit key histogram that holds the quota-th largest key -- nms_kernel has filled the histogram, so
-//             no pass over the survivors is needed: 128 bins per thread as 32 coalesced int4, one scan, the owner's bins again;
-//   counters  the other workgroups, a lane per tile (256 tiles each): they wait for their level's leader (a flag; the leaders
-//             have the lowest workgroup numbers, are dispatched first and wait for nobody), count the tile's survivors above
-//             b*, and append the keys OF b* -- a few dozen on real frames -- to the level's list;
+//             bin b* of the key histogram that holds the quota-th largest key -- nms_kernel has filled the histogram, so no pass
+//             over the survivors is needed: 64 bins per thread as 32 coalesced loads, one scan, the owner's bins again;
+//   counters  the other workgroups, a lane per tile (256 tiles each): they wait for their level's leader (the leaders have the
+//             lowest workgroup numbers, are dispatched first and wait for nobody), count the tile's survivors above b*, append
+//             the keys OF b* -- a few dozen on real frames -- to the level's list, and take every survivor's count out of the
+//             histogram again (it is zero when the frame is done, without a pass that clears it);
 //   last      the counting workgroup that finishes a level last (a counter per level) ranks the list in LDS -> the exact
-//             threshold key, adds the list's selected keys to their tiles' counts and scans the counts in canonical tile order:
-//             every tile's output offset.
+//             threshold key, and scans the tiles' counts (+ the list's selected keys) in canonical order: the output offsets.
+// Everything that crosses workgroups inside the launch is a relaxed device-scope atomic access (a word that is its own flag,
+// counts, list keys): measured on this part, an acquire / release FENCE costs microseconds each (a last workgroup that fenced and
+// read eight leaders' flags with acquire loads spent 30 us there), a device-scope load or store costs a memory round trip.
 // A bin with more than EFX_SEL_LIST_CAP keys (synthetic frames with thousands of equal responses): the last workgroup runs
 // 12-bit radix passes over the level's tiles itself (slow, exact).
 // ================================================================================================
 #define SEL_NT 256
 #define SEL_ILP 8                     // survivors a counting lane has in flight
+#define SEL_SEG 8192                  // tiles whose counts (16 bits each) the last workgroup holds in LDS at a time
+// INVESTIGATION (-DEFX_SEL_TIMING builds only): the leader of level 0 and the workgroup that finishes level 0 print their phase
+// times (10 ns ticks of the constant-frequency counter)
+#ifdef EFX_SEL_TIMING
+#define SEL_TL(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) sel_t[i] = wall_clock64(); } while (0)
+#define SEL_TF(i) do { if (fl == 0 && blockIdx.y == 0 && tid == 0) sel_t[i] = wall_clock64(); } while (0)
+#define SEL_TC(i) do { if (blockIdx.y == 0 && tid == 0) sel_t[i] = wall_clock64(); } while (0)
+#else
+#define SEL_TL(i) do { } while (0)
+#define SEL_TF(i) do { } while (0)
+#define SEL_TC(i) do { } while (0)
+#endif
 
-// a bounded wait for a flag another workgroup of this launch raises (the leaders precede the counters in dispatch order and
-// never wait themselves, so the wait always ends; the bound only keeps a broken build from hanging the GPU)
-__device__ __forceinline__ bool efx_wait_flag(const int* flag)
+// device-scope accesses that are coherent per location without a fence
+template <class V> __device__ __forceinline__ V efx_ld(const V* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class V> __device__ __forceinline__ void efx_st(V* p, V v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// the level's published word A: bit 63 ready | bits 32..47 bin + 1 | bits 0..31 keys in the bin; word B: remaining << 32 | min(n, quota).
+// A bounded wait (the leaders precede the counters in dispatch order and never wait themselves, so it always ends; the bound only
+// keeps a broken build from hanging the GPU)
+__device__ __forceinline__ unsigned long long efx_wait_word(const unsigned long long* w)
 {
     for (int spin = 0; spin < (1 << 22); spin++) {
-        if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0) return true;
+        const unsigned long long v = efx_ld(w);
+        if (v >> 63) return v;
         __builtin_amdgcn_s_sleep(2);
     }
-    return false;
+    return (1ull << 63) | ((unsigned long long)(EFX_HIST_BINS + 1) << 32);      // "nothing is selected"
 }
 
 __global__ __launch_bounds__(SEL_NT) void select_kernel(const LevelTable* __restrict__ T, TileHdr* __restrict__ hdr,
                                                         const Corner* __restrict__ surv_all, const RowCtr* __restrict__ rows,
-                                                        const int* __restrict__ hist, unsigned long long* __restrict__ sel_list,
+                                                        int* __restrict__ hist, unsigned long long* __restrict__ sel_list,
                                                         uint32_t* __restrict__ nsel, Counters* __restrict__ cnt,
                                                         int capacity, const FrameOut out, const FrameStride fs)
 {
@@ -1842,58 +1880,89 @@ __global__ __launch_bounds__(SEL_NT) void select_kernel(const LevelTable* __rest
     __shared__ __attribute__((aligned(16))) int s_scan[8];
     __shared__ int s_own, s_want, s_bin, s_inbin, s_rem, s_last[EFX_MAX_LEVELS], s_m;
     __shared__ unsigned long long s_thresh;
-    __shared__ unsigned long long s_keys[EFX_SEL_LIST_CAP];      // the last workgroup's list (16 KB); the slow path's 4096-bin histogram
+    __shared__ unsigned long long s_keys[EFX_SEL_LIST_CAP];      // the last workgroup's list (16 KB)
+    __shared__ int s_cnt[SEL_SEG / 2];                           // ... a segment of the tiles' counts, two per word (16 KB; a tile has at most
+                                                                 // 4096 + EFX_SEL_LIST_CAP selected survivors); the slow path's 4096-bin histogram
     __shared__ int s_sub[256];
     const int tid = threadIdx.x, nl = T->nlevels;
     constexpr int TOPSH = 64 - EFX_HIST_BITS;
+    constexpr int PER = EFX_HIST_BINS / SEL_NT;                  // bins a leader thread owns
+    static_assert(PER == 64 || PER == 128 || PER == 32, "leader: the owner's bins are re-read by one wave");
+#ifdef EFX_SEL_TIMING
+    unsigned long long sel_t[12] = { 0 };
+#endif
 
     if ((int)blockIdx.x < nl) {
         // ---------------- leader of level l ----------------
         const int l = blockIdx.x;
         const LevelDev& L = T->lv[l];
+        SEL_TL(0);
         int part = 0, partc = 0;
         for (int i = tid; i < L.tiles_y; i += SEL_NT) { part += rows[L.row_base + i].surv; partc += rows[L.row_base + i].cand; }
         int n, nc;
         (void)block_excl_scan4(part, s_scan, &n);
         (void)block_excl_scan4(partc, s_scan + 4, &nc);
+        SEL_TL(1);
         const bool none = !L.active || L.quota <= 0 || cnt->sum.overflow != 0;      // nothing is selected (void frame: N = 0)
         if (tid == 0) { s_bin = none ? EFX_HIST_BINS : -1; s_inbin = 0; s_rem = 0; }
         __syncthreads();
         if (!none && n > L.quota) {
             const int* lh = hist + (size_t)l * EFX_HIST_BINS;
-            const int own = SEL_NT - 1 - tid;                   // bins 128 own .. 128 own + 127: thread 0 owns the top
+            const int own = SEL_NT - 1 - tid;                   // bins PER own .. PER own + PER - 1: thread 0 owns the top
             int sum = 0;
+            // bin PER own + 32 j + v lies at word v (BINS / 32) + (PER / 32) own + j: PER / 32 consecutive words per plane v
 #pragma unroll 8
             for (int v = 0; v < 32; v++) {
-                const int4 q = *reinterpret_cast<const int4*>(lh + v * (EFX_HIST_BINS / 32) + 4 * own);
-                sum += (q.x + q.y) + (q.z + q.w);
+                const int* q = lh + v * (EFX_HIST_BINS / 32) + (PER / 32) * own;
+                if (PER == 128) { const int4 x = *reinterpret_cast<const int4*>(q); sum += (x.x + x.y) + (x.z + x.w); }
+                else if (PER == 64) { const int2 x = *reinterpret_cast<const int2*>(q); sum += x.x + x.y; }
+                else sum += q[0];
             }
+            SEL_TL(2);
             int tot;
             const int before = block_excl_scan4(sum, s_scan, &tot);
             if (before < L.quota && L.quota <= before + sum) { s_own = own; s_want = L.quota - before; }      // exactly one thread
             __syncthreads();
             if (tid < 64) {
-                // the owner's 128 bins from the top, two per lane
-                const int want = s_want, b_hi = s_own * 128 + 127 - 2 * tid, b_lo = b_hi - 1;
-                const int c_hi = lh[efx_hist_word((uint32_t)b_hi)], c_lo = lh[efx_hist_word((uint32_t)b_lo)];
-                const int incl = wave_incl_scan(c_hi + c_lo), excl = incl - (c_hi + c_lo);
-                if (excl < want && want <= excl + c_hi) { s_bin = b_hi; s_inbin = c_hi; s_rem = want - excl; }
-                else if (excl + c_hi < want && want <= incl) { s_bin = b_lo; s_inbin = c_lo; s_rem = want - excl - c_hi; }
+                // the owner's bins from the top, PER / 64 per lane
+                const int want = s_want;
+                int cb[PER / 64 > 0 ? PER / 64 : 1], bb[PER / 64 > 0 ? PER / 64 : 1], tot2 = 0;
+#pragma unroll
+                for (int j = 0; j < (PER >= 64 ? PER / 64 : 1); j++) {
+                    const int idx = tid * (PER >= 64 ? PER / 64 : 1) + j;              // 0 = the top bin
+                    bb[j] = s_own * PER + PER - 1 - idx;
+                    cb[j] = idx < PER ? lh[efx_hist_word((uint32_t)bb[j])] : 0;
+                    tot2 += cb[j];
+                }
+                int excl = wave_incl_scan(tot2) - tot2;
+#pragma unroll
+                for (int j = 0; j < (PER >= 64 ? PER / 64 : 1); j++) {
+                    if (excl < want && want <= excl + cb[j]) { s_bin = bb[j]; s_inbin = cb[j]; s_rem = want - excl; }
+                    excl += cb[j];
+                }
             }
             __syncthreads();
         }
         if (tid == 0) {
             SelLevel& S = cnt->sel[l];
-            S.n = n; S.bin = s_bin; S.in_bin = s_inbin; S.remaining = s_rem;
-            S.kmin = none ? 0 : min(n, L.quota);
+            const int kmin = none ? 0 : min(n, L.quota);
             cnt->sum.surv[l] = n; cnt->sum.cand[l] = nc;
-            __hip_atomic_store(&S.ready, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            efx_st(&S.pub[1], ((unsigned long long)(uint32_t)s_rem << 32) | (uint32_t)kmin);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // program order: word B is out before word A
+            efx_st(&S.pub[0], (1ull << 63) | ((unsigned long long)(uint32_t)(s_bin + 1) << 32) | (uint32_t)s_inbin);
         }
+        SEL_TL(3);
+#ifdef EFX_SEL_TIMING
+        if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)
+            printf("select leader l0 ticks(10ns): rows %llu | hist %llu | scan+bins+publish %llu | n %d bin %d in_bin %d rem %d | start tick %llu\n",
+                   sel_t[1] - sel_t[0], sel_t[2] - sel_t[1], sel_t[3] - sel_t[2], n, s_bin, s_inbin, s_rem, sel_t[0]);
+#endif
         return;
     }
 
     // ---------------- counting workgroup: a lane per tile ----------------
     const int w = (int)blockIdx.x - nl;
+    SEL_TC(0);
     const int gt = w * EFX_SEL_WG_TILES + tid;
     const bool valid = gt < T->total_tiles;
     int l = 0, tx = 0, ty = 0;
@@ -1904,40 +1973,54 @@ __global__ __launch_bounds__(SEL_NT) void select_kernel(const LevelTable* __rest
         start = min(hdr[gt].cand_start, (unsigned)L.cap);
         sc = min((int)min(hdr[gt].surv_count, (uint32_t)(EFX_TILE * EFX_TILE)), L.cap - (int)start);
     }
-    const bool ok = valid ? efx_wait_flag(&cnt->sel[l].ready) : true;
-    int bin = EFX_HIST_BINS, in_bin = 0, rem = 0;
-    if (valid && ok) { bin = cnt->sel[l].bin; in_bin = cnt->sel[l].in_bin; rem = cnt->sel[l].remaining; }
-    if (bin == EFX_HIST_BINS) sc = 0;
-    const bool all_bin = rem == in_bin, listed = !all_bin && in_bin <= EFX_SEL_LIST_CAP;
     const Corner* q = surv_all + L.cand_base + start;
+    // the first survivors are requested before the wait for the leader: most tiles have no more
+    Corner s[SEL_ILP];
+#pragma unroll
+    for (int u = 0; u < SEL_ILP; u++) s[u] = q[min(u, max(sc - 1, 0))];
+    SEL_TC(1);
+    int bin = EFX_HIST_BINS, in_bin = 0, rem = 0;
+    if (valid) {
+        const unsigned long long a = efx_wait_word(&cnt->sel[l].pub[0]);
+        bin = (int)((a >> 32) & 0xffffu) - 1; in_bin = (int)(uint32_t)a;
+        rem = (int)(efx_ld(&cnt->sel[l].pub[1]) >> 32);
+    }
+    SEL_TC(2);
+    const bool all_bin = rem == in_bin, listed = !all_bin && in_bin <= EFX_SEL_LIST_CAP;
     unsigned long long* lst = sel_list + (size_t)l * EFX_SEL_LIST_CAP;
+    int* lhist = hist + (size_t)l * EFX_HIST_BINS;
     int c = 0;
     {
         int scmax = sc;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) scmax = max(scmax, __shfl_xor(scmax, d, 64));
         for (int j0 = 0; j0 < scmax; j0 += SEL_ILP) {
-            Corner s[SEL_ILP];
+            if (j0 > 0) {
 #pragma unroll
-            for (int u = 0; u < SEL_ILP; u++) s[u] = q[min(j0 + u, max(sc - 1, 0))];       // unconditional loads: one round trip per step
+                for (int u = 0; u < SEL_ILP; u++) s[u] = q[min(j0 + u, max(sc - 1, 0))];       // unconditional loads: one round trip per step
+            }
 #pragma unroll
             for (int u = 0; u < SEL_ILP; u++) {
                 if (j0 + u < sc) {
                     const unsigned long long key = efx_select_key(s[u].xy, s[u].resp);
                     const int kb = (int)(key >> TOPSH);
+                    // the survivor's count leaves the key histogram again (nms_kernel added it, the leader has read it)
+                    __hip_atomic_fetch_add(&lhist[efx_hist_word((uint32_t)kb)], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (kb > bin || (kb == bin && all_bin)) c++;
                     else if (kb == bin && listed) {
                         const int pos = atomicAdd(&cnt->sel[l].list_n, 1);
-                        if (pos < EFX_SEL_LIST_CAP) lst[pos] = key;
+                        if (pos < EFX_SEL_LIST_CAP) efx_st(&lst[pos], key);
                     }
                 }
             }
         }
     }
-    if (valid) nsel[gt] = (uint32_t)c;
+    if (bin == EFX_HIST_BINS) c = 0;
+    if (valid) efx_st(&nsel[gt], (uint32_t)c);
+    SEL_TC(3);
     // ---- which levels does this workgroup complete? ----
     if (tid < EFX_MAX_LEVELS) s_last[tid] = 0;
-    __threadfence();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this thread's device-scope stores have been acknowledged
     __syncthreads();
     if (tid == 0) {
         int l0, l1, tx_, ty_;
@@ -1950,26 +2033,37 @@ __global__ __launch_bounds__(SEL_NT) void select_kernel(const LevelTable* __rest
     for (int fl = 0; fl < nl; fl++) {
         if (!s_last[fl]) continue;                              // workgroup-uniform
         // ---------------- last workgroup of level fl: threshold key, counts, scan ----------------
-        __threadfence();
+        SEL_TF(4);
         const LevelDev& F = T->lv[fl];
         const int ntiles = F.tiles_x * F.tiles_y;
-        // every leader's share of N (the leaders wait for nobody)
+        // every leader's share of N (the leaders wait for nobody): lane i asks for level i
         int base = 0, all = 0;
-        for (int i = 0; i < nl; i++) {
-            (void)efx_wait_flag(&cnt->sel[i].ready);
-            const int k = __hip_atomic_load(&cnt->sel[i].kmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (i < fl) base += k;
-            all += k;
+        {
+            int k = 0;
+            if (tid < nl) { (void)efx_wait_word(&cnt->sel[tid].pub[0]); k = (int)(uint32_t)efx_ld(&cnt->sel[tid].pub[1]); }
+            int kb4 = tid < fl ? k : 0;
+            (void)block_excl_scan4(kb4, s_scan, &base);
+            (void)block_excl_scan4(k, s_scan + 4, &all);
         }
-        const int fbin = cnt->sel[fl].bin, fin = cnt->sel[fl].in_bin, frem = cnt->sel[fl].remaining;
+        const unsigned long long fa = efx_ld(&cnt->sel[fl].pub[0]);
+        const int fbin = (int)((fa >> 32) & 0xffffu) - 1, fin = (int)(uint32_t)fa, frem = (int)(efx_ld(&cnt->sel[fl].pub[1]) >> 32);
+        SEL_TF(5);
         unsigned long long thresh = 0ull;
+        int m = 0;                                              // listed keys in s_keys
+        bool slow = false;
         if (fbin == EFX_HIST_BINS) thresh = ~0ull;              // nothing is selected (no key reaches this value)
         else if (fbin < 0) thresh = 0ull;                       // every survivor is
         else if (frem == fin) thresh = (unsigned long long)fbin << TOPSH;      // every key of the bin is wanted: its lower edge
         else if (fin <= EFX_SEL_LIST_CAP) {
-            const int m = min(__hip_atomic_load(&cnt->sel[fl].list_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), EFX_SEL_LIST_CAP);      // == fin
+            m = min(efx_ld(&cnt->sel[fl].list_n), EFX_SEL_LIST_CAP);          // == fin
             const unsigned long long* gl = sel_list + (size_t)fl * EFX_SEL_LIST_CAP;
-            for (int i = tid; i < m; i += SEL_NT) s_keys[i] = __hip_atomic_load(&gl[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            {
+                unsigned long long lk[EFX_SEL_LIST_CAP / SEL_NT];
+#pragma unroll
+                for (int r = 0; r < EFX_SEL_LIST_CAP / SEL_NT; r++) lk[r] = efx_ld(&gl[min(r * SEL_NT + tid, EFX_SEL_LIST_CAP - 1)]);
+#pragma unroll
+                for (int r = 0; r < EFX_SEL_LIST_CAP / SEL_NT; r++) if (r * SEL_NT + tid < m) s_keys[r * SEL_NT + tid] = lk[r];
+            }
             __syncthreads();
             if (m <= SEL_NT) {
                 // rank by counting: the key with exactly frem - 1 larger keys (keys are unique)
@@ -2017,28 +2111,10 @@ __global__ __launch_bounds__(SEL_NT) void select_kernel(const LevelTable* __rest
                 }
                 thresh = prefix;
             }
-            // the list's selected keys join their tiles' counts
-            for (int i = tid; i < m; i += SEL_NT) {
-                const unsigned long long k = s_keys[i];
-                if (k >= thresh) {
-                    const uint32_t xy = 0xffffffffu - (uint32_t)k;      // the key's low word is ~xy
-                    atomicAdd(&nsel[F.tile_base + (int)((xy >> 16) >> 6) * F.tiles_x + (int)((xy & 0xffffu) >> 6)], 1u);
-                }
-            }
-            __threadfence();
-            __syncthreads();
         } else {
             // thousands of keys in one bin: 12-bit radix passes over the level's survivors, below the bits already decided
-            int* s_hist = reinterpret_cast<int*>(s_keys);        // 4096 bins
-            auto for_each_key = [&](auto&& f) {
-                for (int t = tid; t < ntiles; t += SEL_NT) {
-                    const TileHdr& th = hdr[F.tile_base + t];
-                    const unsigned st = min(th.cand_start, (unsigned)F.cap);
-                    const int n2 = min((int)min(th.surv_count, (uint32_t)(EFX_TILE * EFX_TILE)), F.cap - (int)st);
-                    const Corner* q2 = surv_all + F.cand_base + st;
-                    for (int j = 0; j < n2; j++) f(efx_select_key(q2[j].xy, q2[j].resp), t);
-                }
-            };
+            slow = true;
+            int* s_hist = s_cnt;                                 // 4096 bins
             unsigned long long prefix = (unsigned long long)fbin;
             int decided = EFX_HIST_BITS, remaining = frem;
             while (decided < 64) {
@@ -2046,9 +2122,16 @@ __global__ __launch_bounds__(SEL_NT) void select_kernel(const LevelTable* __rest
                 const int shift = 64 - decided - width;
                 for (int i = tid; i < 4096; i += SEL_NT) s_hist[i] = 0;
                 __syncthreads();
-                for_each_key([&](unsigned long long k, int) {
-                    if ((k >> (64 - decided)) == prefix) atomicAdd(&s_hist[(int)((k >> shift) & ((1u << width) - 1))], 1);
-                });
+                for (int t = tid; t < ntiles; t += SEL_NT) {
+                    const TileHdr& th = hdr[F.tile_base + t];
+                    const unsigned st = min(th.cand_start, (unsigned)F.cap);
+                    const int n2 = min((int)min(th.surv_count, (uint32_t)(EFX_TILE * EFX_TILE)), F.cap - (int)st);
+                    const Corner* q2 = surv_all + F.cand_base + st;
+                    for (int j = 0; j < n2; j++) {
+                        const unsigned long long k = efx_select_key(q2[j].xy, q2[j].resp);
+                        if ((k >> (64 - decided)) == prefix) atomicAdd(&s_hist[(int)((k >> shift) & ((1u << width) - 1))], 1);
+                    }
+                }
                 __syncthreads();
                 // walk the bins from the top: thread t owns bins [hi - 16 t - 15, hi - 16 t]
                 const int nb = 1 << width;
@@ -2071,27 +2154,81 @@ __global__ __launch_bounds__(SEL_NT) void select_kernel(const LevelTable* __rest
                 if (remaining == cnt_bin) { prefix = decided < 64 ? (prefix << (64 - decided)) : prefix; decided = 64; }
             }
             thresh = prefix;                 // exactly `quota` keys are >= thresh (keys are unique)
-            // the counting pass left the bin's keys out: add the selected ones
-            for_each_key([&](unsigned long long k, int t) {
-                if ((int)(k >> TOPSH) == fbin && k >= thresh) atomicAdd(&nsel[F.tile_base + t], 1u);
-            });
-            __threadfence();
-            __syncthreads();
         }
-        // ---- the tiles' output offsets: exclusive scan of the counts in canonical tile order; a thread owns a chunk ----
-        const int chunk = (ntiles + SEL_NT - 1) / SEL_NT;
-        const int t0 = min(tid * chunk, ntiles), t1 = min(t0 + chunk, ntiles);
-        const uint32_t* ns = nsel + F.tile_base;
-        int local = 0;
-        for (int t = t0; t < t1; t++) local += (int)__hip_atomic_load(&ns[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int tot;
-        int pre = block_excl_scan4(local, s_scan + 4, &tot);
+        SEL_TF(6);
+        // ---- the tiles' output offsets: exclusive scan of the counts in canonical tile order, SEL_SEG tiles at a time in LDS ----
         TileHdr* hl = hdr + F.tile_base;
-        for (int t = t0; t < t1; t++) { hl[t].out_off = (uint32_t)(base + pre); pre += (int)__hip_atomic_load(&ns[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        const uint32_t* ns = nsel + F.tile_base;
+        int running = 0;
+        for (int seg = 0; seg < ntiles; seg += SEL_SEG) {
+            const int nseg = min(SEL_SEG, ntiles - seg);
+            __syncthreads();
+            // coalesced device-scope loads, 32 independent ones per thread: all requested (indices clamped into the level) before the
+            // first is used -- a load under a condition is waited for on the spot (measured: 10 us per segment instead of 1).  Tiles
+            // 2 j and 2 j + 1 of the segment share word j
+            {
+                constexpr int NL = SEL_SEG / 2 / SEL_NT;        // words per thread
+                uint32_t lo[NL], hi[NL];
+#pragma unroll
+                for (int r = 0; r < NL; r++) {
+                    const int t = 2 * (r * SEL_NT + tid);
+                    lo[r] = efx_ld(&ns[min(seg + t, ntiles - 1)]);
+                    hi[r] = efx_ld(&ns[min(seg + t + 1, ntiles - 1)]);
+                }
+#pragma unroll
+                for (int r = 0; r < NL; r++) {
+                    const int t = 2 * (r * SEL_NT + tid);
+                    s_cnt[r * SEL_NT + tid] = (int)((t < nseg ? lo[r] : 0u) | ((t + 1 < nseg ? hi[r] : 0u) << 16));
+                }
+            }
+            __syncthreads();
+            // the list's selected keys (the counting pass left the threshold bin's keys out) join their tiles' counts
+            for (int i = tid; i < m; i += SEL_NT) {
+                const unsigned long long k = s_keys[i];
+                if (k >= thresh) {
+                    const uint32_t xy = 0xffffffffu - (uint32_t)k;      // the key's low word is ~xy
+                    const int t = (int)((xy >> 16) >> 6) * F.tiles_x + (int)((xy & 0xffffu) >> 6) - seg;
+                    if (t >= 0 && t < nseg) atomicAdd(&s_cnt[t >> 1], 1 << (16 * (t & 1)));
+                }
+            }
+            if (slow) {
+                for (int t = tid; t < nseg; t += SEL_NT) {
+                    const TileHdr& th = hl[seg + t];
+                    const unsigned st = min(th.cand_start, (unsigned)F.cap);
+                    const int n2 = min((int)min(th.surv_count, (uint32_t)(EFX_TILE * EFX_TILE)), F.cap - (int)st);
+                    const Corner* q2 = surv_all + F.cand_base + st;
+                    int add = 0;
+                    for (int j = 0; j < n2; j++) {
+                        const unsigned long long k = efx_select_key(q2[j].xy, q2[j].resp);
+                        add += ((int)(k >> TOPSH) == fbin && k >= thresh) ? 1 : 0;
+                    }
+                    if (add) atomicAdd(&s_cnt[t >> 1], add << (16 * (t & 1)));
+                }
+            }
+            __syncthreads();
+            constexpr int CW = SEL_SEG / 2 / SEL_NT;             // words per thread: tiles 2 CW tid .. 2 CW tid + 2 CW - 1
+            int v[2 * CW], local = 0;
+#pragma unroll
+            for (int r = 0; r < CW; r++) {
+                const uint32_t wv = (uint32_t)s_cnt[tid * CW + r];
+                v[2 * r] = (int)(wv & 0xffffu); v[2 * r + 1] = (int)(wv >> 16);
+                local += v[2 * r] + v[2 * r + 1];
+            }
+            int tot;
+            int pre = running + base + block_excl_scan4(local, s_scan, &tot);
+#pragma unroll
+            for (int r = 0; r < 2 * CW; r++) {
+                const int t = tid * 2 * CW + r;
+                if (t < nseg) hl[seg + t].out_off = (uint32_t)pre;      // (a thread's headers: consecutive 64-byte lines)
+                pre += v[r];
+            }
+            running += tot;
+        }
+        SEL_TF(7);
         if (tid == 0) {
             cnt->thresh[fl] = thresh;
             cnt->level_out_base[fl] = base;
-            cnt->sum.kept[fl] = tot;
+            cnt->sum.kept[fl] = running;
             if (fl == 0) {
                 const int n = all < capacity ? all : capacity;
                 cnt->level_out_base[nl] = all;
@@ -2099,6 +2236,13 @@ __global__ __launch_bounds__(SEL_NT) void select_kernel(const LevelTable* __rest
                 if (d_count) *d_count = n;
             }
         }
+        SEL_TF(8);
+#ifdef EFX_SEL_TIMING
+        if (fl == 0 && blockIdx.y == 0 && tid == 0)
+            printf("select last-of-l0 (wg %d) ticks(10ns): tile loads %llu | wait %llu | count %llu | done %llu | leaders %llu | rank %llu | scan+offsets %llu | end tick %llu\n",
+                   w, sel_t[1] - sel_t[0], sel_t[2] - sel_t[1], sel_t[3] - sel_t[2], sel_t[4] - sel_t[3], sel_t[5] - sel_t[4], sel_t[6] - sel_t[5],
+                   sel_t[7] - sel_t[6], sel_t[8]);
+#endif
         __syncthreads();
     }
 }
@@ -2144,11 +2288,10 @@ __global__ __launch_bounds__(64) void emit_kernel(const LevelTable* __restrict__
                                                   const Corner* __restrict__ surv_all, const Counters* __restrict__ cnt,
                                                   const uint8_t* __restrict__ img0, int pitch0, const uint8_t* __restrict__ pyramid,
                                                   size_t kps_pitch, int capacity,
-                                                  float4* __restrict__ kp4, int* __restrict__ kp_level, int* __restrict__ hist, const FrameOut out, const FrameStride fs)
+                                                  float4* __restrict__ kp4, int* __restrict__ kp_level, const FrameOut out, const FrameStride fs)
 {
     uint8_t* const kps = out.kps[blockIdx.y];
     hdr += blockIdx.y * fs.hdr; surv_all += blockIdx.y * fs.cand; cnt += blockIdx.y; kp4 += blockIdx.y * fs.kp; kp_level += blockIdx.y * fs.kp;
-    hist += blockIdx.y * fs.hist;
     // EMIT_TPW tiles per wave, 64 / EMIT_TPW lanes each (round 3): a tile has three survivors on average and the kernel is a
     // chain of dependent loads per wave (tile word -> header -> survivors), so its time is the number of waves the chip must
     // cycle through: 25 500 one-tile waves took 3.1 rounds of the chip's 8192 wave slots
@@ -2169,21 +2312,13 @@ __global__ __launch_bounds__(64) void emit_kernel(const LevelTable* __restrict__
     if (sc_max == 0) return;
     const unsigned long long thresh = cnt->thresh[l];
     const Corner* q = surv_all + L.cand_base + start;
-    int* lhist = hist + (size_t)l * EFX_HIST_BINS;
 
     int running = 0;
     for (int i0 = 0; i0 < sc_max; i0 += LPT) {
         const int i = i0 + sub;
         Corner c; c.xy = 0; c.resp = 0.f;
         bool sel = false;
-        if (i < sc) {
-            c = q[i];
-            const unsigned long long key = efx_select_key(c.xy, c.resp);
-            sel = key >= thresh;
-            // every survivor's count leaves the level's key histogram again (nms_kernel added it, select_kernel has read it): the
-            // histogram is zero when the frame is done, without a pass that clears its 128 KB per level
-            __hip_atomic_fetch_add(&lhist[efx_hist_word((uint32_t)(key >> (64 - EFX_HIST_BITS)))], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (i < sc) { c = q[i]; sel = efx_select_key(c.xy, c.resp) >= thresh; }
         const unsigned m = (unsigned)(__ballot(sel) >> (LPT * part)) & (unsigned)((1ull << LPT) - 1ull);     // this tile's lanes
         const int rank = __popc(m & ((1u << sub) - 1u));
         const int out = out_off + running + rank;
@@ -2662,7 +2797,7 @@ static hipError_t efx_launch_detect_impl(const DetectLaunch& a, hipStream_t stre
                        a.surv, a.rows, a.hist, a.sel_list, a.nsel, a.counters, a.capacity, out, a.fs);
     EFX_TRACE_POINT("select");
     hipLaunchKernelGGL(emit_kernel, dim3((H.total_tiles + EMIT_TPW - 1) / EMIT_TPW, B), dim3(64), 0, stream, a.d_table, a.hdr, a.surv, a.counters,
-                       a.img0, a.pitch0, a.pyramid, a.kps_pitch, a.capacity, a.kp4, a.kp_level, a.hist, out, a.fs);
+                       a.img0, a.pitch0, a.pyramid, a.kps_pitch, a.capacity, a.kp4, a.kp_level, out, a.fs);
     EFX_TRACE_POINT("emit");
     if (a.capacity > 0) {
         // the image the describer's records refer to: the raw levels, or their blurred copies (blur_levels_kernel above)

@@ -27,7 +27,7 @@
 #define EFX_NXCD 8
 #define EFX_SLOT_LIST 256       // a tile with at most this many FAST corners leaves them as a list in its slot, else as a bitmap
 #define EFX_SLOT_BYTES 512      // 256 x u16 == 64 x u64
-#define EFX_HIST_BITS 15        // selection histogram: top bits of the 64-bit key (sign, exponent, 6 mantissa bits of the response)
+#define EFX_HIST_BITS 14        // selection histogram: top bits of the 64-bit key (sign, exponent, 5 mantissa bits of the response)
 #define EFX_HIST_BINS (1 << EFX_HIST_BITS)
 #define EFX_SEL_LIST_CAP 2048   // keys of the threshold's bin that are ranked exactly in LDS (more: the slow radix path of select_kernel)
 #define EFX_SEL_WG_TILES 256    // tiles per counting workgroup of select_kernel (lane per tile)
@@ -73,17 +73,20 @@ static_assert(sizeof(TileHdr) == 64, "TileHdr must be 64 bytes");
 // nms_kernel).  One 128-B line per row: atomics on one line serialise at ~11.5 ns each, returning or not
 // (tools/microbench/atomic_ff.cpp), so a row's ~120 updates cost ~1.4 us spread over the kernel, a level's 8 000 on one line 94 us.
 // A tile's canonical rank = the sums of the rows above it + the counts of the tiles left of it (harris_kernel): no scan pass.
-struct __attribute__((aligned(128))) RowCtr { int cand; int surv; int pad[30]; };
+#ifndef EFX_ROWCTR_PAD
+#define EFX_ROWCTR_PAD 30
+#endif
+struct __attribute__((aligned(8))) RowCtr { int cand; int surv; int pad[EFX_ROWCTR_PAD]; };
 // select_kernel's per-level state: written by the level's leader workgroup, read by the counting workgroups
-struct SelLevel {
-    int n;                      // survivors of the level
-    int bin;                    // threshold bin of the key histogram (-1: every survivor is selected)
-    int in_bin;                 // keys in that bin
-    int remaining;              // ... of which the largest `remaining` are selected (== in_bin: all of them, no ranking)
+struct __attribute__((aligned(32))) SelLevel {
+    // published by the leader with two device-scope stores, [1] first: [0] = ready << 63 | (bin + 1) << 32 | keys in the bin, where
+    // bin is the threshold bin of the key histogram (-1: every survivor is selected, EFX_HIST_BINS: none); [1] = remaining << 32 |
+    // min(n, quota): the largest `remaining` keys of the bin are selected (== keys in the bin: all of them, no ranking), and the
+    // level's share of N
+    unsigned long long pub[2];
     int list_n;                 // keys of the bin appended to the level's list so far
     int done;                   // counting workgroups of the level that have finished
-    int ready;                  // the fields above are valid (release / acquire)
-    int kmin;                   // min(n, quota): the level's share of N
+    int pad[2];
 };
 struct Summary {                // what the host mirror receives (written by select_kernel)
     int cand[EFX_MAX_LEVELS];
@@ -332,7 +335,7 @@ struct DetectLaunch {
     uint16_t* tcount;           // FAST corners per tile, compact (the row part of a tile's canonical rank)
     uint32_t* nsel;             // selected survivors per tile (select_kernel's counting pass -> its scan)
     RowCtr* rows;               // per tile row: corner / survivor sums
-    int* hist;                  // key histogram of the survivors, EFX_HIST_BINS per level (nms_kernel adds, emit_kernel withdraws)
+    int* hist;                  // key histogram of the survivors, EFX_HIST_BINS per level (nms_kernel adds, select_kernel withdraws)
     unsigned long long* sel_list;   // keys of the threshold's bin, EFX_SEL_LIST_CAP per level
     Corner* cmax;               // strongest corner of every 16x16 cell (quick test of the NMS)
     Corner* surv;
