@@ -135,6 +135,10 @@ def main():
                     help="collective backend for the counters: nccl (= RCCL, the GPU path) or gloo (only with --dry-run)")
     ap.add_argument("--no-affinity", action="store_true",
                     help="do not pin each rank to its slice of the node's CPUs (sharding.pin_to_rank_cpus; N > 1 only)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="N = 1 only: initialise torch.distributed with the nccl (= RCCL) backend at world size 1 and run the counter "
+                         "reductions / gathers through it on device tensors, exactly as the N > 1 ranks do (VERDICT r5 item 6: no "
+                         "multi-GPU box has ever been reachable, so this is the only way RCCL itself executes in a recorded run)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: run the launcher, the rendezvous, the frame sharding and the counter reductions with "
                          "stand-in per-frame numbers (CPU test of the N > 1 plumbing, tests/test_bench_launcher.py)")
@@ -173,10 +177,17 @@ def main():
         cpus = sharding.pin_to_rank_cpus(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     dist = None
     rccl_world = 1
-    if world > 1:
+    rccl_exercised = False
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1 and "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         dist.init_process_group(backend="nccl", rank=rank, world_size=world)   # nccl == RCCL on ROCm
+        rccl_exercised = True
         rccl_world = collective_world(dist, torch.ones(1, dtype=torch.float64, device="cuda"))
         if rccl_world != world:
             raise SystemExit(f"bench.py: RCCL all-reduce saw {rccl_world} ranks, expected {world}")
@@ -449,7 +460,7 @@ def main():
                                "busy_frac": round(lc / 256 / (prof.get("clock_ghz", 2.4) * 1e9) / (iso[dom]["avg_launch_ms"] * 1e-3), 4)}
 
         out = {"metric": "Mkeypoints/s detectAndCompute (8K, 40k kp, BAD512)",
-               "value": round(kp_total / t_max / 1e6, 3), "unit": "Mkeypoints/s", "n_gpus": world, "rccl_world": rccl_world,
+               "value": round(kp_total / t_max / 1e6, 3), "unit": "Mkeypoints/s", "n_gpus": world, "rccl_world": rccl_world, "rccl_exercised": rccl_exercised,
                "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(t_max / args.steps * 1e3, 4),
                "ms_per_step_min_median_max": [round(float(step_ms.min()), 4), round(float(np.median(step_ms)), 4), round(float(step_ms.max()), 4)],

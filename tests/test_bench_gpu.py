@@ -72,3 +72,19 @@ def test_configs_block(line):
         assert r["roofline"]["survey_8d_MB"] > 0 and r["roofline"]["design_MB"] > 0 and r["cpu_baseline"]["repeats"] >= 3
     sizes = {(r.get("mode"), r.get("size"), r.get("descriptor")) for r in by["readme"]}
     assert ("detect", "8k", None) in sizes and ("compute + detectAndCompute", "8k", "BAD512") in sizes
+
+
+def test_force_dist_runs_rccl_at_world_1():
+    """SCALE keeps being skipped, so the N > 1 branch of bench.py has never run with RCCL in a recorded run.
+    `--force-dist` initialises the nccl (= RCCL) process group at world size 1 and sends the same counter reductions / gathers
+    through it on device tensors; `rccl_world` then comes from a real all-reduce.  (No scaling curve is claimed from this.)"""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--force-dist",
+                        "--no-configs", "--no-cpu-baseline", "--sustain-seconds", "0"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    assert j["rccl_exercised"] is True and j["rccl_world"] == 1 and j["n_gpus"] == 1
+    assert j["value"] > 20.0 and len(j["per_rank"]["ms_per_frame"]) == 1
