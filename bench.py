@@ -322,16 +322,19 @@ def main():
         #   blur_levels_kernel (round 4) every level read once, its blurred copy written once: 2 sum_s P_s; the keypoints are then
         #                  described a wave each on the blurred levels (bad_raw_kernel: windows inside the levels + record + descriptor)
         level_blur = bool((lvl == 11).any())
-        kinfo = {0: ("fast_kernel", sumP + 4 * n_corners), 1: ("harris_kernel", sumP + 8 * n_corners),
+        # round 6: fast_kernel leaves 2 B per corner (16-bit tile coordinates in the tile's slot), harris_kernel reads them and
+        # writes one 8-B record per corner below the level's cap
+        kinfo = {0: ("fast_kernel", sumP + 2 * n_corners), 1: ("harris_kernel", sumP + 10 * n_corners),
                  2: ("nms_kernel", 8 * n_corners + 8 * n_surv),
                  10: ("bad_raw_kernel" if level_blur else "bad_det_kernel", sumP + 144 * n_kp), 11: ("blur_levels_kernel", 2 * sumP)}
 
-        def table(ms_, lvl_):
+        def table(ms_, lvl_, frames_per_launch=1):
             t = {}
             for code, (name, nbytes) in kinfo.items():
                 m = ms_[lvl_ == code]
                 if len(m):
                     avg = float(m.mean())
+                    nbytes = nbytes * frames_per_launch        # a frame-batched launch (round 6) moves every frame's bytes
                     t[name] = {"avg_launch_ms": round(avg, 5), "launches_timed": int(len(m)), "algorithmic_bytes": nbytes,
                                "achieved": round(nbytes / (avg * 1e-3) / 1e9, 1), "frac": round(nbytes / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
             return t
@@ -340,8 +343,10 @@ def main():
             nl = max(1, int((lvl_ == 0).sum()))
             return float(ms_[lvl_ >= 100].sum()) / nl            # codes 100 + s: the resize launches
 
-        live = table(ms, lvl)
-        live_chain = chain_ms_per_frame(ms, lvl)
+        # context 0 owns the frames 0, NS, 2 NS, ... of a step: they go through ONE launch of every kernel (round 6)
+        fpl0 = len(range(0, F, NS))
+        live = table(ms, lvl, fpl0)
+        live_chain = chain_ms_per_frame(ms, lvl) / fpl0
         # the same kernels with nothing else running (frames on ONE stream, after the timed region): a kernel property,
         # unlike the live durations, which stretch with the number of frames sharing the GPU -- this is what `frac` quotes
         det.profileEnable(512, stride=1)
@@ -381,7 +386,7 @@ def main():
                        "launch stream around that kernel, frames on one stream (after the timed region), so that the figure is a "
                        "property of the kernel; `live` = the same pairs inside the timed region, three frames in flight",
                 "kernels_isolated": iso,
-                "live": {"concurrent_streams": NS, "kernels": live, "resize_chain_ms_per_frame": round(live_chain, 5)},
+                "live": {"concurrent_streams": NS, "frames_per_launch": fpl0, "kernels": live, "resize_chain_ms_per_frame": round(live_chain, 5)},
                 "whole_frame": {"survey_8d_bytes_per_frame": 0.9e9, "ms_per_frame": round(t_max / args.steps / F * 1e3, 4),
                                 "achieved": round(0.9e9 / (t_max / args.steps / F) / 1e9, 1),
                                 "frac": round(0.9e9 / (t_max / args.steps / F) / 1e9 / HBM_PEAK_GBS, 4)}}
@@ -393,6 +398,9 @@ def main():
             pf_ms = iso_chain + iso["fast_kernel"]["avg_launch_ms"]
             pf_bytes = chain_bytes + iso["fast_kernel"]["algorithmic_bytes"]
             roof["pyramid_fast"] = {"algorithmic_bytes": pf_bytes, "resize_chain_bytes": chain_bytes, "resize_chain_source_levels": srcs,
+                                    "resize_chain_note": "bytes of the row-walking chain under the default EFX_ROWS_SPLIT (an aligned 8K frame takes "
+                                                         "it; a caller's unaligned / odd-width image falls back to the tiled per-level chain, which "
+                                                         "reads every level once more -- ADVICE r5)",
                                     "resize_chain_ms": round(iso_chain, 5),
                                     "fast_kernel_ms": iso["fast_kernel"]["avg_launch_ms"], "ms": round(pf_ms, 5),
                                     "achieved": round(pf_bytes / (pf_ms * 1e-3) / 1e9, 1),
@@ -472,6 +480,7 @@ def main():
                                       "8 levels, scale 1.2, FAST threshold 20, NMS radius 15 (BASELINE.json configs[4])",
                           "frames_per_step_per_gpu": F, "frames_per_step": F * world,
                           "frames_each_once": sorted(sum(all_frames, [])) == list(range(F * world)), "streams_per_gpu": NS,
+                          "frames_per_launch": [len(range(j, F, NS)) for j in range(NS)],
                           "keypoints_per_frame": round(nkp / F, 1), "parallelism": f"frames sharded over {world} GPU(s)"},
                "sustained": sustained if sustained else {"note": "the timed region itself lasted %.2f s" % t_max},
                "per_rank": {"ms_per_frame": [round(t / args.steps / F * 1e3, 4) for t in per_rank_s],

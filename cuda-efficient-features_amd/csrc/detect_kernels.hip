@@ -1303,9 +1303,6 @@ __global__ __launch_bounds__(64 * NW) void harris_kernel(
     const int total = min((int)h.cell_off[EFX_CELLS_PER_TILE], EFX_TILE * EFX_TILE);
     // the tile's canonical rank: loads that need the tile's coordinates only (one memory round trip, beside the header's)
     int rank = 0;
-#ifdef EFX_X_NO_RANK
-    rank = tile * 8;
-#else
     if (lane < 64) {
         // two tile rows and two tiles per lane are requested unconditionally (indices clamped), beside the header: ONE round trip.
         // (A loop with a data-dependent trip count waits for every load where it is issued: measured 7 us of this kernel's 61.)
@@ -1318,7 +1315,6 @@ __global__ __launch_bounds__(64 * NW) void harris_kernel(
         for (int i = lane + 128; i < ty; i += 64) rank += rp[i].cand;       // levels of more than 8192 pixels per side
         for (int i = lane + 128; i < tx; i += 64) rank += (int)tc[i];
     }
-#endif
     auto empty_cells = [&]() {
         // a tile without (valid) corners: sixteen empty cell maxima (smooth frames: most tiles; see nms_kernel)
         if (lane < EFX_CELLS_PER_TILE) {
@@ -1327,9 +1323,7 @@ __global__ __launch_bounds__(64 * NW) void harris_kernel(
         }
     };
     if (total == 0) { empty_cells(); return; }              // no barrier (the header is workgroup-uniform)
-#ifndef EFX_X_NO_RANK
     if (lane < 64) rank = __builtin_amdgcn_readlane(wave_incl_scan(rank), 63);      // DPP steps, no LDS round trips
-#endif
     if (NW > 1) {
         if (lane == 0) s_rank = rank;
         __syncthreads();
@@ -1359,11 +1353,7 @@ __global__ __launch_bounds__(64 * NW) void harris_kernel(
         if ((unsigned)(old >> 32) == (unsigned)(key >> 32)) atomicMax(&s_celltie[cell], (unsigned)(key >> 32));
     };
 
-#ifdef EFX_X_NO_BITMAP
-    if (true) {
-#else
     if (total <= EFX_SLOT_LIST) {
-#endif
         // the common case: fast_kernel left the tile coordinates as a list in canonical order
         const uint16_t* slot = reinterpret_cast<const uint16_t*>(slots + (size_t)gt * EFX_SLOT_BYTES);
         for (int k = lane; k < n_valid; k += 64 * NW) corner(k, (unsigned)slot[k] & 0xfffu);
@@ -1795,7 +1785,7 @@ __global__ __launch_bounds__(64 * NW) void nms_kernel(const LevelTable* __restri
     // second pass: the survivors in canonical order, at the tile's own place in the level's index space (round 6: no allocation --
     // a tile has at most as many survivors as corners, and its corners' places are its own); their number joins the tile row's sum
     // and every survivor one bin of the level's key histogram (select_kernel finds the quota's threshold bin there without a pass
-    // over the survivors; its counting pass withdraws the same counts, so the histogram is zero again when the frame is done)
+    // over the survivors; its leader leaves the histogram zero again for the next frame)
     Corner* surv = surv_all + L.cand_base + own_start;
     int* lhist = hist + (size_t)l * EFX_HIST_BINS;
     int base = 0, round = 0;
@@ -1887,7 +1877,8 @@ __global__ __launch_bounds__(SEL_NT) void select_kernel(const LevelTable* __rest
     const int tid = threadIdx.x, nl = T->nlevels;
     constexpr int TOPSH = 64 - EFX_HIST_BITS;
     constexpr int PER = EFX_HIST_BINS / SEL_NT;                  // bins a leader thread owns
-    static_assert(PER == 64 || PER == 128 || PER == 32, "leader: the owner's bins are re-read by one wave");
+    static_assert(PER == 64 || PER == 128, "leader: the owner's bins are re-read by one wave; owners == threads");
+    static_assert((EFX_HIST_BINS / 32) % PER == 0, "leader: a line's words belong to owners BINS / 32 / PER apart");
 #ifdef EFX_SEL_TIMING
     unsigned long long sel_t[12] = { 0 };
 #endif
@@ -1904,20 +1895,32 @@ __global__ __launch_bounds__(SEL_NT) void select_kernel(const LevelTable* __rest
         (void)block_excl_scan4(partc, s_scan + 4, &nc);
         SEL_TL(1);
         const bool none = !L.active || L.quota <= 0 || cnt->sum.overflow != 0;      // nothing is selected (void frame: N = 0)
-        if (tid == 0) { s_bin = none ? EFX_HIST_BINS : -1; s_inbin = 0; s_rem = 0; }
+        if (tid == 0) { s_bin = none ? EFX_HIST_BINS : -1; s_inbin = 0; s_rem = 0; s_own = 0; s_want = 0; }
         __syncthreads();
         if (!none && n > L.quota) {
             const int* lh = hist + (size_t)l * EFX_HIST_BINS;
             const int own = SEL_NT - 1 - tid;                   // bins PER own .. PER own + PER - 1: thread 0 owns the top
-            int sum = 0;
-            // bin PER own + 32 j + v lies at word v (BINS / 32) + (PER / 32) own + j: PER / 32 consecutive words per plane v
-#pragma unroll 8
-            for (int v = 0; v < 32; v++) {
-                const int* q = lh + v * (EFX_HIST_BINS / 32) + (PER / 32) * own;
-                if (PER == 128) { const int4 x = *reinterpret_cast<const int4*>(q); sum += (x.x + x.y) + (x.z + x.w); }
-                else if (PER == 64) { const int2 x = *reinterpret_cast<const int2*>(q); sum += x.x + x.y; }
-                else sum += q[0];
+            // The whole histogram as coalesced int4 loads (all requested before the first is used); word w of line n is bin
+            // w (BINS / 32) + n (efx_hist_word), whose owner is that bin / PER: the counts meet in s_sub[owner]
+            s_sub[tid] = 0;
+            __syncthreads();
+            {
+                constexpr int NV = EFX_HIST_BINS / 4 / SEL_NT;   // int4 per thread
+                int4 x[NV];
+#pragma unroll
+                for (int k = 0; k < NV; k++) x[k] = reinterpret_cast<const int4*>(lh)[k * SEL_NT + tid];
+#pragma unroll
+                for (int k = 0; k < NV; k++) {
+                    const int i4 = k * SEL_NT + tid, line = i4 >> 3, w0 = (i4 & 7) * 4;
+                    const int o0 = (w0 * (EFX_HIST_BINS / 32) + line) / PER;           // owner of word w0; the next words': + BINS / 32 / PER each
+                    if (x[k].x) atomicAdd(&s_sub[o0], x[k].x);
+                    if (x[k].y) atomicAdd(&s_sub[o0 + EFX_HIST_BINS / 32 / PER], x[k].y);
+                    if (x[k].z) atomicAdd(&s_sub[o0 + 2 * (EFX_HIST_BINS / 32 / PER)], x[k].z);
+                    if (x[k].w) atomicAdd(&s_sub[o0 + 3 * (EFX_HIST_BINS / 32 / PER)], x[k].w);
+                }
             }
+            __syncthreads();
+            const int sum = s_sub[own];
             SEL_TL(2);
             int tot;
             const int before = block_excl_scan4(sum, s_scan, &tot);
@@ -1952,6 +1955,14 @@ __global__ __launch_bounds__(SEL_NT) void select_kernel(const LevelTable* __rest
             efx_st(&S.pub[0], (1ull << 63) | ((unsigned long long)(uint32_t)(s_bin + 1) << 32) | (uint32_t)s_inbin);
         }
         SEL_TL(3);
+        // the level's histogram is read by this workgroup only: it leaves it zero for the next frame (64 KB of coalesced stores behind
+        // the publication, off everybody's path; withdrawing every survivor's count in the counting pass -- the first form -- put
+        // 110 000 more atomics on a natural frame's few hundred hot lines: 12 us of its 19)
+        if (n > 0) {
+            int4* z = reinterpret_cast<int4*>(hist + (size_t)l * EFX_HIST_BINS);
+#pragma unroll
+            for (int k = 0; k < EFX_HIST_BINS / 4 / SEL_NT; k++) z[k * SEL_NT + tid] = make_int4(0, 0, 0, 0);
+        }
 #ifdef EFX_SEL_TIMING
         if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)
             printf("select leader l0 ticks(10ns): rows %llu | hist %llu | scan+bins+publish %llu | n %d bin %d in_bin %d rem %d | start tick %llu\n",
@@ -1988,7 +1999,7 @@ __global__ __launch_bounds__(SEL_NT) void select_kernel(const LevelTable* __rest
     SEL_TC(2);
     const bool all_bin = rem == in_bin, listed = !all_bin && in_bin <= EFX_SEL_LIST_CAP;
     unsigned long long* lst = sel_list + (size_t)l * EFX_SEL_LIST_CAP;
-    int* lhist = hist + (size_t)l * EFX_HIST_BINS;
+    const int lane64 = tid & 63;
     int c = 0;
     {
         int scmax = sc;
@@ -2001,16 +2012,26 @@ __global__ __launch_bounds__(SEL_NT) void select_kernel(const LevelTable* __rest
             }
 #pragma unroll
             for (int u = 0; u < SEL_ILP; u++) {
-                if (j0 + u < sc) {
-                    const unsigned long long key = efx_select_key(s[u].xy, s[u].resp);
-                    const int kb = (int)(key >> TOPSH);
-                    // the survivor's count leaves the key histogram again (nms_kernel added it, the leader has read it)
-                    __hip_atomic_fetch_add(&lhist[efx_hist_word((uint32_t)kb)], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (kb > bin || (kb == bin && all_bin)) c++;
-                    else if (kb == bin && listed) {
-                        const int pos = atomicAdd(&cnt->sel[l].list_n, 1);
+                const unsigned long long key = efx_select_key(s[u].xy, s[u].resp);
+                const int kb = j0 + u < sc ? (int)(key >> TOPSH) : -2;
+                if (kb > bin || (kb == bin && all_bin)) c++;
+                // the keys of the threshold's bin go to the level's list: one returning atomic per level and wave step, not per key
+                // (a natural frame has ~500 of them: 5 us of same-word atomics)
+                const bool app = kb == bin && listed;
+                unsigned long long am = __ballot(app);
+                while (am != 0ull) {
+                    // (the lanes of a wave may hold tiles of two levels where levels meet: one round per level)
+                    const int lead = __ffsll((long long)am) - 1;
+                    const int ll = __shfl(l, lead, 64);
+                    const unsigned long long mine = __ballot(app && l == ll);
+                    int base = 0;
+                    if (lane64 == lead) base = atomicAdd(&cnt->sel[ll].list_n, __popcll(mine));
+                    base = __shfl(base, lead, 64);
+                    if (app && l == ll) {
+                        const int pos = base + __popcll(mine & ((1ull << lane64) - 1ull));
                         if (pos < EFX_SEL_LIST_CAP) efx_st(&lst[pos], key);
                     }
+                    am &= ~mine;
                 }
             }
         }
@@ -2172,7 +2193,7 @@ __global__ __launch_bounds__(SEL_NT) void select_kernel(const LevelTable* __rest
 #pragma unroll
                 for (int r = 0; r < NL; r++) {
                     const int t = 2 * (r * SEL_NT + tid);
-                    lo[r] = efx_ld(&ns[min(seg + t, ntiles - 1)]);
+                    lo[r] = efx_ld(&ns[min(seg + t, ntiles - 1)]);      // (plain loads measured the same: 23.3 against 22.8 us)
                     hi[r] = efx_ld(&ns[min(seg + t + 1, ntiles - 1)]);
                 }
 #pragma unroll
@@ -2219,7 +2240,7 @@ __global__ __launch_bounds__(SEL_NT) void select_kernel(const LevelTable* __rest
 #pragma unroll
             for (int r = 0; r < 2 * CW; r++) {
                 const int t = tid * 2 * CW + r;
-                if (t < nseg) hl[seg + t].out_off = (uint32_t)pre;      // (a thread's headers: consecutive 64-byte lines)
+                if (t < nseg) nsel[F.tile_base + seg + t] = (uint32_t)pre;      // the counts' words now hold the offsets (emit_kernel)
                 pre += v[r];
             }
             running += tot;
@@ -2288,9 +2309,11 @@ __global__ __launch_bounds__(64) void emit_kernel(const LevelTable* __restrict__
                                                   const Corner* __restrict__ surv_all, const Counters* __restrict__ cnt,
                                                   const uint8_t* __restrict__ img0, int pitch0, const uint8_t* __restrict__ pyramid,
                                                   size_t kps_pitch, int capacity,
-                                                  float4* __restrict__ kp4, int* __restrict__ kp_level, const FrameOut out, const FrameStride fs)
+                                                  float4* __restrict__ kp4, int* __restrict__ kp_level, const uint32_t* __restrict__ out_off_all,
+                                                  const FrameOut out, const FrameStride fs)
 {
     uint8_t* const kps = out.kps[blockIdx.y];
+    out_off_all += blockIdx.y * fs.hdr;
     hdr += blockIdx.y * fs.hdr; surv_all += blockIdx.y * fs.cand; cnt += blockIdx.y; kp4 += blockIdx.y * fs.kp; kp_level += blockIdx.y * fs.kp;
     // EMIT_TPW tiles per wave, 64 / EMIT_TPW lanes each (round 3): a tile has three survivors on average and the kernel is a
     // chain of dependent loads per wave (tile word -> header -> survivors), so its time is the number of waves the chip must
@@ -2305,7 +2328,7 @@ __global__ __launch_bounds__(64) void emit_kernel(const LevelTable* __restrict__
     const bool act = tile_ok && L.active;               // (a void frame's threshold is above every key: nothing is selected)
     const unsigned start = act ? min(hdr[gt].cand_start, (unsigned)L.cap) : 0u;
     const int sc = act ? min((int)min(hdr[gt].surv_count, (uint32_t)(EFX_TILE * EFX_TILE)), L.cap - (int)start) : 0;
-    const int out_off = act ? (int)hdr[gt].out_off : 0;
+    const int out_off = act ? (int)out_off_all[gt] : 0;
     int sc_max = sc;
 #pragma unroll
     for (int d = LPT; d < 64; d <<= 1) sc_max = max(sc_max, __shfl_xor(sc_max, d, 64));
@@ -2797,7 +2820,7 @@ static hipError_t efx_launch_detect_impl(const DetectLaunch& a, hipStream_t stre
                        a.surv, a.rows, a.hist, a.sel_list, a.nsel, a.counters, a.capacity, out, a.fs);
     EFX_TRACE_POINT("select");
     hipLaunchKernelGGL(emit_kernel, dim3((H.total_tiles + EMIT_TPW - 1) / EMIT_TPW, B), dim3(64), 0, stream, a.d_table, a.hdr, a.surv, a.counters,
-                       a.img0, a.pitch0, a.pyramid, a.kps_pitch, a.capacity, a.kp4, a.kp_level, out, a.fs);
+                       a.img0, a.pitch0, a.pyramid, a.kps_pitch, a.capacity, a.kp4, a.kp_level, a.nsel, out, a.fs);
     EFX_TRACE_POINT("emit");
     if (a.capacity > 0) {
         // the image the describer's records refer to: the raw levels, or their blurred copies (blur_levels_kernel above)

@@ -400,7 +400,7 @@ struct efx_context {
     LevelTable h_table;
     DevBuf d_table, pyramid, hdr, cand, cmax, surv, counters, kp4, kp_level, img, kps, descout, count, maskbuf;
     DevBuf slots, tcount, nsel, rowsum, hist, sel_list;            // round 6: per-tile corner slots / counts, per-row sums, key histograms (efx_device.h)
-    bool hist_clean = false;        // the key histograms are zero (nms_kernel adds, emit_kernel withdraws: they stay zero across frames
+    bool hist_clean = false;        // the key histograms are zero (nms_kernel adds, select_kernel's leaders read and clear: they stay zero across frames
                                     // unless a call failed half-way or the buffer is new)
     DevBuf rplan; ResizePlanLevel rplan_lv[EFX_MAX_LEVELS];        // resize plan (tables of resize_stream_kernel)
     RowsPlanLaunch rows_plan[EFX_MAX_LEVELS];                       // ... and of resize_rows_kernel, by source level
@@ -955,7 +955,7 @@ int detect_frames(efx_context* c, int nframes, const uint8_t* const* d_images, i
     a.hist = static_cast<int*>(c->hist.p);
     a.sel_list = static_cast<unsigned long long*>(c->sel_list.p);
     if (!c->hist_clean) {
-        // nms_kernel adds to the key histograms, emit_kernel withdraws the same counts: they are zero between frames, and only a new
+        // nms_kernel adds to the key histograms, select_kernel's leaders clear them: they are zero between frames, and only a new
         // buffer (or a call that failed half-way) needs clearing
         HIP_TRY(c->err, hipMemsetAsync(c->hist.p, 0, c->hist.bytes, stream));
     }

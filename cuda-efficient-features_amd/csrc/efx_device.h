@@ -62,7 +62,7 @@ struct __attribute__((aligned(64))) TileHdr {
     uint32_t cand_start;        // canonical rank of the tile's first corner in its level == where its corners (cand) and survivors
                                 // (surv) start in the level's arrays (harris_kernel; may exceed the level's cap: then none exist)
     uint32_t surv_count;        // nms_kernel
-    uint32_t out_off;           // output index of the tile's first selected survivor (select_kernel)
+    uint32_t out_off;           // (unused since round 6: the offsets are a compact array, DetectLaunch::nsel)
     uint32_t pad0;
     uint16_t cell_off[EFX_CELLS_PER_TILE + 1];   // start of each cell's corners inside the tile list (fast_kernel)
     uint16_t pad[7];
@@ -138,10 +138,11 @@ __device__ __forceinline__ float4 efx_load_keypoint(const float4* __restrict__ k
 
 // the frame is void: arena contents that fail their range checks (never a property of the frame itself, see Summary::overflow)
 __device__ __forceinline__ void efx_raise_overflow(const LevelTable*, Counters* cnt) { cnt->sum.overflow = 1; }
-// word of key-histogram bin b: neighbouring bins lie 4 KB apart, so that the survivors' updates (responses of one frame crowd into
-// a few hundred neighbouring bins) spread over ~1000 lines instead of a few dozen, and a thread that owns 128 consecutive bins
-// reads them as 32 coalesced int4 (select_kernel's leader)
-__host__ __device__ inline uint32_t efx_hist_word(uint32_t b) { return ((b & 31u) << (EFX_HIST_BITS - 5)) | (b >> 5); }
+// word of key-histogram bin b: neighbouring bins lie in neighbouring 128-byte LINES (bin b in line b mod BINS / 32, word b / (BINS /
+// 32) of it).  The survivors' responses of one frame crowd into a few hundred neighbouring bins -- ~100 on frames with the
+// statistics of photographs -- and device-scope atomics on one line serialise at ~11 ns each: measured for 100 hit bins and 100 000
+// updates (tools/microbench/hist_layout.cpp), 45 us with neighbouring bins 2 KB apart (32 lines hit), 14 us this way
+__host__ __device__ inline uint32_t efx_hist_word(uint32_t b) { return ((b & (EFX_HIST_BINS / 32 - 1)) << 5) | (b >> (EFX_HIST_BITS - 5)); }
 #endif
 
 // One packed word per tile behind the level table: level | tx << 5 | ty << 15.  The level field must hold EFX_MAX_LEVELS
@@ -333,9 +334,10 @@ struct DetectLaunch {
     Corner* cand;
     unsigned char* slots;       // EFX_SLOT_BYTES per tile: corner list or bitmap (fast_kernel -> harris_kernel)
     uint16_t* tcount;           // FAST corners per tile, compact (the row part of a tile's canonical rank)
-    uint32_t* nsel;             // selected survivors per tile (select_kernel's counting pass -> its scan)
+    uint32_t* nsel;             // selected survivors per tile (select_kernel's counting pass), then -- same words -- the output index of the
+                                // tile's first selected survivor (its scan -> emit_kernel)
     RowCtr* rows;               // per tile row: corner / survivor sums
-    int* hist;                  // key histogram of the survivors, EFX_HIST_BINS per level (nms_kernel adds, select_kernel withdraws)
+    int* hist;                  // key histogram of the survivors, EFX_HIST_BINS per level (nms_kernel adds, select_kernel's leaders read and clear)
     unsigned long long* sel_list;   // keys of the threshold's bin, EFX_SEL_LIST_CAP per level
     Corner* cmax;               // strongest corner of every 16x16 cell (quick test of the NMS)
     Corner* surv;

@@ -72,6 +72,13 @@ def test_configs_block(line):
         assert r["roofline"]["survey_8d_MB"] > 0 and r["roofline"]["design_MB"] > 0 and r["cpu_baseline"]["repeats"] >= 3
     sizes = {(r.get("mode"), r.get("size"), r.get("descriptor")) for r in by["readme"]}
     assert ("detect", "8k", None) in sizes and ("compute + detectAndCompute", "8k", "BAD512") in sizes
+    # frame-batched launches (round 6): FHD x 16 and 4K x 8 per launch chain, beside the per-frame form of the same entry point
+    b = {r["size"]: r for r in by["batch"]}
+    assert b["fhd"]["frames_per_launch"] == 16 and b["4k"]["frames_per_launch"] == 8
+    assert b["fhd"]["batched"]["frames_per_s"] > b["fhd"]["per_frame_calls"]["frames_per_s"] > 1000
+    # dense frames are complete on a context's first call
+    for r in by["data"]:
+        assert r["first_call_keypoints"] == r["keypoints"] == 40000 and r["overflow_events"] == 0
 
 
 def test_force_dist_runs_rccl_at_world_1():

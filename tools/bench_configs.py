@@ -75,7 +75,7 @@ def detect_bytes(det, rows, cols, stats):
     return survey, design, sum(P)
 
 
-def measure(cef, iters=30, cpu_baseline=True, sizes=("fhd", "4k", "8k"), log=lambda s: None, data_rows=True):
+def measure(cef, iters=30, cpu_baseline=True, sizes=("fhd", "4k", "8k"), log=lambda s: None, data_rows=True, batch_rows=True):
     import torch
     EF = cef.EfficientFeatures
     types = (("BAD256", EF.BAD_256, 32), ("BAD512", EF.BAD_512, 64), ("HashSIFT256", EF.HASH_SIFT_256, 32), ("HashSIFT512", EF.HASH_SIFT_512, 64))
@@ -191,8 +191,8 @@ def measure(cef, iters=30, cpu_baseline=True, sizes=("fhd", "4k", "8k"), log=lam
             del d
     # ---- data dependence of the headline: the same call on frames with the statistics of photographs.  The
     # headline's rectangle frames have 2.8 M FAST corners per 8K frame (1 pixel in 37); a 1/f^1.3 texture has ~3 % corners, a 1/f^1.0
-    # one ~17 % -- the reference's 10 % candidate cap (.cpp:252, spec S2) is active and the density-sized corner arenas overflow once
-    # (the context then switches to worst-case arenas: the rows are timed after that)
+    # one ~17 % -- the reference's 10 % candidate cap (.cpp:252, spec S2) is active.  Since round 6 the FIRST call on such a frame is
+    # complete (first_call_keypoints; rounds 2-5: void once, then the context regrew to 2.1 GB)
     if "8k" in sizes and data_rows:
         r_, c_ = synth.SIZES["8k"]
         log("natural-statistics frames")
@@ -201,12 +201,8 @@ def measure(cef, iters=30, cpu_baseline=True, sizes=("fhd", "4k", "8k"), log=lam
             img = torch.from_numpy(f).cuda()
             d = EF.create(workloads.N40K, dtype=EF.BAD_512)
             desc = torch.zeros((workloads.N40K, 64), dtype=torch.uint8, device="cuda")
-            for _ in range(3):                               # arena growth (beta 1.0) happens here, not in the timed calls
-                d.detectAndComputeAsync(img, kps, desc, cnt); torch.cuda.synchronize()
-                try:
-                    d.lastCount()
-                except Exception:                            # EFX_ERR_OVERFLOW: the void frame that makes the context enlarge its arenas
-                    pass
+            d.detectAndComputeAsync(img, kps, desc, cnt); torch.cuda.synchronize()
+            first_n = int(cnt.item())                         # the context's very first call
             t = perf(torch, lambda: d.detectAndComputeAsync(img, kps, desc, cnt), iters)
             n = int(cnt.item())
             st = d.lastLevelStats()
@@ -216,11 +212,56 @@ def measure(cef, iters=30, cpu_baseline=True, sizes=("fhd", "4k", "8k"), log=lam
                                     frame="1/f^%.1f octave noise (tools/synth.py powerlaw_frames_tiled, seed 1000)" % beta,
                                     fast_corners=int(C), fast_corners_frac_of_pixels=round(C / sumP, 4), nms_survivors=int(S), keypoints=n,
                                     cap_active=bool(any(x["n_candidates"] >= 0.1 * x2 for x, x2 in zip(st, [d.levelGeometry(r_, c_, l)[0] * d.levelGeometry(r_, c_, l)[1] for l in range(8)]))),
-                                    overflow_events=int(d.overflowEvents()) if hasattr(d, "overflowEvents") else None,
+                                    first_call_keypoints=first_n, overflow_events=int(d.overflowEvents()) if hasattr(d, "overflowEvents") else None,
                                     device_MB=round(d.deviceBytes() / 1e6, 1) if hasattr(d, "deviceBytes") else None,
                                     **t, Mkeypoints_per_s=round(n / t["ms"] / 1e3, 2),
                                     roofline=roof(bs2 + 7 * sumP + 46 * 46 * 4 * n + n * 64, bd2 + sumP + (80 + 64) * n, t["ms"])))
             del d
+    # ---- frame-batched launches (round 6; SURVEY 8b, samples/sample_image_sequence.cpp:70-105): B same-sized frames per launch
+    # chain on each of two contexts / streams, distinct resident frames, against the same entry point as a loop of single-frame
+    # calls (EFX_NO_BATCH=1, four contexts: the best per-frame form of round 5)
+    if batch_rows:
+        def frames_per_s(size, B, nctx, seconds=1.0):
+            r_, c_ = synth.SIZES[size]
+            nd = min(B * nctx, 16)
+            base = [torch.from_numpy(synth.synth_frame(r_, c_, seed=1000 + k)).cuda() for k in range(nd)]
+            Fn = B * nctx
+            fr = [base[i % nd] for i in range(Fn)]
+            dets = [EF.create(workloads.N40K, dtype=EF.BAD_512) for _ in range(nctx)]
+            sts = [torch.cuda.Stream() for _ in range(nctx)]
+            kk = [torch.zeros((5, workloads.N40K), dtype=torch.float32, device="cuda") for _ in range(Fn)]
+            dd = [torch.zeros((workloads.N40K, 64), dtype=torch.uint8, device="cuda") for _ in range(Fn)]
+            cc = [torch.zeros(1, dtype=torch.int32, device="cuda") for _ in range(Fn)]
+            b = cef.Batch(dets, sts, fr, kk, dd, cc, workloads.N40K)
+            for _ in range(3):
+                b.run()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter(); nrun = 0
+            while True:
+                for _ in range(10):
+                    b.run()
+                nrun += 10
+                torch.cuda.synchronize()
+                if time.perf_counter() - t0 >= seconds:
+                    break
+            dt = time.perf_counter() - t0
+            nk = int(sum(int(c.item()) for c in cc))
+            out = dict(frames_per_s=round(nrun * Fn / dt, 1), ms_per_frame=round(dt / (nrun * Fn) * 1e3, 5), keypoints_per_frame=round(nk / Fn, 1),
+                       Mpx_per_s=round(nrun * Fn * r_ * c_ / dt / 1e6, 1), device_MB_per_context=round(dets[0].deviceBytes() / 1e6, 1))
+            del b, dets
+            return out
+        for size, B in (("fhd", 16), ("4k", 8), ("8k", 2)):
+            if size not in sizes:
+                continue
+            log("batch " + size)
+            row = dict(config="batch", mode="detectAndCompute", size=size, descriptor="BAD512", frames_per_launch=B, contexts=2,
+                       batched=frames_per_s(size, B, 2))
+            os.environ["EFX_NO_BATCH"] = "1"
+            try:
+                row["per_frame_calls"] = dict(frames_per_s(size, 1, 4), contexts=4)
+            finally:
+                del os.environ["EFX_NO_BATCH"]
+            res["rows"].append(row)
     if oracle:
         oracle.set_threads(1)
     return res
