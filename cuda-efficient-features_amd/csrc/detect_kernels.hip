@@ -1272,49 +1272,16 @@ __device__ __forceinline__ int efx_row16_incl_scan(int v)
 
 // NW waves per tile (round 3, as nms_kernel): frames whose tiles do not fill the chip by themselves spread a tile's corners
 // over several waves (the corners are independent; the per-cell maxima meet in LDS atomics).
+// One tile's corners by the whole workgroup: responses, records at cand[rank + k], the tile's sixteen cell maxima.
 template <int NW>
-__global__ __launch_bounds__(64 * NW) void harris_kernel(
-    const LevelTable* __restrict__ T, const uint8_t* __restrict__ img0, int pitch0, int aligned0,
-    const uint8_t* __restrict__ pyramid, const unsigned char* __restrict__ slots, const uint16_t* __restrict__ tcount, const RowCtr* __restrict__ rows,
-    Corner* __restrict__ cand_all, Corner* __restrict__ cmax_all, TileHdr* __restrict__ hdr_all, int dbg_arg, const FrameSet F)
+__device__ __forceinline__ void harris_one_tile(const LevelDev& L, int gt, int tx, int ty, int total, int rank, const uint8_t* __restrict__ src, int spitch,
+                                                bool aligned, const unsigned char* __restrict__ slots, Corner* __restrict__ cand_all,
+                                                Corner* __restrict__ cmax_all, TileHdr& h, int dbg, int lane)
 {
-    const int dbg = EFX_DBG(dbg_arg);
-    {
-        const size_t f = blockIdx.y;
-        img0 = F.in.img0[f]; pyramid += f * F.fs.pyramid; slots += f * F.fs.slots; tcount += f * F.fs.hdr; rows += f * F.fs.rows;
-        cand_all += f * F.fs.cand; cmax_all += f * F.fs.cmax; hdr_all += f * F.fs.hdr;
-    }
     __shared__ unsigned long long s_cellmax[EFX_CELLS_PER_TILE];
     __shared__ unsigned s_celltie[EFX_CELLS_PER_TILE];     // largest response key that two corners of the cell share
     __shared__ uint16_t s_xy[EFX_SLOT_LIST];               // bitmap tiles: a chunk of the corners' tile coordinates in canonical order
     __shared__ unsigned s_enum[4][64];                     // ... and the enumeration state of row r's four segments
-    __shared__ int s_rank;
-    const int lane = threadIdx.x;                           // 0 .. 64 NW - 1: a corner slot of the round, not the hardware lane
-    const int gt = T->total_tiles - 1 - xcd_interleaved(blockIdx.x, T->total_tiles);      // densest tiles first
-    int l, tx, ty;
-    efx_tile_of(T, gt, l, tx, ty);
-    const LevelDev& L = T->lv[l];
-    if (!L.active) return;
-    const int tile = gt - L.tile_base;
-    const uint8_t* src = l == 0 ? img0 : pyramid + L.img_off;
-    const int spitch = l == 0 ? pitch0 : L.pitch;
-    const bool aligned = l == 0 ? aligned0 != 0 : true;
-    TileHdr& h = hdr_all[L.tile_base + tile];
-    const int total = min((int)h.cell_off[EFX_CELLS_PER_TILE], EFX_TILE * EFX_TILE);
-    // the tile's canonical rank: loads that need the tile's coordinates only (one memory round trip, beside the header's)
-    int rank = 0;
-    if (lane < 64) {
-        // two tile rows and two tiles per lane are requested unconditionally (indices clamped), beside the header: ONE round trip.
-        // (A loop with a data-dependent trip count waits for every load where it is issued: measured 7 us of this kernel's 61.)
-        const RowCtr* rp = rows + L.row_base;
-        const uint16_t* tc = tcount + L.tile_base + ty * L.tiles_x;
-        const int ym = max(ty - 1, 0), xm = max(tx - 1, 0);
-        const int v0 = rp[min(lane, ym)].cand, v1 = rp[min(lane + 64, ym)].cand;
-        const int w0 = (int)tc[min(lane, xm)], w1 = (int)tc[min(lane + 64, xm)];
-        rank = (lane < ty ? v0 : 0) + (lane + 64 < ty ? v1 : 0) + (lane < tx ? w0 : 0) + (lane + 64 < tx ? w1 : 0);
-        for (int i = lane + 128; i < ty; i += 64) rank += rp[i].cand;       // levels of more than 8192 pixels per side
-        for (int i = lane + 128; i < tx; i += 64) rank += (int)tc[i];
-    }
     auto empty_cells = [&]() {
         // a tile without (valid) corners: sixteen empty cell maxima (smooth frames: most tiles; see nms_kernel)
         if (lane < EFX_CELLS_PER_TILE) {
@@ -1322,17 +1289,12 @@ __global__ __launch_bounds__(64 * NW) void harris_kernel(
             cmax_all[L.cmax_base + (size_t)(ty * 4 + (lane >> 2)) * (L.tiles_x * 4) + tx * 4 + (lane & 3)] = best;
         }
     };
-    if (total == 0) { empty_cells(); return; }              // no barrier (the header is workgroup-uniform)
-    if (lane < 64) rank = __builtin_amdgcn_readlane(wave_incl_scan(rank), 63);      // DPP steps, no LDS round trips
-    if (NW > 1) {
-        if (lane == 0) s_rank = rank;
-        __syncthreads();
-        rank = s_rank;
-    }
+    if (total == 0) { empty_cells(); return; }              // no barrier (workgroup-uniform)
     if (lane == 0) h.cand_start = (uint32_t)rank;           // nms_kernel: where this tile's (and its neighbours') lists start
     const int n_valid = min(max(L.cap - rank, 0), total);   // the cap in canonical order (spec S2; cuda_fast.cu:245)
     if (n_valid == 0) { empty_cells(); return; }
     Corner* cand = cand_all + L.cand_base + (size_t)rank;
+    __syncthreads();                                        // (a workgroup that takes several tiles: the previous one's cell maxima are out)
     if (lane < EFX_CELLS_PER_TILE) { s_cellmax[lane] = 0ull; s_celltie[lane] = 0u; }
     __syncthreads();
 
@@ -1410,6 +1372,183 @@ __global__ __launch_bounds__(64 * NW) void harris_kernel(
         }
         cmax_all[L.cmax_base + (size_t)(ty * 4 + (lane >> 2)) * (L.tiles_x * 4) + tx * 4 + (lane & 3)] = best;
     }
+}
+
+// Frames with the statistics of photographs have 8 .. 20 FAST corners per 64 x 64 tile, not ~110: a wave per tile then runs one
+// round of Harris arithmetic for a dozen busy lanes.  Such frames are taken EFX_PACK_TPW TILES PER WAVE (harris_packed_kernel: a
+// one-wave workgroup per group of consecutive tiles of a level): a tile's canonical rank is the first tile's rank + the counts of
+// the group's tiles before it (one scan), the group's corners stand side by side -- corner n of the group is corner n - (corners
+// of the tiles before its tile) of its tile -- and go through the arithmetic 64 per round, full rounds whatever the tiles' own
+// counts are; the cell maxima meet in LDS.  Same records, same places: bit-identical, so which kernel a launch takes is a matter
+// of speed alone -- the host picks it from the corner density of the context's PREVIOUS frame (a hint select_kernel leaves in host
+// memory; video frames resemble their predecessors; efx_api.cpp), EFX_PACK=0 / 1 pins it.  On corner-rich frames the packed form
+// is the slower one (63 -> 113 us: few, long waves, nothing hides their load latency).
+// What it buys is modest, and measured why (round 6, 1/f^1.3 8K frame, tools/microbench/pack_ab.sh): 33 -> 26.5 us.  With the Harris
+// arithmetic and its pixel loads compiled out the two forms take 17 and 12 us -- the per-corner part costs the same 14 .. 18 us
+// packed or not: 328 000 scattered corners x 9 footprint rows are ~3 M line requests that miss L1 (on the corner-rich frame
+// neighbouring corners share their lines), i.e. the kernel is bound by the gather from L2 there, not by half-empty waves.
+// (Built and dropped on the way: both kinds of workgroup in every launch, each level's deciding for themselves from the row sums --
+// the 25 500 workgroups that only find out that they are not needed cost a memory round trip each: 41 us instead of 33.)
+__global__ __launch_bounds__(64) void harris_packed_kernel(
+    const LevelTable* __restrict__ T, const uint8_t* __restrict__ img0, int pitch0, int aligned0,
+    const uint8_t* __restrict__ pyramid, const unsigned char* __restrict__ slots, const uint16_t* __restrict__ tcount, const RowCtr* __restrict__ rows,
+    Corner* __restrict__ cand_all, Corner* __restrict__ cmax_all, TileHdr* __restrict__ hdr_all, int dbg_arg, const FrameSet F)
+{
+    const int dbg = EFX_DBG(dbg_arg);
+    {
+        const size_t f = blockIdx.y;
+        img0 = F.in.img0[f]; pyramid += f * F.fs.pyramid; slots += f * F.fs.slots; tcount += f * F.fs.hdr; rows += f * F.fs.rows;
+        cand_all += f * F.fs.cand; cmax_all += f * F.fs.cmax; hdr_all += f * F.fs.hdr;
+    }
+    __shared__ unsigned long long s_cm[EFX_PACK_TPW][EFX_CELLS_PER_TILE];
+    __shared__ unsigned s_ct[EFX_PACK_TPW][EFX_CELLS_PER_TILE];
+    __shared__ int s_P[EFX_PACK_TPW + 1];                  // corners of the group before tile j (valid ones: below the level's cap)
+    __shared__ int s_rk[EFX_PACK_TPW];                     // the tiles' canonical ranks
+    __shared__ uint32_t s_txy[EFX_PACK_TPW];               // tx | ty << 16
+    const int lane = threadIdx.x;
+    int g = (int)blockIdx.x;
+    int l = 0;
+    while (l + 1 < T->nlevels && g >= T->lv[l].pack_groups) { g -= T->lv[l].pack_groups; l++; }
+    const LevelDev& L = T->lv[l];
+    if (!L.active || g >= L.pack_groups) return;
+    const int ntiles = L.tiles_x * L.tiles_y;
+    const int t0 = ntiles - EFX_PACK_TPW * (g + 1);        // densest (last) tiles first; the last group may start below tile 0
+    const int tb = max(t0, 0);                             // the group's first tile
+    const uint8_t* src = l == 0 ? img0 : pyramid + L.img_off;
+    const int spitch = l == 0 ? pitch0 : L.pitch;
+    const bool aligned = l == 0 ? aligned0 != 0 : true;
+    // the first tile's canonical rank by the whole wave (as harris_kernel), the tiles' own counts by lanes 0 .. 15: one round trip
+    const int t = t0 + lane;
+    const bool tile_ok = lane < EFX_PACK_TPW && t >= 0;
+    const int total = tile_ok ? min((int)tcount[L.tile_base + t], EFX_TILE * EFX_TILE) : 0;
+    int btx, bty, bl;
+    efx_tile_of(T, L.tile_base + tb, bl, btx, bty);
+    int rank0;
+    {
+        const RowCtr* rp = rows + L.row_base;
+        const uint16_t* tc = tcount + L.tile_base + bty * L.tiles_x;
+        const int ym = max(bty - 1, 0), xm = max(btx - 1, 0);
+        const int v0 = rp[min(lane, ym)].cand, v1 = rp[min(lane + 64, ym)].cand;
+        const int w0 = (int)tc[min(lane, xm)], w1 = (int)tc[min(lane + 64, xm)];
+        int r = (lane < bty ? v0 : 0) + (lane + 64 < bty ? v1 : 0) + (lane < btx ? w0 : 0) + (lane + 64 < btx ? w1 : 0);
+        for (int q = lane + 128; q < bty; q += 64) r += rp[q].cand;
+        for (int q = lane + 128; q < btx; q += 64) r += (int)tc[q];
+        rank0 = __builtin_amdgcn_readlane(wave_incl_scan(r), 63);
+    }
+    const int rank = rank0 + wave_incl_scan(total) - total; // (lanes beyond the group hold 0)
+    const int n_valid = min(max(L.cap - rank, 0), total);   // the cap in canonical order (spec S2; cuda_fast.cu:245)
+    const int pincl = wave_incl_scan(n_valid);
+    const int sum = __builtin_amdgcn_readlane(pincl, 63);
+    uint32_t txy = 0;
+    if (tile_ok) {
+        int l2, tx, ty;
+        efx_tile_of(T, L.tile_base + t, l2, tx, ty);
+        txy = (uint32_t)tx | ((uint32_t)ty << 16);
+        if (total > 0) hdr_all[L.tile_base + t].cand_start = (uint32_t)rank;     // nms_kernel: where the tile's lists start
+    }
+    if (__ballot(total > EFX_SLOT_LIST) != 0ull) {
+        // a tile whose slot holds its bitmap (more than 256 corners): the group tile by tile, the whole wave each
+        for (int j = 0; j < EFX_PACK_TPW; j++) {
+            if (t0 + j < 0) continue;
+            const uint32_t jxy = (uint32_t)__builtin_amdgcn_readlane((int)txy, j);
+            const int jgt = L.tile_base + t0 + j;
+            harris_one_tile<1>(L, jgt, (int)(jxy & 0xffffu), (int)(jxy >> 16), __builtin_amdgcn_readlane(total, j), __builtin_amdgcn_readlane(rank, j),
+                               src, spitch, aligned, slots, cand_all, cmax_all, hdr_all[jgt], dbg, lane);
+        }
+        return;
+    }
+    if (lane < EFX_PACK_TPW) { s_P[lane] = pincl - n_valid; s_rk[lane] = rank; s_txy[lane] = txy; }
+    if (lane == 0) s_P[EFX_PACK_TPW] = sum;
+    static_assert(EFX_PACK_TPW == 4 || EFX_PACK_TPW == 8 || EFX_PACK_TPW == 16, "a power of two: the tile search; whole rounds of cells per wave");
+#pragma unroll
+    for (int q = 0; q < EFX_PACK_TPW * EFX_CELLS_PER_TILE / 64; q++) { (&s_cm[0][0])[lane + 64 * q] = 0ull; (&s_ct[0][0])[lane + 64 * q] = 0u; }
+    __syncthreads();
+    for (int n = lane; n < sum; n += 64) {
+        // the tile that holds corner n of the group: the last j with s_P[j] <= n
+        int j = 0;
+#pragma unroll
+        for (int step = EFX_PACK_TPW / 2; step >= 1; step >>= 1) if (s_P[j + step] <= n) j += step;
+        const int k = n - s_P[j];
+        const uint32_t jxy = s_txy[j];
+        const int jtx = (int)(jxy & 0xffffu), jty = (int)(jxy >> 16);
+        const unsigned lxy = (unsigned)reinterpret_cast<const uint16_t*>(slots + (size_t)(L.tile_base + t0 + j) * EFX_SLOT_BYTES)[k] & 0xfffu;
+        const int x = jtx * EFX_TILE + (int)(lxy & 63u), yy = jty * EFX_TILE + (int)(lxy >> 6), y = min(yy, L.rows - 1);
+        const uint32_t xy = (uint32_t)x | ((uint32_t)yy << 16);
+        const uint8_t* c = src + (size_t)y * spitch + x;
+        const float resp = (dbg & 4) ? 1.f : (aligned ? harris_rows(c - 4 * spitch - 4, spitch) : harris_bytes(c, spitch));
+        Corner rec; rec.xy = xy; rec.resp = resp;
+        cand_all[L.cand_base + (size_t)s_rk[j] + k] = rec;
+        const int cell = (int)((lxy >> 10) & 3u) * 4 + (int)((lxy >> 4) & 3u);
+        const unsigned long long key = (efx_select_key(0u, resp) & 0xffffffff00000000ull) | xy;
+        const unsigned long long old = atomicMax(&s_cm[j][cell], key);
+        if ((unsigned)(old >> 32) == (unsigned)(key >> 32)) atomicMax(&s_ct[j][cell], (unsigned)(key >> 32));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < EFX_PACK_TPW * EFX_CELLS_PER_TILE / 64; q++) {
+        const int e = lane + 64 * q, j = e >> 4, cell = e & 15;
+        if (t0 + j < 0) continue;
+        const unsigned long long m = s_cm[j][cell];
+        Corner best; best.xy = 0xffffffffu; best.resp = -3.0e38f;
+        if (m != 0ull) {
+            uint32_t u = (uint32_t)(m >> 32);
+            u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;          // inverse of the order-preserving map
+            best.resp = __uint_as_float(u); best.xy = (uint32_t)m;
+            if (s_ct[j][cell] == (uint32_t)(m >> 32)) best.xy |= EFX_CMAX_TIE;
+        }
+        const uint32_t jxy = s_txy[j];
+        cmax_all[L.cmax_base + (size_t)((int)(jxy >> 16) * 4 + (cell >> 2)) * (L.tiles_x * 4) + (int)(jxy & 0xffffu) * 4 + (cell & 3)] = best;
+    }
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void harris_kernel(
+    const LevelTable* __restrict__ T, const uint8_t* __restrict__ img0, int pitch0, int aligned0,
+    const uint8_t* __restrict__ pyramid, const unsigned char* __restrict__ slots, const uint16_t* __restrict__ tcount, const RowCtr* __restrict__ rows,
+    Corner* __restrict__ cand_all, Corner* __restrict__ cmax_all, TileHdr* __restrict__ hdr_all, int dbg_arg, const FrameSet F)
+{
+    const int dbg = EFX_DBG(dbg_arg);
+    {
+        const size_t f = blockIdx.y;
+        img0 = F.in.img0[f]; pyramid += f * F.fs.pyramid; slots += f * F.fs.slots; tcount += f * F.fs.hdr; rows += f * F.fs.rows;
+        cand_all += f * F.fs.cand; cmax_all += f * F.fs.cmax; hdr_all += f * F.fs.hdr;
+    }
+    __shared__ int s_rank;
+    const int lane = threadIdx.x;                           // 0 .. 64 NW - 1: a corner slot of the round, not the hardware lane
+
+    const int gt = T->total_tiles - 1 - xcd_interleaved(blockIdx.x, T->total_tiles);      // densest tiles first
+    int l, tx, ty;
+    efx_tile_of(T, gt, l, tx, ty);
+    const LevelDev& L = T->lv[l];
+    if (!L.active) return;
+    const uint8_t* src = l == 0 ? img0 : pyramid + L.img_off;
+    const int spitch = l == 0 ? pitch0 : L.pitch;
+    const bool aligned = l == 0 ? aligned0 != 0 : true;
+    TileHdr& h = hdr_all[gt];
+    const int total = min((int)h.cell_off[EFX_CELLS_PER_TILE], EFX_TILE * EFX_TILE);
+    // the tile's canonical rank: loads that need the tile's coordinates only (one memory round trip, beside the header's)
+    int rank = 0;
+    if (lane < 64) {
+        // two tile rows and two tiles per lane are requested unconditionally (indices clamped), beside the header: ONE round trip.
+        // (A loop with a data-dependent trip count waits for every load where it is issued: measured 7 us of this kernel's 61.)
+        const RowCtr* rp = rows + L.row_base;
+        const uint16_t* tc = tcount + L.tile_base + ty * L.tiles_x;
+        const int ym = max(ty - 1, 0), xm = max(tx - 1, 0);
+        const int v0 = rp[min(lane, ym)].cand, v1 = rp[min(lane + 64, ym)].cand;
+        const int w0 = (int)tc[min(lane, xm)], w1 = (int)tc[min(lane + 64, xm)];
+        rank = (lane < ty ? v0 : 0) + (lane + 64 < ty ? v1 : 0) + (lane < tx ? w0 : 0) + (lane + 64 < tx ? w1 : 0);
+        for (int i = lane + 128; i < ty; i += 64) rank += rp[i].cand;       // levels of more than 8192 pixels per side
+        for (int i = lane + 128; i < tx; i += 64) rank += (int)tc[i];
+    }
+    if (total > 0) {
+        if (lane < 64) rank = __builtin_amdgcn_readlane(wave_incl_scan(rank), 63);      // DPP steps, no LDS round trips
+        if (NW > 1) {
+            if (lane == 0) s_rank = rank;
+            __syncthreads();
+            rank = s_rank;
+        }
+    }
+    harris_one_tile<NW>(L, gt, tx, ty, total, rank, src, spitch, aligned, slots, cand_all, cmax_all, h, dbg, lane);
 }
 
 // ================================================================================================
@@ -1950,6 +2089,8 @@ __global__ __launch_bounds__(SEL_NT) void select_kernel(const LevelTable* __rest
             SelLevel& S = cnt->sel[l];
             const int kmin = none ? 0 : min(n, L.quota);
             cnt->sum.surv[l] = n; cnt->sum.cand[l] = nc;
+            // the frame's corner density for the host: the context's next launch takes its sparse or its dense form by it (harris_kernel)
+            if (l == 0 && blockIdx.y == 0 && T->host_hint) __hip_atomic_store(T->host_hint, nc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             efx_st(&S.pub[1], ((unsigned long long)(uint32_t)s_rem << 32) | (uint32_t)kmin);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // program order: word B is out before word A
             efx_st(&S.pub[0], (1ull << 63) | ((unsigned long long)(uint32_t)(s_bin + 1) << 32) | (uint32_t)s_inbin);
@@ -2786,7 +2927,12 @@ static hipError_t efx_launch_detect_impl(const DetectLaunch& a, hipStream_t stre
         a.prof.end(prof, 0, stream);
         EFX_TRACE_POINT("fast");
         prof = a.prof.begin(1, stream);
-        if (launch_tiles <= EFX_NMS_WIDE_TILES)
+        int pack_groups = 0;                       // packed launch (a.pack_harris): a workgroup per four tiles of a level
+        for (int s = 0; s < H.nlevels; s++) pack_groups += H.lv[s].pack_groups;
+        if (a.pack_harris && pack_groups > 0)
+            hipLaunchKernelGGL(harris_packed_kernel, dim3(pack_groups, B), dim3(64), 0, stream, a.d_table, a.img0, a.pitch0, aligned0, a.pyramid,
+                               a.slots, a.tcount, a.rows, a.cand, a.cmax, a.hdr, a.knobs.dbg & 15, F);
+        else if (launch_tiles <= EFX_NMS_WIDE_TILES)
             hipLaunchKernelGGL(harris_kernel<4>, dim3(H.total_tiles, B), dim3(256), 0, stream, a.d_table, a.img0, a.pitch0, aligned0, a.pyramid,
                                a.slots, a.tcount, a.rows, a.cand, a.cmax, a.hdr, a.knobs.dbg & 15, F);
         else if (launch_tiles <= EFX_NMS_MID_TILES)

@@ -29,6 +29,8 @@ extern const unsigned char efx_blob_bad256[], efx_blob_bad512[], efx_blob_hashsi
 }
 
 #define HS_KPAD 132
+#define EFX_PACK_AVG 24           // harris_kernel's sparse form: at most this many FAST corners per level-0 tile in the context's last frame
+#define EFX_PACK_MIN_TILES 8192   // ... and a launch beyond the several-waves-per-tile regime (EFX_NMS_MID_TILES, detect_kernels.hip)
 #define EFX_ARENA_DENSITY_MIN_PX (2u << 20)   // levels above 2 Mpx get density-sized corner / survivor arenas (build_geometry)
 #define HS_KB 144             // K of the bf16 projection: 129 padded to 9 MFMA steps of 16
 
@@ -355,7 +357,8 @@ EfxKnobs efx_read_knobs()
     k.no_level_blur = getenv("EFX_NO_LEVEL_BLUR") != nullptr;
     { const char* f = getenv("EFX_BLUR_FORK"); k.blur_fork = f ? atoi(f) : EFX_BLUR_FORK_DEFAULT; }   // DetectLaunch::blur_fork
     k.blur_fork_min_px = getenv("EFX_BLUR_FORK_MIN_PX") ? atoll(getenv("EFX_BLUR_FORK_MIN_PX")) : 0;  // 0: the built-in gate of the per-call fork decision
-    k.no_batch = getenv("EFX_NO_BATCH") != nullptr;       // the batched entry point as a loop of single-frame calls (A/B, parity tests)
+    k.no_batch = getenv("EFX_NO_BATCH") != nullptr;
+    { const char* f = getenv("EFX_PACK"); k.pack = f ? atoi(f) : -1; }      // harris_kernel four tiles per wave: 0 never, 1 always, unset: by the last frame's density       // the batched entry point as a loop of single-frame calls (A/B, parity tests)
     // BAD behind detectAndCompute: every keypoint blurs its own window (A/B, parity tests)
     const char* d = getenv("EFX_DEBUG");
     const char* h = getenv("EFX_DEBUG_HS");
@@ -416,6 +419,8 @@ struct efx_context {
     int n_out_max = 0;              // sum of the active levels' quotas
     std::vector<hipStream_t> streams;   // streams this context has launched on since it last waited for them (ctx_quiesce)
     hipStream_t active_stream = nullptr; bool has_active = false;   // the stream of the call on the stack (QuiesceScope)
+    int* h_hint = nullptr;          // pinned host word select_kernel leaves the last frame's level-0 corner count in (+ 1; 0: none yet)
+    int* d_hint = nullptr;          // ... its device address
     int overflow_events = 0;        // void frames this context has reported (efx_last_count: arena contents that failed their range checks)
     DetectLaunch last_launch;       // investigation (efx_debug_rerun): the last frame's launch arguments
     bool has_frame = false;
@@ -470,6 +475,7 @@ struct efx_context {
         slots.release(); tcount.release(); nsel.release(); rowsum.release(); hist.release(); sel_list.release();
         kp4.release(); kp_level.release(); img.release(); kps.release(); descout.release(); count.release(); maskbuf.release();
         delete h_mirror;
+        if (h_hint) (void)hipHostFree(h_hint);
         for (hipEvent_t e : prof_start) (void)hipEventDestroy(e);
         for (hipEvent_t e : prof_stop) (void)hipEventDestroy(e);
         tl_quiesce = prev;
@@ -726,6 +732,19 @@ int build_geometry(efx_context* c, int rows, int cols, int nframes = 1)
     LevelTable& T = c->h_table;
     memset(&T, 0, sizeof(T));
     T.nlevels = p.nlevels;
+    if (!c->h_hint) {
+        // best effort: without the word every launch takes the dense form
+        void* hp = nullptr; void* dp = nullptr;
+        if (hipHostMalloc(&hp, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
+            c->h_hint = static_cast<int*>(hp); c->d_hint = static_cast<int*>(dp);
+            *c->h_hint = 0;
+        } else {
+            if (hp) (void)hipHostFree(hp);
+            (void)hipGetLastError();
+        }
+    }
+    T.host_hint = c->d_hint;
+
     int quota[EFX_MAX_LEVELS];
     {
         const double factor = (double)(1 / p.scale_factor);       // float division widened to double (.cpp:164)
@@ -781,6 +800,7 @@ int build_geometry(efx_context* c, int rows, int cols, int nframes = 1)
         const int nt = L.tiles_x * L.tiles_y;
         L.sel_wg0 = L.tile_base / EFX_SEL_WG_TILES;
         L.sel_wgs = nt > 0 ? (L.tile_base + nt - 1) / EFX_SEL_WG_TILES - L.sel_wg0 + 1 : 0;
+        L.pack_groups = L.active ? (nt + EFX_PACK_TPW - 1) / EFX_PACK_TPW : 0;      // harris_packed_kernel's workgroups
     }
     T.total_rows = trows;
     T.total_tiles = tiles;
@@ -967,6 +987,16 @@ int detect_frames(efx_context* c, int nframes, const uint8_t* const* d_images, i
     a.first_level = c->p.first_level;
     a.knobs = c->knobs;
     a.mask = d_mask; a.mask_pitch = (int)mask_pitch;
+    {
+        // Sparse or dense form of harris_kernel (the same results either way): by the FAST corners per level-0 tile of the frame this
+        // context processed last -- read from host memory without a synchronisation, possibly a frame or two stale -- once the frame
+        // is large enough for one wave per tile; EFX_PACK pins it
+        const LevelDev& L0 = c->h_table.lv[0];
+        const long long t0 = (long long)L0.tiles_x * L0.tiles_y;
+        const int hint = c->h_hint ? *(volatile int*)c->h_hint : 0;
+        a.pack_harris = c->knobs.pack >= 0 ? c->knobs.pack
+                      : (hint > 0 && (long long)c->h_table.total_tiles * nframes > EFX_PACK_MIN_TILES && (long long)(hint - 1) <= EFX_PACK_AVG * t0) ? 1 : 0;
+    }
     a.d_keypoints = want_kps ? d_keypoints[0] : nullptr; a.kps_pitch = kps_pitch; a.capacity = capacity;
     a.d_count = a.out.count[0];
     a.kp4 = static_cast<float4*>(c->kp4.p);

@@ -31,6 +31,10 @@
 #define EFX_HIST_BINS (1 << EFX_HIST_BITS)
 #define EFX_SEL_LIST_CAP 2048   // keys of the threshold's bin that are ranked exactly in LDS (more: the slow radix path of select_kernel)
 #define EFX_SEL_WG_TILES 256    // tiles per counting workgroup of select_kernel (lane per tile)
+#ifndef EFX_PACK_TPW
+#define EFX_PACK_TPW 4          // tiles per wave of harris_packed_kernel (sparse frames; 4 / 8 / 16 measured: 26.5 / 28.6 / 30.0 us on the
+                                // 1/f^1.3 8K frame, harris_kernel 33 -- tools/microbench/pack_ab.sh)
+#endif
 #define EFX_MAX_BATCH 16       // frames of one size a context runs through ONE launch of every kernel (blockIdx.y = frame)
 
 struct LevelDev {
@@ -48,6 +52,8 @@ struct LevelDev {
     unsigned long long cmax_base;   // entry offset of the level in the per-cell maxima table (tiles_x*4 x tiles_y*4)
     int row_base;                   // index of the level's first tile row in the per-row counters (RowCtr)
     int sel_wg0, sel_wgs;           // counting workgroups of select_kernel that hold tiles of this level: first, how many
+    int pack_groups;                // groups of sixteen tiles (harris_packed_kernel's workgroups): ceil(tiles / 16), 0 for an inactive level
+    int pad2_;
 };
 
 struct LevelTable {
@@ -55,6 +61,7 @@ struct LevelTable {
     int total_tiles;
     int total_rows;                 // tile rows of all levels (RowCtr entries)
     int pad_;
+    int* host_hint;                 // pinned, device-mapped host word (null: none): FAST corners of level 0 of the last frame + 1
     LevelDev lv[EFX_MAX_LEVELS];
 };
 
@@ -214,7 +221,7 @@ __device__ __forceinline__ int efx_wave_incl_scan(int v)
 #else
 #define EFX_DBG(v) 0
 #endif
-struct EfxKnobs { int dbg, dbg_hs, no_tower, no_resize_stream, no_level_blur, blur_fork, no_resize_rows, no_batch; long long tower_max_px, blur_fork_min_px; };
+struct EfxKnobs { int dbg, dbg_hs, no_tower, no_resize_stream, no_level_blur, blur_fork, no_resize_rows, no_batch, pack; long long tower_max_px, blur_fork_min_px; };
 EfxKnobs efx_read_knobs();      // efx_api.cpp
 
 // ---- launchers (host side, defined in the .hip files) ----
@@ -348,6 +355,7 @@ struct DetectLaunch {
     EfxKnobs knobs;             // read at context creation (dbg: EFX_DEBUG_BUILD builds only)
     const uint8_t* mask; int mask_pitch;   // optional level-0 mask (spec S12), null = none
     int pyramid_only;           // 1: build the pyramid and stop (detectAndCompute with provided keypoints)
+    int pack_harris;            // harris_kernel takes four tiles per wave (sparse frames; bit-identical to the other form)
     // outputs
     void* d_keypoints; size_t kps_pitch; int capacity; int* d_count;
     float4* kp4; int* kp_level;

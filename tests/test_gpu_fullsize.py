@@ -201,6 +201,26 @@ def test_c5_8k_detect_and_compute_hashsift512(cef, threaded_oracle):
     assert np.count_nonzero(got != ref["desc"]) <= max(1, int(1e-4 * got.size))       # descriptor_test.cpp:72
 
 
+def test_natural_8k_frame_sparse_form_by_the_previous_frames_density(cef, threaded_oracle):
+    """An 8K frame with the statistics of photographs (1/f^1.3: 8 .. 20 FAST corners per tile): a context's first call takes
+    harris_kernel, the following ones -- by the corner density the previous frame left in host memory -- harris_packed_kernel;
+    then a corner-rich frame, and the sparse one again.  Every call equals the oracle: the choice is a matter of speed alone."""
+    import torch
+    from tools import synth
+    (f,) = synth.powerlaw_frames_tiled(4320, 7680, seed=1000, betas=(1.3,))
+    dense = workloads.frame_c5(0)
+    det = cef.EfficientFeatures.create(workloads.N40K, dtype=cef.EfficientFeatures.BAD_512)
+    refs = {}
+    for name, img in (("sparse", f), ("sparse", f), ("sparse", f), ("dense", dense), ("sparse", f), ("sparse", f)):
+        if name not in refs:
+            refs[name] = threaded_oracle.detect_and_compute(img, nfeatures=workloads.N40K, desc_type=threaded_oracle.BAD_512)
+        kps, desc, cnt = det.detectAndComputeAsync(_dev(img))
+        torch.cuda.synchronize()
+        n = int(cnt.item())
+        _same_keypoints(kps, n, refs[name])
+        assert np.array_equal(desc[:n].cpu().numpy(), refs[name]["desc"])
+
+
 @pytest.mark.parametrize("kind", ["powerlaw", "powerlaw_dense", "blurred_edges"])
 def test_natural_statistics_4k(cef, threaded_oracle, kind):
     """4K frames with the statistics of photographs (the reference tests on 11 photographs,

@@ -937,3 +937,26 @@ def test_matcher_kernels_agree_on_tie_heavy_random_sets(cef, torch_mod, monkeypa
         if nq * nt <= 3_000_000:
             widx, wdist = MO.knn2(q, t)
             assert np.array_equal(d[0].cpu().numpy(), widx) and np.array_equal(d[1].cpu().numpy(), wdist), ("popcount vs oracle", info)
+
+
+@pytest.mark.parametrize("kind", ["sparse", "dense", "noise_bitmap_tiles", "capped", "odd_size"])
+def test_packed_harris_kernel_equals_oracle(cef, torch_mod, oracle, monkeypatch, kind):
+    """harris_packed_kernel (round 6: several tiles per wave for frames with the corner statistics of photographs; the host takes
+    it by the previous frame's density on large frames, EFX_PACK=1 forces it): same records at the same places as harris_kernel --
+    sparse groups side by side in one round, dense ones over several, groups with a bitmap tile (more than 256 corners) tile by
+    tile, the 10 % cap cutting inside a group, a level whose tile count is not a multiple of the group."""
+    monkeypatch.setenv("EFX_PACK", "1")
+    kw = {}
+    if kind == "sparse":
+        img = synth.powerlaw_frame(700, 1000, seed=3, beta=1.3, contrast=45.0)
+    elif kind == "dense":
+        img = synth.synth_frame(600, 900, seed=77, density=3.0)
+    elif kind == "noise_bitmap_tiles":
+        img = synth.noise_frame(500, 700, seed=5); kw = dict(fast_threshold=5)
+    elif kind == "capped":
+        img = synth.noise_frame(640, 640, seed=6)
+    else:
+        img = synth.synth_frame(333, 517, seed=9)
+    got, ref = _detect_both(cef, torch_mod, oracle, img, desc_type=0, nfeatures=3000, **kw)
+    _assert_same_keypoints(got, ref)
+    assert np.array_equal(got["desc"], ref["desc"])
