@@ -334,8 +334,8 @@ class EfficientFeatures:
         return n.value
 
     def overflowEvents(self):
-        """Times the context observed its overflow word set: at least one void frame each time (include/efx.h) -- several
-        void frames enqueued back to back count once."""
+        """Void frames this context has reported (include/efx.h): 0 since round 6 -- a frame of any corner density is complete on
+        the first call; kept for callers of the earlier contract."""
         return int(lib().efx_overflow_events(self._h))
 
     def trackedStreams(self):
@@ -556,7 +556,8 @@ def descriptorsToCsv(descriptors):
 
 class Batch:
     """efx_detect_and_compute_batch_async with prepared pointer tables: nframes frames of one size, frame i on
-    detectors[i % n] / streams[i % n].  The tensors are kept referenced here; run() only crosses the ABI once."""
+    detectors[i % n] / streams[i % n]; the frames of one detector go through ONE launch of every kernel (round 6; up to 16 per
+    launch chain).  The tensors are kept referenced here; run() only crosses the ABI once."""
 
     def __init__(self, detectors, streams, images, keypoints, descriptors, counts, capacity):
         n, f = len(detectors), len(images)
@@ -581,9 +582,8 @@ class Batch:
             raise EfxError(rc, "batch: " + lib().efx_last_error(self._det0._h).decode())
 
     def overflowEvents(self):
-        """Void frames (arena overflow) over all contexts of the batch: a caller that reads the count tensors directly
-        checks this after a step -- non-zero means frames with N == 0 that must be run again (the contexts have enlarged
-        their arenas by the next run())."""
+        """Void frames over all contexts of the batch: always 0 since round 6 (the scratch arenas hold the reference's own 10 %
+        candidate cap; include/efx.h); kept for callers of the earlier contract."""
         return sum(d.overflowEvents() for d in self._keep[0])
 
 

@@ -1935,13 +1935,14 @@ __global__ __launch_bounds__(64 * NW) void nms_kernel(const LevelTable* __restri
         if ((m >> lane) & 1ull) {
             const Corner c = own[k0 + lane];
             surv[slot] = c;
+            if (dbg < 4)      // (debug builds, EFX_DEBUG = 64 / 80: without the histogram / the row sums -- selection invalid, timing only)
             __hip_atomic_fetch_add(&lhist[efx_hist_word((uint32_t)(efx_select_key(c.xy, c.resp) >> (64 - EFX_HIST_BITS)))], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         base += __popcll(m);
     }
     if (lane == 0) {
         hl[tile].surv_count = (uint32_t)nsurv;
-        if (nsurv > 0) __hip_atomic_fetch_add(&rows[L.row_base + ty].surv, nsurv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (nsurv > 0 && dbg < 5) __hip_atomic_fetch_add(&rows[L.row_base + ty].surv, nsurv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

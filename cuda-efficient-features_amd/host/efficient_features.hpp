@@ -38,6 +38,10 @@ public:
     DeviceMatrix() = default;
     DeviceMatrix(const DeviceMatrix&) = delete;
     DeviceMatrix& operator=(const DeviceMatrix&) = delete;
+    DeviceMatrix(DeviceMatrix&& o) noexcept : rows(o.rows), cols(o.cols), elemSize(o.elemSize), step(o.step), data_(o.data_), bytes_(o.bytes_)
+    {
+        o.data_ = nullptr; o.bytes_ = 0; o.rows = o.cols = 0;
+    }
     ~DeviceMatrix() { release(); }
     void create(int rows_, int cols_, int elem_size)
     {
@@ -159,9 +163,33 @@ public:
                                 static_cast<uint8_t*>(descriptors.data()), descriptors.step, stream));
     }
     int lastCount() const { int n = 0; check(efx_last_count(ctx_, &n)); return n; }
-    // frames of this object that were void because they overflowed the density-sized scratch arenas (include/efx.h, "arena
-    // overflow contract": the next call enlarges the arenas by itself; lastCount() throws EFX_ERR_OVERFLOW for such a frame)
+    // void frames this object has reported: 0 since round 6 -- the scratch arenas hold the reference's own 10 % candidate cap, so a
+    // frame of any corner density is complete on the first call (include/efx.h, "scratch arenas"); kept for earlier callers
     int overflowEvents() const { return efx_overflow_events(ctx_); }
+    // The loop of samples/sample_image_sequence.cpp:70-105 over frames of one size as ONE call: the frames go through one launch of
+    // every kernel (up to 16 per launch chain), each frame's results equal detectAndComputeAsync's on it.  keypoints[i] /
+    // descriptors[i] are created here (5 x maxFeatures, maxFeatures x descriptorSize); counts[i]: device ints receiving N_i.
+    void detectAndComputeBatchAsync(const std::vector<DeviceImage>& images, std::vector<DeviceMatrix>& keypoints,
+                                    std::vector<DeviceMatrix>& descriptors, const std::vector<int*>& counts, hipStream_t stream = nullptr)
+    {
+        const size_t n = images.size();
+        if (n == 0) return;
+        if (counts.size() != n) throw Exception(EFX_ERR_BAD_ARG, "one device count per frame");
+        keypoints.resize(n); descriptors.resize(n);
+        const int cap = getMaxFeatures();
+        std::vector<const uint8_t*> img(n); std::vector<void*> kp(n); std::vector<uint8_t*> de(n);
+        for (size_t i = 0; i < n; i++) {
+            if (images[i].rows != images[0].rows || images[i].cols != images[0].cols || images[i].step != images[0].step)
+                throw Exception(EFX_ERR_BAD_ARG, "the frames of a batch have one size and pitch");
+            keypoints[i].create(ROWS_COUNT, cap > 0 ? cap : 1, 4);
+            descriptors[i].create(cap > 0 ? cap : 1, descriptorSize(), 1);
+            img[i] = images[i].data; kp[i] = keypoints[i].data(); de[i] = static_cast<uint8_t*>(descriptors[i].data());
+        }
+        efx_context* ctxs[1] = { ctx_ };
+        void* streams[1] = { stream };
+        check(efx_detect_and_compute_batch_async(ctxs, streams, 1, img.data(), (int)n, images[0].rows, images[0].cols, images[0].step,
+                                                 kp.data(), keypoints[0].step, de.data(), descriptors[0].step, cap, counts.data()));
+    }
     // device blocks of destroyed objects are cached process-wide (at most EFX_BLOCK_CACHE_MB, default 1 GB): give them back
     static size_t trimMemory() { return efx_trim_memory(); }
 

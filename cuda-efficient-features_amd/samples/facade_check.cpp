@@ -75,7 +75,27 @@ int main()
         std::vector<std::vector<efx::DMatch>> kn;
         knn.knnMatch(dd, n, dd, n, 32, kn);
         REQUIRE((int)kn.size() == n && kn[0].size() == 2 && kn[0][0].distance == 0 && kn[0][0].distance <= kn[0][1].distance);
-        printf("facade ok: %d keypoints, %d masked, %d cross-checked self matches\n", n, (int)km.size(), (int)matches.size());
+        // the frame three times as ONE batched call (one launch of every kernel for the three frames): every frame's N and
+        // descriptor bytes equal the single call's
+        {
+            std::vector<efx::DeviceImage> frames(3, dimg);
+            std::vector<efx::DeviceMatrix> bk, bd;
+            int* d_counts = nullptr;
+            REQUIRE(hipMalloc(&d_counts, 3 * sizeof(int)) == hipSuccess);
+            feature->detectAndComputeBatchAsync(frames, bk, bd, { d_counts, d_counts + 1, d_counts + 2 });
+            REQUIRE(hipStreamSynchronize(nullptr) == hipSuccess);
+            int hc[3] = { 0, 0, 0 };
+            REQUIRE(hipMemcpy(hc, d_counts, sizeof(hc), hipMemcpyDeviceToHost) == hipSuccess);
+            std::vector<uint8_t> one((size_t)n * 32), other((size_t)n * 32);
+            REQUIRE(hipMemcpy2D(one.data(), 32, dd.data(), dd.step, 32, n, hipMemcpyDeviceToHost) == hipSuccess);
+            for (int f = 0; f < 3; f++) {
+                REQUIRE(hc[f] == n);
+                REQUIRE(hipMemcpy2D(other.data(), 32, bd[f].data(), bd[f].step, 32, n, hipMemcpyDeviceToHost) == hipSuccess);
+                REQUIRE(other == one);
+            }
+            (void)hipFree(d_counts);
+        }
+        printf("facade ok: %d keypoints, %d masked, %d cross-checked self matches, batch of 3 equal\n", n, (int)km.size(), (int)matches.size());
         return 0;
     } catch (const std::exception& e) {
         printf("exception: %s\n", e.what());

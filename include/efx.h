@@ -38,9 +38,10 @@ typedef enum efx_status {
     EFX_ERR_HIP = -3,           /* a HIP runtime call failed (the reference only printf's: cuda_macro.h:23-28) */
     EFX_ERR_NO_DEVICE = -4,
     EFX_ERR_NOMEM = -5,
-    EFX_ERR_OVERFLOW = -6       /* the frame had more FAST corners / NMS survivors than the context's scratch arenas hold: it
-                                 * is VOID (N = 0).  The arenas are enlarged to the worst case before the context's next
-                                 * frame: repeat the call ("arena overflow contract" at efx_detect_async) */
+    EFX_ERR_OVERFLOW = -6       /* the frame is VOID (N = 0): records in the context's scratch arenas failed their range checks on
+                                 * the device.  Since version 100 / round 6 NO frame content can cause this -- the arenas hold the
+                                 * reference's own 10 % candidate cap and nothing is allocated on the device ("scratch arenas" at
+                                 * efx_detect_async); the code remains for the platform anomaly of DESIGN.md section 7 */
 } efx_status;
 
 /* cuda_efficient_features.h:39-45 */
@@ -130,15 +131,12 @@ int efx_default_norm(const efx_context* ctx);      /* 6 == cv::NORM_HAMMING, .cp
  * No host synchronisation happens inside; once the stream has been synchronised, efx_last_count() and
  * efx_last_level_stats() fetch N and the per-level counts from the device (one small blocking copy per call).
  *
- * Arena overflow contract (every asynchronous detect entry point: efx_detect_async, efx_detect_and_compute_async,
- * efx_detect_and_compute_masked_async).  Levels above 2 Mpx get corner / survivor arenas sized for a corner DENSITY (1/8
- * of the pixels; the reference keeps at most 1/10, .cpp:252), not for the worst case.  A frame that does not fit is void:
- * *d_count == 0, nothing is emitted or described.  The device leaves a sticky flag, and the NEXT call on the context --
- * whichever entry point -- enlarges the arenas to the worst case before it launches, without a synchronisation; so at most
- * the frames already enqueued when the first dense frame ran are lost, never "every dense frame".  A caller who must not
- * lose a frame polls efx_last_count() after synchronising: it returns EFX_ERR_OVERFLOW for a void frame (repeat the
- * call); efx_overflow_events() says whether (not how often) that happened.  The synchronous entry points (efx_detect, ...) rerun
- * the frame by themselves. */
+ * Scratch arenas (every detect entry point).  The reference keeps at most cvRound(0.1 w h) FAST corners per pyramid level
+ * (cuda_efficient_features.cpp:252, cuda_fast.cu:216-219,245: which ones is a race there; here the first ones in canonical order,
+ * DESIGN.md S2).  The context's corner and survivor arrays hold exactly that many records per level and nothing is allocated on the
+ * device, so a frame of ANY corner density is complete on the first call -- there is no "void frame, repeat the call" any more
+ * (rounds 2-5 sized the arenas for a corner density of 1/8 and returned N = 0 once for denser frames).  A context's device memory
+ * depends on the frame size only (8K: ~350 MB with a BAD describer), never on what the frames show. */
 int efx_detect_async(efx_context* ctx, const uint8_t* d_image, int rows, int cols, size_t pitch,
                      void* d_keypoints, size_t kps_pitch, int capacity, int* d_count, void* stream);
 
@@ -162,12 +160,11 @@ int efx_compute_kp4_async(efx_context* ctx, const uint8_t* d_image, int rows, in
                           const float* d_kp4, int n, float max_size,
                           uint8_t* d_descriptors, size_t desc_pitch, void* stream);
 
-/* N of the last detect / detectAndCompute on this context (valid after the stream was synchronised).  Returns
- * EFX_ERR_OVERFLOW when that frame was void because it overflowed the scratch arenas (contract at efx_detect_async). */
+/* N of the last detect / detectAndCompute on this context (valid after the stream was synchronised); behind a batched call: of the
+ * batch's LAST frame.  (EFX_ERR_OVERFLOW: see the status code -- not reachable through frame content.) */
 int efx_last_count(const efx_context* ctx, int* n);
-/* Times this context has OBSERVED its sticky overflow word set (host-side count, no device access): every observation means
- * "at least one frame since the last observation was void" -- several void frames enqueued back to back count once, so this
- * is a did-it-happen counter, not a list of the frames to rerun (poll efx_last_count() per frame for that). */
+/* Times efx_last_count / efx_last_level_stats reported a void frame on this context (EFX_ERR_OVERFLOW).  0 in every run since
+ * round 6; kept for callers of the earlier contract. */
 int efx_overflow_events(const efx_context* ctx);
 /* Diagnostics: streams the context currently tracks for its release waits (a block a regrow or the destructor hands back
  * waits for exactly these; the stream of the call that triggered a regrow stays tracked).  No reference counterpart. */
@@ -245,10 +242,16 @@ int efx_match_crosscheck_async(efx_matcher* m, const uint8_t* d_query, size_t q_
                                const uint8_t* d_train, size_t t_pitch, int nt, int desc_bytes,
                                int* d_match, int* d_dist, void* stream);
 
-/* Batched variant: nframes independent frames of one size in one call.  Frame i runs on context
- * ctxs[i % nctx] and stream streams[i % nctx] (a context is not re-entrant, so nctx frames are in flight at a time and
- * a context's frames are ordered on its stream); d_descriptors may be NULL (detect only).  Equivalent to calling
- * efx_detect_and_compute_async nframes times, without the caller's per-call overhead.  Stops at the first error. */
+/* Batched variant (SURVEY 8b "batched variants (..., nframes) for roofline-sized launches"; the loop of
+ * samples/sample_image_sequence.cpp:70-105): nframes independent frames of one size in one call.  Frame i belongs to context
+ * ctxs[i % nctx] and stream streams[i % nctx]; the frames of ONE context go through ONE launch of every kernel of the path (frame =
+ * blockIdx.y; up to EFX_MAX_BATCH = 16 per launch chain, more in several chains), so a batch of small frames fills the chip like one
+ * large frame: 16 FHD frames per launch chain run at 1.9 x the frame rate of 16 single-frame calls.  Every
+ * frame's results equal those of efx_detect_and_compute_async on that frame, bit for bit.  d_descriptors may be NULL (detect
+ * only); either every frame has a keypoint / descriptor matrix or none.  A context holds its intermediate buffers once per frame of
+ * its largest batch (FHD: 27 MB per frame, 4K: 92 MB, 8K: 350 MB).  BAD describers run batched too; HashSIFT describes frame by
+ * frame behind the batched detector.  efx_last_count / efx_last_level_stats refer to the batch's last frame of that context.
+ * EFX_NO_BATCH=1 (read when a context is created): one single-frame call per frame.  Stops at the first error. */
 int efx_detect_and_compute_batch_async(efx_context* const* ctxs, void* const* streams, int nctx,
                                        const uint8_t* const* d_images, int nframes, int rows, int cols, size_t pitch,
                                        void* const* d_keypoints, size_t kps_pitch,

@@ -12,7 +12,9 @@ tag=${1:-rXX}
 export EFX_GIT_HEAD=${2:-${EFX_GIT_HEAD:-unknown}}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out
-rocprofv3 --kernel-trace --stats -d $O/prof_$tag -o bench -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-configs --sustain-seconds 0 --streams 1 > $O/bench_$tag.log 2>&1
+# (EFX_NO_BATCH=1: one launch chain per frame, so that a kernel's average is its time for ONE frame, as in the earlier rounds' files;
+# the three-stream run below is the default form: every context's frames of a step through one launch of every kernel)
+EFX_NO_BATCH=1 rocprofv3 --kernel-trace --stats -d $O/prof_$tag -o bench -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-configs --sustain-seconds 0 --streams 1 > $O/bench_$tag.log 2>&1
 python tools/prof_summary.py $O/prof_$tag/bench_results.db $O/${tag}_kernel_stats.csv > /dev/null; rm -rf $O/prof_$tag
 rocprofv3 --kernel-trace --stats -d $O/prof_${tag}_3s -o bench -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-configs --sustain-seconds 0 > $O/bench_${tag}_3s.log 2>&1
 python tools/prof_summary.py $O/prof_${tag}_3s/bench_results.db $O/${tag}_kernel_stats_3streams.csv > /dev/null; rm -rf $O/prof_${tag}_3s
