@@ -5,10 +5,12 @@
 //   modules/cuda_efficient_features/src/cuda_efficient_features.cu:62-248 (NMS predicate, Harris, IC angle, scaling)
 //   modules/cuda_efficient_features/src/cuda_efficient_features.cpp:136-321 (pyramid, quotas, border, flow)
 // with the spec decisions of DESIGN.md (canonical order, deterministic cap / ties, integer Harris sums,
-// shared atan2).  How it is computed is MI355X-first: one fused pass per level reads the level once into
-// LDS, runs FAST + Harris on it and writes the next pyramid level; all counts stay on the device (no host
-// synchronisation anywhere, the reference does 16 per frame); compaction is ballot/bitmap based and
-// deterministic.
+// shared atan2).  How it is computed is MI355X-first: the pyramid by waves that walk down strips of columns (several levels per
+// launch), FAST-9 on LDS tiles of ALL levels in one launch, Harris a lane per corner, the suppression a wave per tile on per-cell
+// maxima; all counts stay on the device (no host synchronisation anywhere, the reference does 16 per frame) and NOTHING is
+// allocated there -- corners travel in fixed per-tile slots and lie at canonical ranks in arrays of the reference's own 10 % cap
+// (round 6) --; compaction is ballot / bitmap based and deterministic; every kernel takes the tiles of several same-sized frames in
+// one launch (frame = blockIdx.y).
 //
 // Compile with -ffp-contract=off: the float expressions below must not be fused.
 
@@ -1608,7 +1610,7 @@ __global__ __launch_bounds__(64 * NW) void nms_kernel(const LevelTable* __restri
     const Corner* cand = cand_all + L.cand_base;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     Corner* s_hme = s_hme_all[wv]; uint16_t* s_hidx = s_hidx_all[wv]; uint16_t* s_hneed = s_hneed_all[wv];
-    if (cnt->sum.overflow) return;                          // void frame (arena overflow in fast_kernel)
+    if (cnt->sum.overflow) return;                          // void frame (a record failed its range check: DESIGN.md section 7)
 
     // A wave beyond the tile's corners (most tiles of a sparse frame have fewer than 64 * NW) leaves at once: its slot is
     // free after one load instead of after the tile.  (s_barrier waits for the waves of the workgroup that have not
@@ -1650,7 +1652,7 @@ __global__ __launch_bounds__(64 * NW) void nms_kernel(const LevelTable* __restri
     if (tid < 36 && cell_exists) cm = cmax_all[L.cmax_base + (size_t)cy * (L.tiles_x * 4) + cx];
     __syncthreads();                                     // s_nb is read below
     {
-        // the nine headers address the corner arena: ranges that do not fit it void the frame (see harris_kernel)
+        // the nine headers address the corner array: a count beyond a tile's 4096 pixels voids the frame
         // (every wave evaluates the same nine headers: the exit is workgroup-uniform)
         bool bad = false;
         if (lane < 9) {
@@ -1825,7 +1827,7 @@ __global__ __launch_bounds__(64 * NW) void nms_kernel(const LevelTable* __restri
         int need = 0x1ff;                                     // neighbour cells the exact scan has to walk (all, unless phase A knows better)
         Corner me; me.xy = 0; me.resp = 0.f;
         if (k < n_valid) me = own[k];
-        // range check (see harris_kernel): a record that is not of this tile would index LDS and the arenas out of range;
+        // range check: a record that is not of this tile would index LDS and the arrays out of range;
         // the frame is void (wave-uniform exit: the workgroup is this wave)
         if (__ballot(k < n_valid && ((int)((me.xy & 0xffff) >> 6) != tx || (int)(me.xy >> 22) != ty)) != 0ull) {
             if (lane == 0) { efx_raise_overflow(T, cnt); s_void = 1; }

@@ -31,7 +31,6 @@ extern const unsigned char efx_blob_bad256[], efx_blob_bad512[], efx_blob_hashsi
 #define HS_KPAD 132
 #define EFX_PACK_AVG 24           // harris_kernel's sparse form: at most this many FAST corners per level-0 tile in the context's last frame
 #define EFX_PACK_MIN_TILES 8192   // ... and a launch beyond the several-waves-per-tile regime (EFX_NMS_MID_TILES, detect_kernels.hip)
-#define EFX_ARENA_DENSITY_MIN_PX (2u << 20)   // levels above 2 Mpx get density-sized corner / survivor arenas (build_geometry)
 #define HS_KB 144             // K of the bf16 projection: 129 padded to 9 MFMA steps of 16
 
 namespace {
@@ -1516,7 +1515,7 @@ static int host_detect_impl(efx_context* ctx, const uint8_t* h_image, int rows, 
         if (rc) return rc;
         HIP_TRY(ctx->err, hipStreamSynchronize(nullptr));
         if (fetch_summary(ctx) != EFX_OK) return set_err(ctx->err, EFX_ERR_HIP, "summary copy failed");
-        // the synchronous entry points hide an arena overflow: enlarge (check_overflow) and run the frame again
+        // (a void frame -- records that failed their range checks, DESIGN.md section 7 -- is run once more)
         if (check_overflow(ctx) == EFX_OK || attempt == 1) break;
     }
     if (ctx->h_mirror->overflow) return EFX_ERR_OVERFLOW;
