@@ -320,13 +320,17 @@ int describer_run(Describer& d, std::string& err, DescribeLaunch a, float* dbg_r
     } else {
         if (a.desc && ((((uintptr_t)a.desc) | a.desc_pitch) & 3u))
             return set_err(err, EFX_ERR_BAD_ARG, "HashSIFT descriptors need a 4-byte aligned base and pitch");
-        HIP_TRY(err, d.responses.reserve((size_t)a.n * (HS_KB * sizeof(uint16_t) + EFX_HS_REC_BYTES)));      // 129-vectors, then the per-keypoint records
+        for (int f = 1; f < a.nframes; f++)
+            if (((uintptr_t)a.descs.desc[f]) & 3u) return set_err(err, EFX_ERR_BAD_ARG, "HashSIFT descriptors need a 4-byte aligned base and pitch");
+        // 129-vectors, then the per-keypoint records; behind a batched detect: nframes x kp_stride of each
+        const size_t nrec = a.nframes > 1 ? (size_t)a.nframes * a.kp_stride : (size_t)a.n;
+        HIP_TRY(err, d.responses.reserve(nrec * (HS_KB * sizeof(uint16_t) + EFX_HS_REC_BYTES)));
         HashSiftDev h;
         h.nbits = d.nbits;
         h.W = static_cast<const float*>(d.params.p);
         h.Wb = reinterpret_cast<const uint16_t*>(static_cast<const unsigned char*>(d.params.p) + d.hs_wb_off);
         h.responses = static_cast<uint16_t*>(d.responses.p);
-        h.records = static_cast<unsigned char*>(d.responses.p) + (size_t)a.n * HS_KB * sizeof(uint16_t);     // 288 n: 32-byte aligned
+        h.records = static_cast<unsigned char*>(d.responses.p) + nrec * HS_KB * sizeof(uint16_t);     // 288 n: 32-byte aligned
         h.dbg_responses = dbg_resp;
         h.dbg_T = dbg_T;
         hipError_t e = efx_launch_hashsift(a, h, stream);
@@ -1084,14 +1088,16 @@ int detect_frames(efx_context* c, int nframes, const uint8_t* const* d_images, i
         dl.uniform_size = 1;
         dl.desc = d_descs[0]; dl.desc_pitch = desc_pitch;
         dl.prof = a.prof;
-        if (nframes > 1 && level_blurred) {
-            // every frame's keypoints in one launch of bad_raw_kernel (the records point at each frame's blurred levels)
+        if (nframes > 1 && (level_blurred || c->desc.kind == 1)) {
+            // every frame's keypoints in one launch of bad_raw_kernel (the records point at each frame's blurred levels), or in one
+            // launch of each of the three HashSIFT kernels
             dl.nframes = nframes; dl.aff_stride = (size_t)cap_alloc;
+            dl.kp_stride = (size_t)cap_alloc; dl.pyr_stride = a.fs.pyramid; dl.imgs = a.in;
             for (int f = 0; f < nframes; f++) { dl.counts.count[f] = a.out.count[f]; dl.descs.desc[f] = d_descs[f]; }
             rc = describer_run(c->desc, c->err, dl, nullptr, nullptr, stream);
             if (rc) return rc;
         } else {
-            // (HashSIFT, and BAD outside bad_raw_kernel's conditions, behind a batch: one describe per frame on the frame's buffers)
+            // (BAD outside bad_raw_kernel's conditions behind a batch: one describe per frame on the frame's buffers)
             for (int f = 0; f < nframes; f++) {
                 DescribeLaunch df = dl;
                 df.img0 = d_images[f]; df.pyramid = a.pyramid + f * a.fs.pyramid;

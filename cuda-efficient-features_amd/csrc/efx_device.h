@@ -401,6 +401,9 @@ struct DescribeLaunch {
     // records of frame f start at bad_affine + f * aff_stride, its count is counts.count[f], its descriptors descs.desc[f]
     int nframes; size_t aff_stride; FrameOut counts; FrameDesc descs;
     size_t frame_affine_off;                               // a single frame of a batch described on its own: its records start here (Affine entries)
+    // batched HashSIFT behind a batched detect: frame f's keypoints at kp4 / kp_level + f * kp_stride, its pyramid at pyramid +
+    // f * pyr_stride, its level 0 at imgs.img0[f]; counts / descs as above
+    size_t kp_stride, pyr_stride; FrameIn imgs;
 };
 
 hipError_t efx_launch_bad(const DescribeLaunch& a, const BadParamsDev* d_params, float reach, hipStream_t stream);

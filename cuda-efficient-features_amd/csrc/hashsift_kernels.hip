@@ -55,12 +55,21 @@ struct HsRec {
 };
 static_assert(sizeof(HsRec) == 64, "one record per 64-byte line");
 
+// Frames of a batched describe (blockIdx.y; nframes <= 1: the scalar arguments as they are): frame f's keypoints, records and
+// 129-vectors lie f * kp_stride entries into their arrays, its pyramid f * pyr_stride bytes into the pyramid buffer
+struct HsBatch { int nframes; size_t kp_stride, pyr_stride; FrameIn imgs; FrameOut counts; FrameDesc descs; };
+
 __global__ __launch_bounds__(256) void hs_record_kernel(
     const uint8_t* __restrict__ img0, int pitch0, int rows0, int cols0,
     const uint8_t* __restrict__ pyramid, const LevelTable* __restrict__ T,
     const float4* __restrict__ kp4, const uint8_t* __restrict__ kps5, size_t kps5_pitch, const int* __restrict__ kp_level, const int* __restrict__ d_count, int n,
-    float crop_scale, int smax, int sfixed, int dword_rows, HsRec* __restrict__ rec)
+    float crop_scale, int smax, int sfixed, int dword_rows, HsRec* __restrict__ rec, const HsBatch hb)
 {
+    if (hb.nframes > 1) {
+        const size_t f = blockIdx.y;
+        img0 = hb.imgs.img0[f]; pyramid += f * hb.pyr_stride; kp4 += f * hb.kp_stride; kp_level += f * hb.kp_stride;
+        d_count = hb.counts.count[f]; rec += f * hb.kp_stride;
+    }
     const int count = d_count ? min(*d_count, n) : n;
     const int kid = blockIdx.x * 256 + threadIdx.x;
     if (kid >= count) return;
@@ -127,9 +136,13 @@ __global__ __launch_bounds__(256) void patch_sift_kernel(
     const float* __restrict__ vote_weight16 /*4 x 256: weight x 2^17 of pixel k of thread t*/,
     const float2* __restrict__ grad_lut /*511*511 {orientation bin, magnitude}*/,
     float taps0, float taps1, float taps2, float taps3,
-    uint16_t* __restrict__ responses /* n x HS_KB bf16 */, float* __restrict__ dbg_responses /* n x 129 or null */, int dbg_arg)
+    uint16_t* __restrict__ responses /* n x HS_KB bf16 */, float* __restrict__ dbg_responses /* n x 129 or null */, int dbg_arg, const HsBatch frames)
 {
     const int dbg = EFX_DBG(dbg_arg);
+    if (frames.nframes > 1) {
+        const size_t f = blockIdx.y;
+        d_count = frames.counts.count[f]; rec += f * frames.kp_stride; responses += f * frames.kp_stride * HS_KB;
+    }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // Patch rows HS_PP bytes apart.  With 32 the gradient reads of a wave -- 16 cells x 4 pixels: x = 8 (cell & 3) + w, y = 8 (cell >> 2) --
     // met in FOUR banks, four rows deep (rows 8 apart are 256 bytes = one bank row apart); 36 puts the 16 cells' dwords in 16
@@ -362,8 +375,12 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HS_PROJ_WAVES, HS_PROJ_WAVES))) void project_sign_kernel(const uint16_t* __restrict__ Rm, const uint16_t* __restrict__ Wb,
                                                            const int* __restrict__ d_count, int n, int nbits,
-                                                           uint8_t* __restrict__ desc, size_t desc_pitch, float* __restrict__ dbg_T)
+                                                           uint8_t* __restrict__ desc, size_t desc_pitch, float* __restrict__ dbg_T, const HsBatch hb)
 {
+    if (hb.nframes > 1) {
+        const size_t f = blockIdx.y;
+        d_count = hb.counts.count[f]; Rm += f * hb.kp_stride * HS_KB; desc = hb.descs.desc[f];
+    }
     const int count = d_count ? min(*d_count, n) : n;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     // the waves that share a row group (one per column tile) run on ONE XCD: they read the same rows of R through one L2
@@ -543,20 +560,23 @@ hipError_t efx_launch_hashsift(const DescribeLaunch& a, const HashSiftDev& h, hi
     static_assert(sizeof(HsRec) == EFX_HS_REC_BYTES, "scratch sizing in efx_api.cpp");
     HsRec* rec = static_cast<HsRec*>(h.records);
     const bool fixed48 = a.blur && S == 48 && a.uniform_size;
-    hipLaunchKernelGGL(hs_record_kernel, dim3((a.n + 255) / 256), dim3(256), 0, stream, a.img0, a.pitch0, a.rows0, a.cols0,
-                       a.pyramid, a.d_table, a.kp4, a.kps5, a.kps5_pitch, a.kp_level, a.d_count, a.n, a.scale_factor, S, fixed48 ? 48 : 0, a.blur ? 0 : 1, rec);
+    HsBatch hb = {};
+    const int NF = a.nframes > 1 ? a.nframes : 1;
+    if (NF > 1) { hb.nframes = NF; hb.kp_stride = a.kp_stride; hb.pyr_stride = a.pyr_stride; hb.imgs = a.imgs; hb.counts = a.counts; hb.descs = a.descs; }
+    hipLaunchKernelGGL(hs_record_kernel, dim3((a.n + 255) / 256, NF), dim3(256), 0, stream, a.img0, a.pitch0, a.rows0, a.cols0,
+                       a.pyramid, a.d_table, a.kp4, a.kps5, a.kps5_pitch, a.kp_level, a.d_count, a.n, a.scale_factor, S, fixed48 ? 48 : 0, a.blur ? 0 : 1, rec, hb);
     if (fixed48) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_sift_kernel<true, 48>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((patch_sift_kernel<true, 48>), dim3(a.n), dim3(256), lds, stream, rec, a.d_count, a.n, S, mag, lut,
-                           t[0], t[1], t[2], t[3], h.responses, h.dbg_responses, dbg);
+        hipLaunchKernelGGL((patch_sift_kernel<true, 48>), dim3(a.n, NF), dim3(256), lds, stream, rec, a.d_count, a.n, S, mag, lut,
+                           t[0], t[1], t[2], t[3], h.responses, h.dbg_responses, dbg, hb);
     } else if (a.blur) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_sift_kernel<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((patch_sift_kernel<true, 0>), dim3(a.n), dim3(256), lds, stream, rec, a.d_count, a.n, S, mag, lut,
-                           t[0], t[1], t[2], t[3], h.responses, h.dbg_responses, dbg);
+        hipLaunchKernelGGL((patch_sift_kernel<true, 0>), dim3(a.n, NF), dim3(256), lds, stream, rec, a.d_count, a.n, S, mag, lut,
+                           t[0], t[1], t[2], t[3], h.responses, h.dbg_responses, dbg, hb);
     } else {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_sift_kernel<false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((patch_sift_kernel<false, 0>), dim3(a.n), dim3(256), lds, stream, rec, a.d_count, a.n, S, mag, lut,
-                           t[0], t[1], t[2], t[3], h.responses, h.dbg_responses, dbg);
+        hipLaunchKernelGGL((patch_sift_kernel<false, 0>), dim3(a.n, NF), dim3(256), lds, stream, rec, a.d_count, a.n, S, mag, lut,
+                           t[0], t[1], t[2], t[3], h.responses, h.dbg_responses, dbg, hb);
     }
     if (a.desc || h.dbg_T) {
         // persistent waves: HS_PROJ_WAVES per SIMD (the weights occupy 108 VGPRs), each owning one 32-bit column tile
@@ -564,8 +584,8 @@ hipError_t efx_launch_hashsift(const DescribeLaunch& a, const HashSiftDev& h, hi
         int nblk = (256 * HS_PROJ_WAVES) / ntn * ntn;          // one workgroup (four waves) per CU and wave slot, a multiple of the column tiles
         const int need = (((a.n + 63) / 64) * ntn + 3) / 4;     // never more waves than (row tile, column tile) pairs
         if (nblk > need) nblk = (need + ntn - 1) / ntn * ntn;
-        hipLaunchKernelGGL(project_sign_kernel, dim3(nblk), dim3(256), 0, stream,
-                           h.responses, h.Wb, a.d_count, a.n, h.nbits, a.desc, a.desc_pitch, h.dbg_T);
+        hipLaunchKernelGGL(project_sign_kernel, dim3(nblk, NF), dim3(256), 0, stream,
+                           h.responses, h.Wb, a.d_count, a.n, h.nbits, a.desc, a.desc_pitch, h.dbg_T, hb);
     }
     return hipGetLastError();
 }

@@ -249,8 +249,7 @@ int efx_match_crosscheck_async(efx_matcher* m, const uint8_t* d_query, size_t q_
  * large frame: 16 FHD frames per launch chain run at 1.9 x the frame rate of 16 single-frame calls.  Every
  * frame's results equal those of efx_detect_and_compute_async on that frame, bit for bit.  d_descriptors may be NULL (detect
  * only); either every frame has a keypoint / descriptor matrix or none.  A context holds its intermediate buffers once per frame of
- * its largest batch (FHD: 27 MB per frame, 4K: 92 MB, 8K: 350 MB).  BAD describers run batched too; HashSIFT describes frame by
- * frame behind the batched detector.  efx_last_count / efx_last_level_stats refer to the batch's last frame of that context.
+ * its largest batch (FHD: 27 MB per frame, 4K: 92 MB, 8K: 350 MB).  The describers run batched too (BAD on the blurred levels, HashSIFT's three kernels).  efx_last_count / efx_last_level_stats refer to the batch's last frame of that context.
  * EFX_NO_BATCH=1 (read when a context is created): one single-frame call per frame.  Stops at the first error. */
 int efx_detect_and_compute_batch_async(efx_context* const* ctxs, void* const* streams, int nctx,
                                        const uint8_t* const* d_images, int nframes, int rows, int cols, size_t pitch,
