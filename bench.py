@@ -501,16 +501,25 @@ def main():
         # The reference's own protocol (samples/sample_benchmark.cpp:39-52: 1 warm-up, then N x {detectAndComputeAsync;
         # stream.waitForCompletion()}): one frame at a time on one stream, host wait included.  This is the figure that
         # corresponds cell for cell to BASELINE.md's "8.2 ms"; `value` above keeps several frames in flight.
-        det.profileEnable(0)                             # no event pairs between the kernels of these calls
-        det.detectAndComputeAsync(frames[0], kps[0], desc[0], cnt[0], capacity=NFEATURES)
+        # "One context, one stream": the headline's three contexts, their streams and side streams are released first.  (Measured,
+        # tools/microbench/lat_probe.py: with them alive every one-call figure of the process reads ~25 us higher -- 0.426 instead of
+        # 0.400 ms for 8K BAD512 -- and falls back when they are gone: the waits and the per-call stream queries see every stream.)
+        import gc
+        del batches[:], dets[:], streams[:]
+        det = None
+        gc.collect()
         torch.cuda.synchronize()
-        nlat = 20
+        det = cef.EfficientFeatures.create(NFEATURES, 1.2, 8, 0, 20, 15, cef.EfficientFeatures.BAD_512)
+        for _ in range(3):                               # a new context: first-use allocations, side stream, the per-call fork decision
+            det.detectAndComputeAsync(frames[0], kps[0], desc[0], cnt[0], capacity=NFEATURES)
+            torch.cuda.synchronize()
+        nlat = 24
         t1 = time.perf_counter()
         for i in range(nlat):
             det.detectAndComputeAsync(frames[i % F], kps[i % F], desc[i % F], cnt[i % F], capacity=NFEATURES)
             torch.cuda.current_stream().synchronize()
         t_lat = (time.perf_counter() - t1) / nlat
-        out["latency"] = {"protocol": "sample_benchmark.cpp perf(): 1 warm-up + 20 x (detectAndComputeAsync + stream wait), one stream",
+        out["latency"] = {"protocol": "sample_benchmark.cpp perf(): warm-up + 24 x (detectAndComputeAsync + stream wait), one context, one stream, the step's 8 frames in turn",
                           "ms_per_frame": round(t_lat * 1e3, 4), "vs_baseline_ms": round(BASELINE_MS / (t_lat * 1e3), 2)}
 
         if world == 1 and not args.no_cpu_baseline:
@@ -552,8 +561,8 @@ def main():
             out["parity_8k_frame0"] = bool(same)
         if world == 1 and not args.no_configs:
             # the other BASELINE.json configurations and the README's rows, reference protocol, in the driver-run line
-            for d_ in dets[1:]:
-                d_.profileEnable(0)
+            det = None                                    # (the headline's contexts were released before the latency rows)
+            gc.collect()
             from tools import bench_configs
             out["configs"] = bench_configs.measure(cef, iters=args.config_iters, cpu_baseline=not args.no_cpu_baseline)
         print(json.dumps(out), flush=True)
