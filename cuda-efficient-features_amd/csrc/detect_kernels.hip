@@ -1064,6 +1064,9 @@ __device__ __forceinline__ void efx_tile_of(const LevelTable* T, int gt, int& l,
 //   | append xy to the level's corner array + tile header (responses: harris_kernel)
 // Algorithmic HBM bytes: every level is read once.  Bound by VALU issue.
 // ================================================================================================
+#ifndef EFX_FAST_QUICK16
+#define EFX_FAST_QUICK16 0       // 1: the packed 16-bit quick test of rounds 3 - 5 (A/B builds)
+#endif
 __global__ __launch_bounds__(256) void fast_kernel(
     const LevelTable* __restrict__ T, const uint8_t* __restrict__ img0, int pitch0, int aligned0,
     const uint8_t* __restrict__ pyramid, int threshold, const uint8_t* __restrict__ mask, int mask_pitch,
@@ -1117,11 +1120,6 @@ __global__ __launch_bounds__(256) void fast_kernel(
         unsigned qm = 0;
         {
             const uint32_t* trow = s_tile + (by + EFX_HALO - 3) * (EFX_LP / 4) + cg;
-            uint32_t R[10][3];
-#pragma unroll
-            for (int i = 0; i < 10; i++) {
-                R[i][0] = trow[i * (EFX_LP / 4) + 0]; R[i][1] = trow[i * (EFX_LP / 4) + 1]; R[i][2] = trow[i * (EFX_LP / 4) + 2];
-            }
             const int gx0 = x0 + bx, gy0 = y0 + by;
             // validity of the 16 pixels of the block (border mask, .cpp:176-182) in the layout of qm below: column c of
             // the block in byte c, row j at bit 7 - j of the byte
@@ -1134,6 +1132,13 @@ __global__ __launch_bounds__(256) void fast_kernel(
                     if ((gx0 + i) >= EFX_HALF_PATCH && (gx0 + i) < cols - EFX_HALF_PATCH) xm |= 0xf0u << (8 * i);
                     if ((gy0 + i) >= EFX_HALF_PATCH && (gy0 + i) < rows - EFX_HALF_PATCH) ym |= 0x80808080u >> i;
                 }
+            }
+#if EFX_FAST_QUICK16
+            // (the form of rounds 3 - 5, kept for A/B runs: exact compass test, two pixels per packed 16-bit instruction)
+            uint32_t R[10][3];
+#pragma unroll
+            for (int i = 0; i < 10; i++) {
+                R[i][0] = trow[i * (EFX_LP / 4) + 0]; R[i][1] = trow[i * (EFX_LP / 4) + 1]; R[i][2] = trow[i * (EFX_LP / 4) + 2];
             }
             // Two pixels per instruction on packed 16-bit lanes (v_perm_b32 widens byte pairs, v_pk_max/min_i16).  Two
             // neighbouring compass points brighter than p+t <=> min(max(N,S), max(E,W)) > p+t, and the mirrored form for
@@ -1168,6 +1173,33 @@ __global__ __launch_bounds__(256) void fast_kernel(
                 const uint32_t f = __builtin_amdgcn_perm(sgn[1], sgn[0], 0x07050301u);
                 qm |= (f >> j) & (0x80808080u >> j);
             }
+#else
+            // FOUR pixels per instruction, on the full-rate 32-bit adds and logic (round 6).  The quick test only has to keep every
+            // corner, so it runs on the pixels' upper six bits: with q(v) = v >> 2,  n > p + t  implies  q(n) - q(p) >= tq  for
+            // tq = ceil((t - 2) / 4) = (t + 1) >> 2  (q(n) >= (n - 3) / 4, q(p) <= p / 4), and likewise for darker.  Six-bit values
+            // leave two spare bits per byte, so a whole dword of four neighbouring pixels is compared with ONE 32-bit add or subtract
+            // and no carry ever crosses a byte:  q(n) + (128 - tq - q(p))  lies in [1, 191] and has bit 7 set  <=>  q(n) - q(p) >= tq;
+            // (q(p) + 128 - tq) - q(n)  likewise for darker.  Two neighbouring compass points of one polarity: (N | S) & (E | W) on
+            // those bits.  The packed 16-bit form this replaces took 10 half-rate instructions per pixel PAIR plus the perms that
+            // widen the bytes (profiles/r06_valu_rate.txt: 4.1 cycles against 2.2); this one takes 15 full-rate ones per FOUR
+            // pixels, and 18 LDS dwords per lane instead of 30.  It passes what the exact test passes at a threshold of ~t - 2.5, so
+            // a few more pixels reach the 16-point test of phase 2, which decides as before: the results are the same bit for bit.
+            uint32_t k1 = 0x01010101u * (uint32_t)(128 - min((threshold + 1) >> 2, 64));
+            asm volatile("" : "+v"(k1));        // in a VECTOR register: a full-rate instruction with a scalar source runs at half rate
+            uint32_t Q[10];
+#pragma unroll
+            for (int i = 0; i < 10; i++) Q[i] = (trow[i * (EFX_LP / 4) + 1] >> 2) & 0x3f3f3f3fu;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                // the pixels 3 to the right / left of the block's four columns in footprint row j + 3
+                const uint32_t d0 = (trow[(j + 3) * (EFX_LP / 4) + 0] >> 2) & 0x3f3f3f3fu, d2 = (trow[(j + 3) * (EFX_LP / 4) + 2] >> 2) & 0x3f3f3f3fu;
+                const uint32_t qe = __builtin_amdgcn_alignbyte(d2, Q[j + 3], 3), qw = __builtin_amdgcn_alignbyte(Q[j + 3], d0, 1);
+                const uint32_t qn = Q[j], qs = Q[j + 6];
+                const uint32_t br = k1 - Q[j + 3], dk = k1 + Q[j + 3];
+                const uint32_t f = (((qn + br) | (qs + br)) & ((qe + br) | (qw + br))) | (((dk - qn) | (dk - qs)) & ((dk - qe) | (dk - qw)));
+                qm |= (f >> j) & (0x80808080u >> j);
+            }
+#endif
             qm &= xm & ym;
             if (dbg & 2) qm = 0;
         }
