@@ -239,7 +239,7 @@ def main():
     # HIP event pairs around the kernels of one frame per step on context 0 (each pair costs a few microseconds of
     # stream idle time, so not on every frame;
     # on the first PROF_STEPS steps only: a long run needs no more samples)
-    PROF_STEPS = min(args.steps, 24)
+    PROF_STEPS = min(args.steps, int(os.environ.get("EFX_BENCH_PROF_STEPS", "24")))
     det.profileEnable(PROF_STEPS * 12 + 12, stride=max(1, F // NS))
     # one event per step and stream (no host wait): per-step spread, reported next to the mean
     marks = [[torch.cuda.Event(enable_timing=True) for _ in range(NS)] for _ in range(args.steps + 1)]

@@ -996,8 +996,14 @@ __global__ __launch_bounds__(NT) void pyramid_tower_kernel(const LevelTable* __r
 // least 15 px inside the frame (createMask, cuda_efficient_features.cpp:176-182) and the tests reach 3 px.
 typedef unsigned int efx_u32x2 __attribute__((ext_vector_type(2)));
 
+__device__ __forceinline__ efx_u32x2 efx_six_bits(efx_u32x2 v)
+{
+    return efx_u32x2{ (v.x >> 2) & 0x3f3f3f3fu, (v.y >> 2) & 0x3f3f3f3fu };
+}
+
+// s_q6 (same layout as s_tile): every byte's upper six bits, (v >> 2) & 0x3f -- what fast_kernel's quick test computes on
 template <int NT>
-__device__ __forceinline__ void load_tile_lds(uint32_t* s_tile, const uint8_t* __restrict__ src, int spitch, int rows, int cols,
+__device__ __forceinline__ void load_tile_lds(uint32_t* s_tile, uint32_t* s_q6, const uint8_t* __restrict__ src, int spitch, int rows, int cols,
                                               bool aligned, int x0, int y0, int tid)
 {
     if (aligned) {
@@ -1020,6 +1026,10 @@ __device__ __forceinline__ void load_tile_lds(uint32_t* s_tile, const uint8_t* _
                 *reinterpret_cast<efx_u32x2*>(l) = v0;
                 *reinterpret_cast<efx_u32x2*>(l + 28 * EFX_LP) = v1;
                 if (r0 + 56 < EFX_LT) *reinterpret_cast<efx_u32x2*>(l + 56 * EFX_LP) = v2;
+                uint8_t* q = reinterpret_cast<uint8_t*>(s_q6) + r0 * EFX_LP + c8 * 8;
+                *reinterpret_cast<efx_u32x2*>(q) = efx_six_bits(v0);
+                *reinterpret_cast<efx_u32x2*>(q + 28 * EFX_LP) = efx_six_bits(v1);
+                if (r0 + 56 < EFX_LT) *reinterpret_cast<efx_u32x2*>(q + 56 * EFX_LP) = efx_six_bits(v2);
             }
             return;
         }
@@ -1027,6 +1037,7 @@ __device__ __forceinline__ void load_tile_lds(uint32_t* s_tile, const uint8_t* _
             const int r = i / 9, c8 = i - r * 9;
             const efx_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, base + r * spitch + c8 * 8, 0, 0);
             *reinterpret_cast<efx_u32x2*>(reinterpret_cast<uint8_t*>(s_tile) + r * EFX_LP + c8 * 8) = v;
+            *reinterpret_cast<efx_u32x2*>(reinterpret_cast<uint8_t*>(s_q6) + r * EFX_LP + c8 * 8) = efx_six_bits(v);
         }
         return;
     }
@@ -1046,6 +1057,7 @@ __device__ __forceinline__ void load_tile_lds(uint32_t* s_tile, const uint8_t* _
             }
         }
         *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(s_tile) + r * EFX_LP + c8 * 8) = v;
+        *reinterpret_cast<efx_u32x2*>(reinterpret_cast<uint8_t*>(s_q6) + r * EFX_LP + c8 * 8) = efx_six_bits(efx_u32x2{ v.x, v.y });
     }
 }
 
@@ -1080,7 +1092,7 @@ __global__ __launch_bounds__(256) void fast_kernel(
     }
     __shared__ __attribute__((aligned(16))) uint32_t s_tile[EFX_LT * (EFX_LP / 4)];
     __shared__ unsigned long long s_bitmap[EFX_TILE];
-    __shared__ uint16_t s_list[EFX_TILE * EFX_TILE];     // quick-test survivors (block << 5 | bit), read by the full test and by the append
+    __shared__ __attribute__((aligned(16))) uint16_t s_list[EFX_TILE * EFX_TILE];     // quick-test survivors (block << 5 | bit), read by the full test and by the append
     __shared__ __attribute__((aligned(16))) int s_scan[8];     // two one-barrier scans: [0, 4) and [4, 8)
     __shared__ uint16_t s_rowoff[256];                          // phase 3: corners before row rr of cell c (canonical order), index 16 c + rr
     __shared__ int s_celloff[EFX_CELLS_PER_TILE + 1];
@@ -1104,22 +1116,25 @@ __global__ __launch_bounds__(256) void fast_kernel(
     // ---- phase 0: tile + halo -> LDS.  72 rows x 72 bytes as 9 x 8-byte pieces per row (the global address is
     //      only 4-byte aligned: x0 - 4), LDS row pitch 80 B. ----
     if (tid < EFX_TILE) s_bitmap[tid] = 0ull;
-    load_tile_lds<256>(s_tile, src, spitch, rows, cols, aligned, x0, y0, tid);
+    // the six-bit copy of the tile the quick test reads lies where the survivor list will: the list is written behind the barrier
+    // of phase 1's scan, i.e. after every wave's last read of the copy
+    uint32_t* s_q6 = reinterpret_cast<uint32_t*>(s_list);
+    static_assert(sizeof(s_list) >= EFX_LT * EFX_LP, "the six-bit tile copy aliases the survivor list");
+    load_tile_lds<256>(s_tile, s_q6, src, spitch, rows, cols, aligned, x0, y0, tid);
     __syncthreads();
     if (dbg & 1) return;
 
     int total = 0;
     {
         const int lane = tid & 63, wid = tid >> 6;
-        // ---- phase 1: quick test on all pixels.  A lane owns a 4x4 pixel block and pulls the 10 rows x 12 bytes
-        //      it needs as 30 dwords (1.9 LDS reads per pixel); every byte it compares is a static extract.  A
-        //      9-arc always contains two neighbouring compass points of the same polarity (cuda_fast.cu:193-197
-        //      has the weaker opposing-pair form); pixels that pass go to a per-wave list. ----
+        // ---- phase 1: quick test on all pixels.  A lane owns a 4x4 pixel block and pulls the 18 dwords it needs (10 rows of
+        //      its own dword column, the dwords left and right of its four rows).  A 9-arc always contains two neighbouring
+        //      compass points of the same polarity (cuda_fast.cu:193-197 has the weaker opposing-pair form); pixels that
+        //      pass go to one list per tile. ----
         const int cg = lane & 15, rg = lane >> 4;
         const int bx = cg * 4, by = wid * 16 + rg * 4;
         unsigned qm = 0;
         {
-            const uint32_t* trow = s_tile + (by + EFX_HALO - 3) * (EFX_LP / 4) + cg;
             const int gx0 = x0 + bx, gy0 = y0 + by;
             // validity of the 16 pixels of the block (border mask, .cpp:176-182) in the layout of qm below: column c of
             // the block in byte c, row j at bit 7 - j of the byte
@@ -1135,6 +1150,7 @@ __global__ __launch_bounds__(256) void fast_kernel(
             }
 #if EFX_FAST_QUICK16
             // (the form of rounds 3 - 5, kept for A/B runs: exact compass test, two pixels per packed 16-bit instruction)
+            const uint32_t* trow = s_tile + (by + EFX_HALO - 3) * (EFX_LP / 4) + cg;
             uint32_t R[10][3];
 #pragma unroll
             for (int i = 0; i < 10; i++) {
@@ -1180,19 +1196,22 @@ __global__ __launch_bounds__(256) void fast_kernel(
             // leave two spare bits per byte, so a whole dword of four neighbouring pixels is compared with ONE 32-bit add or subtract
             // and no carry ever crosses a byte:  q(n) + (128 - tq - q(p))  lies in [1, 191] and has bit 7 set  <=>  q(n) - q(p) >= tq;
             // (q(p) + 128 - tq) - q(n)  likewise for darker.  Two neighbouring compass points of one polarity: (N | S) & (E | W) on
-            // those bits.  The packed 16-bit form this replaces took 10 half-rate instructions per pixel PAIR plus the perms that
-            // widen the bytes (profiles/r06_valu_rate.txt: 4.1 cycles against 2.2); this one takes 15 full-rate ones per FOUR
-            // pixels, and 18 LDS dwords per lane instead of 30.  It passes what the exact test passes at a threshold of ~t - 2.5, so
-            // a few more pixels reach the 16-point test of phase 2, which decides as before: the results are the same bit for bit.
+            // those bits.  The six-bit values come from a second copy of the tile in LDS, converted once where the tile is loaded
+            // (load_tile_lds; the copy lies where the survivor list will).  The packed 16-bit form this replaces took 10 half-rate
+            // instructions per pixel PAIR plus the perms that widen the bytes (profiles/r06_valu_rate.txt: 4.1 cycles against 2.2);
+            // this one takes 17 full-rate ones and two v_alignbyte per FOUR pixels.  It passes what the exact test passes at a
+            // threshold of ~t - 2.5, so a few more pixels (+5 %) reach the 16-point test of phase 2, which decides as before: the
+            // results are the same bit for bit.
             uint32_t k1 = 0x01010101u * (uint32_t)(128 - min((threshold + 1) >> 2, 64));
             asm volatile("" : "+v"(k1));        // in a VECTOR register: a full-rate instruction with a scalar source runs at half rate
+            const uint32_t* qrow = s_q6 + (by + EFX_HALO - 3) * (EFX_LP / 4) + cg;
             uint32_t Q[10];
 #pragma unroll
-            for (int i = 0; i < 10; i++) Q[i] = (trow[i * (EFX_LP / 4) + 1] >> 2) & 0x3f3f3f3fu;
+            for (int i = 0; i < 10; i++) Q[i] = qrow[i * (EFX_LP / 4) + 1];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 // the pixels 3 to the right / left of the block's four columns in footprint row j + 3
-                const uint32_t d0 = (trow[(j + 3) * (EFX_LP / 4) + 0] >> 2) & 0x3f3f3f3fu, d2 = (trow[(j + 3) * (EFX_LP / 4) + 2] >> 2) & 0x3f3f3f3fu;
+                const uint32_t d0 = qrow[(j + 3) * (EFX_LP / 4) + 0], d2 = qrow[(j + 3) * (EFX_LP / 4) + 2];
                 const uint32_t qe = __builtin_amdgcn_alignbyte(d2, Q[j + 3], 3), qw = __builtin_amdgcn_alignbyte(Q[j + 3], d0, 1);
                 const uint32_t qn = Q[j], qs = Q[j + 6];
                 const uint32_t br = k1 - Q[j + 3], dk = k1 + Q[j + 3];
