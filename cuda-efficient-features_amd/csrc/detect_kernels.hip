@@ -1082,7 +1082,7 @@ __device__ __forceinline__ void efx_tile_of(const LevelTable* T, int gt, int& l,
 __global__ __launch_bounds__(256) void fast_kernel(
     const LevelTable* __restrict__ T, const uint8_t* __restrict__ img0, int pitch0, int aligned0,
     const uint8_t* __restrict__ pyramid, int threshold, const uint8_t* __restrict__ mask, int mask_pitch,
-    unsigned char* __restrict__ slots, uint16_t* __restrict__ tcount, RowCtr* __restrict__ rowsum, TileHdr* __restrict__ hdr_all, int dbg_arg, int tiles_per_wg, const FrameSet F)
+    unsigned char* __restrict__ slots, uint16_t* __restrict__ tcount, RowCtr* __restrict__ rowsum, TileHdr* __restrict__ hdr_all, int dbg_arg, const FrameSet F)
 {
     const int dbg = EFX_DBG(dbg_arg);
     {   // this frame's buffers (blockIdx.y)
@@ -1097,71 +1097,31 @@ __global__ __launch_bounds__(256) void fast_kernel(
     __shared__ uint16_t s_rowoff[256];                          // phase 3: corners before row rr of cell c (canonical order), index 16 c + rr
     __shared__ int s_celloff[EFX_CELLS_PER_TILE + 1];
 
-    int tid = threadIdx.x;          // (laundered at the top of every tile: see the loop)
+    const int tid = threadIdx.x;
+    // heaviest tiles first: the upper pyramid levels have the densest corners, so they must not form the tail
+    const int gt = T->total_tiles - 1 - xcd_interleaved(blockIdx.x, T->total_tiles);
+    int l, tx, ty;
+    efx_tile_of(T, gt, l, tx, ty);
+    const LevelDev& L = T->lv[l];
+    if (!L.active) return;
+    const int tile = gt - L.tile_base;
+    const int rows = L.rows, cols = L.cols;
+    const uint8_t* src = l == 0 ? img0 : pyramid + L.img_off;
+    const int spitch = l == 0 ? pitch0 : L.pitch;
+    const bool aligned = l == 0 ? aligned0 != 0 : true;
+    const int x0 = tx * EFX_TILE, y0 = ty * EFX_TILE;
+    const uint8_t* tb = reinterpret_cast<const uint8_t*>(s_tile);
+    TileHdr* hdr = hdr_all + L.tile_base;
+
+    // ---- phase 0: tile + halo -> LDS.  72 rows x 72 bytes as 9 x 8-byte pieces per row (the global address is
+    //      only 4-byte aligned: x0 - 4), LDS row pitch 80 B. ----
+    if (tid < EFX_TILE) s_bitmap[tid] = 0ull;
     // the six-bit copy of the tile the quick test reads lies where the survivor list will: the list is written behind the barrier
     // of phase 1's scan, i.e. after every wave's last read of the copy
     uint32_t* s_q6 = reinterpret_cast<uint32_t*>(s_list);
     static_assert(sizeof(s_list) >= EFX_LT * EFX_LP, "the six-bit tile copy aliases the survivor list");
-
-    // Round 6: a workgroup takes `tiles_per_wg` tiles, one after the other, and the NEXT tile's pixels are requested (into
-    // registers: three 8-byte pieces per thread) before this tile's phases start -- with one tile per workgroup the kernel took
-    // ~65 us at 8K whatever its instructions cost (the frame with the corner statistics of photographs issues 40 % fewer and took
-    // as long): eight workgroups per CU, each a chain load -> LDS -> barrier -> phases, the loads' latency in every chain.
-    // Virtual workgroup v = blockIdx.x + it * gridDim.x (gridDim.x is a multiple of the XCD count: v runs on the same XCD as
-    // blockIdx.x); heaviest tiles first: the upper pyramid levels have the densest corners, so they must not form the tail
-    struct Ref { int gt, l, tx, ty, spitch; const uint8_t* src; bool aligned, ok; };
-    auto ref_of = [&](int v) -> Ref {
-        Ref r; r.gt = 0; r.l = 0; r.tx = 0; r.ty = 0; r.spitch = 0; r.src = nullptr; r.aligned = true;
-        r.ok = v < T->total_tiles;
-        if (r.ok) {
-            r.gt = T->total_tiles - 1 - xcd_interleaved(v, T->total_tiles);
-            efx_tile_of(T, r.gt, r.l, r.tx, r.ty);
-            const LevelDev& RL = T->lv[r.l];
-            r.ok = RL.active != 0;
-            r.src = r.l == 0 ? img0 : pyramid + RL.img_off;
-            r.spitch = r.l == 0 ? pitch0 : RL.pitch;
-            r.aligned = r.l == 0 ? aligned0 != 0 : true;
-        }
-        return r;
-    };
-    // tile + halo: 72 rows x 72 bytes as 9 x 8-byte pieces per row (the global address is only 4-byte aligned: x0 - 4), three per
-    // thread (252 of the 256), through a buffer resource: rows above / below the image read as 0 (load_tile_lds has the details)
-    const int pr0 = tid / 9, pc8 = tid - pr0 * 9;
-    auto issue = [&](const Ref& r, efx_u32x2 (&pv)[3]) {
-        if (!r.ok || !r.aligned || tid >= 252) return;
-        const LevelDev& RL = T->lv[r.l];
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(r.src), 0, (RL.rows - 1) * r.spitch + RL.cols, 0x00020000);
-        const int goff = (r.ty * EFX_TILE - EFX_HALO + pr0) * r.spitch + r.tx * EFX_TILE - EFX_HALO + pc8 * 8;
-        pv[0] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, goff, 0, 0);
-        pv[1] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, goff + 28 * r.spitch, 0, 0);
-        pv[2] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, goff + 56 * r.spitch, 0, 0);
-    };
-    auto commit = [&](const Ref& r, const efx_u32x2 (&pv)[3]) {
-        if (!r.aligned) {        // a caller's level 0 with an unaligned base or pitch: bytes, no prefetch
-            const LevelDev& RL = T->lv[r.l];
-            load_tile_lds<256>(s_tile, s_q6, r.src, r.spitch, RL.rows, RL.cols, false, r.tx * EFX_TILE, r.ty * EFX_TILE, tid);
-            return;
-        }
-        if (tid >= 252) return;
-        uint8_t* lt = reinterpret_cast<uint8_t*>(s_tile) + pr0 * EFX_LP + pc8 * 8;
-        uint8_t* lq = reinterpret_cast<uint8_t*>(s_q6) + pr0 * EFX_LP + pc8 * 8;
-        *reinterpret_cast<efx_u32x2*>(lt) = pv[0];
-        *reinterpret_cast<efx_u32x2*>(lt + 28 * EFX_LP) = pv[1];
-        if (pr0 + 56 < EFX_LT) *reinterpret_cast<efx_u32x2*>(lt + 56 * EFX_LP) = pv[2];
-        *reinterpret_cast<efx_u32x2*>(lq) = efx_six_bits(pv[0]);
-        *reinterpret_cast<efx_u32x2*>(lq + 28 * EFX_LP) = efx_six_bits(pv[1]);
-        if (pr0 + 56 < EFX_LT) *reinterpret_cast<efx_u32x2*>(lq + 56 * EFX_LP) = efx_six_bits(pv[2]);
-    };
-
-    // one tile whose pixels are in LDS: phases 1 - 4 (every exit is workgroup-uniform)
-    auto process = [&](const Ref& R) {
-    const int gt = R.gt, l = R.l, tx = R.tx, ty = R.ty;
-    const LevelDev& L = T->lv[l];
-    const int tile = gt - L.tile_base;
-    const int rows = L.rows, cols = L.cols;
-    const int x0 = tx * EFX_TILE, y0 = ty * EFX_TILE;
-    const uint8_t* tb = reinterpret_cast<const uint8_t*>(s_tile);
-    TileHdr* hdr = hdr_all + L.tile_base;
+    load_tile_lds<256>(s_tile, s_q6, src, spitch, rows, cols, aligned, x0, y0, tid);
+    __syncthreads();
     if (dbg & 1) return;
 
     int total = 0;
@@ -1339,30 +1299,6 @@ __global__ __launch_bounds__(256) void fast_kernel(
         } else if (tid < EFX_TILE) {
             reinterpret_cast<unsigned long long*>(slots + (size_t)gt * EFX_SLOT_BYTES)[tid] = s_bitmap[tid];
         }
-    }
-    };
-
-    efx_u32x2 pv[3] = { efx_u32x2{ 0u, 0u }, efx_u32x2{ 0u, 0u }, efx_u32x2{ 0u, 0u } };
-    Ref cur = ref_of((int)blockIdx.x);
-    issue(cur, pv);
-    for (int it = 0; it < tiles_per_wg; it++) {
-        Ref nxt; nxt.gt = 0; nxt.l = 0; nxt.tx = 0; nxt.ty = 0; nxt.spitch = 0; nxt.src = nullptr; nxt.aligned = true; nxt.ok = false;
-        if (it + 1 < tiles_per_wg) nxt = ref_of((int)blockIdx.x + (it + 1) * (int)gridDim.x);
-        // nothing that is derived from the thread index may be carried around the loop: hoisted out of it, the LDS addresses of a
-        // tile's phases took the kernel from 34 to 70 registers (seven waves per SIMD instead of eight)
-        asm volatile("" : "+v"(tid));
-        if (cur.ok) {
-            // ---- phase 0: tile + halo -> LDS (the loads were issued one tile ago) ----
-            if (tid < EFX_TILE) s_bitmap[tid] = 0ull;
-            commit(cur, pv);
-        }
-        issue(nxt, pv);
-        if (cur.ok) {
-            __syncthreads();
-            process(cur);
-            __syncthreads();                                // the next tile's pixels overwrite s_tile and the list
-        }
-        cur = nxt;
     }
 }
 
@@ -2061,405 +1997,6 @@ __global__ __launch_bounds__(64 * NW) void nms_kernel(const LevelTable* __restri
         hl[tile].surv_count = (uint32_t)nsurv;
         if (nsurv > 0 && dbg < 5) __hip_atomic_fetch_add(&rows[L.row_base + ty].surv, nsurv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-}
-
-// ================================================================================================
-// Kernel C, packed form (round 6): frames with the corner statistics of photographs (8 .. 20 corners per tile) spend
-// nms_kernel's time in per-tile fixed costs -- 25 500 one-wave workgroups, each a chain of three to five dependent memory round
-// trips for a dozen busy lanes.  Here ONE WAVE takes EFX_PACK_TPW consecutive tiles of a level (harris_packed_kernel's groups):
-// the 9 neighbouring headers and the 6 x 6 cell maxima of every tile of the group in one round trip, the group's corners side by
-// side through phase A 64 per round, the hard ones through the same exact scans, survivors compacted per tile to the tile's own
-// place.  Same survivors, same places, same histogram: bit-identical to nms_kernel; the host picks the form with
-// harris_packed_kernel's (the previous frame's density), EFX_PACK / EFX_PACK_NMS pin it.  A group with more than 4096 corners
-// (the hint was stale: a dense frame) goes through tile by tile.
-// ================================================================================================
-__global__ __launch_bounds__(64) void nms_packed_kernel(const LevelTable* __restrict__ T, TileHdr* __restrict__ hdr,
-                                                        const Corner* __restrict__ cand_all, const Corner* __restrict__ cmax_all,
-                                                        Corner* __restrict__ surv_all, RowCtr* __restrict__ rows, int* __restrict__ hist,
-                                                        Counters* __restrict__ cnt, int radius, const FrameStride fs)
-{
-    constexpr int NP = EFX_PACK_TPW;
-    {
-        const size_t f = blockIdx.y;
-        hdr += f * fs.hdr; cand_all += f * fs.cand; cmax_all += f * fs.cmax; surv_all += f * fs.cand; rows += f * fs.rows; hist += f * fs.hist;
-        cnt += f;
-    }
-    __shared__ Corner s_hme[NMS_HCAP];
-    __shared__ uint16_t s_hidx[NMS_HCAP];
-    __shared__ uint16_t s_hneed[NMS_HCAP];
-    __shared__ uint8_t s_hj[NMS_HCAP];                    // the group's tile a hard corner belongs to
-    __shared__ unsigned long long s_keep[64];            // survivor bits of round r (64 rounds = 4096 corners)
-    __shared__ __attribute__((aligned(64))) uint32_t s_nb[NP][9][16];   // TileHdr of the 3x3 neighbouring tiles of every tile of the group
-    __shared__ Corner s_cm[NP][6][6];                    // cell maxima of a tile's 4x4 cells + one ring (block_radius 1)
-    __shared__ int s_P[NP + 1];                          // valid corners of the group before tile j
-    __shared__ int s_S[NP + 1];                          // survivors of the group before tile j
-    __shared__ unsigned s_start[NP];                     // where tile j's corners (and survivors) start in the level's arrays
-    __shared__ uint32_t s_txy[NP];                       // tx | ty << 16
-
-    const int lane = threadIdx.x;
-    int g = (int)blockIdx.x;
-    int l = 0;
-    while (l + 1 < T->nlevels && g >= T->lv[l].pack_groups) { g -= T->lv[l].pack_groups; l++; }
-    const LevelDev& L = T->lv[l];
-    if (!L.active || g >= L.pack_groups) return;
-    const int ntiles = L.tiles_x * L.tiles_y;
-    const int t0 = ntiles - NP * (g + 1);                // densest (last) tiles first; the last group may start below tile 0
-    TileHdr* hl = hdr + L.tile_base;
-    const Corner* cand = cand_all + L.cand_base;
-    if (cnt->sum.overflow) return;                        // void frame
-
-    // the tiles' coordinates and their own counts: a group without corners leaves after this one round trip
-    {
-        const int tj = t0 + lane;
-        const bool tile_ok = lane < NP && tj >= 0;
-        uint32_t txy = 0;
-        int own_total = 0;
-        if (tile_ok) {
-            int l2, tx, ty;
-            efx_tile_of(T, L.tile_base + tj, l2, tx, ty);
-            txy = (uint32_t)tx | ((uint32_t)ty << 16);
-            own_total = hl[tj].cell_off[EFX_CELLS_PER_TILE];
-        }
-        if (__ballot(own_total != 0) == 0ull) return;
-        if (lane < NP) s_txy[lane] = txy;
-    }
-    __syncthreads();
-    // 9 headers of 64 bytes per tile: eight lanes x 8 bytes per header, eight headers per pass
-#pragma unroll
-    for (int pass = 0; pass < (9 * NP + 7) / 8; pass++) {
-        const int hh = pass * 8 + (lane >> 3), w2 = lane & 7;
-        if (hh < 9 * NP) {
-            const int j = hh / 9, t = hh - 9 * j;
-            const int dyt = t / 3, dxt = t - 3 * dyt;
-            const uint32_t jxy = s_txy[j];
-            const int ntx = (int)(jxy & 0xffffu) - 1 + dxt, nty = (int)(jxy >> 16) - 1 + dyt;
-            uint2 v = make_uint2(0u, 0u);
-            if (t0 + j >= 0 && ntx >= 0 && ntx < L.tiles_x && nty >= 0 && nty < L.tiles_y)
-                v = reinterpret_cast<const uint2*>(&hl[nty * L.tiles_x + ntx])[w2];
-            *reinterpret_cast<uint2*>(&s_nb[j][t][2 * w2]) = v;
-        }
-    }
-    // the cell maxima in the same round trip (see nms_kernel: a cell beyond the grid is an EMPTY cell)
-    {
-        const int gw_ = (L.cols + EFX_CELL - 1) / EFX_CELL, gh_ = (L.rows + EFX_CELL - 1) / EFX_CELL;
-#pragma unroll
-        for (int q = 0; q < (36 * NP + 63) / 64; q++) {
-            const int e = lane + 64 * q;
-            if (e < 36 * NP) {
-                const int j = e / 36, i = e - 36 * j;
-                const uint32_t jxy = s_txy[j];
-                const int cyu = (int)(jxy >> 16) * 4 - 1 + i / 6, cxu = (int)(jxy & 0xffffu) * 4 - 1 + i % 6;
-                const int cy = min(max(cyu, 0), gh_ - 1), cx = min(max(cxu, 0), gw_ - 1);
-                Corner cm; cm.xy = 0xffffffffu; cm.resp = -3.0e38f;
-                if (t0 + j >= 0 && cyu == cy && cxu == cx) cm = cmax_all[L.cmax_base + (size_t)cy * (L.tiles_x * 4) + cx];
-                s_cm[j][i / 6][i % 6] = cm;
-            }
-        }
-    }
-    __syncthreads();
-    {
-        // the headers address the corner array: a count beyond a tile's 4096 pixels voids the frame
-        bool bad = false;
-        if (lane < 9 * NP) {
-            const TileHdr* nh = reinterpret_cast<const TileHdr*>(&s_nb[lane / 9][lane % 9][0]);
-            bad = (unsigned)nh->cell_off[EFX_CELLS_PER_TILE] > (unsigned)(EFX_TILE * EFX_TILE);
-        }
-        if (__ballot(bad) != 0ull) {
-            if (lane == 0) efx_raise_overflow(T, cnt);
-            return;
-        }
-    }
-    {
-        // a tile's corners start at its canonical rank in the level; those of rank >= cap do not exist (spec S2; cuda_fast.cu:245)
-        int nv = 0; unsigned start = 0;
-        if (lane < NP) {
-            const TileHdr* h = reinterpret_cast<const TileHdr*>(&s_nb[lane][4][0]);
-            start = min(h->cand_start, (unsigned)L.cap);
-            nv = min(L.cap - (int)start, (int)h->cell_off[EFX_CELLS_PER_TILE]);
-        }
-        const int incl = wave_incl_scan(nv);
-        if (lane < NP) { s_P[lane] = incl - nv; s_start[lane] = start; }
-        if (lane == NP - 1) s_P[NP] = incl;
-    }
-    __syncthreads();
-
-    const int image_radius = radius * radius;           // cvCeil(radius * radius), .cu:291
-    const int block_radius = (radius + EFX_CELL - 1) / EFX_CELL;   // cvCeil(radius / CELL_SIZE), .cu:292
-    const int gw = (L.cols + EFX_CELL - 1) / EFX_CELL, gh = (L.rows + EFX_CELL - 1) / EFX_CELL;
-    const int gwp = L.tiles_x * 4;                      // row pitch of the per-cell maxima table
-    const Corner* cmax = cmax_all + L.cmax_base;
-    const bool quick_ok = block_radius <= 2;
-    const int span = 2 * block_radius + 1;
-    const int ncell = span * span;
-    const int grp = lane >> 3, sub = lane & 7;
-    auto wave_sync = [&]() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
-
-    // one cell's list [nb, ne) walked by the 8 lanes of a group (as nms_kernel)
-    auto walk_list = [&](unsigned nbase, int nb, int ne, const Corner& m, bool& kill) {
-        const Corner* lst = cand + (size_t)nbase;
-        if (__ballot(ne - nb > 8) == 0ull) {
-            const int j = nb + sub;
-            if (j < ne) {
-                const Corner o = lst[j];
-                const i16x2 d = __builtin_bit_cast(i16x2, m.xy) - __builtin_bit_cast(i16x2, o.xy);
-                kill |= (o.xy != m.xy && m.resp <= o.resp && __builtin_amdgcn_sdot2(d, d, 0, false) < image_radius);
-            }
-            return;
-        }
-        for (int j = nb + sub; j < ne; j += 32) {
-            Corner o[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) o[u] = lst[min(j + 8 * u, ne - 1)];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const i16x2 d = __builtin_bit_cast(i16x2, m.xy) - __builtin_bit_cast(i16x2, o[u].xy);
-                kill |= (o[u].xy != m.xy && m.resp <= o[u].resp && __builtin_amdgcn_sdot2(d, d, 0, false) < image_radius);
-            }
-        }
-    };
-
-    // phase B over the hard corners collected so far (nms_kernel's, with the corner's own tile's headers)
-    auto scan_hard = [&](int nh) {
-        for (int h0 = 0; h0 < nh; h0 += 8) {
-            const int hi = h0 + grp;
-            const bool act = hi < nh;
-            Corner m; m.xy = 0; m.resp = 0.f;
-            int hj = 0;
-            if (act) { m = s_hme[hi]; hj = s_hj[hi]; }
-            const int mx = m.xy & 0xffff, my = m.xy >> 16;
-            const int tx = mx >> 6, ty = my >> 6;          // the corner's tile
-            const int bx1 = mx / EFX_CELL, by1 = my / EFX_CELL;
-            const int cx0 = max(bx1 - block_radius, 0), cx1 = min(bx1 + block_radius, gw - 1);
-            const int cy0 = max(by1 - block_radius, 0), cy1 = min(by1 + block_radius, gh - 1);
-            // header of the tile that holds cell (bx, by): the LDS copy when it is a neighbour of the corner's tile
-            auto nhdr = [&](int bx, int by) -> const TileHdr* {
-                const int ntx = bx >> 2, nty = by >> 2;
-                const int dx = ntx - tx, dy = nty - ty;
-                if (dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1) return reinterpret_cast<const TileHdr*>(&s_nb[hj][(dy + 1) * 3 + dx + 1][0]);
-                return &hl[nty * L.tiles_x + ntx];
-            };
-            bool kill = false;
-            if (block_radius == 1) {
-                const int needm = act ? (int)s_hneed[hi] : 0;
-                int lb[2] = { 0, 0 }, le[2] = { 0, 0 }; unsigned lbase[2] = { 0u, 0u };
-#pragma unroll
-                for (int q = 0; q < 2; q++) {
-                    const int ci = 8 * q + sub;
-                    if (ci < 9 && ((needm >> ci) & 1)) {
-                        const int bx = min(max(bx1 - 1 + (ci % 3), 0), gw - 1), by = min(max(by1 - 1 + (ci / 3), 0), gh - 1);
-                        const TileHdr* nh2 = reinterpret_cast<const TileHdr*>(&s_nb[hj][((by >> 2) - ty + 1) * 3 + ((bx >> 2) - tx + 1)][0]);
-                        const int c = (by & 3) * 4 + (bx & 3);
-                        lb[q] = nh2->cell_off[c];
-                        le[q] = nh2->cell_off[c + 1];
-                        lbase[q] = min(nh2->cand_start, (unsigned)L.cap);
-                        le[q] = min(le[q], L.cap - (int)lbase[q]);                         // corners beyond the cap do not exist
-                    }
-                }
-                unsigned gneed = ((unsigned)(__ballot(le[0] > lb[0]) >> (grp * 8)) & 0xffu) |
-                                 (((unsigned)(__ballot(le[1] > lb[1]) >> (grp * 8)) & 0x01u) << 8);
-                while (__ballot(gneed != 0u) != 0ull) {
-                    const int i = (gneed & 16u) ? 4 : (gneed ? __ffs(gneed) - 1 : 0);      // the corner's own cell first
-                    const int src = (lane & 56) + (i & 7);
-                    const int b0 = __shfl(lb[0], src, 64), b1 = __shfl(lb[1], src, 64);
-                    const int e0 = __shfl(le[0], src, 64), e1 = __shfl(le[1], src, 64);
-                    const unsigned a0 = (unsigned)__shfl((int)lbase[0], src, 64), a1 = (unsigned)__shfl((int)lbase[1], src, 64);
-                    const int nb = i < 8 ? b0 : b1, ne = i < 8 ? e0 : e1;
-                    const unsigned nbase = i < 8 ? a0 : a1;
-                    if (gneed) walk_list(nbase, nb, ne, m, kill);
-                    gneed &= ~(1u << i);
-                    if (((unsigned)(__ballot(kill) >> (grp * 8)) & 0xffu) != 0u) gneed = 0u;       // one suppressor is enough
-                }
-            } else
-            for (int c0 = 0; c0 < ncell; c0 += 16) {
-                int lb[2] = { 0, 0 }, le[2] = { 0, 0 }; unsigned lbase[2] = { 0u, 0u };
-#pragma unroll
-                for (int q = 0; q < 2; q++) {
-                    const int ci = c0 + 8 * q + sub;
-                    const int oy = ci / span, ox = ci - oy * span;
-                    const int bx = bx1 - block_radius + ox, by = by1 - block_radius + oy;
-                    if (act && ci < ncell && bx >= cx0 && bx <= cx1 && by >= cy0 && by <= cy1) {
-                        const TileHdr* nh2 = nhdr(bx, by);
-                        const int c = (by & 3) * 4 + (bx & 3);
-                        lbase[q] = min(nh2->cand_start, (unsigned)L.cap);
-                        const int nn = L.cap - (int)lbase[q];
-                        lb[q] = nh2->cell_off[c];
-                        le[q] = nh2->cell_off[c + 1];
-                        if (le[q] > nn) le[q] = nn;
-                        if (quick_ok && le[q] > lb[q] && cmax[by * gwp + bx].resp < m.resp) le[q] = lb[q];
-                        const int ex = max(max(bx * EFX_CELL - mx, mx - (bx * EFX_CELL + EFX_CELL - 1)), 0);
-                        const int ey = max(max(by * EFX_CELL - my, my - (by * EFX_CELL + EFX_CELL - 1)), 0);
-                        if (ex * ex + ey * ey >= image_radius) le[q] = lb[q];
-                    }
-                }
-                unsigned gneed = ((unsigned)(__ballot(le[0] > lb[0]) >> (grp * 8)) & 0xffu) |
-                                 (((unsigned)(__ballot(le[1] > lb[1]) >> (grp * 8)) & 0xffu) << 8);
-                while (__ballot(gneed != 0u) != 0ull) {
-                    const int i = gneed ? __ffs(gneed) - 1 : 0;
-                    const int src = (lane & 56) + (i & 7);
-                    const int b0 = __shfl(lb[0], src, 64), b1 = __shfl(lb[1], src, 64);
-                    const int e0 = __shfl(le[0], src, 64), e1 = __shfl(le[1], src, 64);
-                    const unsigned a0 = (unsigned)__shfl((int)lbase[0], src, 64), a1 = (unsigned)__shfl((int)lbase[1], src, 64);
-                    const int nb = i < 8 ? b0 : b1, ne = i < 8 ? e0 : e1;
-                    const unsigned nbase = i < 8 ? a0 : a1;
-                    if (gneed) walk_list(nbase, nb, ne, m, kill);
-                    gneed &= gneed - 1u;
-                    if (((unsigned)(__ballot(kill) >> (grp * 8)) & 0xffu) != 0u) gneed = 0u;
-                }
-                if (__ballot(act && !kill) == 0ull) break;
-            }
-            const unsigned gk = (unsigned)(__ballot(kill) >> (grp * 8)) & 0xffu;
-            if (act && sub == 0 && gk == 0u) {
-                const int idx = s_hidx[hi];
-                atomicOr(&s_keep[idx >> 6], 1ull << (idx & 63));
-            }
-        }
-    };
-
-    // the tiles [jb, je) of the group as one list of corners
-    auto run = [&](int jb, int je) -> bool {
-        const int base = s_P[jb], sum = s_P[je] - base;
-        s_keep[lane] = 0ull;
-        wave_sync();
-        // the tile that holds corner n of the list: the last j with s_P[j] - base <= n
-        auto tile_of = [&](int n) { int j = jb; for (int jj = jb + 1; jj < je; jj++) if (s_P[jj] - base <= n) j = jj; return j; };
-        int nh = 0;
-        for (int n0 = 0; n0 < sum; n0 += 64) {
-            const int n = n0 + lane;
-            const bool actn = n < sum;
-            const int j = tile_of(n);
-            const int k = n - (s_P[j] - base);
-            const uint32_t jxy = s_txy[j];
-            const int tx = (int)(jxy & 0xffffu), ty = (int)(jxy >> 16);
-            bool hard = false, sure = false;
-            int need = 0x1ff;
-            Corner me; me.xy = 0; me.resp = 0.f;
-            if (actn) me = cand[(size_t)s_start[j] + k];
-            // range check: a record that is not of its tile would index LDS and the arrays out of range: the frame is void
-            if (__ballot(actn && ((int)((me.xy & 0xffff) >> 6) != tx || (int)(me.xy >> 22) != ty)) != 0ull) {
-                if (lane == 0) efx_raise_overflow(T, cnt);
-                return false;
-            }
-            if (actn) {
-                const int mx = me.xy & 0xffff, my = me.xy >> 16;
-                const int bx1 = mx / EFX_CELL, by1 = my / EFX_CELL;
-                hard = true;
-                if (quick_ok) {
-                    if (block_radius == 1) {
-                        Corner o[9];
-                        const int cj = bx1 - tx * 4, ci = by1 - ty * 4;      // this corner's cell inside its tile, 0..3
-#pragma unroll
-                        for (int q = 0; q < 9; q++) o[q] = s_cm[j][ci + q / 3][cj + q % 3];
-                        bool kill = false;
-                        int rival = 0;
-                        const int px = mx & (EFX_CELL - 1), py = my & (EFX_CELL - 1);
-                        const int gx[3] = { (px + 1) * (px + 1), 0, (EFX_CELL - px) * (EFX_CELL - px) };
-                        const int gy[3] = { (py + 1) * (py + 1), 0, (EFX_CELL - py) * (EFX_CELL - py) };
-                        const i16x2 mev = __builtin_bit_cast(i16x2, me.xy);
-#pragma unroll
-                        for (int q = 0; q < 9; q++) {
-                            const uint32_t oxy = o[q].xy & ~EFX_CMAX_TIE;
-                            const i16x2 d = mev - __builtin_bit_cast(i16x2, oxy);
-                            const int d2 = __builtin_amdgcn_sdot2(d, d, 0, false);
-                            if (q == 4) {
-                                const bool other = oxy != me.xy;
-                                const bool ge = other && me.resp <= o[q].resp;
-                                if (ge || (!other && (int)o[q].xy < 0)) rival |= 1 << q;
-                                kill = kill || (ge && d2 < image_radius);
-                            } else {
-                                const bool ge = me.resp <= o[q].resp;
-                                if (ge && gx[q % 3] + gy[q / 3] < image_radius) rival |= 1 << q;
-                                kill = kill || (ge && d2 < image_radius);
-                            }
-                        }
-                        hard = !kill;
-                        need = rival;
-                        sure = rival == 0;
-                    } else {
-                        const int minx = max(bx1 - block_radius, 0), maxx = min(bx1 + block_radius, gw - 1);
-                        const int miny = max(by1 - block_radius, 0), maxy = min(by1 + block_radius, gh - 1);
-                        for (int by = miny; by <= maxy; by++)
-                            for (int bx = minx; bx <= maxx; bx++) {
-                                const Corner o = cmax[by * gwp + bx];
-                                const uint32_t oxy = o.xy & ~EFX_CMAX_TIE;
-                                const int dx = mx - (int)(oxy & 0xffff), dy = my - (int)(oxy >> 16);
-                                if (oxy != me.xy && me.resp <= o.resp && dx * dx + dy * dy < image_radius) hard = false;
-                            }
-                    }
-                }
-            }
-            const unsigned long long sm = __ballot(sure);
-            if (lane == 0 && sm) atomicOr(&s_keep[n0 >> 6], sm);
-            hard = hard && !sure;
-            const unsigned long long hm = __ballot(hard);
-            if (hard) {
-                const int pos = nh + __popcll(hm & ((1ull << lane) - 1ull));
-                s_hme[pos] = me;
-                s_hidx[pos] = (uint16_t)n;
-                s_hneed[pos] = (uint16_t)need;
-                s_hj[pos] = (uint8_t)j;
-            }
-            nh += __popcll(hm);
-            if (nh > NMS_HCAP - 64 || n0 + 64 >= sum) {
-                wave_sync();
-                scan_hard(nh);
-                nh = 0;
-                wave_sync();
-            }
-        }
-        wave_sync();
-        // lane r holds the survivor ballot of round r; survivors before position p of the list
-        const unsigned long long my_round_mask = s_keep[lane];
-        const int cnt_r = __popcll(my_round_mask);
-        const int incl = wave_incl_scan(cnt_r);
-        const int total = __shfl(incl, 63, 64);
-        {
-            const int jj = min(jb + lane, je);
-            const int p = s_P[jj] - base, r = min(p >> 6, 63);
-            const unsigned long long m = (unsigned long long)(unsigned)__shfl((int)(my_round_mask & 0xffffffffu), r, 64) |
-                                         ((unsigned long long)(unsigned)__shfl((int)(my_round_mask >> 32), r, 64) << 32);
-            const int e = __shfl(incl - cnt_r, r, 64);
-            const int sb = p >= sum ? total : e + __popcll(m & ((1ull << (p & 63)) - 1ull));
-            if (jb + lane <= je) s_S[jb + lane] = sb;
-        }
-        wave_sync();
-        // the survivors in canonical order at their tile's own place; every survivor one bin of the level's key histogram
-        int* lhist = hist + (size_t)l * EFX_HIST_BINS;
-        int before = 0, round = 0;
-        for (int n0 = 0; n0 < sum; n0 += 64, round++) {
-            const unsigned long long m = (unsigned long long)(unsigned)__shfl((int)(my_round_mask & 0xffffffffu), round, 64) |
-                                         ((unsigned long long)(unsigned)__shfl((int)(my_round_mask >> 32), round, 64) << 32);
-            if ((m >> lane) & 1ull) {
-                const int n = n0 + lane;
-                const int j = tile_of(n);
-                const int k = n - (s_P[j] - base);
-                const int slot = before + __popcll(m & ((1ull << lane) - 1ull)) - s_S[j];
-                const Corner c = cand[(size_t)s_start[j] + k];
-                surv_all[L.cand_base + (size_t)s_start[j] + slot] = c;
-                __hip_atomic_fetch_add(&lhist[efx_hist_word((uint32_t)(efx_select_key(c.xy, c.resp) >> (64 - EFX_HIST_BITS)))], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            before += __popcll(m);
-        }
-        // the tiles' counts; a tile row's tiles of the group join in ONE addition to the row's sum
-        if (jb + lane < je) {
-            const int j = jb + lane;
-            const TileHdr* h = reinterpret_cast<const TileHdr*>(&s_nb[j][4][0]);
-            if (t0 + j >= 0 && h->cell_off[EFX_CELLS_PER_TILE] != 0) hl[t0 + j].surv_count = (uint32_t)(s_S[j + 1] - s_S[j]);
-            const int ty = (int)(s_txy[j] >> 16);
-            const bool first = j == jb || (int)(s_txy[j - 1] >> 16) != ty || t0 + j - 1 < 0;
-            if (first && t0 + j >= 0) {
-                int add = 0;
-                for (int jj = j; jj < je && (int)(s_txy[jj] >> 16) == ty; jj++) add += s_S[jj + 1] - s_S[jj];
-                if (add > 0) __hip_atomic_fetch_add(&rows[L.row_base + ty].surv, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        wave_sync();
-        return true;
-    };
-
-    if (s_P[NP] <= 64 * 64) (void)run(0, NP);
-    else
-        for (int j = 0; j < NP; j++)
-            if (!run(j, j + 1)) break;
 }
 
 // ================================================================================================
@@ -3439,14 +2976,8 @@ static hipError_t efx_launch_detect_impl(const DetectLaunch& a, hipStream_t stre
     {
         const int aligned0 = ((img_bits | (uintptr_t)a.pitch0) & 3u) == 0;
         bool prof = a.prof.begin(0, stream);
-        // tiles per workgroup (the next tile's pixels are requested while this one's phases run): once the launch fills the chip
-        // several times over (256 CUs x 8 workgroups)
-        static const int tpw_env = getenv("EFX_FAST_TPW") ? atoi(getenv("EFX_FAST_TPW")) : 0;
-        const long long ft = (long long)H.total_tiles * B;
-        const int tpw = tpw_env > 0 ? tpw_env : (ft >= 16384 ? 4 : (ft >= 8192 ? 2 : 1));
-        const int fast_wgs = ((H.total_tiles + tpw - 1) / tpw + EFX_NXCD - 1) / EFX_NXCD * EFX_NXCD;
-        hipLaunchKernelGGL(fast_kernel, dim3(fast_wgs, B), dim3(256), 0, stream, a.d_table, a.img0, a.pitch0, aligned0,
-                           a.pyramid, a.threshold, a.mask, a.mask_pitch, a.slots, a.tcount, a.rows, a.hdr, a.knobs.dbg & 15, tpw, F);
+        hipLaunchKernelGGL(fast_kernel, dim3(H.total_tiles, B), dim3(256), 0, stream, a.d_table, a.img0, a.pitch0, aligned0,
+                           a.pyramid, a.threshold, a.mask, a.mask_pitch, a.slots, a.tcount, a.rows, a.hdr, a.knobs.dbg & 15, F);
         a.prof.end(prof, 0, stream);
         EFX_TRACE_POINT("fast");
         prof = a.prof.begin(1, stream);
@@ -3470,14 +3001,8 @@ static hipError_t efx_launch_detect_impl(const DetectLaunch& a, hipStream_t stre
         if (e != hipSuccess) return e;
     }
     bool prof = a.prof.begin(2, stream);
-    // several waves per tile when the tiles alone do not fill the chip (256 CUs x 32 waves); several tiles per wave on frames with
-    // the corner statistics of photographs (a.pack_nms: harris_packed_kernel's groups)
-    int nms_groups = 0;
-    for (int s = 0; s < H.nlevels; s++) nms_groups += H.lv[s].pack_groups;
-    if (a.pack_nms && nms_groups > 0)
-        hipLaunchKernelGGL(nms_packed_kernel, dim3(nms_groups, B), dim3(64), 0, stream, a.d_table, a.hdr, a.cand, a.cmax, a.surv,
-                           a.rows, a.hist, a.counters, a.nonmax_radius, a.fs);
-    else if (launch_tiles <= EFX_NMS_WIDE_TILES)
+    // several waves per tile when the tiles alone do not fill the chip (256 CUs x 32 waves)
+    if (launch_tiles <= EFX_NMS_WIDE_TILES)
         hipLaunchKernelGGL(nms_kernel<4>, dim3(H.total_tiles, B), dim3(256), 0, stream, a.d_table, a.hdr, a.cand, a.cmax, a.surv,
                            a.rows, a.hist, a.counters, a.nonmax_radius, a.knobs.dbg >> 4, a.fs);
     else if (launch_tiles <= EFX_NMS_MID_TILES)

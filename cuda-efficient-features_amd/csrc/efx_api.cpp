@@ -361,7 +361,6 @@ EfxKnobs efx_read_knobs()
     { const char* f = getenv("EFX_BLUR_FORK"); k.blur_fork = f ? atoi(f) : EFX_BLUR_FORK_DEFAULT; }   // DetectLaunch::blur_fork
     k.blur_fork_min_px = getenv("EFX_BLUR_FORK_MIN_PX") ? atoll(getenv("EFX_BLUR_FORK_MIN_PX")) : 0;  // 0: the built-in gate of the per-call fork decision
     k.no_batch = getenv("EFX_NO_BATCH") != nullptr;
-    { const char* f = getenv("EFX_PACK_NMS"); k.pack_nms = f ? atoi(f) : -1; }
     { const char* f = getenv("EFX_PACK"); k.pack = f ? atoi(f) : -1; }      // harris_kernel four tiles per wave: 0 never, 1 always, unset: by the last frame's density       // the batched entry point as a loop of single-frame calls (A/B, parity tests)
     // BAD behind detectAndCompute: every keypoint blurs its own window (A/B, parity tests)
     const char* d = getenv("EFX_DEBUG");
@@ -1000,7 +999,6 @@ int detect_frames(efx_context* c, int nframes, const uint8_t* const* d_images, i
         const int hint = c->h_hint ? *(volatile int*)c->h_hint : 0;
         a.pack_harris = c->knobs.pack >= 0 ? c->knobs.pack
                       : (hint > 0 && (long long)c->h_table.total_tiles * nframes > EFX_PACK_MIN_TILES && (long long)(hint - 1) <= EFX_PACK_AVG * t0) ? 1 : 0;
-        a.pack_nms = c->knobs.pack_nms >= 0 ? c->knobs.pack_nms : a.pack_harris;
     }
     a.d_keypoints = want_kps ? d_keypoints[0] : nullptr; a.kps_pitch = kps_pitch; a.capacity = capacity;
     a.d_count = a.out.count[0];

@@ -221,7 +221,7 @@ __device__ __forceinline__ int efx_wave_incl_scan(int v)
 #else
 #define EFX_DBG(v) 0
 #endif
-struct EfxKnobs { int dbg, dbg_hs, no_tower, no_resize_stream, no_level_blur, blur_fork, no_resize_rows, no_batch, pack, pack_nms; long long tower_max_px, blur_fork_min_px; };
+struct EfxKnobs { int dbg, dbg_hs, no_tower, no_resize_stream, no_level_blur, blur_fork, no_resize_rows, no_batch, pack; long long tower_max_px, blur_fork_min_px; };
 EfxKnobs efx_read_knobs();      // efx_api.cpp
 
 // ---- launchers (host side, defined in the .hip files) ----
@@ -356,7 +356,6 @@ struct DetectLaunch {
     const uint8_t* mask; int mask_pitch;   // optional level-0 mask (spec S12), null = none
     int pyramid_only;           // 1: build the pyramid and stop (detectAndCompute with provided keypoints)
     int pack_harris;            // harris_kernel takes four tiles per wave (sparse frames; bit-identical to the other form)
-    int pack_nms;               // ... and nms_kernel (nms_packed_kernel; EFX_PACK_NMS = 0 / 1 pins it, unset: whenever harris is packed)
     // outputs
     void* d_keypoints; size_t kps_pitch; int capacity; int* d_count;
     float4* kp4; int* kp_level;

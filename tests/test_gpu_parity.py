@@ -960,43 +960,3 @@ def test_packed_harris_kernel_equals_oracle(cef, torch_mod, oracle, monkeypatch,
     got, ref = _detect_both(cef, torch_mod, oracle, img, desc_type=0, nfeatures=3000, **kw)
     _assert_same_keypoints(got, ref)
     assert np.array_equal(got["desc"], ref["desc"])
-
-
-@pytest.mark.parametrize("harris_packed", ["1", "0"])
-@pytest.mark.parametrize("kind,kw", [
-    ("sparse", dict()), ("sparse", dict(nonmax_radius=5)), ("sparse", dict(nonmax_radius=20)), ("sparse", dict(nonmax_radius=40)),
-    ("sparse", dict(nonmax_radius=70)), ("sparse", dict(nonmax_radius=0)), ("sparse", dict(nonmax_radius=1)),
-    ("dense", dict()), ("dense", dict(nonmax_radius=7)), ("dense", dict(nonmax_radius=33)),
-    ("noise", dict(fast_threshold=5)), ("noise", dict(fast_threshold=0, nonmax_radius=3)), ("capped", dict()),
-    ("checker9", dict(nonmax_radius=15, nlevels=4)), ("checker6", dict(nonmax_radius=3, nlevels=4)), ("checker17", dict(nonmax_radius=16, nlevels=4)),
-    ("odd_size", dict()), ("narrow", dict()), ("half_constant", dict())])
-def test_packed_nms_kernel_equals_oracle(cef, torch_mod, oracle, monkeypatch, kind, kw, harris_packed):
-    """nms_packed_kernel (round 6: several tiles per wave, harris_packed_kernel's groups; EFX_PACK_NMS=1 forces it): the same
-    survivors at the same places as nms_kernel -- every suppression radius class (one cell ring from the LDS copy, two rings, the
-    exact scans only, neighbour cells beyond the 3x3 tiles), tied responses, groups that go through tile by tile (more than 4096
-    corners: noise), the 10 % cap cutting inside a group, levels narrower than a group, tiles without corners inside a group --
-    behind either harris kernel."""
-    monkeypatch.setenv("EFX_PACK_NMS", "1")
-    monkeypatch.setenv("EFX_PACK", harris_packed)
-    if kind == "sparse":
-        img = synth.powerlaw_frame(700, 1000, seed=13, beta=1.3, contrast=45.0)
-    elif kind == "dense":
-        img = synth.synth_frame(600, 900, seed=78, density=3.0)
-    elif kind == "noise":
-        img = synth.noise_frame(500, 700, seed=15)
-    elif kind == "capped":
-        img = synth.noise_frame(640, 640, seed=16)
-    elif kind.startswith("checker"):
-        period = int(kind[7:])
-        y, x = np.mgrid[0:300, 0:400]
-        img = ((((x // period) + (y // period)) & 1) * 200).astype(np.uint8)
-    elif kind == "odd_size":
-        img = synth.synth_frame(333, 517, seed=19)
-    elif kind == "narrow":
-        img = synth.synth_frame(900, 150, seed=20, density=1.0)         # levels of one to three tiles per row
-    else:
-        img = synth.synth_frame(512, 1024, seed=21, density=1.0); img[:, 512:] = 90
-    args = dict(nfeatures=3000); args.update(kw)
-    got, ref = _detect_both(cef, torch_mod, oracle, img, desc_type=1, **args)
-    _assert_same_keypoints(got, ref)
-    assert np.array_equal(got["desc"], ref["desc"])
