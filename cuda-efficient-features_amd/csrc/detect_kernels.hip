@@ -2146,7 +2146,10 @@ __global__ __launch_bounds__(SEL_NT) void select_kernel(const LevelTable* __rest
             // the frame's corner density for the host: the context's next launch takes its sparse or its dense form by it (harris_kernel)
             if (l == 0 && blockIdx.y == 0 && T->host_hint) __hip_atomic_store(T->host_hint, nc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             efx_st(&S.pub[1], ((unsigned long long)(uint32_t)s_rem << 32) | (uint32_t)kmin);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // program order: word B is out before word A
+            // word B has ARRIVED before word A leaves: an explicit wait for the store's acknowledgement.  (Until the last session of
+            // round 6 a workgroup-scope release fence stood here and before the `done` counter below, "the stores have been
+            // acknowledged" -- on this target that fence compiles to no wait for global stores at all; see the counting workgroups.)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             efx_st(&S.pub[0], (1ull << 63) | ((unsigned long long)(uint32_t)(s_bin + 1) << 32) | (uint32_t)s_inbin);
         }
         SEL_TL(3);
@@ -2236,7 +2239,13 @@ __global__ __launch_bounds__(SEL_NT) void select_kernel(const LevelTable* __rest
     SEL_TC(3);
     // ---- which levels does this workgroup complete? ----
     if (tid < EFX_MAX_LEVELS) s_last[tid] = 0;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this thread's device-scope stores have been acknowledged
+    // Every thread's device-scope stores (its tile's count, the list keys) must have ARRIVED before the workgroup adds itself to the
+    // level's `done` counter: whoever completes the level reads them right behind that addition.  A workgroup-scope release fence
+    // does not do it -- on gfx950 it waits for LDS traffic only, the stores may still be on their way when thread 0's atomic goes
+    // out, and nothing orders the two on the way to memory.  Found by the determinism soak (tools/microbench/soak_diag.py): one
+    // 8K frame in ~500 000 had a few tiles' counts read as the PREVIOUS frame's offsets by the workgroup that scans the level, so
+    // every later tile of the level was emitted beyond the capacity, i.e. not at all (round6.md section 11).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
         int l0, l1, tx_, ty_;

@@ -1,0 +1,69 @@
+"""Determinism soak with a diagnosis: as soak.py (three contexts / streams, the same 8 frames over and over), but every result of a
+round of 24 calls is kept until the round has been checked, and a result that differs from the first result of its frame is
+described: count, which keypoint rows differ where (level, tile), which descriptor rows.  usage: soak_diag.py <seconds> [max events]"""
+import sys, time; sys.path.insert(0, '.')
+import numpy as np
+import torch, cef_loader
+from tools import synth
+cef = cef_loader.load(); EF = cef.EfficientFeatures
+secs = float(sys.argv[1]) if len(sys.argv) > 1 else 30.0
+max_events = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+CAP = int(sys.argv[3]) if len(sys.argv) > 3 else 40000      # 50000 with an -DEFX_EMIT_DIAG build: emit_kernel's workgroups report in columns 40000 ..
+frames = [torch.from_numpy(synth.synth_frame(4320, 7680, seed=1000 + k)).cuda() for k in range(8)]
+dets = [EF.create(40000, dtype=EF.BAD_512) for _ in range(3)]
+streams = [torch.cuda.Stream() for _ in range(3)]
+ref = {}
+for k, f in enumerate(frames):
+    kps, desc, cnt = dets[0].detectAndComputeAsync(f); torch.cuda.synchronize()
+    n = int(cnt.item()); ref[k] = (n, kps[:, :n].clone(), desc[:n].clone())
+# every call of a round writes into its own output matrices (no reuse inside a round)
+R = 24
+okps = [torch.zeros((5, CAP), dtype=torch.float32, device='cuda') for _ in range(R)]
+odesc = [torch.zeros((40000, 64), dtype=torch.uint8, device='cuda') for _ in range(R)]
+ocnt = [torch.zeros(1, dtype=torch.int32, device='cuda') for _ in range(R)]
+flags = torch.zeros(R, dtype=torch.int64, device='cuda')
+t0 = time.time(); it = 0; events = 0
+while time.time() - t0 < secs and events < max_events:
+    ks = []
+    for j in range(R):
+        i = it * R + j
+        d, s, k = dets[i % 3], streams[i % 3], (i // 3 + i) % 8
+        ks.append(k)
+        with torch.cuda.stream(s):
+            kps, desc, cnt = d.detectAndComputeAsync(frames[k], stream=s, capacity=CAP)
+            okps[j].copy_(kps); odesc[j].copy_(desc[:40000]); ocnt[j].copy_(cnt)
+            n, rk, rd = ref[k]
+            flags[j] = (ocnt[j].to(torch.int64).sum() != n).to(torch.int64) + 2 * (okps[j][:, :n] != rk).any().to(torch.int64) + 4 * (odesc[j][:n] != rd).any().to(torch.int64)
+    torch.cuda.synchronize(); it += 1
+    fl = flags.cpu().numpy()
+    for j in np.nonzero(fl)[0]:
+        events += 1
+        k = ks[j]; n, rk, rd = ref[k]
+        gn = int(ocnt[j].item())
+        gk = okps[j][:, :n].cpu().numpy().view(np.uint32); wk = rk.cpu().numpy().view(np.uint32)
+        gd = odesc[j][:n].cpu().numpy(); wd = rd.cpu().numpy()
+        colbad = np.nonzero((gk != wk).any(axis=0))[0]
+        rowbad = np.nonzero((gd != wd).any(axis=1))[0]
+        print(f"EVENT round {it} call {j} frame {k} context {(it * R - R + j) % 3}: flags {fl[j]} count {gn} (want {n}); keypoint columns differing {colbad.size}: {colbad[:12]}; descriptor rows differing {rowbad.size}: {rowbad[:12]}")
+        for c in colbad[:6]:
+            print("   col", c, "got", okps[j][:, c].cpu().numpy(), "want", rk[:, c].cpu().numpy(), "rows differing", np.nonzero(gk[:, c] != wk[:, c])[0])
+        if colbad.size > 0:
+            # is it a shift (a keypoint missing / extra) or values in place?
+            c0 = int(colbad[0])
+            same_shift_m = np.array_equal(gk[:, c0:n - 1], wk[:, c0 + 1:n]); same_shift_p = np.array_equal(gk[:, c0 + 1:n], wk[:, c0:n - 1])
+            print("   from the first differing column on: got == want shifted by -1:", same_shift_m, " by +1:", same_shift_p, " last differing column", int(colbad[-1]))
+        if CAP > 40000 and colbad.size > 0:
+            d4 = okps[j][:, 40000:].cpu().numpy().view(np.uint32)
+            nwg = int(np.nonzero(d4[4] != 0)[0].max()) + 1 if (d4[4] != 0).any() else 0
+            missing = np.nonzero((d4[4, :6372] >> 16) != 0x5eed)[0]
+            print("   emit workgroups that reported:", nwg, " workgroups without a marker (below 6372):", missing.size, missing[:10])
+            offs = d4[1, :6372].astype(np.int64)
+            lo, hi = int(colbad[0]), int(colbad[-1])
+            wg_lo = int(np.searchsorted(offs, lo, side='right')) - 1; wg_hi = int(np.searchsorted(offs, hi, side='right')) - 1
+            print("   bad columns", lo, "..", hi, "belong to emit workgroups", wg_lo, "..", wg_hi)
+            for w in sorted(set([max(wg_lo - 1, 0), wg_lo, wg_lo + 1, (wg_lo + wg_hi) // 2, wg_hi - 1, wg_hi, wg_hi + 1])):
+                print("     wg", w, "counts %08x" % d4[0, w], "out_off", d4[1, w], "raw surv_count", d4[3, w], "marker %08x" % d4[4, w])
+            seen0 = np.nonzero(d4[0, wg_lo:wg_hi + 1] == 0)[0].size
+            print("   workgroups of the range that saw no survivor in any of their four tiles:", seen0, "of", wg_hi - wg_lo + 1)
+        sys.stdout.flush()
+print('frames', it * R, 'events', events, 'in', round(time.time() - t0, 1), 's')
