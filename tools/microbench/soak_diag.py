@@ -1,6 +1,7 @@
 """Determinism soak with a diagnosis: as soak.py (three contexts / streams, the same 8 frames over and over), but every result of a
 round of 24 calls is kept until the round has been checked, and a result that differs from the first result of its frame is
-described: count, which keypoint rows differ where (level, tile), which descriptor rows.  usage: soak_diag.py <seconds> [max events]"""
+described: count, which keypoint rows differ where (level, tile), which descriptor rows.
+usage: soak_diag.py <seconds> [max events] [capacity: 40000] [size: 8k | 4k | fhd]"""
 import sys, time; sys.path.insert(0, '.')
 import numpy as np
 import torch, cef_loader
@@ -9,7 +10,9 @@ cef = cef_loader.load(); EF = cef.EfficientFeatures
 secs = float(sys.argv[1]) if len(sys.argv) > 1 else 30.0
 max_events = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 CAP = int(sys.argv[3]) if len(sys.argv) > 3 else 40000      # 50000 with an -DEFX_EMIT_DIAG build: emit_kernel's workgroups report in columns 40000 ..
-frames = [torch.from_numpy(synth.synth_frame(4320, 7680, seed=1000 + k)).cuda() for k in range(8)]
+SIZE = sys.argv[4] if len(sys.argv) > 4 else '8k'
+ROWS, COLS = {'8k': (4320, 7680), '4k': (2160, 3840), 'fhd': (1080, 1920)}[SIZE]
+frames = [torch.from_numpy(synth.synth_frame(ROWS, COLS, seed=1000 + k)).cuda() for k in range(8)]
 dets = [EF.create(40000, dtype=EF.BAD_512) for _ in range(3)]
 streams = [torch.cuda.Stream() for _ in range(3)]
 ref = {}
