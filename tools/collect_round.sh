@@ -25,8 +25,10 @@ python tools/pmc_summary.py $O/pmc_lds/pmc_results.db > $O/${tag}_pmc_lds.txt; r
 tools/pmc_run.sh fetch FETCH_SIZE > /dev/null
 tools/pmc_run.sh write WRITE_SIZE > /dev/null
 python tools/traffic_json.py $O/pmc_fetch/pmc_results.db $O/pmc_write/pmc_results.db $O/${tag}_traffic.json > /dev/null; rm -rf $O/pmc_fetch $O/pmc_write
-tools/microbench/valu_rate > $O/${tag}_valu_rate.txt 2>&1
-tools/microbench/wg_rate > $O/wg_rate.txt 2>&1
+# (the issue-rate tables are a property of the chip: without the compiled micro-benchmarks -- tools/microbench/valu_calib.sh builds them --
+# the round's committed table is used)
+if [ -x tools/microbench/valu_rate ]; then tools/microbench/valu_rate > $O/${tag}_valu_rate.txt 2>&1; else cp profiles/${tag}_valu_rate.txt $O/${tag}_valu_rate.txt; fi
+if [ -x tools/microbench/wg_rate ]; then tools/microbench/wg_rate > $O/wg_rate.txt 2>&1; fi
 python tools/counters_json.py $O/${tag}_pmc_sq.txt $O/${tag}_pmc_lds.txt $O/${tag}_traffic.json $O/${tag}_valu_rate.txt $O/${tag}_counters.json profiles/${tag}_valu_mix.json
 if [ -n "$FULL" ]; then
   python tools/bench_configs.py --out $O/${tag}_configs.json > /dev/null
