@@ -2536,6 +2536,21 @@ __global__ __launch_bounds__(64) void emit_kernel(const LevelTable* __restrict__
     int sc_max = sc;
 #pragma unroll
     for (int d = LPT; d < 64; d <<= 1) sc_max = max(sc_max, __shfl_xor(sc_max, d, 64));
+#ifdef EFX_EMIT_DIAG
+    // INVESTIGATION builds (tools/microbench/soak_diag.py with a capacity of 50 000): what this workgroup saw, in the unused columns
+    // 40 000 + blockIdx.x of the keypoint matrix: row 0 the four tiles' survivor counts (a byte each), row 1 the first tile's output
+    // offset, row 3 its raw header count, row 4 a marker.  (How the select_kernel hand-off race was found: round6.md section 11.)
+    if (kps && capacity >= 40000 + (int)gridDim.x) {
+        const int c0 = min(__shfl(sc, 0, 64), 255), c1 = min(__shfl(sc, LPT, 64), 255), c2 = min(__shfl(sc, 2 * LPT, 64), 255), c3 = min(__shfl(sc, 3 * LPT, 64), 255);
+        if (lane == 0) {
+            const size_t col = 40000 + (size_t)blockIdx.x;
+            *reinterpret_cast<uint32_t*>(kps + 0 * kps_pitch + 4 * col) = (uint32_t)c0 | ((uint32_t)c1 << 8) | ((uint32_t)c2 << 16) | ((uint32_t)c3 << 24);
+            *reinterpret_cast<uint32_t*>(kps + 1 * kps_pitch + 4 * col) = (uint32_t)out_off;
+            *reinterpret_cast<uint32_t*>(kps + 3 * kps_pitch + 4 * col) = act ? hdr[gt].surv_count : 0xffffffffu;
+            *reinterpret_cast<uint32_t*>(kps + 4 * kps_pitch + 4 * col) = 0x5eed0000u | (uint32_t)(blockIdx.x & 0xffffu);
+        }
+    }
+#endif
     if (sc_max == 0) return;
     const unsigned long long thresh = cnt->thresh[l];
     const Corner* q = surv_all + L.cand_base + start;
