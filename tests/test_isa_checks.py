@@ -58,3 +58,32 @@ def test_rows_kernel_owns_m0(asm):
         uses = [l.strip() for l in outside.splitlines() if re.search(r"\bm0\b", l) and not l.strip().startswith((";", "."))]
         assert not uses, f"{name}: the compiler uses M0 outside the LDS-DMA statements: {uses[:4]}"
         assert body.count("offen lds") >= 4 and "s_waitcnt vmcnt(10)" in body and "s_waitcnt vmcnt(8)" in body
+
+
+def test_select_kernel_waits_for_its_stores_before_the_hand_offs(asm):
+    """select_kernel hands results from workgroup to workgroup inside one launch with relaxed device-scope stores followed by an
+    atomic counter / a flag word.  The stores must have been ACKNOWLEDGED before the counter or the flag goes out; a workgroup-scope
+    release fence does not do that on gfx950 (it waits for LDS traffic only) -- the race of docs/history/round6.md section 11, one 8K
+    frame in ~500 000.  The waits are explicit `s_waitcnt vmcnt(0)` statements; this test keeps them where they belong:
+      * behind the counting workgroups' count stores (`global_store_dword ... sc1`) and before the barrier that precedes the
+        `done` counter;
+      * between the leader's two published words (two `global_store_dwordx2 ... sc1` of neighbouring offsets)."""
+    ks = {n: b for n, b in _kernels(asm["detect_kernels.hip"]).items() if "select_kernel" in n}
+    assert len(ks) == 1, list(ks)
+    body = next(iter(ks.values()))
+    lines = body.splitlines()
+    explicit = [i for i, l in enumerate(lines) if l.strip() == "s_waitcnt vmcnt(0)" and i > 0 and "ASMSTART" in lines[i - 1]]
+    assert len(explicit) >= 2, "the explicit waits for the stores' acknowledgement are gone"
+    # the count store, then the explicit wait, then the barrier -- in this order, nothing else that stores in between
+    count_store = [i for i, l in enumerate(lines) if re.search(r"global_store_dword v\[\d+:\d+\], v\d+, off sc1", l)]
+    assert count_store, "the counting pass's device-scope count store was not found"
+    i0 = count_store[-1]
+    barrier = next(i for i in range(i0, len(lines)) if lines[i].strip() == "s_barrier")
+    assert any(i0 < i < barrier for i in explicit), "no wait for the count stores before the barrier of the done counter"
+    # the leader: word B (higher offset), the wait, word A
+    pub = [(i, int(re.search(r"offset:(\d+) sc1", l).group(1))) for i, l in enumerate(lines)
+           if re.search(r"global_store_dwordx2 v\d+, v\[\d+:\d+\], s\[\d+:\d+\] offset:\d+ sc1", l)]
+    pairs = [(a, b) for a, b in zip(pub, pub[1:]) if a[1] == b[1] + 8]
+    assert pairs, f"the leader's two published words were not found: {pub}"
+    (ib, _), (ia, _) = pairs[-1]
+    assert any(ib < i < ia for i in explicit), "no wait between the leader's word B and word A"
