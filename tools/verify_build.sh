@@ -1,11 +1,13 @@
 #!/bin/bash
 # usage (GPU box, repo root): tools/verify_build.sh [fuzz cases per leg, default 12000] [first seed, default 900000]
-# The verification legs of a final build in one call: determinism soak of the headline path, seeded fuzz on FRESH seeds (mixed
+# The verification legs of a final build in one call: determinism soaks (single-frame calls on three streams; the batched path the headline takes), seeded fuzz on FRESH seeds (mixed
 # cases; the rows kernel forced onto small frames under four level splits; the tiled chain; harris_packed_kernel forced; batches of
 # frames against single-frame calls), the three Hamming kernels against each other, sixteen processes sharing the GPU.  Prints one line per leg; gpurun_out/verify.log holds the details.
 n=${1:-12000}; first=${2:-900000}
 cd "$GRAFT_REPO_ROOT"; L=gpurun_out/verify.log; : > $L
 echo "soak: $(timeout 300 python tools/microbench/soak.py 60 2>&1 | tail -1)" | tee -a $L
+echo "soak, batched path: $(timeout 300 python tools/microbench/soak_batch.py 45 8k 8 BAD_512 2>&1 | tail -1)" | tee -a $L
+echo "soak, batched path: $(timeout 300 python tools/microbench/soak_batch.py 30 fhd 16 HASH_SIFT_512 2>&1 | tail -1)" | tee -a $L
 echo "fuzz mixed: $(EFX_FUZZ_CASES=$n EFX_FUZZ_FIRST=$first timeout 2400 python -m pytest tests/test_gpu_fuzz.py -m gpu -q -x 2>&1 | tail -1)" | tee -a $L
 k=0
 for split in "2,2,3" "1,1,1,1,1,1,1" "3,4" "4,3"; do
