@@ -960,3 +960,25 @@ def test_packed_harris_kernel_equals_oracle(cef, torch_mod, oracle, monkeypatch,
     got, ref = _detect_both(cef, torch_mod, oracle, img, desc_type=0, nfeatures=3000, **kw)
     _assert_same_keypoints(got, ref)
     assert np.array_equal(got["desc"], ref["desc"])
+
+
+@pytest.mark.parametrize("t", [0, 1, 2, 3, 4, 5, 6, 7, 19, 21, 22, 23, 63, 64, 127, 128, 129, 200, 251, 252, 253, 254, 255])
+def test_fast_quick_test_keeps_every_corner_at_any_threshold(cef, torch_mod, oracle, t):
+    """fast_kernel's quick test compares the pixels' upper six bits (round 6: four pixels per 32-bit add; tq = (t + 1) >> 2 is the
+    largest coarse threshold that still keeps every pixel the exact compass test keeps).  Every residue of t modulo 4, the
+    thresholds around the field boundaries (63 / 64, 127 / 128) and the largest ones, on an image whose pixels use the whole byte
+    range -- uniform noise with saturated blobs -- so that corners exist up to t = 254: the same corners as the oracle's exact
+    test, level by level."""
+    rng = np.random.default_rng(41)
+    img = rng.integers(0, 256, size=(300, 420), dtype=np.uint8)
+    yy, xx = np.mgrid[0:300, 0:420]
+    for k in range(60):                                   # saturated discs and squares on the noise: 0 / 255 corners
+        cy, cx, r = int(rng.integers(20, 280)), int(rng.integers(20, 400)), int(rng.integers(3, 9))
+        v = 255 if k % 2 else 0
+        if k % 3: img[(yy - cy) ** 2 + (xx - cx) ** 2 <= r * r] = v
+        else: img[cy - r:cy + r, cx - r:cx + r] = v
+    got, ref = _detect_both(cef, torch_mod, oracle, img, desc_type=0, nfeatures=20000, fast_threshold=t, nlevels=3)
+    _assert_same_keypoints(got, ref)
+    assert np.array_equal(got["desc"], ref["desc"])
+    if t <= 200:
+        assert sum(s["n_candidates"] for s in got["stats"]) > 0
